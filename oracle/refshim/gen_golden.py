@@ -1,0 +1,452 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Build-container only (needs /root/reference).  The reference's Python is imported through
+ref_loader (no-op numba shim), driven on seeded inputs, and its inputs/outputs are written
+as small .npz fixtures.  No reference source is copied: the fixtures are data.
+
+    python oracle/refshim/gen_golden.py            # regenerate everything
+    python oracle/refshim/gen_golden.py scan ttc   # only some groups
+
+Input map/raceline data files (example_map.{png,yaml}, example_waypoints.csv,
+berlin/skirk.{png,yaml}, unittest/legacy_scan.npz) are copied verbatim as data fixtures.
+"""
+import os
+import shutil
+import sys
+import time
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+GOLD = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
+
+warnings.simplefilter("ignore")
+REF = ref_loader.REF_ROOT
+PARAM_KEYS = ['mu', 'C_Sf', 'C_Sr', 'lf', 'lr', 'h', 'm', 'I', 's_min', 's_max', 'sv_min',
+              'sv_max', 'v_switch', 'a_max', 'v_min', 'v_max', 'width', 'length']
+DEFAULT_PARAMS = {'mu': 1.0489, 'C_Sf': 4.718, 'C_Sr': 5.4562, 'lf': 0.15875, 'lr': 0.17145,
+                  'h': 0.074, 'm': 3.74, 'I': 0.04712, 's_min': -0.4189, 's_max': 0.4189,
+                  'sv_min': -3.2, 'sv_max': 3.2, 'v_switch': 7.319, 'a_max': 9.51,
+                  'v_min': -5.0, 'v_max': 20.0, 'width': 0.31, 'length': 0.58}
+EXAMPLE_MAP = os.path.join(GOLD, "maps", "example_map")
+
+
+def pvec(p):
+    return np.array([p[k] for k in PARAM_KEYS])
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("  wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.))
+
+
+def copy_data():
+    os.makedirs(os.path.join(GOLD, "maps"), exist_ok=True)
+    pairs = [("examples/example_map.png", "maps/example_map.png"),
+             ("examples/example_map.yaml", "maps/example_map.yaml"),
+             ("examples/example_waypoints.csv", "maps/example_waypoints.csv"),
+             ("gym/f110_gym/envs/maps/berlin.png", "maps/berlin.png"),
+             ("gym/f110_gym/envs/maps/berlin.yaml", "maps/berlin.yaml"),
+             ("gym/f110_gym/envs/maps/skirk.png", "maps/skirk.png"),
+             ("gym/f110_gym/envs/maps/skirk.yaml", "maps/skirk.yaml"),
+             ("gym/f110_gym/unittest/legacy_scan.npz", "legacy_scan.npz")]
+    for src, dst in pairs:
+        d = os.path.join(GOLD, dst)
+        shutil.copyfile(os.path.join(REF, src), d)
+        os.chmod(d, 0o644)
+    print("  copied %d data files" % len(pairs))
+
+
+def raceline():
+    w = np.loadtxt(os.path.join(GOLD, "maps", "example_waypoints.csv"), delimiter=';', skiprows=3)
+    return w  # columns s, x, y, psi, kappa, vx, ax
+
+
+# ------------------------------------------------------------------------------ dynamics
+def gen_dynamics(ns):
+    dm = ns.dynamic_models
+    rng = np.random.default_rng(101)
+    n = 400
+    P = DEFAULT_PARAMS
+    p = pvec(P)
+    x = np.empty((n, 7)); u = np.empty((n, 2))
+    x[:, 0] = rng.uniform(-50, 50, n); x[:, 1] = rng.uniform(-50, 50, n)
+    x[:, 2] = rng.uniform(-0.45, 0.45, n)
+    x[:, 3] = np.where(rng.random(n) < 0.35, rng.uniform(-0.6, 0.6, n), rng.uniform(-5.5, 21, n))
+    x[:, 4] = rng.uniform(-0.5, 7.0, n); x[:, 5] = rng.uniform(-3, 3, n)
+    x[:, 6] = rng.uniform(-0.5, 0.5, n)
+    u[:, 0] = rng.uniform(-4, 4, n); u[:, 1] = rng.uniform(-12, 12, n)
+    # constraint edges
+    x[0, 2] = P['s_min']; u[0, 0] = -1.0
+    x[1, 2] = P['s_max']; u[1, 0] = 1.0
+    x[2, 3] = P['v_min']; u[2, 1] = -1.0
+    x[3, 3] = P['v_max']; u[3, 1] = 1.0
+    x[4, 3] = 0.5; x[5, 3] = -0.5; x[6, 3] = 0.4999999; x[7, 3] = 0.0
+    x[8, 3] = 9.0; u[8, 1] = 11.0   # above v_switch
+    f_st = np.array([dm.vehicle_dynamics_st(x[i], u[i], *p[:16]) for i in range(n)])
+    f_ks = np.array([dm.vehicle_dynamics_ks(x[i, :5], u[i], *p[:16]) for i in range(n)])
+    # pid grid
+    m = 300
+    pin = np.empty((m, 4))
+    pin[:, 0] = rng.uniform(-6, 21, m)      # desired speed
+    pin[:, 1] = rng.uniform(-0.5, 0.5, m)   # desired steer
+    pin[:, 2] = rng.uniform(-5, 20, m)      # current speed
+    pin[:, 3] = rng.uniform(-0.42, 0.42, m)  # current steer
+    pin[0, 1] = pin[0, 3] + 5e-5; pin[1, 1] = pin[1, 3] - 2e-4; pin[2, 2] = 0.0
+    pin[3, 0] = pin[3, 2]
+    pout = np.array([dm.pid(pin[i, 0], pin[i, 1], pin[i, 2], pin[i, 3], P['sv_max'], P['a_max'],
+                            P['v_max'], P['v_min']) for i in range(m)])
+    save("dynamics", params=p, x=x, u=u, f_st=f_st, f_ks=f_ks, pid_in=pin, pid_out=pout)
+
+
+# --------------------------------------------------------------------------- update_pose
+def _make_car(ns, integrator, lidar_dist=0.0, params=None):
+    bc = ns.base_classes
+    ref_loader.fresh_racecar_class(ns)
+    car = bc.RaceCar(dict(params or DEFAULT_PARAMS), 12345, is_ego=True, time_step=0.01,
+                     integrator=integrator, lidar_dist=lidar_dist)
+    car.set_map(EXAMPLE_MAP + ".yaml", ".png")
+    return car
+
+
+def gen_update_pose(ns):
+    """RaceCar.update_pose single steps from random states + a rollout (scan discarded:
+    ScanSimulator2D.scan is replaced by a stub while stepping)."""
+    bc = ns.base_classes
+    rng = np.random.default_rng(202)
+    out = {}
+    for name, integ, ld in [("rk4", bc.Integrator.RK4, 0.0), ("euler", bc.Integrator.Euler, 0.0),
+                            ("rk4_lidar", bc.Integrator.RK4, 0.275)]:
+        car = _make_car(ns, integ, ld)
+        poses_seen = []
+        car.scan_simulator.scan = lambda pose, rng_, std_dev=0.01: (poses_seen.append(np.array(pose)) or np.zeros(1080))
+        n = 120
+        st0 = np.empty((n, 7))
+        st0[:, 0] = rng.uniform(-20, 20, n); st0[:, 1] = rng.uniform(-20, 20, n)
+        st0[:, 2] = rng.uniform(-0.4, 0.4, n)
+        st0[:, 3] = np.where(rng.random(n) < 0.3, rng.uniform(-0.6, 0.6, n), rng.uniform(-4, 15, n))
+        st0[:, 4] = rng.uniform(-0.1, 6.4, n); st0[:, 5] = rng.uniform(-2, 2, n)
+        st0[:, 6] = rng.uniform(-0.3, 0.3, n)
+        st0[0, 4] = 6.29; st0[0, 5] = 1.0; st0[1, 4] = 0.001; st0[1, 5] = -2.0  # yaw wrap cases
+        buf0 = rng.uniform(-0.4, 0.4, (n, 2)); cnt0 = rng.integers(0, 3, n)
+        act = np.stack([rng.uniform(-0.45, 0.45, n), rng.uniform(-3, 12, n)], axis=1)
+        st1 = np.empty((n, 7)); buf1 = np.zeros((n, 2)); cnt1 = np.empty(n, dtype=np.int64)
+        sp = np.empty((n, 3))
+        for i in range(n):
+            car.state = st0[i].copy()
+            car.steer_buffer = buf0[i, :cnt0[i]].copy()   # index 0 = newest
+            car.update_pose(act[i, 0], act[i, 1])
+            st1[i] = car.state
+            cnt1[i] = car.steer_buffer.shape[0]
+            buf1[i, :cnt1[i]] = car.steer_buffer
+            sp[i] = poses_seen[-1]
+        out.update({name + "_state0": st0, name + "_buf0": buf0, name + "_cnt0": cnt0,
+                    name + "_action": act, name + "_state1": st1, name + "_buf1": buf1,
+                    name + "_cnt1": cnt1, name + "_scan_pose": sp})
+        if name != "euler":
+            # rollout from reset, 400 steps, piecewise-constant random actions
+            car.reset(np.array([0.7, 0.0, 1.37079632679]))
+            T = 400
+            acts = np.empty((T, 2)); traj = np.empty((T, 7))
+            a = np.zeros(2)
+            for t in range(T):
+                if t % 25 == 0:
+                    a = np.array([rng.uniform(-0.3, 0.3), rng.uniform(0.5, 8.0)])
+                acts[t] = a
+                car.update_pose(a[0], a[1])
+                traj[t] = car.state
+            out.update({name + "_roll_actions": acts, name + "_roll_states": traj})
+    ref_loader.fresh_racecar_class(ns)
+    save("update_pose", params=pvec(DEFAULT_PARAMS), lidar_dist=np.array([0.0, 0.0, 0.275]), **out)
+
+
+# ---------------------------------------------------------------------------------- scan
+class ScanProbe(object):
+    """Instrument laser_models so each trace_ray call reports the table index it used and
+    the (r,c) of the sample that ended its loop (module globals are looked up at call time
+    under the no-op njit shim)."""
+
+    def __init__(self, lm):
+        self.lm = lm
+        self.orig_xy = lm.xy_2_rc
+        self.orig_tr = lm.trace_ray
+        self.last_rc = (0, 0); self.lookups = 0
+        self.rcs = []; self.idx = []
+
+    def __enter__(self):
+        lm = self.lm
+
+        def xy(*a):
+            rc = self.orig_xy(*a)
+            self.last_rc = rc; self.lookups += 1
+            return rc
+
+        def tr(x, y, theta_index, *rest):
+            d = self.orig_tr(x, y, theta_index, *rest)
+            self.rcs.append(self.last_rc); self.idx.append(int(theta_index))
+            return d
+        lm.xy_2_rc = xy; lm.trace_ray = tr
+        return self
+
+    def __exit__(self, *a):
+        self.lm.xy_2_rc = self.orig_xy; self.lm.trace_ray = self.orig_tr
+
+
+def _scan_cases(ns, map_yaml, num_beams, poses, fov=4.7):
+    lm = ns.laser_models
+    sim = lm.ScanSimulator2D(num_beams, fov)
+    sim.set_map(map_yaml, ".png")
+    scans = np.empty((len(poses), num_beams)); rcs = np.empty((len(poses), num_beams, 2), dtype=np.int32)
+    idx = np.empty((len(poses), num_beams), dtype=np.int32); lookups = np.empty(len(poses), dtype=np.int64)
+    for k, pose in enumerate(poses):
+        with ScanProbe(lm) as pr:
+            scans[k] = sim.scan(np.array(pose), None)
+            rcs[k] = np.array(pr.rcs); idx[k] = np.array(pr.idx); lookups[k] = pr.lookups
+    return sim, scans, rcs, idx, lookups
+
+
+def gen_scan(ns):
+    rng = np.random.default_rng(303)
+    w = raceline()
+    # example_map: raceline poses (heading psi+pi/2) + perturbed + far/off-map
+    ks = (np.arange(14) * 57) % w.shape[0]
+    poses = [[w[k, 1], w[k, 2], w[k, 3] + np.pi / 2] for k in ks]
+    for k in ks[:6]:
+        poses.append([w[k, 1] + rng.uniform(-0.4, 0.4), w[k, 2] + rng.uniform(-0.4, 0.4),
+                      rng.uniform(0, 2 * np.pi)])
+    poses += [[0.7, 0.0, 1.37079632679], [0.7, 0.0, 0.0], [0.7, 0.0, 7.5], [0.7, 0.0, -2.2],
+              [-78.0, -44.0, 0.7],       # just inside the map corner, far from the track
+              [-90.0, -50.0, 0.3],       # outside the map: OOB reads dt[-1,-1]
+              [30.0, 70.0, 4.0]]         # outside on the other side
+    poses = np.array(poses)
+    sim, scans, rcs, idx, lk = _scan_cases(ns, EXAMPLE_MAP + ".yaml", 1080, poses)
+    save("scan_example_map", poses=poses, scans=scans, hit_rc=rcs, dir_idx=idx, lookups=lk,
+         dt_corner=np.array([sim.dt[-1, -1]]), dt_shape=np.array(sim.dt.shape),
+         dt_checksum=np.array([sim.dt.sum(), (sim.dt * np.arange(sim.dt.shape[1])[None, :]).sum()]),
+         sines=sim.sines, cosines=sim.cosines,
+         theta_index_increment=np.array([sim.theta_index_increment]))
+    # berlin: dt[-1,-1] == 0 -> rays end where they leave the map
+    bposes = np.array([[0.0, 0.0, th] for th in np.linspace(-1, 1, 4)] +
+                      [[0.5, -0.3, 2.5], [-1.0, 0.4, 5.0], [40.0, 40.0, 1.0]])
+    bsim, bscans, brcs, bidx, blk = _scan_cases(ns, os.path.join(GOLD, "maps", "berlin.yaml"), 1080, bposes)
+    save("scan_berlin", poses=bposes, scans=bscans, hit_rc=brcs, dir_idx=bidx, lookups=blk,
+         dt_corner=np.array([bsim.dt[-1, -1]]), dt_shape=np.array(bsim.dt.shape),
+         dt_checksum=np.array([bsim.dt.sum(), (bsim.dt * np.arange(bsim.dt.shape[1])[None, :]).sum()]))
+    # 4096 beams (BASELINE config 5 shape; theta_dis stays 2000)
+    p4 = poses[[0, 3, 14, 20]]
+    s4, scans4, rcs4, idx4, lk4 = _scan_cases(ns, EXAMPLE_MAP + ".yaml", 4096, p4)
+    save("scan_example_map_4096", poses=p4, scans=scans4, hit_rc=rcs4, dir_idx=idx4, lookups=lk4)
+    # odd beam count / fov
+    p3 = poses[[1, 15]]
+    s3, scans3, rcs3, idx3, lk3 = _scan_cases(ns, EXAMPLE_MAP + ".yaml", 271, p3, fov=6.0)
+    save("scan_example_map_271", poses=p3, scans=scans3, hit_rc=rcs3, dir_idx=idx3, lookups=lk3,
+         fov=np.array([6.0]))
+
+
+# ----------------------------------------------------------------------------------- ttc
+def gen_ttc(ns):
+    lm = ns.laser_models
+    car = _make_car(ns, ns.base_classes.Integrator.RK4)
+    rc = ns.base_classes.RaceCar
+    sa, co, sd = rc.scan_angles.copy(), rc.cosines.copy(), rc.side_distances.copy()
+    rng = np.random.default_rng(404)
+    n = 60
+    scans = np.empty((n, 1080)); vels = np.empty(n); flags = np.empty(n, dtype=np.int32)
+    for i in range(n):
+        base = rng.uniform(0.5, 10.0, 1080)
+        kind = i % 6
+        v = rng.uniform(0.5, 8.0)
+        if kind == 0:
+            pass
+        elif kind == 1:      # one beam just inside the threshold ahead
+            j = rng.integers(400, 680); base[j] = sd[j] + 0.5 * 0.005 * v * co[j]
+        elif kind == 2:      # just outside
+            j = rng.integers(400, 680); base[j] = sd[j] + 1.5 * 0.005 * v * co[j]
+        elif kind == 3:      # reversing
+            v = -rng.uniform(0.5, 4.0); j = rng.integers(0, 60); base[j] = sd[j] + 0.3 * 0.005 * v * co[j]
+        elif kind == 4:
+            v = 0.0; base[:] = 0.0
+        else:                # scan below side distance: negative ttc -> no collision
+            base = sd * 0.9
+        scans[i] = base; vels[i] = v
+        flags[i] = int(lm.check_ttc_jit(base, v, sa, co, sd, 0.005))
+    ref_loader.fresh_racecar_class(ns)
+    save("ttc", scan_angles=sa, cosines=co, side_distances=sd, scans=scans, vels=vels, flags=flags,
+         width=np.array([DEFAULT_PARAMS['width']]), lf=np.array([DEFAULT_PARAMS['lf']]),
+         lr=np.array([DEFAULT_PARAMS['lr']]))
+
+
+# ----------------------------------------------------------------------------- collision
+def gen_collision(ns):
+    cm = ns.collision_models
+    rng = np.random.default_rng(505)
+    L, W = DEFAULT_PARAMS['length'], DEFAULT_PARAMS['width']
+    n = 1500
+    pa = np.stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(-4, 7, n)], axis=1)
+    d = rng.uniform(0.0, 0.9, n); ang = rng.uniform(0, 2 * np.pi, n)
+    pb = np.stack([pa[:, 0] + d * np.cos(ang), pa[:, 1] + d * np.sin(ang), rng.uniform(-4, 7, n)], axis=1)
+    pb[:20] = pa[:20]                      # identical boxes (d == 0 seed direction case)
+    pb[20:40, 2] = pa[20:40, 2]            # parallel boxes
+    va = np.array([cm.get_vertices(pa[i], L, W) for i in range(n)])
+    vb = np.array([cm.get_vertices(pb[i], L, W) for i in range(n)])
+    flags = np.array([int(cm.collision(np.ascontiguousarray(va[i]), np.ascontiguousarray(vb[i]))) for i in range(n)], dtype=np.int32)
+    # collision_multiple on groups of 5 bodies
+    G = 60
+    gp = np.stack([rng.uniform(-1, 1, (G, 5)), rng.uniform(-1, 1, (G, 5)), rng.uniform(0, 6.3, (G, 5))], axis=2)
+    gcol = np.empty((G, 5)); gidx = np.empty((G, 5))
+    for g in range(G):
+        allv = np.array([cm.get_vertices(gp[g, a], L, W) for a in range(5)])
+        gcol[g], gidx[g] = cm.collision_multiple(allv)
+    save("collision", length=np.array([L]), width=np.array([W]), pose_a=pa, pose_b=pb,
+         vert_a=va, vert_b=vb, flags=flags, group_poses=gp, group_collisions=gcol, group_idx=gidx)
+
+
+# ------------------------------------------------------------------------------- raycast
+def gen_raycast(ns):
+    lm, cm = ns.laser_models, ns.collision_models
+    car = _make_car(ns, ns.base_classes.Integrator.RK4)
+    sa = ns.base_classes.RaceCar.scan_angles.copy()
+    ref_loader.fresh_racecar_class(ns)
+    rng = np.random.default_rng(606)
+    L, W = DEFAULT_PARAMS['length'], DEFAULT_PARAMS['width']
+    n = 90
+    ego = np.stack([rng.uniform(-5, 5, n), rng.uniform(-5, 5, n), rng.uniform(0, 2 * np.pi, n)], axis=1)
+    dist = rng.uniform(0.35, 6.0, n); bearing = rng.uniform(-np.pi, np.pi, n)
+    dist[:10] = rng.uniform(0.0, 0.25, 10)            # lidar inside / overlapping the box
+    bearing[10:30] = np.pi + rng.uniform(-0.4, 0.4, 20)  # opponent behind (rear +-pi straddle)
+    dist[10:30] = rng.uniform(0.4, 1.5, 20)
+    ego[30:34, 2] = 0.0                                # ego heading zeroed by a wall hit
+    opp = np.stack([ego[:, 0] + dist * np.cos(ego[:, 2] + bearing),
+                    ego[:, 1] + dist * np.sin(ego[:, 2] + bearing), rng.uniform(0, 2 * np.pi, n)], axis=1)
+    verts = np.array([cm.get_vertices(opp[i], L, W) for i in range(n)])
+    base = 10.0
+    lo = np.empty(n, dtype=np.int32); hi = np.empty(n, dtype=np.int32)
+    scans = np.empty((n, 1080))
+    for i in range(n):
+        lo[i], hi[i] = lm.get_blocked_view_indices(ego[i], verts[i], sa)
+        scans[i] = lm.ray_cast(ego[i], np.full(1080, base), sa, verts[i])
+    # get_range unit cases incl. collinear / parallel
+    gr_in = []
+    for _ in range(200):
+        p = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), 0.0]); bt = rng.uniform(-4, 8)
+        va = rng.uniform(-3, 3, 2); vb = rng.uniform(-3, 3, 2)
+        gr_in.append(np.concatenate([p, [bt], va, vb]))
+    for k in range(12):   # beam exactly along the edge direction (collinear) and parallel offsets
+        p = np.array([0.0, 0.0, 0.0]); bt = 0.0 if k % 2 == 0 else np.pi / 2
+        dirv = np.array([np.cos(bt), np.sin(bt)]); off = 0.0 if k < 6 else 0.5
+        va = dirv * (1.0 + k) + np.array([-dirv[1], dirv[0]]) * off
+        vb = dirv * (3.0 + k) + np.array([-dirv[1], dirv[0]]) * off
+        gr_in.append(np.concatenate([p, [bt], va, vb]))
+    gr_in = np.array(gr_in)
+    gr_out = np.array([lm.get_range(r[:3], r[3], r[4:6], r[6:8]) for r in gr_in])
+    save("raycast", scan_angles=sa, length=np.array([L]), width=np.array([W]), ego=ego, opp=opp,
+         vertices=verts, min_ind=lo, max_ind=hi, base=np.array([base]), scans=scans,
+         get_range_in=gr_in, get_range_out=gr_out)
+
+
+# --------------------------------------------------------------------------- sim rollout
+def gen_sim(ns):
+    """2-agent Simulator.step trajectory on example_map with the seed-12345 noise stream;
+    the ego is driven into a wall (iTTC hit, heading zeroed) with the opponent in view."""
+    bc = ns.base_classes
+    ref_loader.fresh_racecar_class(ns)
+    sim = bc.Simulator(dict(DEFAULT_PARAMS), 2, 12345, time_step=0.01, integrator=bc.Integrator.RK4)
+    sim.set_map(EXAMPLE_MAP + ".yaml", ".png")
+    w = raceline()
+    k0 = 40
+    start = np.array([[w[k0, 1], w[k0, 2], w[k0, 3] + np.pi / 2],
+                      [w[k0 + 8, 1], w[k0 + 8, 2], w[k0 + 8, 3] + np.pi / 2]])  # opponent 1.6 m ahead
+    sim.reset(start)
+    T = 260
+    rng = np.random.default_rng(707)
+    acts = np.empty((T, 2, 2)); states = np.empty((T, 2, 7)); cols = np.empty((T, 2))
+    incol = np.empty((T, 2), dtype=np.int32); cidx = np.empty((T, 2)); snap = np.empty((T, 2, 3))
+    sub = np.empty((T, 2, 135)); ssum = np.empty((T, 2)); full_steps = [0, 1, 2, 60, 130, 200, 259]
+    full = {}
+    a = np.zeros((2, 2))
+    for t in range(T):
+        if t % 20 == 0:
+            a = np.array([[rng.uniform(-0.15, 0.15), rng.uniform(4.0, 7.0)],
+                          [rng.uniform(-0.05, 0.05), rng.uniform(0.5, 2.0)]])
+        if t >= 120:
+            a[0, 0] = 0.4   # steer the ego hard into the wall
+        acts[t] = a
+        obs = sim.step(a)
+        states[t] = np.array([ag.state for ag in sim.agents])
+        cols[t] = obs['collisions']; cidx[t] = sim.collision_idx
+        incol[t] = [int(ag.in_collision) for ag in sim.agents]
+        snap[t] = sim.agent_poses
+        for i in range(2):
+            sc = np.asarray(obs['scans'][i])
+            sub[t, i] = sc[::8]; ssum[t, i] = sc.sum()
+        if t in full_steps:
+            full["scans_t%d" % t] = np.array(obs['scans'])
+    noise = np.random.default_rng(12345).normal(0., 0.01, size=1080)
+    ref_loader.fresh_racecar_class(ns)
+    save("sim_rollout", params=pvec(DEFAULT_PARAMS), start=start, actions=acts, states=states,
+         collisions=cols, in_collision=incol, collision_idx=cidx, agent_poses=snap,
+         scans_sub8=sub, scans_sum=ssum, full_steps=np.array(full_steps),
+         noise_row0=noise, seed=np.array([12345]), **full)
+    print("    wall hits at steps:", np.nonzero(incol.any(axis=1))[0][:10], " gjk:", np.nonzero(cols.any(axis=1))[0][:5])
+
+
+# ----------------------------------------------------------------------------------- env
+def gen_env(ns):
+    """F110Env episode (1 agent, example_map): drive out of the start zone and reverse back
+    into it twice -> toggles 0..4, lap_counts, lap_times, done (f110_env.py:204-246)."""
+    ns = ref_loader.load_reference(with_env=True)
+    ref_loader.fresh_racecar_class(ns)
+    env = ns.f110_env.F110Env(map=EXAMPLE_MAP, map_ext='.png', num_agents=1, seed=12345)
+    start = np.array([[0.7, 0.0, 1.37079632679]])
+    obs, r, done, info = env.reset(start)
+    rec = {k: [] for k in ("x", "y", "th", "v", "lap_time", "lap_count", "done", "toggle", "near", "col", "scan_sum")}
+    acts = []
+
+    def log(obs, done):
+        rec["x"].append(obs['poses_x'][0]); rec["y"].append(obs['poses_y'][0])
+        rec["th"].append(obs['poses_theta'][0]); rec["v"].append(obs['linear_vels_x'][0])
+        rec["lap_time"].append(float(obs['lap_times'][0])); rec["lap_count"].append(float(obs['lap_counts'][0]))
+        rec["done"].append(bool(done)); rec["toggle"].append(float(env.toggle_list[0]))
+        rec["near"].append(bool(env.near_starts[0])); rec["col"].append(float(obs['collisions'][0]))
+        rec["scan_sum"].append(float(np.sum(obs['scans'][0])))
+    log(obs, done)
+    t = 0
+    phase_speed = 2.5
+    while t < 3000 and not done:
+        tog = env.toggle_list[0]
+        # forward until out of the zone (odd toggle), then reverse until back in (even)
+        speed = phase_speed if tog % 2 == 0 else -phase_speed
+        a = np.array([[0.0, speed]])
+        acts.append(a[0].copy())
+        obs, r, done, info = env.step(a)
+        log(obs, done)
+        t += 1
+    print("    env episode: %d steps, toggles=%s done=%s" % (t, env.toggle_list, done))
+    ref_loader.fresh_racecar_class(ns)
+    save("env_episode", start=start, actions=np.array(acts), **{k: np.array(v) for k, v in rec.items()})
+
+
+GROUPS = {"data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
+          "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
+          "sim": gen_sim, "env": gen_env}
+
+
+def main(argv):
+    os.makedirs(GOLD, exist_ok=True)
+    ns = ref_loader.load_reference()
+    which = argv or list(GROUPS)
+    for g in which:
+        t = time.time()
+        print("[%s]" % g)
+        GROUPS[g](ns)
+        print("  %.1f s" % (time.time() - t))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

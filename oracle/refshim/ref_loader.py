@@ -1,0 +1,95 @@
+"""Load the reference's four hot-path modules (and optionally F110Env) from /root/reference.
+
+TEST INFRASTRUCTURE — runs only in the build container (the reference tree does not exist on
+the GPU box).  It is used to (i) pin oracle/f110_oracle.c against the real reference and
+(ii) generate the golden vectors under tests/golden/ (see gen_golden.py).
+
+Recipe: a no-op `numba` shim package, empty `f110_gym` / `f110_gym.envs`
+package objects in sys.modules, then importlib-load dynamic_models.py, laser_models.py,
+collision_models.py, base_classes.py by path.  For F110Env, 10-line stubs of gym / pyglet.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get("F110_REFERENCE_ROOT", "/root/reference")
+_ENV_DIR = os.path.join(REF_ROOT, "gym", "f110_gym", "envs")
+_loaded = {}
+
+
+def reference_available():
+    return os.path.isfile(os.path.join(_ENV_DIR, "laser_models.py"))
+
+
+def _load(name, filename):
+    full = "f110_gym.envs." + name
+    spec = importlib.util.spec_from_file_location(full, os.path.join(_ENV_DIR, filename))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _install_gym_pyglet_stubs():
+    if "gym" not in sys.modules:
+        gym = types.ModuleType("gym")
+
+        class Env(object):
+            pass
+
+        gym.Env = Env
+        gym.error = types.ModuleType("gym.error")
+        gym.spaces = types.ModuleType("gym.spaces")
+        gym.utils = types.ModuleType("gym.utils")
+        gym.utils.seeding = types.ModuleType("gym.utils.seeding")
+        for sub in ("error", "spaces", "utils"):
+            sys.modules["gym." + sub] = getattr(gym, sub)
+        sys.modules["gym.utils.seeding"] = gym.utils.seeding
+        sys.modules["gym"] = gym
+    if "pyglet" not in sys.modules:
+        pyglet = types.ModuleType("pyglet")
+        pyglet.options = {}
+        pyglet.gl = types.ModuleType("pyglet.gl")
+        sys.modules["pyglet"] = pyglet
+        sys.modules["pyglet.gl"] = pyglet.gl
+
+
+def load_reference(with_env=False):
+    """Returns a namespace with .dynamic_models .laser_models .collision_models .base_classes
+    (and .f110_env when with_env=True)."""
+    if not reference_available():
+        raise RuntimeError("reference tree not found at %s" % REF_ROOT)
+    if "core" not in _loaded:
+        shim_dir = os.path.dirname(os.path.abspath(__file__))
+        if "numba" not in sys.modules:
+            sys.path.insert(0, shim_dir)
+            import numba  # noqa: F401  (the shim)
+            sys.path.remove(shim_dir)
+        pkg = types.ModuleType("f110_gym")
+        pkg.__path__ = []
+        envs = types.ModuleType("f110_gym.envs")
+        envs.__path__ = []
+        sys.modules.setdefault("f110_gym", pkg)
+        sys.modules.setdefault("f110_gym.envs", envs)
+        ns = types.SimpleNamespace()
+        ns.dynamic_models = _load("dynamic_models", "dynamic_models.py")
+        ns.laser_models = _load("laser_models", "laser_models.py")
+        ns.collision_models = _load("collision_models", "collision_models.py")
+        ns.base_classes = _load("base_classes", "base_classes.py")
+        _loaded["core"] = ns
+    ns = _loaded["core"]
+    if with_env and not hasattr(ns, "f110_env"):
+        _install_gym_pyglet_stubs()
+        ns.f110_env = _load("f110_env", "f110_env.py")
+    return ns
+
+
+def fresh_racecar_class(ns):
+    """The reference keeps the scan simulator and TTC tables as RaceCar class attributes
+    (base_classes.py:64-67); clear them so a new Simulator rebuilds them."""
+    rc = ns.base_classes.RaceCar
+    rc.scan_simulator = None
+    rc.cosines = None
+    rc.scan_angles = None
+    rc.side_distances = None

@@ -1,0 +1,56 @@
+"""Shared helpers for the test-suite (fixtures, map loading through the ORACLE)."""
+import functools
+import os
+
+import numpy as np
+import yaml
+from PIL import Image
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MAPS = os.path.join(GOLD, "maps")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+@functools.lru_cache(maxsize=None)
+def load_map_image(name):
+    """returns (img uint8 [H,W] top-row-first as PIL decodes it, resolution, origin[3])"""
+    with open(os.path.join(MAPS, name + ".yaml")) as f:
+        meta = yaml.safe_load(f)
+    img = np.array(Image.open(os.path.join(MAPS, name + ".png")))
+    assert img.ndim == 2 and img.dtype == np.uint8
+    return img, float(meta['resolution']), [float(v) for v in meta['origin']]
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_map_dt(name):
+    """distance table of a fixture map computed by the ORACLE's EDT (pinned against scipy in
+    test_oracle_golden.py)."""
+    from oracle import orc
+    img, res, origin = load_map_image(name)
+    return orc.map_dt_from_image(img, res), res, origin
+
+
+def raceline():
+    return np.loadtxt(os.path.join(MAPS, "example_waypoints.csv"), delimiter=';', skiprows=3)
+
+
+def bench_start_poses(num_envs, num_agents=2, gap_wp=10):
+    """SURVEY §8d start poses: env e -> waypoint (e*7919) mod 783, heading psi+pi/2;
+    opponent(s) gap_wp waypoints behind along the raceline."""
+    w = raceline()
+    n = w.shape[0]
+    poses = np.empty((num_envs, num_agents, 3))
+    for a in range(num_agents):
+        k = ((np.arange(num_envs) * 7919) % n - a * gap_wp) % n
+        poses[:, a, 0] = w[k, 1]
+        poses[:, a, 1] = w[k, 2]
+        poses[:, a, 2] = w[k, 3] + np.pi / 2
+    return poses.reshape(num_envs * num_agents, 3)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) if a.size else 0.0
