@@ -1,0 +1,20 @@
+"""f1tenth_gym_amd — MI355X-native batched F1TENTH env.step() hot path.
+
+Python host + ctypes over a C ABI (include/f110.h) + hand-written HIP kernels for gfx950.
+The names mirror the reference package f110_gym.envs so existing code ports by changing the
+import:  F110Env, Simulator, Integrator, ScanSimulator2D and the free kernel functions.
+"""
+from .core import BatchSim, DeviceArray, DEFAULT_PARAMS  # noqa: F401
+from .sim import Integrator, Simulator  # noqa: F401
+from .laser import ScanSimulator2D  # noqa: F401
+from .env import F110Env, F110VecEnv  # noqa: F401
+from .functional import (vehicle_dynamics_st, vehicle_dynamics_ks, pid, get_vertices, collision,  # noqa: F401
+                         collision_multiple, check_ttc_jit, ray_cast)
+
+__version__ = "0.1.0"
+
+
+def register_gym():
+    """Register 'f110-v0' like gym/f110_gym/__init__.py:1-5 (needs gym)."""
+    from gym.envs.registration import register
+    register(id='f110-v0', entry_point='f1tenth_gym_amd.env:F110Env')

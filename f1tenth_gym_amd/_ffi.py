@@ -1,0 +1,179 @@
+"""ctypes binding of libf110_hip.so (include/f110.h).  No torch, no cffi.
+
+The library is the product: if it cannot be loaded, or no MI355X is visible, every entry point
+raises — there is deliberately no CPU fallback (the CPU oracle lives under oracle/ and is
+test infrastructure only; nothing here imports it).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libf110_hip.so")
+ABI_VERSION = 1
+NPARAMS = 18
+PARAM_KEYS = ['mu', 'C_Sf', 'C_Sr', 'lf', 'lr', 'h', 'm', 'I', 's_min', 's_max', 'sv_min',
+              'sv_max', 'v_switch', 'a_max', 'v_min', 'v_max', 'width', 'length']
+
+OK, ERR_INVALID, ERR_NO_MAP, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
+MAP_ROWMAJOR_F64, MAP_TILED_F64 = 0, 1
+INTEGRATOR_RK4, INTEGRATOR_EULER = 1, 2
+
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("num_envs", C.c_int32), ("num_agents", C.c_int32),
+                ("num_beams", C.c_int32), ("theta_dis", C.c_int32), ("integrator", C.c_int32),
+                ("device_id", C.c_int32), ("map_layout", C.c_int32), ("scan_block", C.c_int32),
+                ("reserved0", C.c_int32), ("fov", C.c_double), ("eps", C.c_double),
+                ("max_range", C.c_double), ("time_step", C.c_double), ("lidar_dist", C.c_double),
+                ("ttc_thresh", C.c_double), ("params", C.c_double * NPARAMS)]
+
+
+class ObsHost(C.Structure):
+    _fields_ = [("scans", _dp), ("poses_x", _dp), ("poses_y", _dp), ("poses_theta", _dp),
+                ("linear_vels_x", _dp), ("ang_vels_z", _dp), ("collisions", _dp),
+                ("collision_idx", _dp), ("state", _dp), ("agent_poses", _dp),
+                ("in_collision", _i32p), ("step_count", _i32p)]
+
+
+class DeviceViews(C.Structure):
+    _fields_ = [("scans", C.c_void_p), ("state", C.c_void_p), ("agent_poses", C.c_void_p),
+                ("collisions", C.c_void_p), ("collision_idx", C.c_void_p),
+                ("in_collision", C.c_void_p), ("step_count", C.c_void_p), ("stream", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/f110.h declares
+PROTOTYPES = {
+    "f110_last_error": (C.c_char_p, [C.c_void_p]),
+    "f110_abi_version": (C.c_int, []),
+    "f110_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "f110_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "f110_destroy": (None, [C.c_void_p]),
+    "f110_sync": (C.c_int, [C.c_void_p]),
+    "f110_set_map_image": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32] + [C.c_double] * 4),
+    "f110_set_map_dt": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32] + [C.c_double] * 5),
+    "f110_get_map_dt": (C.c_int, [C.c_void_p, _dp]),
+    "f110_map_shape": (C.c_int, [C.c_void_p, _i32p, _i32p]),
+    "f110_set_trig_tables": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32]),
+    "f110_set_beam_tables": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int32]),
+    "f110_set_params": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
+    "f110_set_noise_table": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32]),
+    "f110_reset": (C.c_int, [C.c_void_p, _dp, _u8p]),
+    "f110_reset_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "f110_step": (C.c_int, [C.c_void_p, _dp]),
+    "f110_step_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "f110_get_obs": (C.c_int, [C.c_void_p, C.POINTER(ObsHost)]),
+    "f110_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _i32p]),
+    "f110_get_device_views": (C.c_int, [C.c_void_p, C.POINTER(DeviceViews)]),
+    "f110_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "f110_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "f110_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "f110_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "f110_timer_begin": (C.c_int, [C.c_void_p]),
+    "f110_timer_end_ms": (C.c_int, [C.c_void_p, _dp]),
+    "f110_profile_kernels": (C.c_int, [C.c_void_p, C.c_int32]),
+    "f110_profile_read": (C.c_int, [C.c_void_p, _i32p, _dp, _dp]),
+    "f110_scan_batch": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp, _i32p, _i64p]),
+    "f110_dynamics_batch": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int32, _dp, _dp]),
+    "f110_pid_batch": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp]),
+    "f110_update_pose_batch": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _dp, _dp, C.c_double, C.c_int32,
+                                         C.c_double, C.c_int32, _dp, _dp, _i32p, _dp]),
+    "f110_get_vertices_batch": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_double, C.c_int32, _dp]),
+    "f110_gjk_batch": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _i32p]),
+    "f110_collision_multiple_batch": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, _dp, _dp]),
+    "f110_ttc_batch": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, C.c_double, _i32p]),
+    "f110_raycast_batch": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp, _i32p]),
+    "f110_get_range_batch": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp]),
+    "f110_edt_sq": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, _u32p]),
+    "f110_beam_dir_index_batch": (C.c_int, [C.c_void_p, _dp, C.c_int32, _i32p]),
+}
+
+_lib = None
+
+
+class F110LibraryError(RuntimeError):
+    """libf110_hip.so is missing/unloadable, or the HIP runtime reported an error."""
+
+
+def lib():
+    """Load libf110_hip.so (built in-tree by f1tenth_gym_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise F110LibraryError(
+                "%s not found — build it with `python -m f1tenth_gym_amd.build` "
+                "(there is no CPU fallback for the MI355X hot path)" % LIB_PATH)
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as ex:
+            raise F110LibraryError("cannot load %s: %s" % (LIB_PATH, ex))
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                raise F110LibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+            fn.restype = res
+            fn.argtypes = args
+        if L.f110_abi_version() != ABI_VERSION:
+            raise F110LibraryError("ABI version mismatch: library %d, binding %d"
+                                   % (L.f110_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def last_error(handle=None):
+    msg = lib().f110_last_error(handle)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, handle=None, invalid_exc=ValueError):
+    """Map a return code to the exception type the reference raises for the same condition."""
+    if rc == OK:
+        return
+    msg = last_error(handle)
+    if rc == ERR_NO_MAP:
+        raise ValueError(msg or 'Map is not set for scan simulator.')   # laser_models.py:445-446
+    if rc == ERR_INVALID:
+        if "out of bounds for list of agents" in msg:
+            raise IndexError(msg)                                        # base_classes.py:534
+        if "Invalid Integrator" in msg:
+            raise SyntaxError(msg)                                       # base_classes.py:398
+        raise invalid_exc(msg)
+    if rc == ERR_NOMEM:
+        raise MemoryError(msg)
+    raise F110LibraryError(msg or ("libf110_hip error %d" % rc))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().f110_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("expected array of shape %s, got %s" % (tuple(shape), tuple(a.shape)))
+    return a
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def i32ptr(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def params_vector(params):
+    try:
+        return np.array([float(params[k]) for k in PARAM_KEYS], dtype=np.float64)
+    except KeyError as ex:
+        raise KeyError("vehicle params dict is missing %s" % ex)

@@ -1,0 +1,47 @@
+"""Compile the gfx950 extension in-tree: f1tenth_gym_amd/csrc/f110_hip.hip -> libf110_hip.so.
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the parity contract
+(DESIGN.md): float64 in the reference's operation order, never contracted into FMAs.
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(PKG_DIR, "csrc", "f110_hip.hip")
+DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "f110_math.hpp"),
+        os.path.join(os.path.dirname(PKG_DIR), "include", "f110.h")]
+LIB = os.path.join(PKG_DIR, "libf110_hip.so")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def find_hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.isfile(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X extension cannot be built")
+
+
+def is_stale():
+    if not os.path.isfile(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    """Build libf110_hip.so if missing or older than its sources.  Returns the path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [find_hipcc()] + HIPCC_FLAGS + [SRC, "-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + proc.stdout)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

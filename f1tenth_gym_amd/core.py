@@ -1,0 +1,398 @@
+"""BatchSim — the thin Python owner of one libf110_hip handle (one MI355X, one HIP stream).
+
+E independent environments x A agents are stepped in lockstep on the device.  This class only
+marshals NumPy arrays to the C ABI (include/f110.h); all arithmetic happens in the HIP kernels.
+The reference-compatible façades (Simulator, ScanSimulator2D, F110Env) are built on it.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, as_f64, dptr, i32ptr
+
+DEFAULT_PARAMS = {'mu': 1.0489, 'C_Sf': 4.718, 'C_Sr': 5.4562, 'lf': 0.15875, 'lr': 0.17145,
+                  'h': 0.074, 'm': 3.74, 'I': 0.04712, 's_min': -0.4189, 's_max': 0.4189,
+                  'sv_min': -3.2, 'sv_max': 3.2, 'v_switch': 7.319, 'a_max': 9.51,
+                  'v_min': -5.0, 'v_max': 20.0, 'width': 0.31, 'length': 0.58}  # f110_env.py:130
+
+
+def trig_tables(theta_dis):
+    """laser_models.py:379-381 — NumPy-computed so the device table is bit-identical."""
+    theta_arr = np.linspace(0.0, 2 * np.pi, num=theta_dis)
+    return np.sin(theta_arr), np.cos(theta_arr)
+
+
+def beam_tables(num_beams, fov, params):
+    """RaceCar's class-level per-beam tables, base_classes.py:125-158: beam angles (built by a
+    Python loop, not linspace), their cosines, and the lidar-to-body-edge distance."""
+    incr = fov / (num_beams - 1)
+    scan_angles = np.zeros((num_beams,))
+    cosines = np.zeros((num_beams,))
+    side_distances = np.zeros((num_beams,))
+    dist_sides = params['width'] / 2.
+    dist_fr = (params['lf'] + params['lr']) / 2.
+    half_pi = np.pi / 2
+    for i in range(num_beams):
+        angle = -fov / 2. + i * incr
+        scan_angles[i] = angle
+        cosines[i] = np.cos(angle)
+        if angle > 0:
+            if angle < half_pi:
+                to_side, to_fr = dist_sides / np.sin(angle), dist_fr / np.cos(angle)
+            else:
+                to_side, to_fr = dist_sides / np.cos(angle - np.pi / 2.), dist_fr / np.sin(angle - np.pi / 2.)
+        else:
+            if angle > -half_pi:
+                to_side, to_fr = dist_sides / np.sin(-angle), dist_fr / np.cos(-angle)
+            else:
+                to_side, to_fr = dist_sides / np.cos(-angle - np.pi / 2), dist_fr / np.sin(-angle - np.pi / 2)
+        side_distances[i] = min(to_side, to_fr)
+    return scan_angles, cosines, side_distances
+
+
+def load_map_files(map_path, map_ext):
+    """ScanSimulator2D.set_map's file handling, laser_models.py:397-416: <stem><ext> image +
+    yaml with 'resolution' and 'origin'.  Returns (uint8 image top-row-first, resolution, origin)."""
+    import yaml
+    from PIL import Image
+    map_img_path = os.path.splitext(map_path)[0] + map_ext
+    img = np.array(Image.open(map_img_path))
+    if img.ndim != 2:
+        raise ValueError("map image must be single-channel grayscale, got shape %s" % (img.shape,))
+    if img.dtype != np.uint8:
+        # the reference thresholds the decoded values at 128 (laser_models.py:403-404)
+        img = np.where(img.astype(np.float64) > 128., 255, 0).astype(np.uint8)
+    with open(map_path, 'r') as yaml_stream:
+        meta = yaml.safe_load(yaml_stream)
+    return np.ascontiguousarray(img), float(meta['resolution']), [float(v) for v in meta['origin']]
+
+
+class DeviceArray(object):
+    """A device buffer owned by a BatchSim handle (exposes __cuda_array_interface__ so torch /
+    cupy can wrap it without a copy; ROCm uses the same protocol)."""
+
+    def __init__(self, sim, shape, dtype=np.float64, ptr=None):
+        self.sim = sim
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._owned = ptr is None
+        if ptr is None:
+            p = C.c_void_p()
+            check(_ffi.lib().f110_device_alloc(sim._h, self.nbytes, C.byref(p)), sim._h)
+            ptr = p.value
+        self.ptr = ptr
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2}
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.nbytes != self.nbytes:
+            raise ValueError("size mismatch")
+        check(_ffi.lib().f110_memcpy_h2d(self.sim._h, self.ptr, host.ctypes.data, self.nbytes), self.sim._h)
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(_ffi.lib().f110_memcpy_d2h(self.sim._h, out.ctypes.data, self.ptr, self.nbytes), self.sim._h)
+        return out
+
+    def free(self):
+        if self._owned and self.ptr and self.sim._h:
+            _ffi.lib().f110_device_free(self.sim._h, self.ptr)
+        self.ptr = None
+
+
+class BatchSim(object):
+    def __init__(self, params=None, num_envs=1, num_agents=2, num_beams=1080, fov=4.7, eps=0.0001,
+                 theta_dis=2000, max_range=30.0, time_step=0.01, integrator=_ffi.INTEGRATOR_RK4,
+                 lidar_dist=0.0, ttc_thresh=0.005, device_id=0, map_layout=_ffi.MAP_ROWMAJOR_F64,
+                 scan_block=0):
+        self._h = None
+        L = _ffi.lib()
+        self.params = dict(DEFAULT_PARAMS if params is None else params)
+        self.E, self.A, self.B = int(num_envs), int(num_agents), int(num_beams)
+        self.N = self.E * self.A
+        self.fov, self.theta_dis, self.time_step = float(fov), int(theta_dis), float(time_step)
+        self.device_id = int(device_id)
+        cfg = _ffi.Config()
+        cfg.abi_version = _ffi.ABI_VERSION
+        cfg.num_envs, cfg.num_agents, cfg.num_beams = self.E, self.A, self.B
+        cfg.theta_dis, cfg.integrator, cfg.device_id = self.theta_dis, int(integrator), self.device_id
+        cfg.map_layout, cfg.scan_block = int(map_layout), int(scan_block)
+        cfg.fov, cfg.eps, cfg.max_range = float(fov), float(eps), float(max_range)
+        cfg.time_step, cfg.lidar_dist, cfg.ttc_thresh = float(time_step), float(lidar_dist), float(ttc_thresh)
+        pv = _ffi.params_vector(self.params)
+        for i in range(_ffi.NPARAMS):
+            cfg.params[i] = pv[i]
+        h = C.c_void_p()
+        check(L.f110_create(C.byref(cfg), C.byref(h)), None)
+        self._h = h.value
+        # NumPy-computed tables (bit-identical to the reference's)
+        s, c = trig_tables(self.theta_dis)
+        check(L.f110_set_trig_tables(self._h, dptr(s), dptr(c), self.theta_dis), self._h)
+        self.scan_angles, self.cosines, self.side_distances = beam_tables(self.B, self.fov, self.params)
+        check(L.f110_set_beam_tables(self._h, dptr(self.scan_angles), dptr(self.cosines),
+                                     dptr(self.side_distances), self.B), self._h)
+        self.has_map = False
+        self.noise_rows = 0
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if self._h:
+            _ffi.lib().f110_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(_ffi.lib().f110_sync(self._h), self._h)
+
+    # ------------------------------------------------------------------ configuration
+    def set_map(self, map_path, map_ext):
+        img, res, origin = load_map_files(map_path, map_ext)
+        self.set_map_image(img, res, origin)
+
+    def set_map_image(self, img_top_first, resolution, origin):
+        img = np.ascontiguousarray(img_top_first, dtype=np.uint8)
+        if img.ndim != 2:
+            raise ValueError("map image must be 2-D")
+        check(_ffi.lib().f110_set_map_image(self._h, img.ctypes.data_as(_ffi._u8p), img.shape[0], img.shape[1],
+                                            float(resolution), float(origin[0]), float(origin[1]),
+                                            float(origin[2])), self._h)
+        self.has_map = True
+        self.map_resolution, self.map_origin = float(resolution), list(origin)
+
+    def set_map_dt(self, dt, resolution, origin):
+        dt = as_f64(dt)
+        if dt.ndim != 2:
+            raise ValueError("distance table must be 2-D")
+        check(_ffi.lib().f110_set_map_dt(self._h, dptr(dt), dt.shape[0], dt.shape[1], float(resolution),
+                                         float(origin[0]), float(origin[1]), float(np.cos(origin[2])),
+                                         float(np.sin(origin[2]))), self._h)
+        self.has_map = True
+        self.map_resolution, self.map_origin = float(resolution), list(origin)
+
+    def get_map_dt(self):
+        h, w = C.c_int32(), C.c_int32()
+        check(_ffi.lib().f110_map_shape(self._h, C.byref(h), C.byref(w)), self._h)
+        out = np.empty((h.value, w.value))
+        check(_ffi.lib().f110_get_map_dt(self._h, dptr(out)), self._h)
+        return out
+
+    def set_params(self, params, agent_idx=-1):
+        pv = _ffi.params_vector(params)
+        check(_ffi.lib().f110_set_params(self._h, int(agent_idx), dptr(pv)), self._h, IndexError)
+
+    def set_noise_table(self, noise):
+        if noise is None:
+            check(_ffi.lib().f110_set_noise_table(self._h, None, 0, self.B), self._h)
+            self.noise_rows = 0
+            return
+        noise = as_f64(noise)
+        if noise.ndim != 2 or noise.shape[1] != self.B:
+            raise ValueError("noise table must be [rows][num_beams]")
+        check(_ffi.lib().f110_set_noise_table(self._h, dptr(noise), noise.shape[0], self.B), self._h)
+        self.noise_rows = noise.shape[0]
+
+    # ------------------------------------------------------------------ reset / step
+    def reset(self, poses, env_mask=None):
+        poses = as_f64(poses)
+        if poses.shape[0] != self.N:
+            raise ValueError('Number of poses for reset does not match number of agents.')  # base_classes.py:625
+        poses = as_f64(poses, (self.N, 3))
+        mptr = None
+        if env_mask is not None:
+            m = np.ascontiguousarray(env_mask, dtype=np.uint8)
+            if m.shape != (self.E,):
+                raise ValueError("env_mask must have num_envs entries")
+            mptr = m.ctypes.data_as(_ffi._u8p)
+        check(_ffi.lib().f110_reset(self._h, dptr(poses), mptr), self._h)
+
+    def step(self, actions):
+        actions = as_f64(actions, (self.N, 2))
+        check(_ffi.lib().f110_step(self._h, dptr(actions)), self._h)
+
+    def step_device(self, d_actions):
+        ptr = d_actions.ptr if isinstance(d_actions, DeviceArray) else int(d_actions)
+        check(_ffi.lib().f110_step_device(self._h, ptr), self._h)
+
+    def reset_device(self, d_poses, d_mask=None):
+        p = d_poses.ptr if isinstance(d_poses, DeviceArray) else int(d_poses)
+        m = None if d_mask is None else (d_mask.ptr if isinstance(d_mask, DeviceArray) else int(d_mask))
+        check(_ffi.lib().f110_reset_device(self._h, p, m), self._h)
+
+    def device_array(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype)
+
+    def device_views(self):
+        v = _ffi.DeviceViews()
+        check(_ffi.lib().f110_get_device_views(self._h, C.byref(v)), self._h)
+        N, B = self.N, self.B
+        return {"scans": DeviceArray(self, (N, B), np.float64, v.scans),
+                "state": DeviceArray(self, (7, N), np.float64, v.state),
+                "agent_poses": DeviceArray(self, (3, N), np.float64, v.agent_poses),
+                "collisions": DeviceArray(self, (N,), np.float64, v.collisions),
+                "collision_idx": DeviceArray(self, (N,), np.float64, v.collision_idx),
+                "in_collision": DeviceArray(self, (N,), np.int32, v.in_collision),
+                "step_count": DeviceArray(self, (N,), np.int32, v.step_count),
+                "stream": v.stream}
+
+    _F64 = ("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions",
+            "collision_idx", "state", "agent_poses")
+    _I32 = ("in_collision", "step_count")
+
+    def get(self, *fields):
+        """Read back (and synchronise).  fields from: scans poses_x poses_y poses_theta
+        linear_vels_x ang_vels_z collisions collision_idx state agent_poses in_collision step_count."""
+        N, B = self.N, self.B
+        shapes = {"scans": (N, B), "state": (N, 7), "agent_poses": (N, 3)}
+        o = _ffi.ObsHost()
+        out = {}
+        for f in fields:
+            if f in self._F64:
+                out[f] = np.empty(shapes.get(f, (N,)), dtype=np.float64)
+                setattr(o, f, dptr(out[f]))
+            elif f in self._I32:
+                out[f] = np.empty((N,), dtype=np.int32)
+                setattr(o, f, i32ptr(out[f]))
+            else:
+                raise KeyError(f)
+        check(_ffi.lib().f110_get_obs(self._h, C.byref(o)), self._h)
+        return out
+
+    def set_state(self, state, steer_buf=None, buf_count=None):
+        state = as_f64(state, (self.N, 7))
+        sb = None if steer_buf is None else as_f64(steer_buf, (self.N, 2))
+        bc = None if buf_count is None else np.ascontiguousarray(buf_count, dtype=np.int32)
+        check(_ffi.lib().f110_set_state(self._h, dptr(state), None if sb is None else dptr(sb),
+                                        None if bc is None else i32ptr(bc)), self._h)
+
+    # ------------------------------------------------------------------ timing (bench.py)
+    def timer_begin(self):
+        check(_ffi.lib().f110_timer_begin(self._h), self._h)
+
+    def timer_end_ms(self):
+        ms = C.c_double()
+        check(_ffi.lib().f110_timer_end_ms(self._h, C.byref(ms)), self._h)
+        return ms.value
+
+    def profile_kernels(self, enable):
+        check(_ffi.lib().f110_profile_kernels(self._h, 1 if enable else 0), self._h)
+
+    def profile_read(self):
+        n = C.c_int32(); s = C.c_double(); d = C.c_double()
+        check(_ffi.lib().f110_profile_read(self._h, C.byref(n), C.byref(s), C.byref(d)), self._h)
+        return n.value, s.value, d.value
+
+    # ------------------------------------------------------------------ unit entry points
+    def scan_batch(self, poses, want_hits=False, want_lookups=False):
+        poses = as_f64(poses)
+        if poses.ndim != 2 or poses.shape[1] != 3:
+            raise ValueError("poses must be [M][3]")
+        m = poses.shape[0]
+        ranges = np.empty((m, self.B))
+        hits = np.empty((m, self.B, 2), dtype=np.int32) if want_hits else None
+        lk = np.zeros((m,), dtype=np.int64) if want_lookups else None
+        check(_ffi.lib().f110_scan_batch(self._h, dptr(poses), m, dptr(ranges),
+                                         None if hits is None else i32ptr(hits),
+                                         None if lk is None else lk.ctypes.data_as(_ffi._i64p)), self._h)
+        res = [ranges]
+        if want_hits:
+            res.append(hits)
+        if want_lookups:
+            res.append(lk)
+        return res[0] if len(res) == 1 else tuple(res)
+
+    def beam_dir_index_batch(self, thetas):
+        thetas = as_f64(thetas).reshape(-1)
+        idx = np.empty((thetas.shape[0], self.B), dtype=np.int32)
+        check(_ffi.lib().f110_beam_dir_index_batch(self._h, dptr(thetas), thetas.shape[0], i32ptr(idx)), self._h)
+        return idx
+
+    def dynamics_batch(self, x, u, params):
+        x = as_f64(x); u = as_f64(u); pv = _ffi.params_vector(params) if isinstance(params, dict) else as_f64(params, (18,))
+        m = x.shape[0]
+        x = as_f64(x, (m, 7)); u = as_f64(u, (m, 2))
+        f_st = np.empty((m, 7)); f_ks = np.empty((m, 5))
+        check(_ffi.lib().f110_dynamics_batch(self._h, dptr(x), dptr(u), dptr(pv), m, dptr(f_st), dptr(f_ks)), self._h)
+        return f_st, f_ks
+
+    def pid_batch(self, inputs, params):
+        inputs = as_f64(inputs); pv = _ffi.params_vector(params) if isinstance(params, dict) else as_f64(params, (18,))
+        m = inputs.shape[0]
+        inputs = as_f64(inputs, (m, 4))
+        out = np.empty((m, 2))
+        check(_ffi.lib().f110_pid_batch(self._h, dptr(inputs), dptr(pv), m, dptr(out)), self._h)
+        return out
+
+    def update_pose_batch(self, state0, buf0, cnt0, actions, params, time_step, integrator, lidar_dist):
+        state0 = as_f64(state0); m = state0.shape[0]
+        state0 = as_f64(state0, (m, 7)); buf0 = as_f64(buf0, (m, 2)); actions = as_f64(actions, (m, 2))
+        cnt0 = np.ascontiguousarray(cnt0, dtype=np.int32)
+        pv = _ffi.params_vector(params) if isinstance(params, dict) else as_f64(params, (18,))
+        s1 = np.empty((m, 7)); b1 = np.empty((m, 2)); c1 = np.empty((m,), dtype=np.int32); sp = np.empty((m, 3))
+        check(_ffi.lib().f110_update_pose_batch(self._h, dptr(state0), dptr(buf0), i32ptr(cnt0), dptr(actions),
+                                                dptr(pv), float(time_step), int(integrator), float(lidar_dist),
+                                                m, dptr(s1), dptr(b1), i32ptr(c1), dptr(sp)), self._h, SyntaxError)
+        return s1, b1, c1, sp
+
+    def get_vertices_batch(self, poses, length, width):
+        poses = as_f64(poses); m = poses.shape[0]
+        poses = as_f64(poses, (m, 3))
+        out = np.empty((m, 4, 2))
+        check(_ffi.lib().f110_get_vertices_batch(self._h, dptr(poses), float(length), float(width), m, dptr(out)), self._h)
+        return out
+
+    def gjk_batch(self, va, vb):
+        va = as_f64(va); m = va.shape[0]
+        va = as_f64(va, (m, 4, 2)); vb = as_f64(vb, (m, 4, 2))
+        flags = np.empty((m,), dtype=np.int32)
+        check(_ffi.lib().f110_gjk_batch(self._h, dptr(va), dptr(vb), m, i32ptr(flags)), self._h)
+        return flags
+
+    def collision_multiple_batch(self, vertices):
+        vertices = as_f64(vertices)
+        g, n = vertices.shape[0], vertices.shape[1]
+        vertices = as_f64(vertices, (g, n, 4, 2))
+        col = np.empty((g, n)); idx = np.empty((g, n))
+        check(_ffi.lib().f110_collision_multiple_batch(self._h, dptr(vertices), g, n, dptr(col), dptr(idx)), self._h)
+        return col, idx
+
+    def ttc_batch(self, scans, vels, ttc_thresh=0.005):
+        scans = as_f64(scans); m = scans.shape[0]
+        scans = as_f64(scans, (m, self.B)); vels = as_f64(vels, (m,))
+        flags = np.empty((m,), dtype=np.int32)
+        check(_ffi.lib().f110_ttc_batch(self._h, dptr(scans), dptr(vels), m, float(ttc_thresh), i32ptr(flags)), self._h)
+        return flags
+
+    def raycast_batch(self, ego, vertices, scans):
+        ego = as_f64(ego); m = ego.shape[0]
+        ego = as_f64(ego, (m, 3)); vertices = as_f64(vertices, (m, 4, 2))
+        out = np.array(scans, dtype=np.float64, order='C')
+        if out.shape != (m, self.B):
+            raise ValueError("scans must be [M][num_beams]")
+        mm = np.empty((m, 2), dtype=np.int32)
+        check(_ffi.lib().f110_raycast_batch(self._h, dptr(ego), dptr(vertices), m, dptr(out), i32ptr(mm)), self._h)
+        return out, mm
+
+    def get_range_batch(self, rows):
+        rows = as_f64(rows); m = rows.shape[0]
+        rows = as_f64(rows, (m, 8))
+        out = np.empty((m,))
+        check(_ffi.lib().f110_get_range_batch(self._h, dptr(rows), m, dptr(out)), self._h)
+        return out
+
+    def edt_sq(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        out = np.empty(img.shape, dtype=np.uint32)
+        check(_ffi.lib().f110_edt_sq(self._h, img.ctypes.data_as(_ffi._u8p), img.shape[0], img.shape[1],
+                                     out.ctypes.data_as(_ffi._u32p)), self._h)
+        return out

@@ -1,0 +1,1441 @@
+// f110_hip.hip — gfx950 kernels + the C ABI (include/f110.h) of the batched F1TENTH hot path.
+//
+// One handle owns one MI355X and one HIP stream.  A step is four launches on that stream:
+//   k_integrate   1 lane / agent   pid + steering delay + RK4|Euler + yaw wrap + lidar pose
+//                                  (base_classes.py:256-409), SoA columns, coalesced
+//   k_collide     1 lane / agent   get_vertices + GJK against the env's other agents
+//                                  (collision_models.py:113-260, base_classes.py:536-550)
+//   k_scan_rays   1 lane / ray, rays numbered agent*B + beam so a wave holds 64 consecutive
+//                                  beams: sphere-trace the distance table (laser_models.py:106-186),
+//                                  add the noise row (:450-452), evaluate the iTTC predicate
+//                                  (:188-217) and write the range once, coalesced.  Kept free of
+//                                  everything else so it runs at 8 waves/SIMD.
+//   k_finalize    1 wave / agent   wall-hit state zeroing (base_classes.py:246-249), collision
+//                                  flags (:588-589), opponent ray-cast on the beams each opponent
+//                                  blocks (laser_models.py:282-346).
+// Compiled with -ffp-contract=off: float64, reference operation order, no FMA contraction.
+// There is no CPU fallback in this library.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/f110.h"
+#include "f110_math.hpp"
+
+using namespace f110;
+
+// ============================================================================ device side
+
+struct AgentArrays {
+    int32_t n_agents_total;  // N
+    int32_t agents_per_env;  // A
+    double *state;           // [7][N]
+    double *steer_buf;       // [2][N]
+    int32_t *buf_cnt;        // [N]
+    double *scan_pose;       // [3][N]  lidar pose after integration
+    double *snap_pose;       // [3][N]  Simulator.agent_poses (:574)
+    double *dir_start;       // [N]     wrapped theta_index of beam 0
+    double *scans;           // [N][B]
+    double *collisions;      // [N]
+    double *collision_idx;   // [N]
+    int32_t *in_collision;   // [N]
+    int32_t *step_count;     // [N]
+    const double *params;    // [A][18]
+    const double *noise;     // [noise_rows][B] or nullptr
+    const double *scan_angles, *beam_cos, *side_dist;  // [B]
+    int32_t noise_rows, integrator;
+    double time_step, lidar_dist, ttc_thresh, angle_inc;
+    double box_length, box_width;  // Simulator.params used by check_collision (:549)
+};
+
+__device__ __forceinline__ VehicleParams load_params(const double *p)
+{
+    VehicleParams vp;
+#pragma unroll
+    for (int i = 0; i < NPARAMS; ++i) vp.v[i] = p[i];
+    return vp;
+}
+
+// ---- K1: integrate every agent one time step ------------------------------------------
+__global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, const double *__restrict__ actions)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.n_agents_total;
+    if (i >= N) return;
+    const VehicleParams vp = load_params(a.params + (size_t)(i % a.agents_per_env) * NPARAMS);
+    double st[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) st[c] = a.state[(size_t)c * N + i];
+    double b0 = a.steer_buf[i], b1 = a.steer_buf[(size_t)N + i];
+    int cnt = a.buf_cnt[i];
+    const double2 act = reinterpret_cast<const double2 *>(actions)[i];
+    double sp[3];
+    advance_vehicle(st, b0, b1, cnt, act.x, act.y, vp, a.time_step, a.integrator, a.lidar_dist, sp);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = st[c];
+    a.steer_buf[i] = b0;
+    a.steer_buf[(size_t)N + i] = b1;
+    a.buf_cnt[i] = cnt;
+    a.scan_pose[i] = sp[0];
+    a.scan_pose[(size_t)N + i] = sp[1];
+    a.scan_pose[2 * (size_t)N + i] = sp[2];
+    a.snap_pose[i] = st[0];
+    a.snap_pose[(size_t)N + i] = st[1];
+    a.snap_pose[2 * (size_t)N + i] = st[4];
+    a.dir_start[i] = scan_start_index(k, sp[2]);
+    a.in_collision[i] = 0;  // raised by k_scan_rays when any beam's iTTC is under the threshold
+}
+
+// ---- K1b: pairwise body collisions inside each env ------------------------------------
+// collision_multiple visits pairs (i<j) ascending and overwrites collision_idx, so an agent's
+// final index is the largest colliding partner; flags are symmetric.  Each lane evaluates the
+// GJK of its pairs in the reference's (lower, higher) argument order.
+__global__ void __launch_bounds__(256) k_collide(AgentArrays a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.n_agents_total, A = a.agents_per_env;
+    if (i >= N) return;
+    const int env = i / A, me = i - env * A;
+    double mine[8];
+    const double mx = a.snap_pose[i], my = a.snap_pose[(size_t)N + i];
+    box_vertices(mx, my, a.snap_pose[2 * (size_t)N + i], a.box_length, a.box_width, mine);
+    // bodies whose centres are further apart than a box diagonal (+1 mm) cannot overlap
+    const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+    bool hit = false;
+    int partner = -1;
+    for (int j = 0; j < A; ++j) {
+        if (j == me) continue;
+        const int o = env * A + j;
+        const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o];
+        const double dx = ox - mx, dy = oy - my;
+        if (dx * dx + dy * dy > reach * reach) continue;
+        double other[8];
+        box_vertices(ox, oy, a.snap_pose[2 * (size_t)N + o], a.box_length, a.box_width, other);
+        const bool c = (me < j) ? gjk_overlap(mine, other) : gjk_overlap(other, mine);
+        if (c) {
+            hit = true;
+            partner = j;  // j ascending -> ends at the largest colliding index
+        }
+    }
+    a.collisions[i] = hit ? 1.0 : 0.0;
+    a.collision_idx[i] = (double)partner;
+}
+
+// ---- K2: ray march -------------------------------------------------------------------------
+// Rays are numbered ray = pose*B + beam, one lane per ray, so the 64 lanes of a wave are
+// consecutive beams of (at most two) poses: neighbouring beams touch neighbouring cells and
+// have correlated lengths.  STEP=true is the env.step() form (SoA poses written by
+// k_integrate, noise row, iTTC predicate); STEP=false is ScanSimulator2D.scan for the unit
+// entry point (also reports terminating cells and lookup counts).
+struct RayJob {
+    uint32_t n_rays;          // poses * B
+    int32_t n_poses;
+    const double *pose_x, *pose_y, *dir_start;  // [n_poses]
+    double *ranges;           // [n_poses][B]
+    // STEP only
+    const double *vel;        // [n_poses] post-integration longitudinal velocity
+    const int32_t *step_count;
+    const double *noise;      // [noise_rows][B] or nullptr
+    const double *beam_cos, *side_dist;
+    int32_t *wall_flag;       // [n_poses], zeroed by k_integrate
+    int32_t noise_rows;
+    double ttc_thresh;
+    // unit only
+    int32_t *hit_rc;                 // [n_poses][B][2] or nullptr
+    unsigned long long *lookups;     // [n_poses] or nullptr
+};
+
+template <int LAYOUT, bool POW2, bool IDENT, bool STEP>
+__global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
+{
+    const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= j.n_rays) return;
+    const uint32_t B = (uint32_t)k.num_beams;
+    const uint32_t p = ray / B;
+    const int b = (int)(ray - p * B);
+    const int idx = beam_dir_index(k, j.dir_start[p], b);
+    const double2 cs = k.cs[idx];
+    int hr, hc, nl;
+    double r = march_ray<LAYOUT, POW2, IDENT>(k, j.pose_x[p], j.pose_y[p], cs.x, cs.y, hr, hc, nl);
+    if (STEP) {
+        if (j.noise) r += j.noise[(size_t)(j.step_count[p] % j.noise_rows) * B + b];
+        const double vel = j.vel[p];
+        // check_ttc_jit is an any-over-beams: every hitting lane raises the agent's flag
+        if (vel != 0.0 && ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh)) j.wall_flag[p] = 1;
+    } else {
+        if (j.hit_rc) {
+            j.hit_rc[(size_t)ray * 2] = hr;
+            j.hit_rc[(size_t)ray * 2 + 1] = hc;
+        }
+        if (j.lookups) atomicAdd(&j.lookups[p], (unsigned long long)nl);
+    }
+    j.ranges[ray] = r;
+}
+
+// ---- K3: finalize ---------------------------------------------------------------------------
+// One wave per agent.  RaceCar.check_ttc's side effects (:246-252), Simulator's collision OR
+// (:588-589), then RaceCar.ray_cast_agents (:206-227): opponents from the :574 snapshot, ego
+// pose = live state (heading already zeroed on a wall hit), box = the ego's own params.
+__global__ void __launch_bounds__(64) k_finalize(AgentArrays a, int32_t B)
+{
+    __shared__ int li[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int N = a.n_agents_total, A = a.agents_per_env;
+    const int wall = a.in_collision[i];
+    const double ex = a.state[i], ey = a.state[(size_t)N + i];
+    const double eth = wall ? 0.0 : a.state[4 * (size_t)N + i];
+    if (tid == 0) {
+        if (wall) {
+            a.state[3 * (size_t)N + i] = 0.;
+            a.state[4 * (size_t)N + i] = 0.;
+            a.state[5 * (size_t)N + i] = 0.;
+            a.state[6 * (size_t)N + i] = 0.;
+            a.collisions[i] = 1.0;
+        }
+        a.step_count[i] += 1;
+    }
+    if (A == 1) return;
+    const int env = i / A, me = i - env * A;
+    const double blen = a.params[(size_t)me * NPARAMS + P_LENGTH];
+    const double bwid = a.params[(size_t)me * NPARAMS + P_WIDTH];
+    double *sc = a.scans + (size_t)i * B;
+    for (int jj = 0; jj < A; ++jj) {
+        if (jj == me) continue;
+        const int o = env * A + jj;
+        double v[8];
+        box_vertices(a.snap_pose[o], a.snap_pose[(size_t)N + o], a.snap_pose[2 * (size_t)N + o], blen, bwid, v);
+        if (tid < 4) {
+            const double vx = tid == 0 ? v[0] : tid == 1 ? v[2] : tid == 2 ? v[4] : v[6];
+            const double vy = tid == 0 ? v[1] : tid == 1 ? v[3] : tid == 2 ? v[5] : v[7];
+            li[tid] = vertex_beam_index(ex, ey, eth, vx, vy, a.scan_angles, B, a.angle_inc);
+        }
+        __syncthreads();
+        const int i0 = li[0], i1 = li[1], i2 = li[2], i3 = li[3];
+        __syncthreads();
+        const int lo = min(min(i0, i1), min(i2, i3));
+        const int hi = max(max(i0, i1), max(i2, i3));
+        for (int b = lo + tid; b <= hi; b += 64) {
+            const double bt = eth + a.scan_angles[b];
+            const double v3x = cos(bt + kPi / 2.), v3y = sin(bt + kPi / 2.);
+            const double r0 = sc[b];
+            double r = r0;
+            double rr = edge_range(ex, ey, v3x, v3y, v[0], v[1], v[2], v[3]);
+            if (rr < r) r = rr;
+            rr = edge_range(ex, ey, v3x, v3y, v[2], v[3], v[4], v[5]);
+            if (rr < r) r = rr;
+            rr = edge_range(ex, ey, v3x, v3y, v[4], v[5], v[6], v[7]);
+            if (rr < r) r = rr;
+            rr = edge_range(ex, ey, v3x, v3y, v[6], v[7], v[0], v[1]);
+            if (rr < r) r = rr;
+            if (r < r0) sc[b] = r;
+        }
+        // the next opponent may touch the same beams: make this wave's stores visible to it
+        __threadfence_block();
+    }
+}
+
+// single-agent envs: no opponents, one lane per agent is enough
+__global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.n_agents_total;
+    if (i >= N) return;
+    if (a.in_collision[i]) {
+        a.state[3 * (size_t)N + i] = 0.;
+        a.state[4 * (size_t)N + i] = 0.;
+        a.state[5 * (size_t)N + i] = 0.;
+        a.state[6 * (size_t)N + i] = 0.;
+        a.collisions[i] = 1.0;
+    }
+    a.step_count[i] += 1;
+}
+
+// unit-path helper: AoS poses [M][3] -> pose_x, pose_y, dir_start
+__global__ void k_prepare_poses(ScanConst k, const double *__restrict__ poses, int m, double *__restrict__ px,
+                                double *__restrict__ py, double *__restrict__ start)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    px[i] = poses[3 * i];
+    py[i] = poses[3 * i + 1];
+    start[i] = scan_start_index(k, poses[3 * i + 2]);
+}
+
+// ---- reset ------------------------------------------------------------------------------
+__global__ void k_reset(AgentArrays a, const double *__restrict__ poses, const uint8_t *__restrict__ env_mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.n_agents_total;
+    if (i >= N) return;
+    if (env_mask && !env_mask[i / a.agents_per_env]) return;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = 0.;
+    a.state[i] = poses[3 * (size_t)i];
+    a.state[(size_t)N + i] = poses[3 * (size_t)i + 1];
+    a.state[4 * (size_t)N + i] = poses[3 * (size_t)i + 2];
+    a.steer_buf[i] = 0.;
+    a.steer_buf[(size_t)N + i] = 0.;
+    a.buf_cnt[i] = 0;
+    a.in_collision[i] = 0;
+    a.step_count[i] = 0;
+}
+
+// ---- unit kernels (one per reference function; parity tests) ------------------------------
+__global__ void k_dir_index_unit(ScanConst k, const double *__restrict__ thetas, int m, int32_t *__restrict__ idx)
+{
+    const int p = blockIdx.x;
+    const double start = scan_start_index(k, thetas[p]);
+    for (int b = threadIdx.x; b < k.num_beams; b += blockDim.x) idx[(size_t)p * k.num_beams + b] = beam_dir_index(k, start, b);
+}
+
+__global__ void k_dynamics_unit(const double *__restrict__ x, const double *__restrict__ u, const double *__restrict__ params,
+                                int m, double *__restrict__ f_st, double *__restrict__ f_ks)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const VehicleParams vp = load_params(params);
+    double xs[7], f[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) xs[c] = x[7 * (size_t)i + c];
+    rhs_single_track(xs, u[2 * i], u[2 * i + 1], vp, f);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) f_st[7 * (size_t)i + c] = f[c];
+    rhs_kinematic(xs, u[2 * i], u[2 * i + 1], vp, f);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) f_ks[5 * (size_t)i + c] = f[c];
+}
+
+__global__ void k_pid_unit(const double *__restrict__ in, const double *__restrict__ params, int m, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const VehicleParams vp = load_params(params);
+    double accl, sv;
+    speed_steer_controller(in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3], vp, accl, sv);
+    out[2 * i] = accl;
+    out[2 * i + 1] = sv;
+}
+
+__global__ void k_update_pose_unit(const double *__restrict__ s0, const double *__restrict__ buf0, const int32_t *__restrict__ cnt0,
+                                   const double *__restrict__ act, const double *__restrict__ params, double dt, int integ,
+                                   double lidar_dist, int m, double *__restrict__ s1, double *__restrict__ buf1,
+                                   int32_t *__restrict__ cnt1, double *__restrict__ spose)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const VehicleParams vp = load_params(params);
+    double st[7], sp[3];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) st[c] = s0[7 * (size_t)i + c];
+    double b0 = buf0[2 * i], b1 = buf0[2 * i + 1];
+    int cnt = cnt0[i];
+    advance_vehicle(st, b0, b1, cnt, act[2 * i], act[2 * i + 1], vp, dt, integ, lidar_dist, sp);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) s1[7 * (size_t)i + c] = st[c];
+    buf1[2 * i] = b0;
+    buf1[2 * i + 1] = b1;
+    cnt1[i] = cnt;
+    spose[3 * i] = sp[0];
+    spose[3 * i + 1] = sp[1];
+    spose[3 * i + 2] = sp[2];
+}
+
+__global__ void k_vertices_unit(const double *__restrict__ poses, double length, double width, int m, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double v[8];
+    box_vertices(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2], length, width, v);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[8 * (size_t)i + c] = v[c];
+}
+
+__global__ void k_gjk_unit(const double *__restrict__ va, const double *__restrict__ vb, int m, int32_t *__restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double a[8], b[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        a[c] = va[8 * (size_t)i + c];
+        b[c] = vb[8 * (size_t)i + c];
+    }
+    flags[i] = gjk_overlap(a, b) ? 1 : 0;
+}
+
+// collision_multiple :184-212 — one lane per body, same last-writer rule as k_collide
+__global__ void k_collision_multiple_unit(const double *__restrict__ verts, int groups, int n, double *__restrict__ col,
+                                          double *__restrict__ idx)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= groups * n) return;
+    const int g = t / n, me = t - g * n;
+    double mine[8], other[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) mine[c] = verts[8 * (size_t)t + c];
+    bool hit = false;
+    int partner = -1;
+    for (int j = 0; j < n; ++j) {
+        if (j == me) continue;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) other[c] = verts[8 * ((size_t)g * n + j) + c];
+        const bool cc = (me < j) ? gjk_overlap(mine, other) : gjk_overlap(other, mine);
+        if (cc) {
+            hit = true;
+            partner = j;
+        }
+    }
+    col[t] = hit ? 1.0 : 0.0;
+    idx[t] = (double)partner;
+}
+
+__global__ void k_ttc_unit(const double *__restrict__ scans, const double *__restrict__ vels, int m, int B,
+                           const double *__restrict__ beam_cos, const double *__restrict__ side, double thresh,
+                           int32_t *__restrict__ flags)
+{
+    const int p = blockIdx.x;
+    const double vel = vels[p];
+    int hit = 0;
+    if (vel != 0.0)
+        for (int b = threadIdx.x; b < B; b += blockDim.x)
+            if (ttc_beam_hit(scans[(size_t)p * B + b], side[b], vel, beam_cos[b], thresh)) hit = 1;
+    const int any = __syncthreads_or(hit);
+    if (threadIdx.x == 0) flags[p] = any;
+}
+
+__global__ void k_raycast_unit(const double *__restrict__ ego, const double *__restrict__ verts, int m, int B,
+                               const double *__restrict__ scan_angles, double angle_inc, double *__restrict__ scans,
+                               int32_t *__restrict__ minmax)
+{
+    __shared__ int li[4];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const double ex = ego[3 * p], ey = ego[3 * p + 1], eth = ego[3 * p + 2];
+    double v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = verts[8 * (size_t)p + c];
+    if (tid < 4) {
+        const double vx = tid == 0 ? v[0] : tid == 1 ? v[2] : tid == 2 ? v[4] : v[6];
+        const double vy = tid == 0 ? v[1] : tid == 1 ? v[3] : tid == 2 ? v[5] : v[7];
+        li[tid] = vertex_beam_index(ex, ey, eth, vx, vy, scan_angles, B, angle_inc);
+    }
+    __syncthreads();
+    const int lo = min(min(li[0], li[1]), min(li[2], li[3]));
+    const int hi = max(max(li[0], li[1]), max(li[2], li[3]));
+    if (minmax && tid == 0) {
+        minmax[2 * p] = lo;
+        minmax[2 * p + 1] = hi;
+    }
+    double *sc = scans + (size_t)p * B;
+    for (int b = lo + tid; b <= hi; b += blockDim.x) {
+        const double bt = eth + scan_angles[b];
+        const double v3x = cos(bt + kPi / 2.), v3y = sin(bt + kPi / 2.);
+        double r = sc[b];
+        double rr = edge_range(ex, ey, v3x, v3y, v[0], v[1], v[2], v[3]);
+        if (rr < r) r = rr;
+        rr = edge_range(ex, ey, v3x, v3y, v[2], v[3], v[4], v[5]);
+        if (rr < r) r = rr;
+        rr = edge_range(ex, ey, v3x, v3y, v[4], v[5], v[6], v[7]);
+        if (rr < r) r = rr;
+        rr = edge_range(ex, ey, v3x, v3y, v[6], v[7], v[0], v[1]);
+        if (rr < r) r = rr;
+        sc[b] = r;
+    }
+}
+
+__global__ void k_get_range_unit(const double *__restrict__ in, int m, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double *r = in + 8 * (size_t)i;
+    const double bt = r[3];
+    out[i] = edge_range(r[0], r[1], cos(bt + kPi / 2.), sin(bt + kPi / 2.), r[4], r[5], r[6], r[7]);
+}
+
+// ---- map pipeline: flip + threshold + exact EDT + dt = res*sqrt(d2) ------------------------
+// laser_models.py:398-404
+__global__ void k_flip_threshold(const uint8_t *__restrict__ img_top_first, int H, int W, uint8_t *__restrict__ bin)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)H * W) return;
+    const int r = (int)(t / W), c = (int)(t - (size_t)r * W);
+    bin[t] = img_top_first[(size_t)(H - 1 - r) * W + c] > 128 ? 1 : 0;
+}
+
+constexpr uint32_t kEdtInf = 0x00007FFFu;  // "no obstacle in this column": larger than any map side
+
+// phase 1: per column, distance to the nearest obstacle cell in that column (lane = column)
+__global__ void k_edt_columns(const uint8_t *__restrict__ bin, int H, int W, uint32_t *__restrict__ g)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
+    uint32_t run = kEdtInf;
+    for (int y = 0; y < H; ++y) {
+        run = bin[(size_t)y * W + x] ? (run >= kEdtInf ? kEdtInf : run + 1) : 0;
+        g[(size_t)y * W + x] = run;
+    }
+    run = kEdtInf;
+    for (int y = H - 1; y >= 0; --y) {
+        const uint32_t cur = g[(size_t)y * W + x];
+        run = (cur == 0) ? 0 : (run >= kEdtInf ? kEdtInf : run + 1);
+        if (run < cur) g[(size_t)y * W + x] = run;
+    }
+}
+
+// phase 2: per row, d2[u] = min_i (u-i)^2 + g[i]^2 — exact integer lower envelope by brute
+// force; the row of g^2 is staged in LDS and every lane walks it (LDS broadcast reads).
+__global__ void __launch_bounds__(256) k_edt_rows(const uint32_t *__restrict__ g, int H, int W, uint32_t *__restrict__ d2)
+{
+    extern __shared__ uint32_t g2[];
+    const int y = blockIdx.x;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const uint32_t v = g[(size_t)y * W + i];
+        g2[i] = v * v;  // <= 0x7FFF^2 < 2^30
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < W; u += blockDim.x) {
+        uint32_t best = 0xFFFFFFFFu;
+        for (int i = 0; i < W; ++i) {
+            const int d = u - i;
+            const uint32_t cand = (uint32_t)(d * d) + g2[i];
+            best = cand < best ? cand : best;
+        }
+        d2[(size_t)y * W + u] = best;
+    }
+}
+
+__global__ void k_dt_from_d2(const uint32_t *__restrict__ d2, size_t n, double res, double *__restrict__ dt)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dt[t] = res * sqrt((double)d2[t]);  // laser_models.py:52
+}
+
+__global__ void k_retile(const double *__restrict__ rowmajor, int H, int W, int tiles_w, int tiles_h, double *__restrict__ tiled)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)tiles_w * tiles_h * 16;
+    if (t >= total) return;
+    const size_t tile = t >> 4;
+    const int within = (int)(t & 15);
+    const int r = (int)(tile / tiles_w) * 4 + (within >> 2);
+    const int c = (int)(tile % tiles_w) * 4 + (within & 3);
+    tiled[t] = (r < H && c < W) ? rowmajor[(size_t)r * W + c] : 0.0;
+}
+
+__global__ void k_interleave_cs(const double *__restrict__ sines, const double *__restrict__ cosines, int n, double2 *__restrict__ cs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cs[i] = make_double2(cosines[i], sines[i]);
+}
+
+// ============================================================================ host side
+
+struct f110_sim {
+    f110_config cfg{};
+    int N = 0;
+    hipStream_t stream = nullptr;
+    AgentArrays dev{};
+    ScanConst k{};
+    bool has_map = false;
+    int scan_block = 128;
+    double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
+    double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_actions = nullptr, *d_poses = nullptr;
+    double2 *d_cs = nullptr;
+    uint8_t *d_mask = nullptr;
+    // timing
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events;  // triples: before integrate, before scan, after scan
+    size_t prof_used = 0;
+    char err[512] = {0};
+};
+
+static thread_local char g_err[512] = {0};
+
+static int fail(f110_sim *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    snprintf(g_err, sizeof g_err, "%s", buf);
+    if (h) snprintf(h->err, sizeof h->err, "%s", buf);
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(h, F110_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+static int dmalloc(f110_sim *h, T **p, size_t count)
+{
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) > 0 ? count * sizeof(T) : 8));
+    return F110_OK;
+}
+
+#define TRY(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != F110_OK) return rc_; \
+    } while (0)
+
+// RAII scratch for the unit entry points
+struct Scratch {
+    f110_sim *h;
+    std::vector<void *> ptrs;
+    explicit Scratch(f110_sim *hh) : h(hh) {}
+    ~Scratch()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    int up(const T *host, size_t count, T **dev)
+    {
+        TRY(dmalloc(h, dev, count));
+        ptrs.push_back(*dev);
+        if (host) HIPCHK(h, hipMemcpyAsync(*dev, host, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+        return F110_OK;
+    }
+    template <typename T>
+    int down(T *host, const T *dev, size_t count)
+    {
+        HIPCHK(h, hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        return F110_OK;
+    }
+};
+
+static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+typedef void (*scan_rays_fn)(RayJob, ScanConst);
+
+template <bool STEP>
+static scan_rays_fn pick_rays(const ScanConst &k, int layout)
+{
+#define SEL(L) (k.res_pow2 ? (k.ident_rot ? k_scan_rays<L, true, true, STEP> : k_scan_rays<L, true, false, STEP>) \
+                           : (k.ident_rot ? k_scan_rays<L, false, true, STEP> : k_scan_rays<L, false, false, STEP>))
+    return layout == F110_MAP_TILED_F64 ? SEL(LAYOUT_TILED) : SEL(LAYOUT_ROWMAJOR);
+#undef SEL
+}
+
+extern "C" {
+
+const char *f110_last_error(const f110_sim *h) { return (h && h->err[0]) ? h->err : g_err; }
+int f110_abi_version(void) { return F110_ABI_VERSION; }
+
+int f110_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        if (count) *count = 0;
+        return fail(nullptr, F110_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    if (count) *count = n;
+    return F110_OK;
+}
+
+static void default_beam_tables(const f110_config &c, std::vector<double> &sa, std::vector<double> &co, std::vector<double> &sd)
+{
+    // base_classes.py:125-158 (the Python host normally overrides these with NumPy's values)
+    const int B = c.num_beams;
+    const double incr = c.fov / (B - 1);
+    const double dist_sides = c.params[F110_P_WIDTH] / 2., dist_fr = (c.params[F110_P_LF] + c.params[F110_P_LR]) / 2.;
+    sa.resize(B); co.resize(B); sd.resize(B);
+    for (int i = 0; i < B; ++i) {
+        const double angle = -c.fov / 2. + i * incr;
+        double to_side, to_fr;
+        sa[i] = angle;
+        co[i] = std::cos(angle);
+        if (angle > 0) {
+            if (angle < kPi / 2) { to_side = dist_sides / std::sin(angle); to_fr = dist_fr / std::cos(angle); }
+            else { to_side = dist_sides / std::cos(angle - kPi / 2.); to_fr = dist_fr / std::sin(angle - kPi / 2.); }
+        } else {
+            if (angle > -kPi / 2) { to_side = dist_sides / std::sin(-angle); to_fr = dist_fr / std::cos(-angle); }
+            else { to_side = dist_sides / std::cos(-angle - kPi / 2); to_fr = dist_fr / std::sin(-angle - kPi / 2); }
+        }
+        sd[i] = to_side < to_fr ? to_side : to_fr;
+    }
+}
+
+int f110_create(const f110_config *cfg, f110_sim **out)
+{
+    if (!cfg || !out) return fail(nullptr, F110_ERR_INVALID, "f110_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != F110_ABI_VERSION) return fail(nullptr, F110_ERR_INVALID, "ABI version mismatch (%d vs %d)", cfg->abi_version, F110_ABI_VERSION);
+    if (cfg->num_envs < 1 || cfg->num_agents < 1 || cfg->num_beams < 2 || cfg->theta_dis < 2)
+        return fail(nullptr, F110_ERR_INVALID, "f110_create: num_envs/num_agents >= 1, num_beams/theta_dis >= 2 required");
+    if (cfg->integrator != F110_INTEGRATOR_RK4 && cfg->integrator != F110_INTEGRATOR_EULER)
+        return fail(nullptr, F110_ERR_INVALID, "Invalid Integrator Specified. Please choose RK4 or Euler");
+    if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_TILED_F64)
+        return fail(nullptr, F110_ERR_INVALID, "unknown map_layout %d", cfg->map_layout);
+    if ((long long)cfg->num_envs * cfg->num_agents * (long long)cfg->num_beams > 0xFFFFFF00LL) return fail(nullptr, F110_ERR_INVALID, "num_envs*num_agents*num_beams must stay below 2^32");
+    int ndev = 0;
+    {
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev < 1)
+            return fail(nullptr, F110_ERR_HIP, "no usable HIP device (%s); libf110_hip has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, F110_ERR_INVALID, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+    f110_sim *h = new (std::nothrow) f110_sim();
+    if (!h) return fail(nullptr, F110_ERR_NOMEM, "out of host memory");
+    h->cfg = *cfg;
+    h->N = cfg->num_envs * cfg->num_agents;
+    const int N = h->N, B = cfg->num_beams;
+    h->scan_block = cfg->scan_block > 0 ? cfg->scan_block : 128;
+    if (h->scan_block % 64 != 0 || h->scan_block > 256) { delete h; return fail(nullptr, F110_ERR_INVALID, "scan_block must be 64, 128, 192 or 256"); }
+#define CK(expr) do { int rc_ = (expr); if (rc_ != F110_OK) { snprintf(g_err, sizeof g_err, "%s", h->err); f110_destroy(h); return rc_; } } while (0)
+#define CKH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(nullptr, F110_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); f110_destroy(h); return F110_ERR_HIP; } } while (0)
+    CKH(hipSetDevice(cfg->device_id));
+    CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CKH(hipEventCreate(&h->ev_begin));
+    CKH(hipEventCreate(&h->ev_end));
+    AgentArrays &d = h->dev;
+    d.n_agents_total = N;
+    d.agents_per_env = cfg->num_agents;
+    CK(dmalloc(h, &d.state, (size_t)7 * N));
+    CK(dmalloc(h, &d.steer_buf, (size_t)2 * N));
+    CK(dmalloc(h, &d.buf_cnt, (size_t)N));
+    CK(dmalloc(h, &d.scan_pose, (size_t)3 * N));
+    CK(dmalloc(h, &d.snap_pose, (size_t)3 * N));
+    CK(dmalloc(h, &d.dir_start, (size_t)N));
+    CK(dmalloc(h, &d.scans, (size_t)N * B));
+    CK(dmalloc(h, &d.collisions, (size_t)N));
+    CK(dmalloc(h, &d.collision_idx, (size_t)N));
+    CK(dmalloc(h, &d.in_collision, (size_t)N));
+    CK(dmalloc(h, &d.step_count, (size_t)N));
+    CK(dmalloc(h, &h->d_params, (size_t)cfg->num_agents * NPARAMS));
+    CK(dmalloc(h, &h->d_scan_angles, (size_t)B));
+    CK(dmalloc(h, &h->d_beam_cos, (size_t)B));
+    CK(dmalloc(h, &h->d_side, (size_t)B));
+    CK(dmalloc(h, &h->d_cs, (size_t)cfg->theta_dis));
+    CK(dmalloc(h, &h->d_actions, (size_t)2 * N));
+    CK(dmalloc(h, &h->d_poses, (size_t)3 * N));
+    CK(dmalloc(h, &h->d_mask, (size_t)cfg->num_envs));
+    CKH(hipMemsetAsync(d.state, 0, sizeof(double) * 7 * N, h->stream));
+    CKH(hipMemsetAsync(d.steer_buf, 0, sizeof(double) * 2 * N, h->stream));
+    CKH(hipMemsetAsync(d.buf_cnt, 0, sizeof(int32_t) * N, h->stream));
+    CKH(hipMemsetAsync(d.scan_pose, 0, sizeof(double) * 3 * N, h->stream));
+    CKH(hipMemsetAsync(d.snap_pose, 0, sizeof(double) * 3 * N, h->stream));
+    CKH(hipMemsetAsync(d.dir_start, 0, sizeof(double) * N, h->stream));
+    CKH(hipMemsetAsync(d.scans, 0, sizeof(double) * (size_t)N * B, h->stream));
+    CKH(hipMemsetAsync(d.collisions, 0, sizeof(double) * N, h->stream));
+    CKH(hipMemsetAsync(d.in_collision, 0, sizeof(int32_t) * N, h->stream));
+    CKH(hipMemsetAsync(d.step_count, 0, sizeof(int32_t) * N, h->stream));
+    {
+        std::vector<double> minus1(N, -1.0);  // collision_idx = -1 (base_classes.py:488)
+        CKH(hipMemcpy(d.collision_idx, minus1.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    }
+    d.params = h->d_params;
+    d.noise = nullptr;
+    d.noise_rows = 0;
+    d.scan_angles = h->d_scan_angles;
+    d.beam_cos = h->d_beam_cos;
+    d.side_dist = h->d_side;
+    d.integrator = cfg->integrator;
+    d.time_step = cfg->time_step;
+    d.lidar_dist = cfg->lidar_dist;
+    d.ttc_thresh = cfg->ttc_thresh;
+    d.angle_inc = cfg->fov / (B - 1);  // laser_models.py:367
+    d.box_length = cfg->params[F110_P_LENGTH];
+    d.box_width = cfg->params[F110_P_WIDTH];
+    // scan constants that do not depend on the map
+    ScanConst &k = h->k;
+    k.cs = h->d_cs;
+    k.theta_dis = cfg->theta_dis;
+    k.num_beams = B;
+    k.eps = cfg->eps;
+    k.max_range = cfg->max_range;
+    k.fov = cfg->fov;
+    k.theta_inc = cfg->theta_dis * d.angle_inc / (2. * kPi);  // :368
+    {
+        const double g = 64.0 * (double)B * 2.2737367544323206e-13;  // 64 * B * 2^-42
+        k.dir_guard = g > 1e-8 ? g : 1e-8;
+    }
+    CK(f110_set_params(h, -1, cfg->params));
+    {
+        std::vector<double> s(cfg->theta_dis), c(cfg->theta_dis);
+        for (int i = 0; i < cfg->theta_dis; ++i) {  // np.linspace(0, 2pi, theta_dis), laser_models.py:379
+            const double th = i * (kTwoPi / (cfg->theta_dis - 1));
+            s[i] = std::sin(th);
+            c[i] = std::cos(th);
+        }
+        CK(f110_set_trig_tables(h, s.data(), c.data(), cfg->theta_dis));
+        std::vector<double> sa, co, sd;
+        default_beam_tables(*cfg, sa, co, sd);
+        CK(f110_set_beam_tables(h, sa.data(), co.data(), sd.data(), B));
+    }
+    CKH(hipStreamSynchronize(h->stream));
+#undef CK
+#undef CKH
+    *out = h;
+    return F110_OK;
+}
+
+void f110_destroy(f110_sim *h)
+{
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    AgentArrays &d = h->dev;
+    void *ptrs[] = {d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
+                    d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
+                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_actions, h->d_poses, h->d_cs, h->d_mask};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int f110_sync(f110_sim *h)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+// ---- map ---------------------------------------------------------------------------------
+static int finish_map(f110_sim *h, int H, int W, double res, double ox, double oy, double oc, double os)
+{
+    ScanConst &k = h->k;
+    k.height = H;
+    k.width = W;
+    k.tiles_w = (W + 3) / 4;
+    k.res = res;
+    k.inv_res = 1.0 / res;
+    {
+        int e = 0;
+        const double mant = std::frexp(res, &e);
+        k.res_pow2 = (mant == 0.5) ? 1 : 0;
+    }
+    k.orig_x = ox;
+    k.orig_y = oy;
+    k.orig_c = oc;
+    k.orig_s = os;
+    k.ident_rot = (oc == 1.0 && os == 0.0) ? 1 : 0;
+    k.w_res = W * res;  // width * resolution, laser_models.py:79
+    k.h_res = H * res;
+    HIPCHK(h, hipMemcpyAsync(&k.oob_value, h->d_dt_row + ((size_t)H * W - 1), sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (h->cfg.map_layout == F110_MAP_TILED_F64) {
+        const int tiles_h = (H + 3) / 4;
+        if (h->d_dt_tiled) { (void)hipFree(h->d_dt_tiled); h->d_dt_tiled = nullptr; }
+        const size_t total = (size_t)k.tiles_w * tiles_h * 16;
+        TRY(dmalloc(h, &h->d_dt_tiled, total));
+        hipLaunchKernelGGL(k_retile, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_row, H, W, k.tiles_w, tiles_h, h->d_dt_tiled);
+        HIPCHK(h, hipGetLastError());
+        k.table = h->d_dt_tiled;
+    } else {
+        k.table = h->d_dt_row;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->has_map = true;
+    return F110_OK;
+}
+
+int f110_set_map_image(f110_sim *h, const uint8_t *h_img, int32_t H, int32_t W, double res, double ox, double oy, double oyaw)
+{
+    if (!h || !h_img) return fail(h, F110_ERR_INVALID, "f110_set_map_image: null argument");
+    if (H < 1 || W < 1 || H > 16384 || W > 16384 || !(res > 0)) return fail(h, F110_ERR_INVALID, "f110_set_map_image: bad shape %dx%d or resolution", H, W);
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const size_t n = (size_t)H * W;
+    uint8_t *d_img = nullptr, *d_bin = nullptr;
+    uint32_t *d_g = nullptr, *d_d2 = nullptr;
+    Scratch s(h);
+    TRY(s.up(h_img, n, &d_img));
+    TRY(s.up<uint8_t>(nullptr, n, &d_bin));
+    TRY(s.up<uint32_t>(nullptr, n, &d_g));
+    TRY(s.up<uint32_t>(nullptr, n, &d_d2));
+    if (h->d_dt_row) { (void)hipFree(h->d_dt_row); h->d_dt_row = nullptr; }
+    TRY(dmalloc(h, &h->d_dt_row, n));
+    hipLaunchKernelGGL(k_flip_threshold, grid1d(n, 256), dim3(256), 0, h->stream, d_img, H, W, d_bin);
+    hipLaunchKernelGGL(k_edt_columns, grid1d(W, 64), dim3(64), 0, h->stream, d_bin, H, W, d_g);
+    hipLaunchKernelGGL(k_edt_rows, dim3(H), dim3(256), (size_t)W * sizeof(uint32_t), h->stream, d_g, H, W, d_d2);
+    hipLaunchKernelGGL(k_dt_from_d2, grid1d(n, 256), dim3(256), 0, h->stream, d_d2, n, res, h->d_dt_row);
+    HIPCHK(h, hipGetLastError());
+    return finish_map(h, H, W, res, ox, oy, std::cos(oyaw), std::sin(oyaw));  // :421-422
+}
+
+int f110_set_map_dt(f110_sim *h, const double *h_dt, int32_t H, int32_t W, double res, double ox, double oy, double oc, double os)
+{
+    if (!h || !h_dt) return fail(h, F110_ERR_INVALID, "f110_set_map_dt: null argument");
+    if (H < 1 || W < 1 || !(res > 0)) return fail(h, F110_ERR_INVALID, "f110_set_map_dt: bad shape or resolution");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const size_t n = (size_t)H * W;
+    if (h->d_dt_row) { (void)hipFree(h->d_dt_row); h->d_dt_row = nullptr; }
+    TRY(dmalloc(h, &h->d_dt_row, n));
+    HIPCHK(h, hipMemcpyAsync(h->d_dt_row, h_dt, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return finish_map(h, H, W, res, ox, oy, oc, os);
+}
+
+int f110_get_map_dt(f110_sim *h, double *out)
+{
+    if (!h || !out) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    HIPCHK(h, hipMemcpyAsync(out, h->d_dt_row, (size_t)h->k.height * h->k.width * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_map_shape(f110_sim *h, int32_t *H, int32_t *W)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    if (H) *H = h->k.height;
+    if (W) *W = h->k.width;
+    return F110_OK;
+}
+
+int f110_set_trig_tables(f110_sim *h, const double *s, const double *c, int32_t n)
+{
+    if (!h || !s || !c) return fail(h, F110_ERR_INVALID, "null argument");
+    if (n != h->cfg.theta_dis) return fail(h, F110_ERR_INVALID, "trig tables must have theta_dis=%d entries (got %d)", h->cfg.theta_dis, n);
+    Scratch sc(h);
+    double *ds = nullptr, *dc = nullptr;
+    TRY(sc.up(s, (size_t)n, &ds));
+    TRY(sc.up(c, (size_t)n, &dc));
+    hipLaunchKernelGGL(k_interleave_cs, grid1d(n, 256), dim3(256), 0, h->stream, ds, dc, n, h->d_cs);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_set_beam_tables(f110_sim *h, const double *sa, const double *co, const double *sd, int32_t B)
+{
+    if (!h || !sa || !co || !sd) return fail(h, F110_ERR_INVALID, "null argument");
+    if (B != h->cfg.num_beams) return fail(h, F110_ERR_INVALID, "beam tables must have num_beams=%d entries (got %d)", h->cfg.num_beams, B);
+    HIPCHK(h, hipMemcpyAsync(h->d_scan_angles, sa, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_beam_cos, co, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_side, sd, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // beam spacing of THIS table (seed of the nearest-beam search in the opponent ray-cast)
+    h->dev.angle_inc = (sa[B - 1] - sa[0]) / (B - 1);
+    return F110_OK;
+}
+
+int f110_set_params(f110_sim *h, int32_t agent_idx, const double *p)
+{
+    if (!h || !p) return fail(h, F110_ERR_INVALID, "null argument");
+    const int A = h->cfg.num_agents;
+    if (agent_idx >= A) return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
+    for (int a = 0; a < A; ++a)
+        if (agent_idx < 0 || agent_idx == a)
+            HIPCHK(h, hipMemcpyAsync(h->d_params + (size_t)a * NPARAMS, p, sizeof(double) * NPARAMS, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_set_noise_table(f110_sim *h, const double *noise, int32_t rows, int32_t B)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_noise) { (void)hipFree(h->d_noise); h->d_noise = nullptr; }
+    h->dev.noise = nullptr;
+    h->dev.noise_rows = 0;
+    if (!noise || rows <= 0) return F110_OK;
+    if (B != h->cfg.num_beams) return fail(h, F110_ERR_INVALID, "noise table must have num_beams=%d columns (got %d)", h->cfg.num_beams, B);
+    TRY(dmalloc(h, &h->d_noise, (size_t)rows * B));
+    HIPCHK(h, hipMemcpyAsync(h->d_noise, noise, sizeof(double) * (size_t)rows * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->dev.noise = h->d_noise;
+    h->dev.noise_rows = rows;
+    return F110_OK;
+}
+
+// ---- reset / step ------------------------------------------------------------------------
+int f110_reset_device(f110_sim *h, const double *d_poses, const uint8_t *d_env_mask)
+{
+    if (!h || !d_poses) return fail(h, F110_ERR_INVALID, "null argument");
+    hipLaunchKernelGGL(k_reset, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, d_poses, d_env_mask);
+    HIPCHK(h, hipGetLastError());
+    return F110_OK;
+}
+
+int f110_reset(f110_sim *h, const double *poses, const uint8_t *env_mask)
+{
+    if (!h || !poses) return fail(h, F110_ERR_INVALID, "null argument");
+    HIPCHK(h, hipMemcpyAsync(h->d_poses, poses, sizeof(double) * 3 * h->N, hipMemcpyHostToDevice, h->stream));
+    if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->cfg.num_envs, hipMemcpyHostToDevice, h->stream));
+    TRY(f110_reset_device(h, h->d_poses, env_mask ? h->d_mask : nullptr));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // host buffers are consumed on return
+    return F110_OK;
+}
+
+static hipEvent_t prof_event(f110_sim *h)
+{
+    if (h->prof_used == h->prof_events.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->prof_events.push_back(e);
+    }
+    return h->prof_events[h->prof_used++];
+}
+
+int f110_step_device(f110_sim *h, const double *d_actions)
+{
+    if (!h || !d_actions) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    const int N = h->N;
+    const bool prof = h->profiling && h->prof_used + 3 <= 3 * 65536;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (prof) {
+        e0 = prof_event(h); e1 = prof_event(h); e2 = prof_event(h);
+        if (!e0 || !e1 || !e2) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+    }
+    hipLaunchKernelGGL(k_integrate, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->k, d_actions);
+    if (h->cfg.num_agents > 1) hipLaunchKernelGGL(k_collide, grid1d(N, 256), dim3(256), 0, h->stream, h->dev);
+    if (prof) HIPCHK(h, hipEventRecord(e1, h->stream));
+    {
+        RayJob j{};
+        j.n_rays = (uint32_t)N * (uint32_t)h->k.num_beams;
+        j.n_poses = N;
+        j.pose_x = h->dev.scan_pose;
+        j.pose_y = h->dev.scan_pose + N;
+        j.dir_start = h->dev.dir_start;
+        j.ranges = h->dev.scans;
+        j.vel = h->dev.state + 3 * (size_t)N;
+        j.step_count = h->dev.step_count;
+        j.noise = h->dev.noise;
+        j.noise_rows = h->dev.noise_rows;
+        j.beam_cos = h->dev.beam_cos;
+        j.side_dist = h->dev.side_dist;
+        j.wall_flag = h->dev.in_collision;
+        j.ttc_thresh = h->dev.ttc_thresh;
+        scan_rays_fn fn = pick_rays<true>(h->k, h->cfg.map_layout);
+        hipLaunchKernelGGL(fn, grid1d(j.n_rays, h->scan_block), dim3(h->scan_block), 0, h->stream, j, h->k);
+    }
+    if (prof) HIPCHK(h, hipEventRecord(e2, h->stream));
+    if (h->cfg.num_agents > 1)
+        hipLaunchKernelGGL(k_finalize, dim3(N), dim3(64), 0, h->stream, h->dev, h->k.num_beams);
+    else
+        hipLaunchKernelGGL(k_finalize_solo, grid1d(N, 256), dim3(256), 0, h->stream, h->dev);
+    HIPCHK(h, hipGetLastError());
+    return F110_OK;
+}
+
+int f110_step(f110_sim *h, const double *actions)
+{
+    if (!h || !actions) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, sizeof(double) * 2 * h->N, hipMemcpyHostToDevice, h->stream));
+    TRY(f110_step_device(h, h->d_actions));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // pageable host buffer: consumed on return
+    return F110_OK;
+}
+
+// ---- read-back ---------------------------------------------------------------------------
+static int copy_col(f110_sim *h, double *dst, const double *src, size_t n)
+{
+    if (dst) HIPCHK(h, hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return F110_OK;
+}
+
+int f110_get_obs(f110_sim *h, const f110_obs_host *o)
+{
+    if (!h || !o) return fail(h, F110_ERR_INVALID, "null argument");
+    const size_t N = (size_t)h->N;
+    const AgentArrays &d = h->dev;
+    TRY(copy_col(h, o->scans, d.scans, N * h->cfg.num_beams));
+    TRY(copy_col(h, o->poses_x, d.state, N));
+    TRY(copy_col(h, o->poses_y, d.state + N, N));
+    TRY(copy_col(h, o->poses_theta, d.state + 4 * N, N));
+    TRY(copy_col(h, o->linear_vels_x, d.state + 3 * N, N));
+    TRY(copy_col(h, o->ang_vels_z, d.state + 5 * N, N));
+    TRY(copy_col(h, o->collisions, d.collisions, N));
+    TRY(copy_col(h, o->collision_idx, d.collision_idx, N));
+    std::vector<double> soa, poses;
+    if (o->state) {
+        soa.resize(7 * N);
+        HIPCHK(h, hipMemcpyAsync(soa.data(), d.state, 7 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (o->agent_poses) {
+        poses.resize(3 * N);
+        HIPCHK(h, hipMemcpyAsync(poses.data(), d.snap_pose, 3 * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (o->in_collision) HIPCHK(h, hipMemcpyAsync(o->in_collision, d.in_collision, N * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (o->step_count) HIPCHK(h, hipMemcpyAsync(o->step_count, d.step_count, N * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (o->state)
+        for (size_t i = 0; i < N; ++i)
+            for (int c = 0; c < 7; ++c) o->state[7 * i + c] = soa[(size_t)c * N + i];
+    if (o->agent_poses)
+        for (size_t i = 0; i < N; ++i)
+            for (int c = 0; c < 3; ++c) o->agent_poses[3 * i + c] = poses[(size_t)c * N + i];
+    return F110_OK;
+}
+
+int f110_set_state(f110_sim *h, const double *state7, const double *steer_buf, const int32_t *buf_count)
+{
+    if (!h || !state7) return fail(h, F110_ERR_INVALID, "null argument");
+    const size_t N = (size_t)h->N;
+    std::vector<double> soa(7 * N);
+    for (size_t i = 0; i < N; ++i)
+        for (int c = 0; c < 7; ++c) soa[(size_t)c * N + i] = state7[7 * i + c];
+    HIPCHK(h, hipMemcpyAsync(h->dev.state, soa.data(), 7 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    std::vector<double> sb;
+    if (steer_buf) {
+        sb.resize(2 * N);
+        for (size_t i = 0; i < N; ++i) {
+            sb[i] = steer_buf[2 * i];
+            sb[N + i] = steer_buf[2 * i + 1];
+        }
+        HIPCHK(h, hipMemcpyAsync(h->dev.steer_buf, sb.data(), 2 * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    if (buf_count) HIPCHK(h, hipMemcpyAsync(h->dev.buf_cnt, buf_count, N * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_get_device_views(f110_sim *h, f110_device_views *v)
+{
+    if (!h || !v) return fail(h, F110_ERR_INVALID, "null argument");
+    v->scans = h->dev.scans;
+    v->state = h->dev.state;
+    v->agent_poses = h->dev.snap_pose;
+    v->collisions = h->dev.collisions;
+    v->collision_idx = h->dev.collision_idx;
+    v->in_collision = h->dev.in_collision;
+    v->step_count = h->dev.step_count;
+    v->stream = (void *)h->stream;
+    return F110_OK;
+}
+
+int f110_device_alloc(f110_sim *h, size_t bytes, void **out)
+{
+    if (!h || !out) return fail(h, F110_ERR_INVALID, "null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipMalloc(out, bytes ? bytes : 8));
+    return F110_OK;
+}
+
+int f110_device_free(f110_sim *h, void *p)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    if (p) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(p));
+    }
+    return F110_OK;
+}
+
+int f110_memcpy_h2d(f110_sim *h, void *dst, const void *src, size_t bytes)
+{
+    if (!h || !dst || !src) return fail(h, F110_ERR_INVALID, "null argument");
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_memcpy_d2h(f110_sim *h, void *dst, const void *src, size_t bytes)
+{
+    if (!h || !dst || !src) return fail(h, F110_ERR_INVALID, "null argument");
+    HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------
+int f110_timer_begin(f110_sim *h)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    HIPCHK(h, hipEventRecord(h->ev_begin, h->stream));
+    return F110_OK;
+}
+
+int f110_timer_end_ms(f110_sim *h, double *ms)
+{
+    if (!h || !ms) return fail(h, F110_ERR_INVALID, "null argument");
+    HIPCHK(h, hipEventRecord(h->ev_end, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev_end));
+    float f = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&f, h->ev_begin, h->ev_end));
+    *ms = (double)f;
+    return F110_OK;
+}
+
+int f110_profile_kernels(f110_sim *h, int32_t enable)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->profiling = enable != 0;
+    h->prof_used = 0;
+    return F110_OK;
+}
+
+int f110_profile_read(f110_sim *h, int32_t *n_launches, double *scan_ms, double *dyn_ms)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double s = 0, dsum = 0;
+    int n = 0;
+    for (size_t i = 0; i + 3 <= h->prof_used; i += 3) {
+        float a = 0.f, b = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&a, h->prof_events[i], h->prof_events[i + 1]));
+        HIPCHK(h, hipEventElapsedTime(&b, h->prof_events[i + 1], h->prof_events[i + 2]));
+        dsum += a;
+        s += b;
+        ++n;
+    }
+    if (n_launches) *n_launches = n;
+    if (scan_ms) *scan_ms = s;
+    if (dyn_ms) *dyn_ms = dsum;
+    return F110_OK;
+}
+
+// ---- unit entry points ---------------------------------------------------------------------
+int f110_scan_batch(f110_sim *h, const double *poses, int32_t m, double *ranges, int32_t *hit_rc, int64_t *lookups)
+{
+    if (!h || !poses || !ranges || m < 0) return fail(h, F110_ERR_INVALID, "f110_scan_batch: bad argument");
+    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    if (m == 0) return F110_OK;
+    const size_t B = (size_t)h->cfg.num_beams;
+    Scratch s(h);
+    double *dp = nullptr, *dr = nullptr;
+    int32_t *dh = nullptr;
+    unsigned long long *dl = nullptr;
+    TRY(s.up(poses, (size_t)3 * m, &dp));
+    TRY(s.up<double>(nullptr, (size_t)m * B, &dr));
+    if (hit_rc) TRY(s.up<int32_t>(nullptr, (size_t)m * B * 2, &dh));
+    if (lookups) {
+        TRY(s.up<unsigned long long>(nullptr, (size_t)m, &dl));
+        HIPCHK(h, hipMemsetAsync(dl, 0, sizeof(unsigned long long) * m, h->stream));
+    }
+    double *dpx = nullptr, *dpy = nullptr, *dst = nullptr;
+    TRY(s.up<double>(nullptr, (size_t)m, &dpx));
+    TRY(s.up<double>(nullptr, (size_t)m, &dpy));
+    TRY(s.up<double>(nullptr, (size_t)m, &dst));
+    hipLaunchKernelGGL(k_prepare_poses, grid1d(m, 128), dim3(128), 0, h->stream, h->k, dp, m, dpx, dpy, dst);
+    RayJob j{};
+    j.n_rays = (uint32_t)m * (uint32_t)B;
+    j.n_poses = m;
+    j.pose_x = dpx;
+    j.pose_y = dpy;
+    j.dir_start = dst;
+    j.ranges = dr;
+    j.hit_rc = dh;
+    j.lookups = dl;
+    scan_rays_fn fn = pick_rays<false>(h->k, h->cfg.map_layout);
+    hipLaunchKernelGGL(fn, grid1d(j.n_rays, h->scan_block), dim3(h->scan_block), 0, h->stream, j, h->k);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(ranges, dr, (size_t)m * B));
+    if (hit_rc) TRY(s.down(hit_rc, dh, (size_t)m * B * 2));
+    if (lookups) TRY(s.down(reinterpret_cast<unsigned long long *>(lookups), dl, (size_t)m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_beam_dir_index_batch(f110_sim *h, const double *thetas, int32_t m, int32_t *idx)
+{
+    if (!h || !thetas || !idx || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (m == 0) return F110_OK;
+    Scratch s(h);
+    double *dt = nullptr;
+    int32_t *di = nullptr;
+    TRY(s.up(thetas, (size_t)m, &dt));
+    TRY(s.up<int32_t>(nullptr, (size_t)m * h->cfg.num_beams, &di));
+    hipLaunchKernelGGL(k_dir_index_unit, dim3(m), dim3(128), 0, h->stream, h->k, dt, m, di);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(idx, di, (size_t)m * h->cfg.num_beams));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_dynamics_batch(f110_sim *h, const double *x, const double *u, const double *params, int32_t m, double *f_st, double *f_ks)
+{
+    if (!h || !x || !u || !params || !f_st || !f_ks || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (m == 0) return F110_OK;
+    Scratch s(h);
+    double *dx, *du, *dp, *dfs, *dfk;
+    TRY(s.up(x, (size_t)7 * m, &dx));
+    TRY(s.up(u, (size_t)2 * m, &du));
+    TRY(s.up(params, (size_t)NPARAMS, &dp));
+    TRY(s.up<double>(nullptr, (size_t)7 * m, &dfs));
+    TRY(s.up<double>(nullptr, (size_t)5 * m, &dfk));
+    hipLaunchKernelGGL(k_dynamics_unit, grid1d(m, 128), dim3(128), 0, h->stream, dx, du, dp, m, dfs, dfk);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(f_st, dfs, (size_t)7 * m));
+    TRY(s.down(f_ks, dfk, (size_t)5 * m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_pid_batch(f110_sim *h, const double *in, const double *params, int32_t m, double *out)
+{
+    if (!h || !in || !params || !out || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (m == 0) return F110_OK;
+    Scratch s(h);
+    double *di, *dp, *dout;
+    TRY(s.up(in, (size_t)4 * m, &di));
+    TRY(s.up(params, (size_t)NPARAMS, &dp));
+    TRY(s.up<double>(nullptr, (size_t)2 * m, &dout));
+    hipLaunchKernelGGL(k_pid_unit, grid1d(m, 128), dim3(128), 0, h->stream, di, dp, m, dout);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(out, dout, (size_t)2 * m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_update_pose_batch(f110_sim *h, const double *s0, const double *b0, const int32_t *c0, const double *act,
+                           const double *params, double dt, int32_t integ, double lidar_dist, int32_t m, double *s1,
+                           double *b1, int32_t *c1, double *spose)
+{
+    if (!h || !s0 || !b0 || !c0 || !act || !params || !s1 || !b1 || !c1 || !spose || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (integ != F110_INTEGRATOR_RK4 && integ != F110_INTEGRATOR_EULER) return fail(h, F110_ERR_INVALID, "Invalid Integrator Specified. Please choose RK4 or Euler");
+    if (m == 0) return F110_OK;
+    Scratch s(h);
+    double *ds0, *db0, *dact, *dp, *ds1, *db1, *dsp;
+    int32_t *dc0, *dc1;
+    TRY(s.up(s0, (size_t)7 * m, &ds0));
+    TRY(s.up(b0, (size_t)2 * m, &db0));
+    TRY(s.up(c0, (size_t)m, &dc0));
+    TRY(s.up(act, (size_t)2 * m, &dact));
+    TRY(s.up(params, (size_t)NPARAMS, &dp));
+    TRY(s.up<double>(nullptr, (size_t)7 * m, &ds1));
+    TRY(s.up<double>(nullptr, (size_t)2 * m, &db1));
+    TRY(s.up<int32_t>(nullptr, (size_t)m, &dc1));
+    TRY(s.up<double>(nullptr, (size_t)3 * m, &dsp));
+    hipLaunchKernelGGL(k_update_pose_unit, grid1d(m, 128), dim3(128), 0, h->stream, ds0, db0, dc0, dact, dp, dt, integ, lidar_dist, m, ds1, db1, dc1, dsp);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(s1, ds1, (size_t)7 * m));
+    TRY(s.down(b1, db1, (size_t)2 * m));
+    TRY(s.down(c1, dc1, (size_t)m));
+    TRY(s.down(spose, dsp, (size_t)3 * m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_get_vertices_batch(f110_sim *h, const double *poses, double length, double width, int32_t m, double *verts)
+{
+    if (!h || !poses || !verts || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (m == 0) return F110_OK;
+    Scratch s(h);
+    double *dp, *dv;
+    TRY(s.up(poses, (size_t)3 * m, &dp));
+    TRY(s.up<double>(nullptr, (size_t)8 * m, &dv));
+    hipLaunchKernelGGL(k_vertices_unit, grid1d(m, 128), dim3(128), 0, h->stream, dp, length, width, m, dv);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(verts, dv, (size_t)8 * m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_gjk_batch(f110_sim *h, const double *va, const double *vb, int32_t m, int32_t *flags)
+{
+    if (!h || !va || !vb || !flags || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (m == 0) return F110_OK;
+    Scratch s(h);
+    double *da, *db;
+    int32_t *df;
+    TRY(s.up(va, (size_t)8 * m, &da));
+    TRY(s.up(vb, (size_t)8 * m, &db));
+    TRY(s.up<int32_t>(nullptr, (size_t)m, &df));
+    hipLaunchKernelGGL(k_gjk_unit, grid1d(m, 128), dim3(128), 0, h->stream, da, db, m, df);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(flags, df, (size_t)m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_collision_multiple_batch(f110_sim *h, const double *verts, int32_t groups, int32_t n, double *col, double *idx)
+{
+    if (!h || !verts || !col || !idx || groups < 0 || n < 1) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (groups == 0) return F110_OK;
+    const size_t t = (size_t)groups * n;
+    Scratch s(h);
+    double *dv, *dc, *di;
+    TRY(s.up(verts, 8 * t, &dv));
+    TRY(s.up<double>(nullptr, t, &dc));
+    TRY(s.up<double>(nullptr, t, &di));
+    hipLaunchKernelGGL(k_collision_multiple_unit, grid1d(t, 128), dim3(128), 0, h->stream, dv, groups, n, dc, di);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(col, dc, t));
+    TRY(s.down(idx, di, t));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_ttc_batch(f110_sim *h, const double *scans, const double *vels, int32_t m, double thresh, int32_t *flags)
+{
+    if (!h || !scans || !vels || !flags || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (m == 0) return F110_OK;
+    const size_t B = (size_t)h->cfg.num_beams;
+    Scratch s(h);
+    double *ds, *dv;
+    int32_t *df;
+    TRY(s.up(scans, (size_t)m * B, &ds));
+    TRY(s.up(vels, (size_t)m, &dv));
+    TRY(s.up<int32_t>(nullptr, (size_t)m, &df));
+    hipLaunchKernelGGL(k_ttc_unit, dim3(m), dim3(128), 0, h->stream, ds, dv, m, (int)B, h->d_beam_cos, h->d_side, thresh, df);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(flags, df, (size_t)m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_raycast_batch(f110_sim *h, const double *ego, const double *verts, int32_t m, double *scans, int32_t *minmax)
+{
+    if (!h || !ego || !verts || !scans || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (m == 0) return F110_OK;
+    const size_t B = (size_t)h->cfg.num_beams;
+    Scratch s(h);
+    double *de, *dv, *ds;
+    int32_t *dm = nullptr;
+    TRY(s.up(ego, (size_t)3 * m, &de));
+    TRY(s.up(verts, (size_t)8 * m, &dv));
+    TRY(s.up(scans, (size_t)m * B, &ds));
+    if (minmax) TRY(s.up<int32_t>(nullptr, (size_t)2 * m, &dm));
+    hipLaunchKernelGGL(k_raycast_unit, dim3(m), dim3(128), 0, h->stream, de, dv, m, (int)B, h->d_scan_angles, h->dev.angle_inc, ds, dm);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(scans, ds, (size_t)m * B));
+    if (minmax) TRY(s.down(minmax, dm, (size_t)2 * m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_get_range_batch(f110_sim *h, const double *in, int32_t m, double *out)
+{
+    if (!h || !in || !out || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    if (m == 0) return F110_OK;
+    Scratch s(h);
+    double *di, *dout;
+    TRY(s.up(in, (size_t)8 * m, &di));
+    TRY(s.up<double>(nullptr, (size_t)m, &dout));
+    hipLaunchKernelGGL(k_get_range_unit, grid1d(m, 128), dim3(128), 0, h->stream, di, m, dout);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(out, dout, (size_t)m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_edt_sq(f110_sim *h, const uint8_t *img, int32_t H, int32_t W, uint32_t *d2)
+{
+    if (!h || !img || !d2) return fail(h, F110_ERR_INVALID, "null argument");
+    if (H < 1 || W < 1 || H > 16384 || W > 16384) return fail(h, F110_ERR_INVALID, "f110_edt_sq: bad shape %dx%d", H, W);
+    const size_t n = (size_t)H * W;
+    Scratch s(h);
+    uint8_t *dimg;
+    uint32_t *dg, *dd;
+    TRY(s.up(img, n, &dimg));
+    TRY(s.up<uint32_t>(nullptr, n, &dg));
+    TRY(s.up<uint32_t>(nullptr, n, &dd));
+    hipLaunchKernelGGL(k_edt_columns, grid1d(W, 64), dim3(64), 0, h->stream, dimg, H, W, dg);
+    hipLaunchKernelGGL(k_edt_rows, dim3(H), dim3(256), (size_t)W * sizeof(uint32_t), h->stream, dg, H, W, dd);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(d2, dd, n));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,459 @@
+// f110_math.hpp — scalar float64 building blocks of the env.step() hot path for gfx950.
+//
+// Every function is `__host__ __device__` so the very same code that the HIP kernels inline can
+// be exercised on the build container's CPU by tests/host_harness (there is no GPU there);
+// the product only ever runs the __device__ instantiations (f110_hip.hip).
+//
+// Bit-parity discipline: IEEE float64, the reference's operation order, and
+// the translation unit is compiled with -ffp-contract=off so `a*b + c` never becomes an FMA.
+// Reference citations are gym/f110_gym/envs/<file>:<line> of f1tenth_gym v0.2.1.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define F110_HD __host__ __device__ __forceinline__
+
+namespace f110 {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kTwoPi = 2.0 * kPi;
+
+// vehicle parameter slots, key order of f110_env.py:130
+enum { P_MU = 0, P_CSF, P_CSR, P_LF, P_LR, P_H, P_M, P_I, P_SMIN, P_SMAX, P_SVMIN, P_SVMAX,
+       P_VSWITCH, P_AMAX, P_VMIN, P_VMAX, P_WIDTH, P_LENGTH, NPARAMS };
+
+struct VehicleParams {
+    double v[NPARAMS];
+};
+
+// ------------------------------------------------------------------ dynamic_models.py
+// accl_constraints :29-60
+F110_HD double clamp_accel(double vel, double accl, const VehicleParams &p)
+{
+    const double a_max = p.v[P_AMAX];
+    const double pos_limit = (vel > p.v[P_VSWITCH]) ? a_max * p.v[P_VSWITCH] / vel : a_max;
+    if ((vel <= p.v[P_VMIN] && accl <= 0) || (vel >= p.v[P_VMAX] && accl >= 0)) return 0.;
+    if (accl <= -a_max) return -a_max;
+    if (accl >= pos_limit) return pos_limit;
+    return accl;
+}
+
+// steering_constraint :62-87
+F110_HD double clamp_steer_rate(double steer_angle, double sv, const VehicleParams &p)
+{
+    if ((steer_angle <= p.v[P_SMIN] && sv <= 0) || (steer_angle >= p.v[P_SMAX] && sv >= 0)) return 0.;
+    if (sv <= p.v[P_SVMIN]) return p.v[P_SVMIN];
+    if (sv >= p.v[P_SVMAX]) return p.v[P_SVMAX];
+    return sv;
+}
+
+// vehicle_dynamics_ks :90-121 — x[0..4], raw inputs (sv, accl); f[0..4]
+F110_HD void rhs_kinematic(const double *x, double sv_in, double accl_in, const VehicleParams &p, double *f)
+{
+    const double lwb = p.v[P_LF] + p.v[P_LR];
+    const double u0 = clamp_steer_rate(x[2], sv_in, p);
+    const double u1 = clamp_accel(x[3], accl_in, p);
+    f[0] = x[3] * cos(x[4]);
+    f[1] = x[3] * sin(x[4]);
+    f[2] = u0;
+    f[3] = u1;
+    f[4] = x[3] / lwb * tan(x[2]);
+}
+
+// vehicle_dynamics_st :123-176 — x[0..6] = (x, y, steer, v, yaw, yaw_rate, slip)
+F110_HD void rhs_single_track(const double *x, double sv_in, double accl_in, const VehicleParams &p, double *f)
+{
+    const double g = 9.81;
+    const double u0 = clamp_steer_rate(x[2], sv_in, p);
+    const double u1 = clamp_accel(x[3], accl_in, p);
+    if (fabs(x[3]) < 0.5) {
+        // :152-160 low-speed kinematic branch; the reference feeds the constrained inputs
+        // through vehicle_dynamics_ks, which constrains them once more.
+        const double lwb = p.v[P_LF] + p.v[P_LR];
+        rhs_kinematic(x, u0, u1, p, f);
+        const double cd = cos(x[2]);
+        f[5] = u1 / lwb * tan(x[2]) + x[3] / (lwb * (cd * cd)) * u0;
+        f[6] = 0.;
+        return;
+    }
+    const double mu = p.v[P_MU], csf = p.v[P_CSF], csr = p.v[P_CSR], lf = p.v[P_LF], lr = p.v[P_LR];
+    const double h = p.v[P_H], m = p.v[P_M], iz = p.v[P_I];
+    const double rear = g * lr - u1 * h;   // (g*lr - u[1]*h)
+    const double front = g * lf + u1 * h;  // (g*lf + u[1]*h)
+    const double wb = lr + lf;
+    f[0] = x[3] * cos(x[6] + x[4]);
+    f[1] = x[3] * sin(x[6] + x[4]);
+    f[2] = u0;
+    f[3] = u1;
+    f[4] = x[5];
+    // :169-171
+    const double t1 = -mu * m / (x[3] * iz * wb) * ((lf * lf) * csf * rear + (lr * lr) * csr * front) * x[5];
+    const double t2 = mu * m / (iz * wb) * (lr * csr * front - lf * csf * rear) * x[6];
+    const double t3 = mu * m / (iz * wb) * lf * csf * rear * x[2];
+    f[5] = t1 + t2 + t3;
+    // :172-174
+    const double s1 = (mu / ((x[3] * x[3]) * wb) * (csr * front * lr - csf * rear * lf) - 1) * x[5];
+    const double s2 = mu / (x[3] * wb) * (csr * front + csf * rear) * x[6];
+    const double s3 = mu / (x[3] * wb) * (csf * rear) * x[2];
+    f[6] = s1 - s2 + s3;
+}
+
+// pid :178-221
+F110_HD void speed_steer_controller(double speed, double steer, double cur_speed, double cur_steer,
+                                    const VehicleParams &p, double &accl, double &sv)
+{
+    const double steer_diff = steer - cur_steer;
+    sv = (fabs(steer_diff) > 1e-4) ? (steer_diff / fabs(steer_diff)) * p.v[P_SVMAX] : 0.0;
+    const double vel_diff = speed - cur_speed;
+    double kp;
+    if (cur_speed > 0.)
+        kp = (vel_diff > 0) ? 10.0 * p.v[P_AMAX] / p.v[P_VMAX] : 10.0 * p.v[P_AMAX] / (-p.v[P_VMIN]);
+    else
+        kp = (vel_diff > 0) ? 2.0 * p.v[P_AMAX] / p.v[P_VMAX] : 2.0 * p.v[P_AMAX] / (-p.v[P_VMIN]);
+    accl = kp * vel_diff;
+}
+
+// ------------------------------------------------------------------ base_classes.py
+// RaceCar.update_pose :256-409 minus the scan.  buf[0] = newest delayed steer command.
+F110_HD void advance_vehicle(double *st, double &buf0, double &buf1, int &buf_cnt, double raw_steer,
+                             double speed_cmd, const VehicleParams &p, double dt, int integrator,
+                             double lidar_dist, double *scan_pose)
+{
+    // :271-278 two-step steering delay
+    double steer = 0.;
+    if (buf_cnt < 2) {
+        buf_cnt += 1;
+    } else {
+        steer = buf1;
+    }
+    buf1 = buf0;
+    buf0 = raw_steer;
+
+    double accl, sv;
+    speed_steer_controller(speed_cmd, steer, st[3], st[2], p, accl, sv);  // :282
+
+    if (integrator == 1) {  // Integrator.RK4 :284-373
+        double k1[7], k2[7], k3[7], k4[7], tmp[7];
+        rhs_single_track(st, sv, accl, p, k1);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tmp[i] = st[i] + dt * (k1[i] / 2);
+        rhs_single_track(tmp, sv, accl, p, k2);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tmp[i] = st[i] + dt * (k2[i] / 2);
+        rhs_single_track(tmp, sv, accl, p, k3);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tmp[i] = st[i] + dt * k3[i];
+        rhs_single_track(tmp, sv, accl, p, k4);
+        const double w = dt * (1. / 6.);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) st[i] = st[i] + w * (((k1[i] + 2 * k2[i]) + 2 * k3[i]) + k4[i]);
+    } else {  // Integrator.Euler :375-395
+        double f[7];
+        rhs_single_track(st, sv, accl, p, f);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) st[i] = st[i] + dt * f[i];
+    }
+    // :400-404
+    if (st[4] > kTwoPi)
+        st[4] = st[4] - kTwoPi;
+    else if (st[4] < 0)
+        st[4] = st[4] + kTwoPi;
+    // :407-409
+    scan_pose[0] = st[0] + lidar_dist * cos(st[4]);
+    scan_pose[1] = st[1] + lidar_dist * sin(st[4]);
+    scan_pose[2] = st[4];
+}
+
+// ------------------------------------------------------------------ laser_models.py
+enum { LAYOUT_ROWMAJOR = 0, LAYOUT_TILED = 1 };
+
+struct ScanConst {
+    const double *table;   // distance table in the chosen layout
+    const double2 *cs;     // (cos, sin) of linspace(0, 2pi, theta_dis), interleaved
+    int32_t height, width, tiles_w, theta_dis;
+    int32_t num_beams, res_pow2, ident_rot, pad0;
+    double res, inv_res, orig_x, orig_y, orig_c, orig_s;
+    double w_res, h_res;   // width*resolution, height*resolution (xy_2_rc :79)
+    double oob_value;      // dt[-1,-1]: what an out-of-bounds sample reads (:80-81,:103)
+    double eps, max_range, fov, theta_inc, dir_guard;
+};
+
+template <int LAYOUT>
+F110_HD double table_fetch(const ScanConst &k, int r, int c)
+{
+    if (LAYOUT == LAYOUT_ROWMAJOR) {
+        return k.table[(uint32_t)r * (uint32_t)k.width + (uint32_t)c];
+    } else {
+        const uint32_t tile = (uint32_t)(r >> 2) * (uint32_t)k.tiles_w + (uint32_t)(c >> 2);
+        return k.table[tile * 16u + (uint32_t)(((r & 3) << 2) | (c & 3))];
+    }
+}
+
+// int(v / resolution) of xy_2_rc :83-84 for v in [0, extent).  When the resolution is a power
+// of two the reciprocal multiply is exact; otherwise the multiply decides unless the quotient
+// lands within 1e-9 of a cell boundary, where the true IEEE division is evaluated.
+template <bool POW2>
+F110_HD int cell_index(double v, const ScanConst &k)
+{
+    const double q = v * k.inv_res;
+    int ci = (int)q;
+    if (!POW2) {
+        const double fr = q - (double)ci;
+        if (fr < 1e-9 || fr > 1.0 - 1e-9) ci = (int)(v / k.res);
+    }
+    return ci;
+}
+
+// xy_2_rc :55-86 + distance_transform :88-104.  rc = (-1,-1) when out of bounds.
+template <int LAYOUT, bool POW2, bool IDENT>
+F110_HD double sample_distance(const ScanConst &k, double x, double y, int &r, int &c)
+{
+    const double xt = x - k.orig_x;
+    const double yt = y - k.orig_y;
+    double xr, yr;
+    if (IDENT) {  // origin yaw == 0: x_trans*1 + y_trans*0 == x_trans for finite values
+        xr = xt;
+        yr = yt;
+    } else {
+        xr = xt * k.orig_c + yt * k.orig_s;
+        yr = -xt * k.orig_s + yt * k.orig_c;
+    }
+    if (xr < 0 || xr >= k.w_res || yr < 0 || yr >= k.h_res) {
+        r = -1;
+        c = -1;
+        return k.oob_value;
+    }
+    c = cell_index<POW2>(xr, k);
+    r = cell_index<POW2>(yr, k);
+    return table_fetch<LAYOUT>(k, r, c);
+}
+
+// trace_ray :106-146 (sphere tracing over the distance table)
+template <int LAYOUT, bool POW2, bool IDENT>
+F110_HD double march_ray(const ScanConst &k, double x, double y, double c, double s, int &hit_r,
+                         int &hit_c, int &lookups)
+{
+    double d = sample_distance<LAYOUT, POW2, IDENT>(k, x, y, hit_r, hit_c);
+    double total = d;
+    int n = 1;
+    while (d > k.eps && total <= k.max_range) {
+        x += d * c;
+        y += d * s;
+        d = sample_distance<LAYOUT, POW2, IDENT>(k, x, y, hit_r, hit_c);
+        total += d;
+        ++n;
+    }
+    lookups = n;
+    return (total > k.max_range) ? k.max_range : total;
+}
+
+// get_scan :166-172
+F110_HD double scan_start_index(const ScanConst &k, double pose_theta)
+{
+    double ti = k.theta_dis * (pose_theta - k.fov / 2.) / (2. * kPi);
+    ti = fmod(ti, (double)k.theta_dis);
+    while (ti < 0) ti += k.theta_dis;
+    return ti;
+}
+
+// int(theta_index) of beam i (:124 with the running index of :177-184).  The reference adds
+// theta_index_increment i times in floating point; start + i*inc reproduces that to ~1e-10, so
+// the truncation is decided in closed form unless the value is within dir_guard of an integer,
+// in which case the sequential additions are replayed exactly.
+F110_HD int beam_dir_index(const ScanConst &k, double start, int i)
+{
+    const double td = (double)k.theta_dis;
+    double t = start + (double)i * k.theta_inc;
+    t -= floor(t / td) * td;
+    const double fr = t - floor(t);
+    if (fr < k.dir_guard || fr > 1.0 - k.dir_guard || t < 0 || t >= td) {
+        double ti = start;
+        for (int j = 0; j < i; ++j) {
+            ti += k.theta_inc;
+            while (ti >= td) ti -= td;
+        }
+        t = ti;
+    }
+    int idx = (int)t;
+    // theta_index == theta_dis can only arise from start + theta_dis rounding (:172); the
+    // reference would then index one past the table — clamp instead of reading out of bounds.
+    return idx >= k.theta_dis ? k.theta_dis - 1 : idx;
+}
+
+// check_ttc_jit :188-217 — one beam's predicate
+F110_HD bool ttc_beam_hit(double range, double side_distance, double vel, double beam_cos, double thresh)
+{
+    const double proj_vel = vel * beam_cos;
+    const double ttc = (range - side_distance) / proj_vel;
+    return (ttc < thresh) && (ttc >= 0.0);
+}
+
+// get_range :249-280 with v3 = (cos, sin)(beam_theta + pi/2) supplied by the caller
+F110_HD double edge_range(double ox, double oy, double v3x, double v3y, double vax, double vay,
+                          double vbx, double vby)
+{
+    const double v1x = ox - vax, v1y = oy - vay;
+    const double v2x = vbx - vax, v2y = vby - vay;
+    const double denom = v2x * v3x + v2y * v3y;
+    double distance = INFINITY;
+    if (fabs(denom) > 0.0) {
+        const double d1 = (v2x * v1y - v2y * v1x) / denom;
+        const double d2 = (v1x * v3x + v1y * v3y) / denom;
+        if (d1 >= 0.0 && d2 >= 0.0 && d2 <= 1.0) distance = d1;
+    } else {
+        // are_collinear(o, va, vb) :232-247
+        const double bax = vax - ox, bay = vay - oy;
+        const double cax = ox - vbx, cay = oy - vby;
+        if (fabs(bax * cay - bay * cax) < 1e-8) {
+            const double da = sqrt(bax * bax + bay * bay);
+            const double dbx = vbx - ox, dby = vby - oy;
+            const double db = sqrt(dbx * dbx + dby * dby);
+            distance = da < db ? da : db;
+        }
+    }
+    return distance;
+}
+
+// first index minimising |scan_angles[i] - a| (np.argmin, :310-313).  scan_angles is strictly
+// increasing (base_classes.py:133-134), so the minimum sits next to the closed-form estimate;
+// a +-3 neighbourhood is scanned with the reference's own comparison.
+F110_HD int nearest_beam(const double *scan_angles, int num_beams, double angle_inc, double a)
+{
+    double est = (a - scan_angles[0]) / angle_inc;
+    int i0 = est < 0 ? 0 : (est > (double)(num_beams - 1) ? num_beams - 1 : (int)est);
+    int lo = i0 - 3 < 0 ? 0 : i0 - 3;
+    int hi = i0 + 3 > num_beams - 1 ? num_beams - 1 : i0 + 3;
+    int best = lo;
+    double bv = fabs(scan_angles[lo] - a);
+    for (int i = lo + 1; i <= hi; ++i) {
+        const double v = fabs(scan_angles[i] - a);
+        if (v < bv) {
+            bv = v;
+            best = i;
+        }
+    }
+    return best;
+}
+
+// one vertex's beam index of get_blocked_view_indices :282-315
+F110_HD int vertex_beam_index(double ex, double ey, double etheta, double vx, double vy,
+                              const double *scan_angles, int num_beams, double angle_inc)
+{
+    const double dx = vx - ex, dy = vy - ey;
+    const double norm = sqrt(dx * dx + dy * dy);
+    const double ux = dx / norm, uy = dy / norm;
+    double angle = atan2(sin(etheta), cos(etheta)) - atan2(uy, ux);
+    if (angle > kPi)
+        angle = angle - 2 * kPi;
+    else if (angle < -kPi)
+        angle = angle + 2 * kPi;
+    return nearest_beam(scan_angles, num_beams, angle_inc, -angle);
+}
+
+// ------------------------------------------------------------------ collision_models.py
+// get_vertices :218-260 — order [rl, rr, fr, fl]; v[2*i], v[2*i+1]
+F110_HD void box_vertices(double x, double y, double th, double length, double width, double *v)
+{
+    const double c = cos(th), s = sin(th);
+    const double hx = length / 2, hy = width / 2;
+    const double bx[4] = {-hx, -hx, hx, hx};
+    const double by[4] = {hy, -hy, -hy, hy};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = ((c * bx[i] + (-s) * by[i]) + 0.) + x;
+        v[2 * i + 1] = ((s * bx[i] + c * by[i]) + 0.) + y;
+    }
+}
+
+F110_HD int furthest_vertex(const double *v, double dx, double dy)
+{
+    int best = 0;
+    double bv = v[0] * dx + v[1] * dy;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        const double val = v[2 * i] * dx + v[2 * i + 1] * dy;
+        if (val > bv) {
+            bv = val;
+            best = i;
+        }
+    }
+    return best;
+}
+
+F110_HD void minkowski_support(const double *v1, const double *v2, double dx, double dy, double &ax, double &ay)
+{
+    const int i = furthest_vertex(v1, dx, dy);
+    const int j = furthest_vertex(v2, -dx, -dy);
+    ax = v1[2 * i] - v2[2 * j];
+    ay = v1[2 * i + 1] - v2[2 * j + 1];
+}
+
+// tripleProduct(a, b, c) = b*(a.c) - a*(b.c)  :51-64
+F110_HD void triple_product(double ax, double ay, double bx, double by, double cx, double cy, double &ox, double &oy)
+{
+    const double ac = ax * cx + ay * cy;
+    const double bc = bx * cx + by * cy;
+    ox = bx * ac - ax * bc;
+    oy = by * ac - ay * bc;
+}
+
+// collision (GJK) :113-182 on two 4-vertex convex bodies
+F110_HD bool gjk_overlap(const double *v1, const double *v2)
+{
+    // simplex slots kept in scalars (no runtime-indexed arrays -> no scratch on gfx950)
+    double s0x, s0y, s1x = 0, s1y = 0;
+    double dx = (((v1[0] + v1[2]) + v1[4]) + v1[6]) / 4 - (((v2[0] + v2[2]) + v2[4]) + v2[6]) / 4;
+    double dy = (((v1[1] + v1[3]) + v1[5]) + v1[7]) / 4 - (((v2[1] + v2[3]) + v2[5]) + v2[7]) / 4;
+    if (dx == 0 && dy == 0) dx = 1.0;
+    double ax, ay;
+    minkowski_support(v1, v2, dx, dy, ax, ay);
+    s0x = ax;
+    s0y = ay;
+    if (dx * ax + dy * ay <= 0) return false;
+    dx = -ax;
+    dy = -ay;
+    int index = 0;
+    for (int iter = 0; iter < 1000;) {
+        minkowski_support(v1, v2, dx, dy, ax, ay);
+        index += 1;
+        if (dx * ax + dy * ay <= 0) return false;
+        const double aox = -ax, aoy = -ay;
+        if (index < 2) {
+            // line case: new point becomes simplex[1]
+            s1x = ax;
+            s1y = ay;
+            const double abx = s0x - ax, aby = s0y - ay;
+            triple_product(abx, aby, aox, aoy, abx, aby, dx, dy);
+            if (sqrt(dx * dx + dy * dy) < 1e-10) {  // perpendicular(ab) :34-48
+                dx = aby;
+                dy = -1 * abx;
+            }
+            continue;
+        }
+        // triangle case: a = simplex[2], b = simplex[1], c = simplex[0]
+        const double abx = s1x - ax, aby = s1y - ay;
+        const double acx = s0x - ax, acy = s0y - ay;
+        double px, py;
+        triple_product(abx, aby, acx, acy, acx, acy, px, py);  // acperp
+        if (px * aox + py * aoy >= 0) {
+            dx = px;
+            dy = py;
+        } else {
+            triple_product(acx, acy, abx, aby, abx, aby, px, py);  // abperp
+            if (px * aox + py * aoy < 0) return true;
+            s0x = s1x;
+            s0y = s1y;
+            dx = px;
+            dy = py;
+        }
+        s1x = ax;
+        s1y = ay;
+        index -= 1;
+        ++iter;
+    }
+    return false;
+}
+
+}  // namespace f110

@@ -1,0 +1,212 @@
+"""`F110Env` — the reference's gym façade (f110_env.py:53-418) over the MI355X simulator, plus
+`F110VecEnv`, the batched form RL loops should use (E envs per step, observations as arrays).
+
+Kept from the reference: constructor kwargs and defaults (:104-159), `reset(poses)` that
+advances one zero-action step and returns a 4-tuple (:306-349), `step(action)` returning
+(obs, reward=timestep, done, info={'checkpoint_done': ...}) (:263-304), the lap/finish logic
+(:204-246), `update_map`, `update_params`, `add_render_callback`.  Rendering (pyglet) is out of
+scope for this build: `render()` raises NotImplementedError.
+`gym` is optional: when importable F110Env subclasses gym.Env, otherwise `object`.
+"""
+import os
+
+import numpy as np
+
+from . import _ffi
+from .core import DEFAULT_PARAMS
+from .sim import Integrator, Simulator
+
+try:  # pragma: no cover - gym is absent from the build image
+    import gym as _gym
+    _EnvBase = _gym.Env
+except Exception:  # noqa: BLE001
+    _EnvBase = object
+
+_PKG_MAPS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "maps")
+
+
+def _resolve_map_path(kwargs):
+    """f110_env.py:108-120: named maps ship with the package, anything else is a path stem."""
+    if 'map' not in kwargs:
+        return 'vegas', os.path.join(_PKG_MAPS, 'vegas.yaml')
+    name = kwargs['map']
+    if name in ('berlin', 'skirk', 'levine', 'vegas', 'stata_basement'):
+        return name, os.path.join(_PKG_MAPS, name + '.yaml')
+    return name, name + '.yaml'
+
+
+class _LapLogic(object):
+    """The start/finish bookkeeping of F110Env._check_done (f110_env.py:204-246), vectorised
+    over a leading env axis: arrays are [E][A]."""
+
+    def __init__(self, num_envs, num_agents, ego_idx):
+        self.E, self.A, self.ego = num_envs, num_agents, ego_idx
+        self.start_xs = np.zeros((num_envs, num_agents))
+        self.start_ys = np.zeros((num_envs, num_agents))
+        self.start_thetas = np.zeros((num_envs, num_agents))
+        self.rot_c = np.ones((num_envs,))
+        self.rot_s = np.zeros((num_envs,))
+        self.near_starts = np.ones((num_envs, num_agents), dtype=bool)
+        self.toggle_list = np.zeros((num_envs, num_agents))
+        self.lap_times = np.zeros((num_envs, num_agents))
+        self.lap_counts = np.zeros((num_envs, num_agents))
+        self.current_time = np.zeros((num_envs,))
+
+    def reset(self, poses, env_mask=None):
+        m = np.ones((self.E,), dtype=bool) if env_mask is None else np.asarray(env_mask, dtype=bool)
+        poses = np.asarray(poses, dtype=np.float64).reshape(self.E, self.A, 3)
+        self.current_time[m] = 0.0
+        self.near_starts[m] = True
+        self.toggle_list[m] = 0
+        self.start_xs[m] = poses[m, :, 0]
+        self.start_ys[m] = poses[m, :, 1]
+        self.start_thetas[m] = poses[m, :, 2]
+        th = -self.start_thetas[:, self.ego]
+        self.rot_c[m] = np.cos(th)[m]
+        self.rot_s[m] = np.sin(th)[m]
+
+    def update(self, poses_x, poses_y, collisions, timestep):
+        """returns done[E], checkpoint_done[E][A]"""
+        left_t, right_t = 2, 2
+        self.current_time = self.current_time + timestep
+        px = np.asarray(poses_x, dtype=np.float64).reshape(self.E, self.A) - self.start_xs
+        py = np.asarray(poses_y, dtype=np.float64).reshape(self.E, self.A) - self.start_ys
+        c, s = self.rot_c[:, None], self.rot_s[:, None]
+        dx = c * px + (-s) * py          # start_rot @ [px; py], f110_env.py:223,331
+        temp_y = s * px + c * py
+        idx1 = temp_y > left_t
+        idx2 = temp_y < -right_t
+        temp_y = np.where(idx1, temp_y - left_t, np.where(idx2, -right_t - temp_y, 0.0))
+        dist2 = dx ** 2 + temp_y ** 2
+        closes = dist2 <= 0.1
+        entered = closes & ~self.near_starts
+        left = ~closes & self.near_starts
+        self.near_starts = np.where(entered, True, np.where(left, False, self.near_starts))
+        self.toggle_list = self.toggle_list + (entered | left)
+        self.lap_counts[...] = self.toggle_list // 2
+        running = self.toggle_list < 4
+        self.lap_times[...] = np.where(running, self.current_time[:, None], self.lap_times)
+        col = np.asarray(collisions).reshape(self.E, self.A)
+        done = (col[:, self.ego] != 0) | np.all(self.toggle_list >= 4, axis=1)
+        return done, self.toggle_list >= 4
+
+
+class F110Env(_EnvBase):
+    metadata = {'render.modes': ['human', 'human_fast']}
+    render_callbacks = []
+
+    def __init__(self, **kwargs):
+        self.seed = kwargs.get('seed', 12345)
+        self.map_name, self.map_path = _resolve_map_path(kwargs)
+        self.map_ext = kwargs.get('map_ext', '.png')
+        self.params = kwargs.get('params', dict(DEFAULT_PARAMS))
+        self.num_agents = kwargs.get('num_agents', 2)
+        self.timestep = kwargs.get('timestep', 0.01)
+        self.ego_idx = kwargs.get('ego_idx', 0)
+        self.integrator = kwargs.get('integrator', Integrator.RK4)
+        self.lidar_dist = kwargs.get('lidar_dist', 0.0)
+        self.start_thresh = 0.5
+        self.poses_x, self.poses_y, self.poses_theta = [], [], []
+        self.collisions = np.zeros((self.num_agents,))
+        self._lap = _LapLogic(1, self.num_agents, self.ego_idx)
+        self.sim = Simulator(self.params, self.num_agents, self.seed, time_step=self.timestep,
+                             ego_idx=self.ego_idx, integrator=self.integrator, lidar_dist=self.lidar_dist,
+                             device_id=kwargs.get('device_id', 0),
+                             map_layout=kwargs.get('map_layout', _ffi.MAP_ROWMAJOR_F64))
+        self.sim.set_map(self.map_path, self.map_ext)
+        self.render_obs = None
+        self.current_obs = None
+
+    # attributes user code reads off the reference env
+    lap_times = property(lambda self: self._lap.lap_times[0])
+    lap_counts = property(lambda self: self._lap.lap_counts[0])
+    current_time = property(lambda self: float(self._lap.current_time[0]))
+    toggle_list = property(lambda self: self._lap.toggle_list[0])
+    near_starts = property(lambda self: self._lap.near_starts[0])
+    start_xs = property(lambda self: self._lap.start_xs[0])
+    start_ys = property(lambda self: self._lap.start_ys[0])
+    start_thetas = property(lambda self: self._lap.start_thetas[0])
+
+    def step(self, action):
+        obs = self.sim.step(action)
+        obs['lap_times'] = self._lap.lap_times[0]
+        obs['lap_counts'] = self._lap.lap_counts[0]
+        self.current_obs = obs
+        self.render_obs = {k: obs[k] for k in ('ego_idx', 'poses_x', 'poses_y', 'poses_theta', 'lap_times', 'lap_counts')}
+        reward = self.timestep
+        self.poses_x, self.poses_y, self.poses_theta = obs['poses_x'], obs['poses_y'], obs['poses_theta']
+        self.collisions = obs['collisions']
+        done, toggles = self._lap.update(obs['poses_x'], obs['poses_y'], obs['collisions'], self.timestep)
+        info = {'checkpoint_done': toggles[0]}
+        return obs, reward, bool(done[0]), info
+
+    def reset(self, poses):
+        poses = np.asarray(poses, dtype=np.float64)
+        self.collisions = np.zeros((self.num_agents,))
+        self.sim.reset(poses)               # raises ValueError on a pose-count mismatch
+        self._lap.reset(poses)
+        action = np.zeros((self.num_agents, 2))
+        return self.step(action)            # f110_env.py:337-338: reset advances one step
+
+    def update_map(self, map_path, map_ext):
+        self.sim.set_map(map_path, map_ext)
+
+    def update_params(self, params, index=-1):
+        self.sim.update_params(params, agent_idx=index)
+
+    def add_render_callback(self, callback_func):
+        F110Env.render_callbacks.append(callback_func)
+
+    def render(self, mode='human'):
+        assert mode in ['human', 'human_fast']
+        raise NotImplementedError("rendering (pyglet) is outside this build's scope; use obs['poses_*']")
+
+
+class F110VecEnv(object):
+    """E independent F110 environments stepped by one device launch sequence.
+
+    reset(poses[E][A][3], env_mask=None) / step(actions[E][A][2]) -> (obs, reward, done[E], info)
+    with array observations (leading env axis).  `auto_reset=True` re-seats finished envs at
+    their start poses inside step() (mask reset in place) — like the reference's
+    reset() that costs them one zero-action step, taken on the next call.
+    """
+
+    def __init__(self, num_envs, auto_reset=False, **kwargs):
+        self.num_envs = int(num_envs)
+        self.seed = kwargs.get('seed', 12345)
+        self.map_name, self.map_path = _resolve_map_path(kwargs)
+        self.map_ext = kwargs.get('map_ext', '.png')
+        self.params = kwargs.get('params', dict(DEFAULT_PARAMS))
+        self.num_agents = kwargs.get('num_agents', 2)
+        self.timestep = kwargs.get('timestep', 0.01)
+        self.ego_idx = kwargs.get('ego_idx', 0)
+        self.auto_reset = auto_reset
+        self._lap = _LapLogic(self.num_envs, self.num_agents, self.ego_idx)
+        self.sim = Simulator(self.params, self.num_agents, self.seed, time_step=self.timestep,
+                             ego_idx=self.ego_idx, integrator=kwargs.get('integrator', Integrator.RK4),
+                             lidar_dist=kwargs.get('lidar_dist', 0.0), num_envs=self.num_envs,
+                             num_beams=kwargs.get('num_beams', 1080), fov=kwargs.get('fov', 4.7),
+                             scan_noise_std=kwargs.get('scan_noise_std', 0.01),
+                             device_id=kwargs.get('device_id', 0),
+                             map_layout=kwargs.get('map_layout', _ffi.MAP_ROWMAJOR_F64))
+        self.sim.set_map(self.map_path, self.map_ext)
+        self._start_poses = None
+
+    def reset(self, poses, env_mask=None):
+        poses = np.asarray(poses, dtype=np.float64).reshape(self.num_envs, self.num_agents, 3)
+        self._start_poses = poses.copy() if self._start_poses is None or env_mask is None else \
+            np.where(np.asarray(env_mask, dtype=bool)[:, None, None], poses, self._start_poses)
+        self.sim.reset(poses, env_mask)
+        self._lap.reset(poses, env_mask)
+        return self.step(np.zeros((self.num_envs, self.num_agents, 2)))
+
+    def step(self, actions):
+        obs = self.sim.step(actions)
+        done, toggles = self._lap.update(obs['poses_x'], obs['poses_y'], obs['collisions'], self.timestep)
+        obs['lap_times'] = self._lap.lap_times
+        obs['lap_counts'] = self._lap.lap_counts
+        info = {'checkpoint_done': toggles}
+        if self.auto_reset and done.any():
+            self.sim.reset(self._start_poses, done)
+            self._lap.reset(self._start_poses, done)
+        return obs, self.timestep, done, info

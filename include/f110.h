@@ -1,0 +1,213 @@
+/*
+ * f110.h — C ABI of libf110_hip.so: the MI355X (gfx950) batched F1TENTH env.step() hot path.
+ *
+ * The reference (f1tenth/f1tenth_gym v0.2.1) has no FFI: its operator boundary is the set of
+ * Python call sites where RaceCar/Simulator call the @njit kernels.  Each entry point below
+ * names the reference interface it replaces (paths relative to gym/f110_gym/envs/).  The
+ * Python host package f1tenth_gym_amd binds exactly these symbols with ctypes
+ * (f1tenth_gym_amd/_ffi.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every call returns 0 (F110_OK) or a negative code and
+ *     leaves a message retrievable with f110_last_error() (handle may be NULL for create).
+ *   - "h_" pointers are host memory owned by the caller, consumed before the call returns
+ *     (or before f110_sync for *_async variants); "d_" pointers are device memory.
+ *   - one handle = one GPU + one HIP stream; calls on one handle must be serialised by the
+ *     caller, different handles may be driven from different threads / processes.
+ *   - agents are indexed i = env * num_agents + agent  (N = num_envs * num_agents);
+ *     all arithmetic is IEEE float64 in the reference's operation order (no FMA contraction).
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails.
+ */
+#ifndef F110_H
+#define F110_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F110_ABI_VERSION 1
+
+enum {
+    F110_OK = 0,
+    F110_ERR_INVALID = -1,   /* bad argument (ValueError / IndexError on the Python side) */
+    F110_ERR_NO_MAP = -2,    /* scan/step before a map is set (laser_models.py:445-446) */
+    F110_ERR_HIP = -3,       /* HIP runtime / device error */
+    F110_ERR_STATE = -4,     /* call not valid in the handle's current state */
+    F110_ERR_NOMEM = -5
+};
+
+/* vehicle parameter vector: key order of f110_env.py:130 */
+enum {
+    F110_P_MU = 0, F110_P_CSF, F110_P_CSR, F110_P_LF, F110_P_LR, F110_P_H, F110_P_M, F110_P_I,
+    F110_P_SMIN, F110_P_SMAX, F110_P_SVMIN, F110_P_SVMAX, F110_P_VSWITCH, F110_P_AMAX,
+    F110_P_VMIN, F110_P_VMAX, F110_P_WIDTH, F110_P_LENGTH, F110_NPARAMS
+};
+
+enum { F110_INTEGRATOR_RK4 = 1, F110_INTEGRATOR_EULER = 2 }; /* base_classes.py:40-42 */
+
+/* distance-table layouts in HBM (DESIGN.md §data layout) */
+enum {
+    F110_MAP_ROWMAJOR_F64 = 0, /* dt[r][c] as the reference stores it */
+    F110_MAP_TILED_F64 = 1     /* 4x4-cell tiles, one 128-byte line per tile */
+};
+
+/* Simulator(params, num_agents, seed, time_step, ego_idx, integrator, lidar_dist)
+ * base_classes.py:465 + RaceCar(num_beams=1080, fov=4.7) :69 + ScanSimulator2D(eps, theta_dis,
+ * max_range) laser_models.py:360 + ttc_thresh base_classes.py:115.  */
+typedef struct f110_config {
+    int32_t abi_version;   /* F110_ABI_VERSION */
+    int32_t num_envs;      /* E independent environments (extension; reference has 1) */
+    int32_t num_agents;    /* A agents per environment */
+    int32_t num_beams;     /* B */
+    int32_t theta_dis;
+    int32_t integrator;
+    int32_t device_id;     /* HIP device ordinal */
+    int32_t map_layout;    /* F110_MAP_* */
+    int32_t scan_block;    /* threads per scan workgroup (0 = default) */
+    int32_t reserved0;
+    double fov, eps, max_range;
+    double time_step, lidar_dist, ttc_thresh;
+    double params[F110_NPARAMS]; /* initial vehicle params for every agent slot */
+} f110_config;
+
+typedef struct f110_sim f110_sim;
+
+const char *f110_last_error(const f110_sim *h);
+int f110_abi_version(void);
+int f110_device_count(int *count);
+
+int f110_create(const f110_config *cfg, f110_sim **out);
+void f110_destroy(f110_sim *h);
+int f110_sync(f110_sim *h);
+
+/* ---- ScanSimulator2D.set_map  laser_models.py:383-427 ----
+ * image: h_img [height][width] uint8, top row first as PIL decodes it; the library does the
+ * FLIP_TOP_BOTTOM (:399), the <=128 threshold (:403-404), the exact EDT (:425,:40-53) and
+ * dt = resolution*sqrt(d2) on the device.  origin = yaml 'origin' (x, y, yaw). */
+int f110_set_map_image(f110_sim *h, const uint8_t *h_img, int32_t height, int32_t width,
+                       double resolution, double origin_x, double origin_y, double origin_yaw);
+/* same, from a caller-supplied distance table (row 0 = bottom of the picture). */
+int f110_set_map_dt(f110_sim *h, const double *h_dt, int32_t height, int32_t width,
+                    double resolution, double origin_x, double origin_y, double origin_c,
+                    double origin_s);
+int f110_get_map_dt(f110_sim *h, double *h_dt_out); /* row-major [height][width] */
+int f110_map_shape(f110_sim *h, int32_t *height, int32_t *width);
+
+/* sines/cosines = sin/cos(linspace(0, 2pi, theta_dis))  laser_models.py:379-381 (host-computed
+ * so they are bit-identical to NumPy's). */
+int f110_set_trig_tables(f110_sim *h, const double *h_sines, const double *h_cosines, int32_t n);
+/* RaceCar class-level per-beam tables, base_classes.py:125-158 */
+int f110_set_beam_tables(f110_sim *h, const double *h_scan_angles, const double *h_cosines,
+                         const double *h_side_distances, int32_t num_beams);
+/* Simulator.update_params base_classes.py:514-534 (agent_idx<0: all slots) */
+int f110_set_params(f110_sim *h, int32_t agent_idx, const double *h_params18);
+/* scan noise, laser_models.py:450-452 with base_classes.py:204: row k is added to every
+ * agent's scan on its k-th step after reset (rows wrap modulo n_rows).  n_rows=0: no noise. */
+int f110_set_noise_table(f110_sim *h, const double *h_noise, int32_t n_rows, int32_t num_beams);
+
+/* Simulator.reset base_classes.py:614-630 / RaceCar.reset :183-204.
+ * h_poses [N][3]; h_env_mask [num_envs] or NULL (all). */
+int f110_reset(f110_sim *h, const double *h_poses, const uint8_t *h_env_mask);
+int f110_reset_device(f110_sim *h, const double *d_poses, const uint8_t *d_env_mask);
+
+/* Simulator.step base_classes.py:553-612.  actions [N][2] = (steer, speed).
+ * Asynchronous on the handle's stream; outputs are read with f110_get_* (which sync). */
+int f110_step(f110_sim *h, const double *h_actions);
+int f110_step_device(f110_sim *h, const double *d_actions);
+
+/* observation / state read-back (device -> host).  Any pointer may be NULL. */
+typedef struct f110_obs_host {
+    double *scans;          /* [N][B]  obs['scans'] */
+    double *poses_x;        /* [N] */
+    double *poses_y;        /* [N] */
+    double *poses_theta;    /* [N] */
+    double *linear_vels_x;  /* [N] */
+    double *ang_vels_z;     /* [N] */
+    double *collisions;     /* [N]  GJK flag OR wall flag (base_classes.py:588-589) */
+    double *collision_idx;  /* [N]  collision_models.py:184-212 */
+    double *state;          /* [N][7] RaceCar.state */
+    double *agent_poses;    /* [N][3] Simulator.agent_poses (:574 snapshot) */
+    int32_t *in_collision;  /* [N]  RaceCar.in_collision */
+    int32_t *step_count;    /* [N]  steps since reset */
+} f110_obs_host;
+int f110_get_obs(f110_sim *h, const f110_obs_host *out);
+int f110_set_state(f110_sim *h, const double *h_state7 /* [N][7] */,
+                   const double *h_steer_buf /* [N][2] newest first, or NULL */,
+                   const int32_t *h_buf_count /* [N] or NULL */);
+
+/* device-resident observation buffers (valid until f110_destroy; contents valid after the
+ * step that produced them completes on the stream).  SoA columns of N doubles. */
+typedef struct f110_device_views {
+    double *scans;        /* [N][B] */
+    double *state;        /* [7][N] columns x, y, steer, v, yaw, yaw_rate, slip */
+    double *agent_poses;  /* [3][N] */
+    double *collisions;   /* [N] */
+    double *collision_idx;
+    int32_t *in_collision;
+    int32_t *step_count;
+    void *stream;         /* hipStream_t */
+} f110_device_views;
+int f110_get_device_views(f110_sim *h, f110_device_views *out);
+int f110_device_alloc(f110_sim *h, size_t bytes, void **d_out);
+int f110_device_free(f110_sim *h, void *d_ptr);
+int f110_memcpy_h2d(f110_sim *h, void *d_dst, const void *h_src, size_t bytes);
+int f110_memcpy_d2h(f110_sim *h, void *h_dst, const void *d_src, size_t bytes);
+
+/* HIP-event timing on the handle's stream (bench.py roofline leg).
+ * f110_timer_begin/_end bracket a region; f110_profile_kernels(1) additionally brackets
+ * every scan-kernel launch inside f110_step with its own event pair. */
+int f110_timer_begin(f110_sim *h);
+int f110_timer_end_ms(f110_sim *h, double *ms);
+int f110_profile_kernels(f110_sim *h, int32_t enable);
+int f110_profile_read(f110_sim *h, int32_t *n_launches, double *scan_ms_total,
+                      double *dyn_ms_total);
+
+/* ---- unit entry points (one per reference kernel; used by the parity tests) ---- */
+/* ScanSimulator2D.scan(pose, None)  laser_models.py:429-454 -> get_scan :148-186.
+ * h_ranges [M][B]; h_hit_rc [M][B][2] (r,c) of the terminating sample or NULL;
+ * h_lookups [M] table lookups per pose or NULL. */
+int f110_scan_batch(f110_sim *h, const double *h_poses, int32_t m, double *h_ranges,
+                    int32_t *h_hit_rc, int64_t *h_lookups);
+/* vehicle_dynamics_st / vehicle_dynamics_ks  dynamic_models.py:90-176; x [M][7], u [M][2] */
+int f110_dynamics_batch(f110_sim *h, const double *h_x, const double *h_u,
+                        const double *h_params18, int32_t m, double *h_f_st, double *h_f_ks);
+/* pid  dynamic_models.py:178-221; in [M][4] = (speed, steer, current_speed, current_steer) */
+int f110_pid_batch(f110_sim *h, const double *h_in, const double *h_params18, int32_t m,
+                   double *h_accl_sv /* [M][2] */);
+/* RaceCar.update_pose  base_classes.py:256-409 (without the scan) */
+int f110_update_pose_batch(f110_sim *h, const double *h_state0, const double *h_buf0,
+                           const int32_t *h_cnt0, const double *h_actions,
+                           const double *h_params18, double time_step, int32_t integrator,
+                           double lidar_dist, int32_t m, double *h_state1, double *h_buf1,
+                           int32_t *h_cnt1, double *h_scan_pose);
+/* get_vertices collision_models.py:237-260; poses [M][3] -> [M][4][2] */
+int f110_get_vertices_batch(f110_sim *h, const double *h_poses, double length, double width,
+                            int32_t m, double *h_vertices);
+/* collision (GJK) collision_models.py:113-182 on M pairs of [4][2] */
+int f110_gjk_batch(f110_sim *h, const double *h_va, const double *h_vb, int32_t m,
+                   int32_t *h_flags);
+/* collision_multiple :184-212 on G groups of n bodies [G][n][4][2] */
+int f110_collision_multiple_batch(f110_sim *h, const double *h_vertices, int32_t groups,
+                                  int32_t n, double *h_collisions, double *h_collision_idx);
+/* check_ttc_jit laser_models.py:188-217 on M scans [M][B] with the handle's beam tables */
+int f110_ttc_batch(f110_sim *h, const double *h_scans, const double *h_vels, int32_t m,
+                   double ttc_thresh, int32_t *h_flags);
+/* ray_cast laser_models.py:318-346 (+ get_blocked_view_indices :282-315) on M cases:
+ * ego pose [M][3], opponent vertices [M][4][2], scans in/out [M][B], window [M][2] or NULL */
+int f110_raycast_batch(f110_sim *h, const double *h_ego, const double *h_vertices, int32_t m,
+                       double *h_scans_inout, int32_t *h_min_max_ind);
+/* get_range laser_models.py:249-280; in [M][8] = (pose3, beam_theta, va2, vb2) */
+int f110_get_range_batch(f110_sim *h, const double *h_in, int32_t m, double *h_out);
+/* exact squared EDT of a binary image (nonzero = free), laser_models.py:40-53 */
+int f110_edt_sq(f110_sim *h, const uint8_t *h_img, int32_t height, int32_t width,
+                uint32_t *h_d2);
+/* table index int(theta_index) of every beam for M headings (get_scan :167-184) */
+int f110_beam_dir_index_batch(f110_sim *h, const double *h_thetas, int32_t m, int32_t *h_idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* F110_H */

@@ -1,0 +1,171 @@
+// tests/host_harness/harness.hip — TEST TOOLING, not part of the product.
+//
+// f1tenth_gym_amd/csrc/f110_math.hpp is written as __host__ __device__ code.  The build
+// container has no GPU, so this harness compiles the HOST instantiation of those same
+// functions into a small shared library that tests/test_host_math.py compares with the
+// oracle.  It catches arithmetic/ordering mistakes before GPU minutes are spent; the GPU
+// parity tests (-m gpu) remain the parity proof for the device instantiation.
+#include <vector>
+
+#include "../../f1tenth_gym_amd/csrc/f110_math.hpp"
+
+using namespace f110;
+
+extern "C" {
+
+void hh_rhs(const double *x, const double *u, const double *p, double *f_st, double *f_ks)
+{
+    VehicleParams vp;
+    for (int i = 0; i < NPARAMS; ++i) vp.v[i] = p[i];
+    rhs_single_track(x, u[0], u[1], vp, f_st);
+    rhs_kinematic(x, u[0], u[1], vp, f_ks);
+}
+
+void hh_pid(const double *in, const double *p, double *out)
+{
+    VehicleParams vp;
+    for (int i = 0; i < NPARAMS; ++i) vp.v[i] = p[i];
+    speed_steer_controller(in[0], in[1], in[2], in[3], vp, out[0], out[1]);
+}
+
+void hh_advance(double *st, double *buf, int *cnt, double steer, double speed, const double *p, double dt,
+                int integ, double lidar_dist, double *scan_pose)
+{
+    VehicleParams vp;
+    for (int i = 0; i < NPARAMS; ++i) vp.v[i] = p[i];
+    advance_vehicle(st, buf[0], buf[1], *cnt, steer, speed, vp, dt, integ, lidar_dist, scan_pose);
+}
+
+// layout: 0 row-major, 1 tiled 4x4
+void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, double oy, double oc, double os,
+             const double *sines, const double *cosines, int theta_dis, int B, double fov, double eps,
+             double max_range, const double *pose, double *ranges, int *hit_rc, int *dir_idx, long long *lookups)
+{
+    ScanConst k{};
+    std::vector<double> tiled;
+    std::vector<double2> cs(theta_dis);
+    for (int i = 0; i < theta_dis; ++i) cs[i] = make_double2(cosines[i], sines[i]);
+    k.cs = cs.data();
+    k.height = H; k.width = W; k.tiles_w = (W + 3) / 4; k.theta_dis = theta_dis; k.num_beams = B;
+    k.res = res; k.inv_res = 1.0 / res;
+    int e; k.res_pow2 = (frexp(res, &e) == 0.5) ? 1 : 0;
+    k.orig_x = ox; k.orig_y = oy; k.orig_c = oc; k.orig_s = os;
+    k.ident_rot = (oc == 1.0 && os == 0.0) ? 1 : 0;
+    k.w_res = W * res; k.h_res = H * res;
+    k.oob_value = dt[(size_t)H * W - 1];
+    k.eps = eps; k.max_range = max_range; k.fov = fov;
+    k.theta_inc = theta_dis * (fov / (B - 1)) / (2. * kPi);
+    const double g = 64.0 * (double)B * 2.2737367544323206e-13;
+    k.dir_guard = g > 1e-8 ? g : 1e-8;
+    if (layout == 1) {
+        const int th = (H + 3) / 4;
+        tiled.assign((size_t)k.tiles_w * th * 16, 0.0);
+        for (int r = 0; r < H; ++r)
+            for (int c = 0; c < W; ++c)
+                tiled[((size_t)(r >> 2) * k.tiles_w + (c >> 2)) * 16 + ((r & 3) << 2 | (c & 3))] = dt[(size_t)r * W + c];
+        k.table = tiled.data();
+    } else {
+        k.table = dt;
+    }
+    const double start = scan_start_index(k, pose[2]);
+    long long total = 0;
+    for (int b = 0; b < B; ++b) {
+        const int idx = beam_dir_index(k, start, b);
+        dir_idx[b] = idx;
+        int hr, hc, nl;
+        double r;
+#define RUN(L, P, I) r = march_ray<L, P, I>(k, pose[0], pose[1], cs[idx].x, cs[idx].y, hr, hc, nl)
+        if (layout == 1) {
+            if (k.res_pow2) { if (k.ident_rot) RUN(1, true, true); else RUN(1, true, false); }
+            else { if (k.ident_rot) RUN(1, false, true); else RUN(1, false, false); }
+        } else {
+            if (k.res_pow2) { if (k.ident_rot) RUN(0, true, true); else RUN(0, true, false); }
+            else { if (k.ident_rot) RUN(0, false, true); else RUN(0, false, false); }
+        }
+#undef RUN
+        ranges[b] = r;
+        hit_rc[2 * b] = hr;
+        hit_rc[2 * b + 1] = hc;
+        total += nl;
+    }
+    *lookups = total;
+}
+
+// force the generic (non-pow2 / rotated) code path on any map: used to cross-check the
+// specialisations against each other
+void hh_scan_generic(const double *dt, int H, int W, double res, double ox, double oy, double oc, double os,
+                     const double *sines, const double *cosines, int theta_dis, int B, double fov, double eps,
+                     double max_range, const double *pose, double *ranges)
+{
+    ScanConst k{};
+    std::vector<double2> cs(theta_dis);
+    for (int i = 0; i < theta_dis; ++i) cs[i] = make_double2(cosines[i], sines[i]);
+    k.cs = cs.data(); k.table = dt;
+    k.height = H; k.width = W; k.tiles_w = (W + 3) / 4; k.theta_dis = theta_dis; k.num_beams = B;
+    k.res = res; k.inv_res = 1.0 / res; k.orig_x = ox; k.orig_y = oy; k.orig_c = oc; k.orig_s = os;
+    k.w_res = W * res; k.h_res = H * res; k.oob_value = dt[(size_t)H * W - 1];
+    k.eps = eps; k.max_range = max_range; k.fov = fov;
+    k.theta_inc = theta_dis * (fov / (B - 1)) / (2. * kPi);
+    k.dir_guard = 1e-8;
+    const double start = scan_start_index(k, pose[2]);
+    for (int b = 0; b < B; ++b) {
+        const int idx = beam_dir_index(k, start, b);
+        int hr, hc, nl;
+        ranges[b] = march_ray<0, false, false>(k, pose[0], pose[1], cs[idx].x, cs[idx].y, hr, hc, nl);
+    }
+}
+
+// beam_dir_index with an artificially huge guard band: every beam takes the exact replay path
+void hh_dir_index(int theta_dis, int B, double fov, double theta, double guard, int *idx)
+{
+    ScanConst k{};
+    k.theta_dis = theta_dis; k.num_beams = B; k.fov = fov;
+    k.theta_inc = theta_dis * (fov / (B - 1)) / (2. * kPi);
+    k.dir_guard = guard;
+    const double start = scan_start_index(k, theta);
+    for (int b = 0; b < B; ++b) idx[b] = beam_dir_index(k, start, b);
+}
+
+int hh_gjk(const double *a, const double *b) { return gjk_overlap(a, b) ? 1 : 0; }
+
+void hh_vertices(const double *pose, double length, double width, double *v) { box_vertices(pose[0], pose[1], pose[2], length, width, v); }
+
+int hh_ttc(const double *scan, int B, double vel, const double *beam_cos, const double *side, double thresh)
+{
+    if (vel == 0.0) return 0;
+    for (int b = 0; b < B; ++b)
+        if (ttc_beam_hit(scan[b], side[b], vel, beam_cos[b], thresh)) return 1;
+    return 0;
+}
+
+double hh_get_range(const double *r)
+{
+    return edge_range(r[0], r[1], cos(r[3] + kPi / 2.), sin(r[3] + kPi / 2.), r[4], r[5], r[6], r[7]);
+}
+
+// the per-beam loop of k_finalize / k_raycast_unit, serialised
+void hh_raycast(const double *ego, const double *v, const double *scan_angles, int B, double *scan, int *minmax)
+{
+    const double inc = (scan_angles[B - 1] - scan_angles[0]) / (B - 1);
+    int lo = 0, hi = 0;
+    for (int t = 0; t < 4; ++t) {
+        const int ind = vertex_beam_index(ego[0], ego[1], ego[2], v[2 * t], v[2 * t + 1], scan_angles, B, inc);
+        if (t == 0) lo = hi = ind;
+        lo = ind < lo ? ind : lo;
+        hi = ind > hi ? ind : hi;
+    }
+    minmax[0] = lo;
+    minmax[1] = hi;
+    for (int b = lo; b <= hi; ++b) {
+        const double bt = ego[2] + scan_angles[b];
+        const double v3x = cos(bt + kPi / 2.), v3y = sin(bt + kPi / 2.);
+        double r = scan[b], rr;
+        rr = edge_range(ego[0], ego[1], v3x, v3y, v[0], v[1], v[2], v[3]); if (rr < r) r = rr;
+        rr = edge_range(ego[0], ego[1], v3x, v3y, v[2], v[3], v[4], v[5]); if (rr < r) r = rr;
+        rr = edge_range(ego[0], ego[1], v3x, v3y, v[4], v[5], v[6], v[7]); if (rr < r) r = rr;
+        rr = edge_range(ego[0], ego[1], v3x, v3y, v[6], v[7], v[0], v[1]); if (rr < r) r = rr;
+        scan[b] = r;
+    }
+}
+
+}  // extern "C"

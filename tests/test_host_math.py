@@ -1,0 +1,191 @@
+"""CPU check of the product's scalar math (f1tenth_gym_amd/csrc/f110_math.hpp).
+
+The header is __host__ __device__; tests/host_harness compiles its HOST instantiation.  Here
+that code is compared with the oracle and the golden vectors so ordering/arith mistakes are
+caught without a GPU.  The GPU parity tests (-m gpu) prove the device instantiation.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from _util import gold, oracle_map_dt, rel_err
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HDIR = os.path.join(HERE, "host_harness")
+HLIB = os.path.join(HDIR, "libhost_harness.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.isfile("/opt/rocm/bin/hipcc"),
+                                reason="hipcc needed to build the host harness")
+
+
+@pytest.fixture(scope="module")
+def hh():
+    src = os.path.join(HDIR, "harness.hip")
+    hdr = os.path.join(os.path.dirname(HERE), "f1tenth_gym_amd", "csrc", "f110_math.hpp")
+    if not os.path.isfile(HLIB) or os.path.getmtime(HLIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                               "-shared", src, "-o", HLIB], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    L = C.CDLL(HLIB)
+    L.hh_get_range.restype = C.c_double
+    return L
+
+
+def d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def test_rhs_and_pid(hh):
+    g = gold("dynamics")
+    p, pp = d(g["params"])
+    for x, u, fs, fk in zip(g["x"], g["u"], g["f_st"], g["f_ks"]):
+        x_, xp = d(x); u_, up = d(u)
+        f_st = np.empty(7); f_ks = np.empty(5)
+        hh.hh_rhs(xp, up, pp, f_st.ctypes.data_as(_dp), f_ks.ctypes.data_as(_dp))
+        # bit-equal to the oracle (same libm); NumPy's tan differs from libm by 1 ulp on a few inputs
+        assert np.array_equal(f_st, orc.vehicle_dynamics_st(x, u, p)) and np.array_equal(f_ks, orc.vehicle_dynamics_ks(x[:5], u, p))
+        assert rel_err(f_st, fs) < 1e-12 and rel_err(f_ks, fk) < 1e-12
+    for r, o in zip(g["pid_in"], g["pid_out"]):
+        r_, rp = d(r); out = np.empty(2)
+        hh.hh_pid(rp, pp, out.ctypes.data_as(_dp))
+        assert np.array_equal(out, o)
+
+
+@pytest.mark.parametrize("name,integ,ld", [("rk4", 1, 0.0), ("euler", 2, 0.0), ("rk4_lidar", 1, 0.275)])
+def test_advance_vehicle(hh, name, integ, ld):
+    g = gold("update_pose")
+    p, pp = d(g["params"])
+    for i in range(g[name + "_state0"].shape[0]):
+        st = np.array(g[name + "_state0"][i]); buf = np.zeros(2)
+        c0 = int(g[name + "_cnt0"][i])
+        buf[:c0] = g[name + "_buf0"][i, :c0]
+        cnt = C.c_int(c0); sp = np.empty(3)
+        hh.hh_advance(st.ctypes.data_as(_dp), buf.ctypes.data_as(_dp), C.byref(cnt), C.c_double(g[name + "_action"][i, 0]),
+                      C.c_double(g[name + "_action"][i, 1]), pp, C.c_double(0.01), integ, C.c_double(ld),
+                      sp.ctypes.data_as(_dp))
+        o_st, o_sb, o_cnt, o_sp = orc.update_pose(g[name + "_state0"][i], buf if False else np.concatenate([g[name + "_buf0"][i, :c0], np.zeros(2 - c0)]),
+                                                  c0, g[name + "_action"][i, 0], g[name + "_action"][i, 1], p, 0.01, integ, ld)
+        assert np.array_equal(st, o_st) and np.array_equal(sp, o_sp)
+        assert rel_err(st, g[name + "_state1"][i]) < 1e-12
+        assert cnt.value == g[name + "_cnt1"][i]
+        assert np.array_equal(buf[:cnt.value], g[name + "_buf1"][i, :cnt.value])
+        assert rel_err(sp, g[name + "_scan_pose"][i]) < 1e-12
+
+
+def _hh_scan(hh, layout, dt, res, origin, sines, cosines, B, fov, pose, theta_dis=2000):
+    dt_, dtp = d(dt); s_, sp = d(sines); c_, cp = d(cosines); pose_, pp = d(pose)
+    ranges = np.empty(B); hits = np.empty((B, 2), dtype=np.intc); idx = np.empty(B, dtype=np.intc)
+    lk = C.c_longlong(0)
+    hh.hh_scan(layout, dtp, dt.shape[0], dt.shape[1], C.c_double(res), C.c_double(origin[0]), C.c_double(origin[1]),
+               C.c_double(np.cos(origin[2])), C.c_double(np.sin(origin[2])), sp, cp, theta_dis, B, C.c_double(fov),
+               C.c_double(1e-4), C.c_double(30.0), pp, ranges.ctypes.data_as(_dp), hits.ctypes.data_as(_ip),
+               idx.ctypes.data_as(_ip), C.byref(lk))
+    return ranges, hits, idx, lk.value
+
+
+@pytest.mark.parametrize("fixture,mapname,beams,fov", [
+    ("scan_example_map", "example_map", 1080, 4.7), ("scan_berlin", "berlin", 1080, 4.7),
+    ("scan_example_map_4096", "example_map", 4096, 4.7), ("scan_example_map_271", "example_map", 271, 6.0)])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_scan_matches_golden(hh, fixture, mapname, beams, fov, layout):
+    g = gold(fixture)
+    dt, res, origin = oracle_map_dt(mapname)
+    so = orc.ScanOracle(beams, fov)
+    for k, pose in enumerate(g["poses"]):
+        ranges, hits, idx, lk = _hh_scan(hh, layout, dt, res, origin, so.sines, so.cosines, beams, fov, pose)
+        assert np.array_equal(idx, g["dir_idx"][k])
+        assert np.array_equal(hits, g["hit_rc"][k])
+        assert np.array_equal(ranges, g["scans"][k])
+        assert lk == g["lookups"][k]
+
+
+def test_scan_generic_path_and_rotated_origin(hh):
+    """non-power-of-two resolution + rotated origin take the guarded-division / rotation code;
+    compare with the oracle on a synthetic transform of example_map's table."""
+    dt, res, origin = oracle_map_dt("example_map")
+    sub = np.ascontiguousarray(dt[600:1000, 900:1300])
+    so = orc.ScanOracle(1080, 4.7)
+    rng = np.random.default_rng(11)
+    for res2, org in [(0.05, [-3.0, -4.0, 0.3]), (0.0625, [1.0, 2.0, -1.1]), (0.07, [0.0, 0.0, 0.0])]:
+        so.set_map_dt(sub * (res2 / res), res2, org)
+        c, s = np.cos(org[2]), np.sin(org[2])
+        for _ in range(6):
+            u, v = rng.uniform(5, 15, 2) * res2 / 0.05
+            pose = [org[0] + c * u - s * v, org[1] + s * u + c * v, rng.uniform(0, 6.28)]
+            ref, ref_hits = so.scan(pose, want_hits=True)
+            ranges, hits, idx, lk = _hh_scan(hh, 0, so.dt, res2, org, so.sines, so.cosines, 1080, 4.7, pose)
+            assert np.array_equal(hits, ref_hits)
+            assert np.array_equal(ranges, ref)
+            assert lk == so.last_lookups
+
+
+def test_dir_index_exact_replay(hh):
+    """closed-form beam index == sequential replay (guard=2 forces the replay on every beam)
+    == oracle, for many headings incl. wrap boundaries."""
+    so = orc.ScanOracle(1080, 4.7)
+    rng = np.random.default_rng(12)
+    thetas = list(rng.uniform(-10, 10, 60)) + [0.0, 2.35, 2.35 + 1e-12, np.pi, 2 * np.pi, -2.35, 4.7 / 2]
+    for B, fov in [(1080, 4.7), (4096, 4.7), (271, 6.0)]:
+        so = orc.ScanOracle(B, fov)
+        for th in thetas:
+            ref = so.beam_dir_indices(th)
+            a = np.empty(B, dtype=np.intc); b = np.empty(B, dtype=np.intc)
+            hh.hh_dir_index(2000, B, C.c_double(fov), C.c_double(th), C.c_double(1e-8), a.ctypes.data_as(_ip))
+            hh.hh_dir_index(2000, B, C.c_double(fov), C.c_double(th), C.c_double(2.0), b.ctypes.data_as(_ip))
+            assert np.array_equal(a, ref) and np.array_equal(b, ref)
+
+
+def test_gjk_vertices_ttc(hh):
+    g = gold("collision")
+    L, W = g["length"][0], g["width"][0]
+    for pa, va in zip(g["pose_a"][:200], g["vert_a"][:200]):
+        p_, pp = d(pa); v = np.empty(8)
+        hh.hh_vertices(pp, C.c_double(L), C.c_double(W), v.ctypes.data_as(_dp))
+        assert np.array_equal(v.reshape(4, 2), orc.get_vertices(pa, L, W))
+        assert rel_err(v.reshape(4, 2), va) < 1e-12
+    flags = []
+    for a, b in zip(g["vert_a"], g["vert_b"]):
+        a_, ap = d(a); b_, bp = d(b)
+        flags.append(hh.hh_gjk(ap, bp))
+    assert np.array_equal(flags, g["flags"])
+    np.random.seed(1234)   # collision_models.py:274,306-311
+    v1 = np.asarray([[4, 11.], [5, 5], [9, 9], [10, 10]])
+    for _ in range(300):
+        a_, ap = d(v1 + np.random.normal(size=v1.shape) / 100.); b_, bp = d(v1 + np.random.normal(size=v1.shape) / 100.)
+        assert hh.hh_gjk(ap, bp) == 1
+    t = gold("ttc")
+    co, cp = d(t["cosines"]); sd, sp = d(t["side_distances"])
+    out = []
+    for s, v in zip(t["scans"], t["vels"]):
+        s_, spn = d(s)
+        out.append(hh.hh_ttc(spn, 1080, C.c_double(v), cp, sp, C.c_double(0.005)))
+    assert np.array_equal(out, t["flags"])
+
+
+def test_raycast_and_get_range(hh):
+    g = gold("raycast")
+    sa, sap = d(g["scan_angles"])
+    for i in range(g["ego"].shape[0]):
+        e_, ep = d(g["ego"][i]); v_, vp = d(g["vertices"][i])
+        scan = np.full(1080, g["base"][0]); mm = np.empty(2, dtype=np.intc)
+        hh.hh_raycast(ep, vp, sap, 1080, scan.ctypes.data_as(_dp), mm.ctypes.data_as(_ip))
+        assert tuple(mm) == (g["min_ind"][i], g["max_ind"][i])
+        ref = orc.ray_cast(g["ego"][i], np.full(1080, g["base"][0]), g["scan_angles"], g["vertices"][i])
+        assert np.array_equal(scan, ref)
+        assert np.array_equal(scan != g["base"][0], g["scans"][i] != g["base"][0])
+    out = []
+    for r in g["get_range_in"]:
+        r_, rp = d(r)
+        out.append(hh.hh_get_range(rp))
+    out = np.array(out); ref = g["get_range_out"]
+    assert np.array_equal(np.isinf(out), np.isinf(ref))
+    fin = ~np.isinf(ref)
+    assert rel_err(out[fin], ref[fin]) < 1e-9
