@@ -67,6 +67,7 @@ PROTOTYPES = {
     "f110_set_noise_table": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32]),
     "f110_reset": (C.c_int, [C.c_void_p, _dp, _u8p]),
     "f110_reset_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "f110_reset_collided_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "f110_step": (C.c_int, [C.c_void_p, _dp]),
     "f110_step_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_get_obs": (C.c_int, [C.c_void_p, C.POINTER(ObsHost)]),

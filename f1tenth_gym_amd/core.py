@@ -229,6 +229,12 @@ class BatchSim(object):
         m = None if d_mask is None else (d_mask.ptr if isinstance(d_mask, DeviceArray) else int(d_mask))
         check(_ffi.lib().f110_reset_device(self._h, p, m), self._h)
 
+    def reset_collided_device(self, d_start_poses, ego_idx=0, d_count=None):
+        """device-side mask reset of every env whose ego has collided (no host sync)"""
+        p = d_start_poses.ptr if isinstance(d_start_poses, DeviceArray) else int(d_start_poses)
+        c = None if d_count is None else (d_count.ptr if isinstance(d_count, DeviceArray) else int(d_count))
+        check(_ffi.lib().f110_reset_collided_device(self._h, p, int(ego_idx), c), self._h, IndexError)
+
     def device_array(self, shape, dtype=np.float64):
         return DeviceArray(self, shape, dtype)
 

@@ -286,6 +286,31 @@ __global__ void k_reset(AgentArrays a, const double *__restrict__ poses, const u
     a.step_count[i] = 0;
 }
 
+// in-place re-seat of finished environments (SURVEY §8d "mask reset"): an env whose ego agent
+// has collisions != 0 is reset to its start poses, exactly as k_reset would with that env masked.
+__global__ void k_reset_collided(AgentArrays a, const double *__restrict__ start_poses, int ego_idx,
+                                 int32_t *__restrict__ n_reset)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.n_agents_total, A = a.agents_per_env;
+    if (i >= N) return;
+    const int env = i / A;
+    if (a.collisions[env * A + ego_idx] == 0.0) return;
+    // every lane of the env reads the ego flag before any lane of the env can have cleared it:
+    // collisions[] is not written here (it keeps the step's value, as Simulator.collisions does)
+#pragma unroll
+    for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = 0.;
+    a.state[i] = start_poses[3 * (size_t)i];
+    a.state[(size_t)N + i] = start_poses[3 * (size_t)i + 1];
+    a.state[4 * (size_t)N + i] = start_poses[3 * (size_t)i + 2];
+    a.steer_buf[i] = 0.;
+    a.steer_buf[(size_t)N + i] = 0.;
+    a.buf_cnt[i] = 0;
+    a.in_collision[i] = 0;
+    a.step_count[i] = 0;
+    if (n_reset && i - env * A == ego_idx) atomicAdd(n_reset, 1);
+}
+
 // ---- unit kernels (one per reference function; parity tests) ------------------------------
 __global__ void k_dir_index_unit(ScanConst k, const double *__restrict__ thetas, int m, int32_t *__restrict__ idx)
 {
@@ -617,6 +642,7 @@ struct Scratch {
 static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 typedef void (*scan_rays_fn)(RayJob, ScanConst);
+
 
 template <bool STEP>
 static scan_rays_fn pick_rays(const ScanConst &k, int layout)
@@ -958,6 +984,15 @@ int f110_reset_device(f110_sim *h, const double *d_poses, const uint8_t *d_env_m
 {
     if (!h || !d_poses) return fail(h, F110_ERR_INVALID, "null argument");
     hipLaunchKernelGGL(k_reset, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, d_poses, d_env_mask);
+    HIPCHK(h, hipGetLastError());
+    return F110_OK;
+}
+
+int f110_reset_collided_device(f110_sim *h, const double *d_start_poses, int32_t ego_idx, int32_t *d_count)
+{
+    if (!h || !d_start_poses) return fail(h, F110_ERR_INVALID, "null argument");
+    if (ego_idx < 0 || ego_idx >= h->cfg.num_agents) return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
+    hipLaunchKernelGGL(k_reset_collided, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, d_start_poses, ego_idx, d_count);
     HIPCHK(h, hipGetLastError());
     return F110_OK;
 }

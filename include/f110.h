@@ -112,6 +112,11 @@ int f110_set_noise_table(f110_sim *h, const double *h_noise, int32_t n_rows, int
  * h_poses [N][3]; h_env_mask [num_envs] or NULL (all). */
 int f110_reset(f110_sim *h, const double *h_poses, const uint8_t *h_env_mask);
 int f110_reset_device(f110_sim *h, const double *d_poses, const uint8_t *d_env_mask);
+/* in-place re-seat on the device, no host round trip: every env whose agent `ego_idx` has
+ * collisions != 0 (the `done` condition of f110_env.py:244) is reset to d_start_poses [N][3];
+ * *d_count (device int32, may be NULL) is incremented once per env reset. */
+int f110_reset_collided_device(f110_sim *h, const double *d_start_poses, int32_t ego_idx,
+                               int32_t *d_count);
 
 /* Simulator.step base_classes.py:553-612.  actions [N][2] = (steer, speed).
  * Asynchronous on the handle's stream; outputs are read with f110_get_* (which sync). */

@@ -1,0 +1,93 @@
+"""CPU-only tests of the Python host logic that sits above the C ABI: lap/finish bookkeeping
+(f110_env.py:204-246), the shared noise table, map-file loading, integrator validation."""
+import os
+
+import numpy as np
+import pytest
+
+from _util import gold, MAPS
+
+
+def test_lap_logic_matches_reference_episode():
+    from f1tenth_gym_amd.env import _LapLogic
+    e = gold("env_episode")
+    lap = _LapLogic(1, 1, 0)
+    lap.reset(e["start"].reshape(1, 1, 3))
+    for k in range(len(e["x"])):
+        done, tog = lap.update([e["x"][k]], [e["y"][k]], [e["col"][k]], 0.01)
+        assert float(lap.toggle_list[0, 0]) == e["toggle"][k], k
+        assert bool(lap.near_starts[0, 0]) == bool(e["near"][k])
+        assert float(lap.lap_counts[0, 0]) == e["lap_count"][k]
+        assert abs(lap.lap_times[0, 0] - e["lap_time"][k]) < 1e-12
+        assert bool(done[0]) == bool(e["done"][k])
+    assert bool(tog[0, 0]) and e["toggle"][-1] == 4
+
+
+def test_lap_logic_vectorised_envs_are_independent():
+    from f1tenth_gym_amd.env import _LapLogic
+    e = gold("env_episode")
+    E = 3
+    lap = _LapLogic(E, 1, 0)
+    starts = np.tile(e["start"].reshape(1, 1, 3), (E, 1, 1))
+    starts[1, 0, :2] += 5.0
+    lap.reset(starts)
+    K = len(e["x"])
+    for k in range(K):
+        xs = np.array([e["x"][k], e["x"][k] + 5.0, e["x"][0]])
+        ys = np.array([e["y"][k], e["y"][k] + 5.0, e["y"][0]])
+        done, tog = lap.update(xs, ys, np.zeros(E), 0.01)
+    assert list(lap.toggle_list[:, 0]) == [4, 4, 0] and list(done) == [True, True, False]
+    lap.reset(starts, env_mask=[True, False, False])
+    assert list(lap.toggle_list[:, 0]) == [0, 4, 0] and lap.current_time[0] == 0 and lap.current_time[1] > 0
+
+
+def test_scan_noise_table_is_numpys_stream():
+    """row k == the k-th successive rng.normal(0, .01, B) of a generator seeded like
+    RaceCar.reset does (base_classes.py:204, laser_models.py:451); pinned by the golden row 0"""
+    from f1tenth_gym_amd.sim import ScanNoise
+
+    class FakeBatch(object):
+        noise_rows = 0
+
+        def set_noise_table(self, rows):
+            self.rows = rows.copy(); self.noise_rows = rows.shape[0]
+    fb = FakeBatch()
+    sn = ScanNoise(12345, 1080, 0.01, chunk=4)
+    sn.ensure(fb, 1)
+    assert fb.noise_rows == 4
+    sn.ensure(fb, 9)
+    assert fb.noise_rows == 16
+    rng = np.random.default_rng(seed=12345)
+    for k in range(16):
+        assert np.array_equal(fb.rows[k], rng.normal(0., 0.01, size=1080))
+    assert np.array_equal(fb.rows[0], gold("sim_rollout")["noise_row0"])
+    calls = fb.noise_rows
+    sn.ensure(fb, 10)
+    assert fb.noise_rows == calls
+
+
+def test_map_file_loading():
+    from f1tenth_gym_amd.core import load_map_files
+    img, res, origin = load_map_files(os.path.join(MAPS, "example_map.yaml"), ".png")
+    assert img.shape == (1600, 1600) and img.dtype == np.uint8 and res == 0.0625
+    assert origin == [-78.21853769831466, -44.37590462453829, 0.0]
+    with pytest.raises(FileNotFoundError):
+        load_map_files(os.path.join(MAPS, "nope.yaml"), ".png")
+
+
+def test_integrator_enum_and_validation():
+    from f1tenth_gym_amd.sim import Integrator, _integrator_code
+    assert Integrator.RK4.value == 1 and Integrator.Euler.value == 2
+    assert _integrator_code(Integrator.Euler) == 2 and _integrator_code(1) == 1
+    with pytest.raises(SyntaxError):
+        _integrator_code("Heun")
+
+
+def test_named_maps_ship_with_the_package():
+    from f1tenth_gym_amd.env import _resolve_map_path
+    for name in ("berlin", "skirk", "vegas"):
+        n, path = _resolve_map_path({'map': name})
+        assert os.path.isfile(path) and os.path.isfile(path[:-5] + ".png")
+    n, path = _resolve_map_path({})
+    assert n == 'vegas' and os.path.isfile(path)
+    assert _resolve_map_path({'map': '/x/custom'})[1] == '/x/custom.yaml'
