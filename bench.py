@@ -166,8 +166,9 @@ def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
     elapsed = time.perf_counter() - t0
     out = {"elapsed_s": elapsed, "gpu_ms": gpu_ms, "n_reset": int(d_count.download()[0]), "E": E, "A": A}
     if profile_events:
-        n, scan_ms, dyn_ms = sim.profile_read()
-        out.update({"scan_ms_avg": scan_ms / max(n, 1), "dyn_ms_avg": dyn_ms / max(n, 1), "n_prof": n})
+        n, scan_ms, dyn_ms, fin_ms = sim.profile_read()
+        out.update({"scan_ms_avg": scan_ms / max(n, 1), "dyn_ms_avg": dyn_ms / max(n, 1),
+                    "fin_ms_avg": fin_ms / max(n, 1), "n_prof": n})
         sim.profile_kernels(False)
     out["final"] = sim.get("collisions", "in_collision", "step_count")
     for d in d_sets + [d_start, d_count]:
@@ -309,7 +310,8 @@ def main():
             line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": ach / HBM_PEAK_GBS, "traffic": load_pmc_traffic(args, args.agents),
                                 "kernel": "k_scan_rays", "kernel_ms_avg": res["scan_ms_avg"],
-                                "other_kernels_ms_avg": res["dyn_ms_avg"], "launches_timed": res["n_prof"],
+                                "integrate_collide_ms_avg": res["dyn_ms_avg"], "finalize_ms_avg": res["fin_ms_avg"],
+                                "launches_timed": res["n_prof"],
                                 "alg_bytes_per_launch": scan_bytes, "lookups_per_ray": lbar,
                                 "step_alg_bytes": step_bytes,
                                 "step_achieved_GBs": step_bytes * args.steps / elapsed / 1e9}

@@ -80,7 +80,7 @@ PROTOTYPES = {
     "f110_timer_begin": (C.c_int, [C.c_void_p]),
     "f110_timer_end_ms": (C.c_int, [C.c_void_p, _dp]),
     "f110_profile_kernels": (C.c_int, [C.c_void_p, C.c_int32]),
-    "f110_profile_read": (C.c_int, [C.c_void_p, _i32p, _dp, _dp]),
+    "f110_profile_read": (C.c_int, [C.c_void_p, _i32p, _dp, _dp, _dp]),
     "f110_scan_batch": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp, _i32p, _i64p]),
     "f110_dynamics_batch": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int32, _dp, _dp]),
     "f110_pid_batch": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp]),

@@ -294,9 +294,9 @@ class BatchSim(object):
         check(_ffi.lib().f110_profile_kernels(self._h, 1 if enable else 0), self._h)
 
     def profile_read(self):
-        n = C.c_int32(); s = C.c_double(); d = C.c_double()
-        check(_ffi.lib().f110_profile_read(self._h, C.byref(n), C.byref(s), C.byref(d)), self._h)
-        return n.value, s.value, d.value
+        n = C.c_int32(); s = C.c_double(); d = C.c_double(); f = C.c_double()
+        check(_ffi.lib().f110_profile_read(self._h, C.byref(n), C.byref(s), C.byref(d), C.byref(f)), self._h)
+        return n.value, s.value, d.value, f.value
 
     # ------------------------------------------------------------------ unit entry points
     def scan_batch(self, poses, want_hits=False, want_lookups=False):

@@ -46,6 +46,7 @@ struct AgentArrays {
     double *collision_idx;   // [N]
     int32_t *in_collision;   // [N]
     int32_t *step_count;     // [N]
+    int32_t *opp_window;     // [N][A][2] beam range each opponent can occupy (no-wall-hit heading)
     const double *params;    // [A][18]
     const double *noise;     // [noise_rows][B] or nullptr
     const double *scan_angles, *beam_cos, *side_dist;  // [B]
@@ -96,32 +97,45 @@ __global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, c
 // collision_multiple visits pairs (i<j) ascending and overwrites collision_idx, so an agent's
 // final index is the largest colliding partner; flags are symmetric.  Each lane evaluates the
 // GJK of its pairs in the reference's (lower, higher) argument order.
-__global__ void __launch_bounds__(256) k_collide(AgentArrays a)
+__global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = a.n_agents_total, A = a.agents_per_env;
     if (i >= N) return;
     const int env = i / A, me = i - env * A;
     double mine[8];
-    const double mx = a.snap_pose[i], my = a.snap_pose[(size_t)N + i];
-    box_vertices(mx, my, a.snap_pose[2 * (size_t)N + i], a.box_length, a.box_width, mine);
+    const double mx = a.snap_pose[i], my = a.snap_pose[(size_t)N + i], mth = a.snap_pose[2 * (size_t)N + i];
+    box_vertices(mx, my, mth, a.box_length, a.box_width, mine);
     // bodies whose centres are further apart than a box diagonal (+1 mm) cannot overlap
     const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+    // RaceCar.ray_cast_agents draws the opponents with the EGO's length/width (:223)
+    const double blen = a.params[(size_t)me * NPARAMS + P_LENGTH];
+    const double bwid = a.params[(size_t)me * NPARAMS + P_WIDTH];
+    const double disc_r = 0.5 * sqrt(blen * blen + bwid * bwid);
     bool hit = false;
     int partner = -1;
     for (int j = 0; j < A; ++j) {
         if (j == me) continue;
         const int o = env * A + j;
-        const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o];
+        const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
         const double dx = ox - mx, dy = oy - my;
-        if (dx * dx + dy * dy > reach * reach) continue;
         double other[8];
-        box_vertices(ox, oy, a.snap_pose[2 * (size_t)N + o], a.box_length, a.box_width, other);
-        const bool c = (me < j) ? gjk_overlap(mine, other) : gjk_overlap(other, mine);
-        if (c) {
-            hit = true;
-            partner = j;  // j ascending -> ends at the largest colliding index
+        if (dx * dx + dy * dy <= reach * reach) {
+            box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
+            const bool c = (me < j) ? gjk_overlap(mine, other) : gjk_overlap(other, mine);
+            if (c) {
+                hit = true;
+                partner = j;  // j ascending -> ends at the largest colliding index
+            }
         }
+        // beam window this opponent can occupy in my scan, for the common case that my iTTC
+        // check does not fire (then my live heading is the snapshot heading); k_finalize
+        // recomputes it with heading 0 for agents that did hit a wall.
+        int ref_lo, ref_hi, lo, hi;
+        box_vertices(ox, oy, oth, blen, bwid, other);
+        opponent_beam_window(mx, my, mth, other, ox, oy, disc_r, a.scan_angles, B, a.angle_inc, ref_lo, ref_hi, lo, hi);
+        a.opp_window[((size_t)i * A + j) * 2] = lo;
+        a.opp_window[((size_t)i * A + j) * 2 + 1] = hi;
     }
     a.collisions[i] = hit ? 1.0 : 0.0;
     a.collision_idx[i] = (double)partner;
@@ -184,7 +198,6 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
 // pose = live state (heading already zeroed on a wall hit), box = the ego's own params.
 __global__ void __launch_bounds__(64) k_finalize(AgentArrays a, int32_t B)
 {
-    __shared__ int li[4];
     const int i = blockIdx.x, tid = threadIdx.x;
     const int N = a.n_agents_total, A = a.agents_per_env;
     const int wall = a.in_collision[i];
@@ -200,7 +213,6 @@ __global__ void __launch_bounds__(64) k_finalize(AgentArrays a, int32_t B)
         }
         a.step_count[i] += 1;
     }
-    if (A == 1) return;
     const int env = i / A, me = i - env * A;
     const double blen = a.params[(size_t)me * NPARAMS + P_LENGTH];
     const double bwid = a.params[(size_t)me * NPARAMS + P_WIDTH];
@@ -208,31 +220,22 @@ __global__ void __launch_bounds__(64) k_finalize(AgentArrays a, int32_t B)
     for (int jj = 0; jj < A; ++jj) {
         if (jj == me) continue;
         const int o = env * A + jj;
+        int lo = a.opp_window[((size_t)i * A + jj) * 2];
+        int hi = a.opp_window[((size_t)i * A + jj) * 2 + 1];
+        if (!wall && hi < lo) continue;  // nothing of this opponent is visible
+        const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o];
         double v[8];
-        box_vertices(a.snap_pose[o], a.snap_pose[(size_t)N + o], a.snap_pose[2 * (size_t)N + o], blen, bwid, v);
-        if (tid < 4) {
-            const double vx = tid == 0 ? v[0] : tid == 1 ? v[2] : tid == 2 ? v[4] : v[6];
-            const double vy = tid == 0 ? v[1] : tid == 1 ? v[3] : tid == 2 ? v[5] : v[7];
-            li[tid] = vertex_beam_index(ex, ey, eth, vx, vy, a.scan_angles, B, a.angle_inc);
+        box_vertices(ox, oy, a.snap_pose[2 * (size_t)N + o], blen, bwid, v);
+        if (wall) {  // heading was zeroed: the window of k_collide does not apply (rare path)
+            int ref_lo, ref_hi;
+            opponent_beam_window(ex, ey, eth, v, ox, oy, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B,
+                                 a.angle_inc, ref_lo, ref_hi, lo, hi);
         }
-        __syncthreads();
-        const int i0 = li[0], i1 = li[1], i2 = li[2], i3 = li[3];
-        __syncthreads();
-        const int lo = min(min(i0, i1), min(i2, i3));
-        const int hi = max(max(i0, i1), max(i2, i3));
         for (int b = lo + tid; b <= hi; b += 64) {
             const double bt = eth + a.scan_angles[b];
             const double v3x = cos(bt + kPi / 2.), v3y = sin(bt + kPi / 2.);
             const double r0 = sc[b];
-            double r = r0;
-            double rr = edge_range(ex, ey, v3x, v3y, v[0], v[1], v[2], v[3]);
-            if (rr < r) r = rr;
-            rr = edge_range(ex, ey, v3x, v3y, v[2], v[3], v[4], v[5]);
-            if (rr < r) r = rr;
-            rr = edge_range(ex, ey, v3x, v3y, v[4], v[5], v[6], v[7]);
-            if (rr < r) r = rr;
-            rr = edge_range(ex, ey, v3x, v3y, v[6], v[7], v[0], v[1]);
-            if (rr < r) r = rr;
+            const double r = box_range(ex, ey, v3x, v3y, v, r0);
             if (r < r0) sc[b] = r;
         }
         // the next opponent may touch the same beams: make this wave's stores visible to it
@@ -438,38 +441,31 @@ __global__ void k_raycast_unit(const double *__restrict__ ego, const double *__r
                                const double *__restrict__ scan_angles, double angle_inc, double *__restrict__ scans,
                                int32_t *__restrict__ minmax)
 {
-    __shared__ int li[4];
     const int p = blockIdx.x, tid = threadIdx.x;
     const double ex = ego[3 * p], ey = ego[3 * p + 1], eth = ego[3 * p + 2];
     double v[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = verts[8 * (size_t)p + c];
-    if (tid < 4) {
-        const double vx = tid == 0 ? v[0] : tid == 1 ? v[2] : tid == 2 ? v[4] : v[6];
-        const double vy = tid == 0 ? v[1] : tid == 1 ? v[3] : tid == 2 ? v[5] : v[7];
-        li[tid] = vertex_beam_index(ex, ey, eth, vx, vy, scan_angles, B, angle_inc);
+    // circumscribed disc of the quadrilateral: centroid + largest vertex distance
+    const double cx = (((v[0] + v[2]) + v[4]) + v[6]) / 4, cy = (((v[1] + v[3]) + v[5]) + v[7]) / 4;
+    double r2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double dx = v[2 * c] - cx, dy = v[2 * c + 1] - cy;
+        r2 = fmax(r2, dx * dx + dy * dy);
     }
-    __syncthreads();
-    const int lo = min(min(li[0], li[1]), min(li[2], li[3]));
-    const int hi = max(max(li[0], li[1]), max(li[2], li[3]));
+    int ref_lo, ref_hi, lo, hi;
+    opponent_beam_window(ex, ey, eth, v, cx, cy, sqrt(r2) * 1.000001, scan_angles, B, angle_inc, ref_lo, ref_hi, lo, hi);
     if (minmax && tid == 0) {
-        minmax[2 * p] = lo;
-        minmax[2 * p + 1] = hi;
+        minmax[2 * p] = ref_lo;
+        minmax[2 * p + 1] = ref_hi;
     }
     double *sc = scans + (size_t)p * B;
     for (int b = lo + tid; b <= hi; b += blockDim.x) {
         const double bt = eth + scan_angles[b];
-        const double v3x = cos(bt + kPi / 2.), v3y = sin(bt + kPi / 2.);
-        double r = sc[b];
-        double rr = edge_range(ex, ey, v3x, v3y, v[0], v[1], v[2], v[3]);
-        if (rr < r) r = rr;
-        rr = edge_range(ex, ey, v3x, v3y, v[2], v[3], v[4], v[5]);
-        if (rr < r) r = rr;
-        rr = edge_range(ex, ey, v3x, v3y, v[4], v[5], v[6], v[7]);
-        if (rr < r) r = rr;
-        rr = edge_range(ex, ey, v3x, v3y, v[6], v[7], v[0], v[1]);
-        if (rr < r) r = rr;
-        sc[b] = r;
+        const double r0 = sc[b];
+        const double r = box_range(ex, ey, cos(bt + kPi / 2.), sin(bt + kPi / 2.), v, r0);
+        if (r < r0) sc[b] = r;
     }
 }
 
@@ -567,7 +563,7 @@ struct f110_sim {
     AgentArrays dev{};
     ScanConst k{};
     bool has_map = false;
-    int scan_block = 128;
+    int scan_block = 64;
     double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
     double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_actions = nullptr, *d_poses = nullptr;
     double2 *d_cs = nullptr;
@@ -575,7 +571,7 @@ struct f110_sim {
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool profiling = false;
-    std::vector<hipEvent_t> prof_events;  // triples: before integrate, before scan, after scan
+    std::vector<hipEvent_t> prof_events;  // per step: before integrate, before scan, after scan, after finalize
     size_t prof_used = 0;
     char err[512] = {0};
 };
@@ -718,7 +714,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     h->cfg = *cfg;
     h->N = cfg->num_envs * cfg->num_agents;
     const int N = h->N, B = cfg->num_beams;
-    h->scan_block = cfg->scan_block > 0 ? cfg->scan_block : 128;
+    h->scan_block = cfg->scan_block > 0 ? cfg->scan_block : 64;
     if (h->scan_block % 64 != 0 || h->scan_block > 256) { delete h; return fail(nullptr, F110_ERR_INVALID, "scan_block must be 64, 128, 192 or 256"); }
 #define CK(expr) do { int rc_ = (expr); if (rc_ != F110_OK) { snprintf(g_err, sizeof g_err, "%s", h->err); f110_destroy(h); return rc_; } } while (0)
 #define CKH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(nullptr, F110_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); f110_destroy(h); return F110_ERR_HIP; } } while (0)
@@ -740,6 +736,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     CK(dmalloc(h, &d.collision_idx, (size_t)N));
     CK(dmalloc(h, &d.in_collision, (size_t)N));
     CK(dmalloc(h, &d.step_count, (size_t)N));
+    CK(dmalloc(h, &d.opp_window, (size_t)N * cfg->num_agents * 2));
     CK(dmalloc(h, &h->d_params, (size_t)cfg->num_agents * NPARAMS));
     CK(dmalloc(h, &h->d_scan_angles, (size_t)B));
     CK(dmalloc(h, &h->d_beam_cos, (size_t)B));
@@ -813,7 +810,7 @@ void f110_destroy(f110_sim *h)
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     AgentArrays &d = h->dev;
-    void *ptrs[] = {d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
+    void *ptrs[] = {d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
                     h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_actions, h->d_poses, h->d_cs, h->d_mask};
     for (void *p : ptrs)
@@ -1022,15 +1019,15 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     if (!h || !d_actions) return fail(h, F110_ERR_INVALID, "null argument");
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
     const int N = h->N;
-    const bool prof = h->profiling && h->prof_used + 3 <= 3 * 65536;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    const bool prof = h->profiling && h->prof_used + 4 <= 4 * 65536;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     if (prof) {
-        e0 = prof_event(h); e1 = prof_event(h); e2 = prof_event(h);
-        if (!e0 || !e1 || !e2) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
+        e0 = prof_event(h); e1 = prof_event(h); e2 = prof_event(h); e3 = prof_event(h);
+        if (!e0 || !e1 || !e2 || !e3) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
     hipLaunchKernelGGL(k_integrate, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->k, d_actions);
-    if (h->cfg.num_agents > 1) hipLaunchKernelGGL(k_collide, grid1d(N, 256), dim3(256), 0, h->stream, h->dev);
+    if (h->cfg.num_agents > 1) hipLaunchKernelGGL(k_collide, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
     if (prof) HIPCHK(h, hipEventRecord(e1, h->stream));
     {
         RayJob j{};
@@ -1056,6 +1053,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         hipLaunchKernelGGL(k_finalize, dim3(N), dim3(64), 0, h->stream, h->dev, h->k.num_beams);
     else
         hipLaunchKernelGGL(k_finalize_solo, grid1d(N, 256), dim3(256), 0, h->stream, h->dev);
+    if (prof) HIPCHK(h, hipEventRecord(e3, h->stream));
     HIPCHK(h, hipGetLastError());
     return F110_OK;
 }
@@ -1209,20 +1207,23 @@ int f110_profile_kernels(f110_sim *h, int32_t enable)
     return F110_OK;
 }
 
-int f110_profile_read(f110_sim *h, int32_t *n_launches, double *scan_ms, double *dyn_ms)
+int f110_profile_read(f110_sim *h, int32_t *n_launches, double *scan_ms, double *dyn_ms, double *fin_ms)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    double s = 0, dsum = 0;
+    double s = 0, dsum = 0, fsum = 0;
     int n = 0;
-    for (size_t i = 0; i + 3 <= h->prof_used; i += 3) {
-        float a = 0.f, b = 0.f;
+    for (size_t i = 0; i + 4 <= h->prof_used; i += 4) {
+        float a = 0.f, b = 0.f, c = 0.f;
         HIPCHK(h, hipEventElapsedTime(&a, h->prof_events[i], h->prof_events[i + 1]));
         HIPCHK(h, hipEventElapsedTime(&b, h->prof_events[i + 1], h->prof_events[i + 2]));
+        HIPCHK(h, hipEventElapsedTime(&c, h->prof_events[i + 2], h->prof_events[i + 3]));
         dsum += a;
         s += b;
+        fsum += c;
         ++n;
     }
+    if (fin_ms) *fin_ms = fsum;
     if (n_launches) *n_launches = n;
     if (scan_ms) *scan_ms = s;
     if (dyn_ms) *dyn_ms = dsum;

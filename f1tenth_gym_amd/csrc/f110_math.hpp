@@ -352,6 +352,78 @@ F110_HD int vertex_beam_index(double ex, double ey, double etheta, double vx, do
     return nearest_beam(scan_angles, num_beams, angle_inc, -angle);
 }
 
+// Conservative beam-index range whose rays can touch a disc (centre c, radius R) seen from the
+// ego at (ex, ey, eth).  ray_cast (:338-345) evaluates every beam of [min_ind, max_ind] against
+// the opponent's four edges, but a beam whose ray misses the box's circumscribed disc returns
+// inf from all four get_range calls and leaves the scan untouched — skipping it is
+// result-preserving.  (When the opponent straddles the rear +-pi direction the reference window
+// degenerates to all B beams although none of them can hit: this cull removes that work.)
+// Beams are sa[0] + b*inc to within rounding; the range is padded by 3 beams + 1e-6 rad.
+F110_HD void disc_beam_range(double ex, double ey, double eth, double cx, double cy, double R,
+                             const double *scan_angles, int num_beams, double angle_inc, int &cl, int &ch)
+{
+    const double dx = cx - ex, dy = cy - ey;
+    const double dist = sqrt(dx * dx + dy * dy);
+    if (!(dist > R * 1.000001 + 1e-9)) {  // lidar inside / on the disc (or NaN): no cull
+        cl = 0;
+        ch = num_beams - 1;
+        return;
+    }
+    double phi = atan2(dy, dx) - eth;
+    phi -= kTwoPi * rint(phi / kTwoPi);  // (-pi, pi]
+    const double psi = asin(R / dist) + 3.0 * angle_inc + 1e-6;
+    const double sa0 = scan_angles[0];
+    const double last = (double)(num_beams - 1);
+    cl = num_beams;
+    ch = -1;
+#pragma unroll
+    for (int k = -1; k <= 1; ++k) {
+        double lo = ceil((phi + kTwoPi * k - psi - sa0) / angle_inc);
+        double hi = floor((phi + kTwoPi * k + psi - sa0) / angle_inc);
+        lo = lo < 0.0 ? 0.0 : lo;
+        hi = hi > last ? last : hi;
+        if (lo <= hi) {
+            cl = (int)lo < cl ? (int)lo : cl;
+            ch = (int)hi > ch ? (int)hi : ch;
+        }
+    }
+}
+
+// get_blocked_view_indices :282-315 (min/max of the four vertex beam indices) intersected with
+// the disc cull above.  Returns an empty range (hi < lo) when no beam of the window can hit.
+F110_HD void opponent_beam_window(double ex, double ey, double eth, const double *v, double cx, double cy,
+                                  double R, const double *scan_angles, int num_beams, double angle_inc,
+                                  int &ref_lo, int &ref_hi, int &lo, int &hi)
+{
+    const int i0 = vertex_beam_index(ex, ey, eth, v[0], v[1], scan_angles, num_beams, angle_inc);
+    const int i1 = vertex_beam_index(ex, ey, eth, v[2], v[3], scan_angles, num_beams, angle_inc);
+    const int i2 = vertex_beam_index(ex, ey, eth, v[4], v[5], scan_angles, num_beams, angle_inc);
+    const int i3 = vertex_beam_index(ex, ey, eth, v[6], v[7], scan_angles, num_beams, angle_inc);
+    int a = i0 < i1 ? i0 : i1, b = i2 < i3 ? i2 : i3;
+    ref_lo = a < b ? a : b;
+    a = i0 > i1 ? i0 : i1;
+    b = i2 > i3 ? i2 : i3;
+    ref_hi = a > b ? a : b;
+    int cl, ch;
+    disc_beam_range(ex, ey, eth, cx, cy, R, scan_angles, num_beams, angle_inc, cl, ch);
+    lo = ref_lo > cl ? ref_lo : cl;
+    hi = ref_hi < ch ? ref_hi : ch;
+}
+
+// the four get_range calls of ray_cast's inner loop (:341-345) for one beam
+F110_HD double box_range(double ex, double ey, double v3x, double v3y, const double *v, double r)
+{
+    double rr = edge_range(ex, ey, v3x, v3y, v[0], v[1], v[2], v[3]);
+    if (rr < r) r = rr;
+    rr = edge_range(ex, ey, v3x, v3y, v[2], v[3], v[4], v[5]);
+    if (rr < r) r = rr;
+    rr = edge_range(ex, ey, v3x, v3y, v[4], v[5], v[6], v[7]);
+    if (rr < r) r = rr;
+    rr = edge_range(ex, ey, v3x, v3y, v[6], v[7], v[0], v[1]);
+    if (rr < r) r = rr;
+    return r;
+}
+
 // ------------------------------------------------------------------ collision_models.py
 // get_vertices :218-260 — order [rl, rr, fr, fl]; v[2*i], v[2*i+1]
 F110_HD void box_vertices(double x, double y, double th, double length, double width, double *v)

@@ -168,7 +168,7 @@ int f110_timer_begin(f110_sim *h);
 int f110_timer_end_ms(f110_sim *h, double *ms);
 int f110_profile_kernels(f110_sim *h, int32_t enable);
 int f110_profile_read(f110_sim *h, int32_t *n_launches, double *scan_ms_total,
-                      double *dyn_ms_total);
+                      double *dyn_ms_total, double *finalize_ms_total);
 
 /* ---- unit entry points (one per reference kernel; used by the parity tests) ---- */
 /* ScanSimulator2D.scan(pose, None)  laser_models.py:429-454 -> get_scan :148-186.

@@ -143,28 +143,27 @@ double hh_get_range(const double *r)
     return edge_range(r[0], r[1], cos(r[3] + kPi / 2.), sin(r[3] + kPi / 2.), r[4], r[5], r[6], r[7]);
 }
 
-// the per-beam loop of k_finalize / k_raycast_unit, serialised
+// the per-beam loop of k_finalize / k_raycast_unit, serialised (same window + disc cull code)
 void hh_raycast(const double *ego, const double *v, const double *scan_angles, int B, double *scan, int *minmax)
 {
     const double inc = (scan_angles[B - 1] - scan_angles[0]) / (B - 1);
-    int lo = 0, hi = 0;
-    for (int t = 0; t < 4; ++t) {
-        const int ind = vertex_beam_index(ego[0], ego[1], ego[2], v[2 * t], v[2 * t + 1], scan_angles, B, inc);
-        if (t == 0) lo = hi = ind;
-        lo = ind < lo ? ind : lo;
-        hi = ind > hi ? ind : hi;
+    const double cx = (((v[0] + v[2]) + v[4]) + v[6]) / 4, cy = (((v[1] + v[3]) + v[5]) + v[7]) / 4;
+    double r2 = 0.0;
+    for (int c = 0; c < 4; ++c) {
+        const double dx = v[2 * c] - cx, dy = v[2 * c + 1] - cy;
+        r2 = fmax(r2, dx * dx + dy * dy);
     }
-    minmax[0] = lo;
-    minmax[1] = hi;
+    int ref_lo, ref_hi, lo, hi;
+    opponent_beam_window(ego[0], ego[1], ego[2], v, cx, cy, sqrt(r2) * 1.000001, scan_angles, B, inc, ref_lo, ref_hi, lo, hi);
+    minmax[0] = ref_lo;
+    minmax[1] = ref_hi;
+    minmax[2] = lo;
+    minmax[3] = hi;
     for (int b = lo; b <= hi; ++b) {
         const double bt = ego[2] + scan_angles[b];
-        const double v3x = cos(bt + kPi / 2.), v3y = sin(bt + kPi / 2.);
-        double r = scan[b], rr;
-        rr = edge_range(ego[0], ego[1], v3x, v3y, v[0], v[1], v[2], v[3]); if (rr < r) r = rr;
-        rr = edge_range(ego[0], ego[1], v3x, v3y, v[2], v[3], v[4], v[5]); if (rr < r) r = rr;
-        rr = edge_range(ego[0], ego[1], v3x, v3y, v[4], v[5], v[6], v[7]); if (rr < r) r = rr;
-        rr = edge_range(ego[0], ego[1], v3x, v3y, v[6], v[7], v[0], v[1]); if (rr < r) r = rr;
-        scan[b] = r;
+        const double r0 = scan[b];
+        const double r = box_range(ego[0], ego[1], cos(bt + kPi / 2.), sin(bt + kPi / 2.), v, r0);
+        if (r < r0) scan[b] = r;
     }
 }
 

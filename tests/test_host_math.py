@@ -175,9 +175,9 @@ def test_raycast_and_get_range(hh):
     sa, sap = d(g["scan_angles"])
     for i in range(g["ego"].shape[0]):
         e_, ep = d(g["ego"][i]); v_, vp = d(g["vertices"][i])
-        scan = np.full(1080, g["base"][0]); mm = np.empty(2, dtype=np.intc)
+        scan = np.full(1080, g["base"][0]); mm = np.empty(4, dtype=np.intc)
         hh.hh_raycast(ep, vp, sap, 1080, scan.ctypes.data_as(_dp), mm.ctypes.data_as(_ip))
-        assert tuple(mm) == (g["min_ind"][i], g["max_ind"][i])
+        assert tuple(mm[:2]) == (g["min_ind"][i], g["max_ind"][i])
         ref = orc.ray_cast(g["ego"][i], np.full(1080, g["base"][0]), g["scan_angles"], g["vertices"][i])
         assert np.array_equal(scan, ref)
         assert np.array_equal(scan != g["base"][0], g["scans"][i] != g["base"][0])
@@ -189,3 +189,29 @@ def test_raycast_and_get_range(hh):
     assert np.array_equal(np.isinf(out), np.isinf(ref))
     fin = ~np.isinf(ref)
     assert rel_err(out[fin], ref[fin]) < 1e-9
+
+
+def test_disc_cull_is_result_preserving(hh):
+    """the product only evaluates window beams whose ray can touch the opponent's circumscribed
+    disc; the oracle evaluates the whole [min_ind, max_ind] window like the reference.  Results
+    must be identical on random placements, incl. opponents behind / overlapping / far away."""
+    sa, co, sd = orc.build_beam_tables(1080, 4.7, 0.31, 0.15875, 0.17145)
+    sa_, sap = d(sa)
+    rng = np.random.default_rng(21)
+    culled_total = ref_total = 0
+    for i in range(1500):
+        ego = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(0, 2 * np.pi) if i % 7 else 0.0])
+        dist = rng.uniform(0.0, 0.5) if i % 10 == 0 else rng.uniform(0.3, 12.0)
+        bearing = rng.uniform(-np.pi, np.pi) if i % 3 else np.pi + rng.uniform(-0.5, 0.5)
+        opp = np.array([ego[0] + dist * np.cos(ego[2] + bearing), ego[1] + dist * np.sin(ego[2] + bearing), rng.uniform(0, 2 * np.pi)])
+        v = orc.get_vertices(opp, 0.58, 0.31)
+        base = rng.uniform(0.2, 15.0, 1080)
+        ref = orc.ray_cast(ego, base, sa, v)
+        e_, ep = d(ego); v_, vp = d(v)
+        scan = base.copy(); mm = np.empty(4, dtype=np.intc)
+        hh.hh_raycast(ep, vp, sap, 1080, scan.ctypes.data_as(_dp), mm.ctypes.data_as(_ip))
+        assert tuple(mm[:2]) == orc.get_blocked_view_indices(ego, v, sa)
+        assert np.array_equal(scan, ref), i
+        ref_total += mm[1] - mm[0] + 1
+        culled_total += max(0, mm[3] - mm[2] + 1)
+    assert culled_total < 0.7 * ref_total     # the cull actually removes work

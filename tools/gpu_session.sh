@@ -1,29 +1,61 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench (+variants), rocprofv3 stats and PMC passes.
-# Usage (from the build container):  gpurun --timeout 1800 -- 'bash tools/gpu_session.sh [quick]'
+# One GPU-box session.  Usage (from the build container):
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh test'     parity tests + smoke + default bench
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh perf'     bench variants
+#   gpurun --timeout 1800 -- 'bash tools/gpu_session.sh prof'     rocprofv3 kernel stats + PMC passes
+# Modes may be combined: 'test perf prof'.
 cd "${GRAFT_REPO_ROOT:-.}"
+R="$PWD"
 export TMPDIR=/tmp
-OUT=gpurun_out; mkdir -p $OUT
-{ rocminfo | grep -E "Marketing Name|gfx9|Compute Unit" | head -8; nproc; lscpu | grep "Model name"; free -g | head -2; } > $OUT/box.txt 2>&1
+OUT=$R/gpurun_out; mkdir -p $OUT
+MODES="${*:-test}"
+{ rocminfo | grep -E "Marketing Name|gfx9|Compute Unit" | head -8; nproc; lscpu | grep "Model name" | head -1; } > $OUT/box.txt 2>&1
 python -c "import __graft_entry__ as g; print(g.build())" > $OUT/build.log 2>&1
-timeout 1200 python -m pytest tests -m gpu -q --maxfail=12 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
-timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
-timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo "bench exit $?" >> $OUT/bench_default.log
-if [ "$1" != "quick" ]; then
-  for layout in 0 1; do for blk in 64 128 256; do
-    timeout 200 python bench.py --layout $layout --scan-block $blk --steps 100 --warmup 10 --no-cpu-baseline --secondary 0 > $OUT/bench_l${layout}_b${blk}.log 2>&1
+SHORT="--no-cpu-baseline --secondary 0"
+for MODE in $MODES; do
+case $MODE in
+test)
+  timeout 1200 python -m pytest tests -m gpu -q --maxfail=12 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
+  timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo "bench exit $?" >> $OUT/bench_default.log
+  ;;
+perf)
+  for layout in 0 1; do for blk in 64 128; do
+    timeout 200 python bench.py --layout $layout --scan-block $blk --steps 200 --warmup 20 $SHORT > $OUT/bench_l${layout}_b${blk}.log 2>&1
   done; done
-  timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --secondary 0 --no-noise --no-reset > $OUT/bench_nonoise_noreset.log 2>&1
-fi
-cd /tmp
-R="$OLDPWD"
-timeout 400 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_stats -o stats -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --secondary 0 --no-profile-events > $R/$OUT/prof_stats.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d $R/$OUT/pmc_fetch -o fetch -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --secondary 0 --no-profile-events > $R/$OUT/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d $R/$OUT/pmc_write -o write -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --secondary 0 --no-profile-events > $R/$OUT/pmc_write.log 2>&1
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $R/$OUT/pmc_sq -o sq -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --secondary 0 --no-profile-events > $R/$OUT/pmc_sq.log 2>&1
-timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -d $R/$OUT/pmc_cache -o cache -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --secondary 0 --no-profile-events > $R/$OUT/pmc_cache.log 2>&1
+  timeout 200 python bench.py --steps 200 --warmup 20 $SHORT --no-noise --no-reset > $OUT/bench_nonoise_noreset.log 2>&1
+  timeout 200 python bench.py --steps 200 --warmup 20 $SHORT --agents 4096 > $OUT/bench_4096.log 2>&1
+  timeout 200 python bench.py --steps 200 --warmup 20 $SHORT --agents 16384 > $OUT/bench_16384.log 2>&1
+  timeout 300 python bench.py --steps 100 --warmup 10 $SHORT --agents 262144 > $OUT/bench_262144.log 2>&1
+  timeout 300 python bench.py --steps 100 --warmup 10 $SHORT --beams 4096 --agents 16384 > $OUT/bench_4096beams.log 2>&1
+  ;;
+prof)
+  cd /tmp
+  PB="python $R/bench.py $SHORT --no-profile-events"
+  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats -o stats -- $PB --steps 100 --warmup 10 > $OUT/prof_stats.log 2>&1
+  python $R/tools/summarize_prof.py stats $OUT/prof_stats $OUT/kernel_stats.txt
+  timeout 400 rocprofv3 --pmc FETCH_SIZE -T -f csv -d $OUT/pmc_fetch -o fetch -- $PB --steps 20 --warmup 3 > $OUT/pmc_fetch.log 2>&1
+  python $R/tools/summarize_prof.py pmc $OUT/pmc_fetch $OUT/pmc_fetch.json
+  timeout 400 rocprofv3 --pmc WRITE_SIZE -T -f csv -d $OUT/pmc_write -o write -- $PB --steps 20 --warmup 3 > $OUT/pmc_write.log 2>&1
+  python $R/tools/summarize_prof.py pmc $OUT/pmc_write $OUT/pmc_write.json
+  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -T -f csv -d $OUT/pmc_sq -o sq -- $PB --steps 20 --warmup 3 > $OUT/pmc_sq.log 2>&1
+  python $R/tools/summarize_prof.py pmc $OUT/pmc_sq $OUT/pmc_sq.json
+  timeout 400 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -T -f csv -d $OUT/pmc_sq2 -o sq2 -- $PB --steps 20 --warmup 3 > $OUT/pmc_sq2.log 2>&1
+  python $R/tools/summarize_prof.py pmc $OUT/pmc_sq2 $OUT/pmc_sq2.json
+  timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -T -f csv -d $OUT/pmc_tcc -o tcc -- $PB --steps 20 --warmup 3 > $OUT/pmc_tcc.log 2>&1
+  python $R/tools/summarize_prof.py pmc $OUT/pmc_tcc $OUT/pmc_tcc.json
+  timeout 400 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum TA_BUSY_avr TA_TA_BUSY_sum -T -f csv -d $OUT/pmc_tcp -o tcp -- $PB --steps 20 --warmup 3 > $OUT/pmc_tcp.log 2>&1
+  python $R/tools/summarize_prof.py pmc $OUT/pmc_tcp $OUT/pmc_tcp.json
+  cd "$R"
+  rm -rf $OUT/prof_stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_tcc $OUT/pmc_tcp
+  ;;
+esac
+done
 cd "$R"
-find $OUT -name "*.csv" -size +3M -delete
-find $OUT -name "*.db" -delete
-ls -laR $OUT | head -80 > $OUT/listing.txt
-tail -3 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log; tail -2 $OUT/bench_default.log
+for f in $OUT/pytest_gpu.log $OUT/smoke.log; do [ -f $f ] && tail -2 $f; done
+grep -h '^{' $OUT/bench_*.log 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); r = d.get('roofline', {})
+    print('%.2fM/s ms/step %.3f scan %.3f int+col %.3f fin %.3f | %s' % (d['value']/1e6, d['ms_per_step'], r.get('kernel_ms_avg', 0), r.get('integrate_collide_ms_avg', 0), r.get('finalize_ms_avg', 0), d['config']['workload'][:40] + ' ' + d['config']['map_layout']))
+"

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats / counter collection) into small text+JSON
+summaries that are cheap to pull from the GPU box and to commit under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def kernel_stats(d, out):
+    files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    lines = []
+    for f in files:
+        rows = list(csv.DictReader(open(f)))
+        lines.append("# %s" % os.path.basename(f))
+        lines.append("%-70s %8s %12s %12s %12s %12s %7s" % ("Name", "Calls", "Total(ns)", "Avg(ns)", "Min(ns)", "Max(ns)", "Pct"))
+        for r in rows:
+            lines.append("%-70s %8s %12s %12.1f %12s %12s %7s" % (r["Name"][:70], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]),
+                                                                r["MinNs"], r["MaxNs"], r["Percentage"]))
+    open(out, "w").write("\n".join(lines) + "\n")
+
+
+def counters(d, out, kernel_filter=None):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    meta = {}
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0][:60]
+            if kernel_filter and kernel_filter not in k:
+                continue
+            a = acc[k][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+            meta[k] = {x: r.get(x) for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+    res = {k: {"dispatches": max(v[1] for v in c.values()), "mean_per_dispatch": {n: v[0] / v[1] for n, v in c.items()}, "meta": meta[k]}
+           for k, c in acc.items()}
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    mode, d, out = sys.argv[1:4]
+    if mode == "stats":
+        kernel_stats(d, out)
+    else:
+        counters(d, out, sys.argv[4] if len(sys.argv) > 4 else None)
