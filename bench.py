@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--agents", type=int, default=65536, help="agents per GPU (envs x 2)")
     ap.add_argument("--agents-per-env", type=int, default=2)
     ap.add_argument("--beams", type=int, default=1080)
-    ap.add_argument("--layout", type=int, default=int(os.environ.get("F110_MAP_LAYOUT", "1")), help="0 row-major, 1 tiled 4x4")
+    ap.add_argument("--layout", type=int, default=int(os.environ.get("F110_MAP_LAYOUT", "0")), help="0 row-major, 1 tiled 4x4")
     ap.add_argument("--scan-block", type=int, default=int(os.environ.get("F110_SCAN_BLOCK", "0")))
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--no-reset", action="store_true")

@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
 struct RayJob {
     uint32_t n_rays;          // poses * B
     int32_t n_poses;
+    uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
     const double *pose_x, *pose_y, *dir_start;  // [n_poses]
     double *ranges;           // [n_poses][B]
     // STEP only
@@ -171,14 +172,18 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
     const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
     if (ray >= j.n_rays) return;
     const uint32_t B = (uint32_t)k.num_beams;
-    const uint32_t p = ray / B;
+    const uint32_t p = j.div_magic ? (__umulhi(ray, j.div_magic) >> j.div_shift) : ray / B;
     const int b = (int)(ray - p * B);
     const int idx = beam_dir_index(k, j.dir_start[p], b);
     const double2 cs = k.cs[idx];
     int hr, hc, nl;
     double r = march_ray<LAYOUT, POW2, IDENT>(k, j.pose_x[p], j.pose_y[p], cs.x, cs.y, hr, hc, nl);
     if (STEP) {
-        if (j.noise) r += j.noise[(size_t)(j.step_count[p] % j.noise_rows) * B + b];
+        if (j.noise) {
+            int row = j.step_count[p];
+            if (row >= j.noise_rows) row %= j.noise_rows;  // only when the table wraps
+            r += j.noise[(size_t)row * B + b];
+        }
         const double vel = j.vel[p];
         // check_ttc_jit is an any-over-beams: every hitting lane raises the agent's flag
         if (vel != 0.0 && ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh)) j.wall_flag[p] = 1;
@@ -563,6 +568,7 @@ struct f110_sim {
     AgentArrays dev{};
     ScanConst k{};
     bool has_map = false;
+    uint32_t step_magic = 0, step_shift = 0;  // ray -> agent division constants of the step launch
     int scan_block = 64;
     double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
     double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_actions = nullptr, *d_poses = nullptr;
@@ -638,6 +644,44 @@ struct Scratch {
 static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 typedef void (*scan_rays_fn)(RayJob, ScanConst);
+
+// ray / B by multiply-high: find (magic, shift) with umulhi(x, magic) >> shift == x / B for every
+// x < n (verified at every multiple of B and its predecessor, which is sufficient because both
+// sides are monotone step functions of x).  Returns false when no 32-bit magic works.
+static bool find_div_magic(uint32_t B, uint32_t n, uint32_t *magic, uint32_t *shift)
+{
+    if (B < 2) return false;
+    for (uint32_t s = 0; s < 32; ++s) {
+        const unsigned long long m = ((1ull << (32 + s)) + B - 1) / B;  // ceil(2^(32+s) / B)
+        if (m >> 32) break;
+        bool ok = true;
+        for (unsigned long long x = B; ok && x <= (unsigned long long)n + B; x += B) {
+            const unsigned long long xs[2] = {x - 1, x};
+            for (unsigned long long v : xs) {
+                if (v >= n) continue;
+                if ((((v * m) >> 32) >> s) != v / B) ok = false;
+            }
+        }
+        if (ok) {
+            *magic = (uint32_t)m;
+            *shift = s;
+            return true;
+        }
+    }
+    return false;
+}
+
+static void set_div_magic(RayJob &j, uint32_t B)
+{
+    uint32_t m = 0, s = 0;
+    if (find_div_magic(B, j.n_rays, &m, &s)) {
+        j.div_magic = m;
+        j.div_shift = s;
+    } else {
+        j.div_magic = 0;
+        j.div_shift = 0;
+    }
+}
 
 
 template <bool STEP>
@@ -781,6 +825,14 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     k.max_range = cfg->max_range;
     k.fov = cfg->fov;
     k.theta_inc = cfg->theta_dis * d.angle_inc / (2. * kPi);  // :368
+    k.inv_theta_dis = 1.0 / (double)cfg->theta_dis;
+    {
+        RayJob tmp{};
+        tmp.n_rays = (uint32_t)N * (uint32_t)B;
+        set_div_magic(tmp, (uint32_t)B);
+        h->step_magic = tmp.div_magic;
+        h->step_shift = tmp.div_shift;
+    }
     {
         const double g = 64.0 * (double)B * 2.2737367544323206e-13;  // 64 * B * 2^-42
         k.dir_guard = g > 1e-8 ? g : 1e-8;
@@ -836,6 +888,7 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
     k.height = H;
     k.width = W;
     k.tiles_w = (W + 3) / 4;
+    k.row_bytes = W * 8;
     k.res = res;
     k.inv_res = 1.0 / res;
     {
@@ -894,6 +947,7 @@ int f110_set_map_dt(f110_sim *h, const double *h_dt, int32_t H, int32_t W, doubl
 {
     if (!h || !h_dt) return fail(h, F110_ERR_INVALID, "f110_set_map_dt: null argument");
     if (H < 1 || W < 1 || !(res > 0)) return fail(h, F110_ERR_INVALID, "f110_set_map_dt: bad shape or resolution");
+    if ((unsigned long long)(H + 3) * (unsigned long long)(W + 3) * 8ull >= 0xFFFFFFFFull) return fail(h, F110_ERR_INVALID, "distance table must stay below 4 GiB");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const size_t n = (size_t)H * W;
     if (h->d_dt_row) { (void)hipFree(h->d_dt_row); h->d_dt_row = nullptr; }
@@ -1045,6 +1099,8 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         j.side_dist = h->dev.side_dist;
         j.wall_flag = h->dev.in_collision;
         j.ttc_thresh = h->dev.ttc_thresh;
+        j.div_magic = h->step_magic;
+        j.div_shift = h->step_shift;
         scan_rays_fn fn = pick_rays<true>(h->k, h->cfg.map_layout);
         hipLaunchKernelGGL(fn, grid1d(j.n_rays, h->scan_block), dim3(h->scan_block), 0, h->stream, j, h->k);
     }
@@ -1262,6 +1318,7 @@ int f110_scan_batch(f110_sim *h, const double *poses, int32_t m, double *ranges,
     j.ranges = dr;
     j.hit_rc = dh;
     j.lookups = dl;
+    set_div_magic(j, (uint32_t)B);
     scan_rays_fn fn = pick_rays<false>(h->k, h->cfg.map_layout);
     hipLaunchKernelGGL(fn, grid1d(j.n_rays, h->scan_block), dim3(h->scan_block), 0, h->stream, j, h->k);
     HIPCHK(h, hipGetLastError());

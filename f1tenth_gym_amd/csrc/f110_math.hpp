@@ -173,22 +173,37 @@ struct ScanConst {
     const double *table;   // distance table in the chosen layout
     const double2 *cs;     // (cos, sin) of linspace(0, 2pi, theta_dis), interleaved
     int32_t height, width, tiles_w, theta_dis;
-    int32_t num_beams, res_pow2, ident_rot, pad0;
+    int32_t num_beams, res_pow2, ident_rot, row_bytes;  // row_bytes = width * 8
     double res, inv_res, orig_x, orig_y, orig_c, orig_s;
     double w_res, h_res;   // width*resolution, height*resolution (xy_2_rc :79)
     double oob_value;      // dt[-1,-1]: what an out-of-bounds sample reads (:80-81,:103)
-    double eps, max_range, fov, theta_inc, dir_guard;
+    double eps, max_range, fov, theta_inc, dir_guard, inv_theta_dis;
 };
+
+// 24-bit multiply (v_mul_u32_u24 / v_mad_u32_u24 are full-rate; the 32-bit v_mul_lo_u32 is not).
+// Rows, columns and row pitches of any realistic map are far below 2^24.
+F110_HD uint32_t mul24(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
 
 template <int LAYOUT>
 F110_HD double table_fetch(const ScanConst &k, int r, int c)
 {
+    // 32-bit BYTE offset from the (wave-uniform) table base: lets the compiler use the
+    // scalar-base + 32-bit-VGPR-offset form of global_load (tables are < 4 GiB, checked on upload)
+    uint32_t off;
     if (LAYOUT == LAYOUT_ROWMAJOR) {
-        return k.table[(uint32_t)r * (uint32_t)k.width + (uint32_t)c];
+        off = mul24((uint32_t)r, (uint32_t)k.row_bytes) + ((uint32_t)c << 3);
     } else {
-        const uint32_t tile = (uint32_t)(r >> 2) * (uint32_t)k.tiles_w + (uint32_t)(c >> 2);
-        return k.table[tile * 16u + (uint32_t)(((r & 3) << 2) | (c & 3))];
+        const uint32_t tile = mul24((uint32_t)(r >> 2), (uint32_t)k.tiles_w) + (uint32_t)(c >> 2);
+        off = tile * 128u + (uint32_t)(((r & 3) << 2) | (c & 3)) * 8u;
     }
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(k.table) + off);
 }
 
 // int(v / resolution) of xy_2_rc :83-84 for v in [0, extent).  When the resolution is a power
@@ -220,14 +235,19 @@ F110_HD double sample_distance(const ScanConst &k, double x, double y, int &r, i
         xr = xt * k.orig_c + yt * k.orig_s;
         yr = -xt * k.orig_s + yt * k.orig_c;
     }
-    if (xr < 0 || xr >= k.w_res || yr < 0 || yr >= k.h_res) {
-        r = -1;
-        c = -1;
-        return k.oob_value;
+    // one combined predicate (bitwise &, no short-circuit) -> a single divergent region per
+    // sample.  The reference's "x_rot < 0 or x_rot >= w*res or ..." (:79) is its complement
+    // for every non-NaN position.
+    const bool inside = (xr >= 0) & (xr < k.w_res) & (yr >= 0) & (yr < k.h_res);
+    double d = k.oob_value;
+    r = -1;
+    c = -1;
+    if (inside) {
+        c = cell_index<POW2>(xr, k);
+        r = cell_index<POW2>(yr, k);
+        d = table_fetch<LAYOUT>(k, r, c);
     }
-    c = cell_index<POW2>(xr, k);
-    r = cell_index<POW2>(yr, k);
-    return table_fetch<LAYOUT>(k, r, c);
+    return d;
 }
 
 // trace_ray :106-146 (sphere tracing over the distance table)
@@ -265,10 +285,13 @@ F110_HD double scan_start_index(const ScanConst &k, double pose_theta)
 F110_HD int beam_dir_index(const ScanConst &k, double start, int i)
 {
     const double td = (double)k.theta_dis;
-    double t = start + (double)i * k.theta_inc;
-    t -= floor(t / td) * td;
+    // closed form (approximate on purpose: explicit FMAs, reciprocal instead of a division);
+    // any value that lands within dir_guard of an integer — which includes the wrap points 0 and
+    // theta_dis — is recomputed exactly below
+    double t = fma((double)i, k.theta_inc, start);
+    t = fma(-floor(t * k.inv_theta_dis), td, t);
     const double fr = t - floor(t);
-    if (fr < k.dir_guard || fr > 1.0 - k.dir_guard || t < 0 || t >= td) {
+    if (!(fabs(fr - 0.5) < 0.5 - k.dir_guard)) {
         double ti = start;
         for (int j = 0; j < i; ++j) {
             ti += k.theta_inc;
@@ -285,8 +308,15 @@ F110_HD int beam_dir_index(const ScanConst &k, double start, int i)
 // check_ttc_jit :188-217 — one beam's predicate
 F110_HD bool ttc_beam_hit(double range, double side_distance, double vel, double beam_cos, double thresh)
 {
+    // ttc = (scan[i] - side_distances[i]) / (vel*cosines[i]);  hit <=> 0 <= ttc < thresh.
+    // Decided without the float64 division unless |num| is within 1e-12 (relative) of
+    // thresh*|den| — there, and for NaN / 0/0, the reference expression itself is evaluated.
     const double proj_vel = vel * beam_cos;
-    const double ttc = (range - side_distance) / proj_vel;
+    const double num = range - side_distance;
+    const double a = fabs(num), b = fabs(proj_vel);
+    if (a < (thresh * (1.0 - 1e-12)) * b) return (num == 0.0) || ((num > 0.0) == (proj_vel > 0.0));
+    if (a > (thresh * (1.0 + 1e-12)) * b) return false;
+    const double ttc = num / proj_vel;
     return (ttc < thresh) && (ttc >= 0.0);
 }
 

@@ -46,7 +46,7 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
     std::vector<double2> cs(theta_dis);
     for (int i = 0; i < theta_dis; ++i) cs[i] = make_double2(cosines[i], sines[i]);
     k.cs = cs.data();
-    k.height = H; k.width = W; k.tiles_w = (W + 3) / 4; k.theta_dis = theta_dis; k.num_beams = B;
+    k.height = H; k.width = W; k.tiles_w = (W + 3) / 4; k.row_bytes = W * 8; k.theta_dis = theta_dis; k.num_beams = B;
     k.res = res; k.inv_res = 1.0 / res;
     int e; k.res_pow2 = (frexp(res, &e) == 0.5) ? 1 : 0;
     k.orig_x = ox; k.orig_y = oy; k.orig_c = oc; k.orig_s = os;
@@ -57,6 +57,7 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
     k.theta_inc = theta_dis * (fov / (B - 1)) / (2. * kPi);
     const double g = 64.0 * (double)B * 2.2737367544323206e-13;
     k.dir_guard = g > 1e-8 ? g : 1e-8;
+    k.inv_theta_dis = 1.0 / (double)theta_dis;
     if (layout == 1) {
         const int th = (H + 3) / 4;
         tiled.assign((size_t)k.tiles_w * th * 16, 0.0);
@@ -101,12 +102,13 @@ void hh_scan_generic(const double *dt, int H, int W, double res, double ox, doub
     std::vector<double2> cs(theta_dis);
     for (int i = 0; i < theta_dis; ++i) cs[i] = make_double2(cosines[i], sines[i]);
     k.cs = cs.data(); k.table = dt;
-    k.height = H; k.width = W; k.tiles_w = (W + 3) / 4; k.theta_dis = theta_dis; k.num_beams = B;
+    k.height = H; k.width = W; k.tiles_w = (W + 3) / 4; k.row_bytes = W * 8; k.theta_dis = theta_dis; k.num_beams = B;
     k.res = res; k.inv_res = 1.0 / res; k.orig_x = ox; k.orig_y = oy; k.orig_c = oc; k.orig_s = os;
     k.w_res = W * res; k.h_res = H * res; k.oob_value = dt[(size_t)H * W - 1];
     k.eps = eps; k.max_range = max_range; k.fov = fov;
     k.theta_inc = theta_dis * (fov / (B - 1)) / (2. * kPi);
     k.dir_guard = 1e-8;
+    k.inv_theta_dis = 1.0 / (double)theta_dis;
     const double start = scan_start_index(k, pose[2]);
     for (int b = 0; b < B; ++b) {
         const int idx = beam_dir_index(k, start, b);
@@ -122,6 +124,7 @@ void hh_dir_index(int theta_dis, int B, double fov, double theta, double guard, 
     k.theta_dis = theta_dis; k.num_beams = B; k.fov = fov;
     k.theta_inc = theta_dis * (fov / (B - 1)) / (2. * kPi);
     k.dir_guard = guard;
+    k.inv_theta_dis = 1.0 / (double)theta_dis;
     const double start = scan_start_index(k, theta);
     for (int b = 0; b < B; ++b) idx[b] = beam_dir_index(k, start, b);
 }

@@ -215,3 +215,33 @@ def test_disc_cull_is_result_preserving(hh):
         ref_total += mm[1] - mm[0] + 1
         culled_total += max(0, mm[3] - mm[2] + 1)
     assert culled_total < 0.7 * ref_total     # the cull actually removes work
+
+
+def test_ttc_predicate_guard_band(hh):
+    """the division-free iTTC predicate must agree with the reference expression everywhere,
+    in particular within a few ulp of the threshold and at the 0 / inf / nan corner cases"""
+    rng = np.random.default_rng(31)
+    B = 64
+    co = np.cos(np.linspace(-2.35, 2.35, B)); sd = rng.uniform(0.1, 0.4, B)
+    thresh = 0.005
+    co_, cp = d(co); sd_, sp = d(sd)
+    cases = []
+    for _ in range(400):
+        v = rng.uniform(-6, 8)
+        scan = rng.uniform(0.0, 5.0, B)
+        j = rng.integers(B)
+        den = v * co[j]
+        for delta in (0.0, 1e-16, -1e-16, 3e-16, -3e-16, 1e-13, -1e-13, 1e-11, -1e-11, 1e-9, -1e-9):
+            s2 = scan.copy(); s2[:] = 5.0 + sd        # everything else far away
+            s2[j] = sd[j] + thresh * den * (1.0 + delta)
+            cases.append((s2, v))
+    cases += [(np.full(B, 1.0), 0.0), (sd.copy(), 3.0), (sd.copy(), -3.0), (np.full(B, np.inf), 2.0),
+              (np.full(B, np.nan), 2.0), (sd * 0.5, 2.0), (sd * 0.5, -2.0)]
+    n_hit = 0
+    for scan, v in cases:
+        s_, spn = d(scan)
+        got = hh.hh_ttc(spn, B, C.c_double(v), cp, sp, C.c_double(thresh))
+        ref = int(orc.check_ttc(scan, v, co, sd, thresh))
+        assert got == ref, (v, scan[:4])
+        n_hit += ref
+    assert 100 < n_hit < len(cases) - 100
