@@ -43,8 +43,10 @@ def parse_args():
     ap.add_argument("--agents", type=int, default=65536, help="agents per GPU (envs x 2)")
     ap.add_argument("--agents-per-env", type=int, default=2)
     ap.add_argument("--beams", type=int, default=1080)
-    ap.add_argument("--layout", type=int, default=int(os.environ.get("F110_MAP_LAYOUT", "0")), help="0 row-major, 1 tiled 4x4")
+    ap.add_argument("--layout", type=int, default=int(os.environ.get("F110_MAP_LAYOUT", "0")), help="0 row-major f64, 1 tiled 4x4 f64, 2 byte codes + LDS LUT")
     ap.add_argument("--scan-block", type=int, default=int(os.environ.get("F110_SCAN_BLOCK", "0")))
+    ap.add_argument("--scan-tasks", type=int, default=int(os.environ.get("F110_SCAN_TASKS", "0")),
+                    help="consecutive 64-ray tasks per wave (0 = default)")
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--no-reset", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,7 +130,7 @@ def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
     env_ids = shard_envs(E, rdv.rank)
     img, res, origin = load_map_image("example_map")
     sim = BatchSim(num_envs=E, num_agents=A, num_beams=args.beams, device_id=rdv.local_rank,
-                   map_layout=args.layout, scan_block=args.scan_block)
+                   map_layout=args.layout, scan_block=args.scan_block, scan_tasks_per_wave=args.scan_tasks)
     sim.set_map_image(img, res, origin)
     total = warmup + steps
     if not args.no_noise:
@@ -188,7 +190,7 @@ def parity_gate(args, rdv):
     dt, _, _ = oracle_map_dt("example_map")
     noise = None if args.no_noise else np.random.default_rng(12345).normal(0., 0.01, size=(T + 2, args.beams))
     sim = BatchSim(num_envs=E, num_agents=A, num_beams=args.beams, device_id=rdv.local_rank, map_layout=args.layout,
-                   scan_block=args.scan_block)
+                   scan_block=args.scan_block, scan_tasks_per_wave=args.scan_tasks)
     sim.set_map_image(img, res, origin)
     ref = orc.SimOracle(E, A, num_beams=args.beams)
     ref.set_map_dt(dt, res, origin)
@@ -290,7 +292,8 @@ def main():
                                % (args.agents, args.agents // args.agents_per_env, args.agents_per_env, args.beams,
                                   "off" if args.no_noise else "on", "off" if args.no_reset else "on"),
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
-                   "map_layout": "tiled4x4_f64" if args.layout == 1 else "rowmajor_f64",
+                   "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut"}[args.layout],
+                   "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks,
                    "parallelism": "env-sharded x%d, no data-path collective" % n_gpus,
                    "env_resets_in_timed_region": int(n_reset)},
     }

@@ -110,7 +110,7 @@ class BatchSim(object):
     def __init__(self, params=None, num_envs=1, num_agents=2, num_beams=1080, fov=4.7, eps=0.0001,
                  theta_dis=2000, max_range=30.0, time_step=0.01, integrator=_ffi.INTEGRATOR_RK4,
                  lidar_dist=0.0, ttc_thresh=0.005, device_id=0, map_layout=_ffi.MAP_ROWMAJOR_F64,
-                 scan_block=0):
+                 scan_block=0, scan_tasks_per_wave=0):
         self._h = None
         L = _ffi.lib()
         self.params = dict(DEFAULT_PARAMS if params is None else params)
@@ -123,6 +123,7 @@ class BatchSim(object):
         cfg.num_envs, cfg.num_agents, cfg.num_beams = self.E, self.A, self.B
         cfg.theta_dis, cfg.integrator, cfg.device_id = self.theta_dis, int(integrator), self.device_id
         cfg.map_layout, cfg.scan_block = int(map_layout), int(scan_block)
+        cfg.scan_tasks_per_wave = int(scan_tasks_per_wave)
         cfg.fov, cfg.eps, cfg.max_range = float(fov), float(eps), float(max_range)
         cfg.time_step, cfg.lidar_dist, cfg.ttc_thresh = float(time_step), float(lidar_dist), float(ttc_thresh)
         pv = _ffi.params_vector(self.params)

@@ -17,6 +17,7 @@
 // There is no CPU fallback in this library.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -149,6 +150,8 @@ __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
 // entry point (also reports terminating cells and lookup counts).
 struct RayJob {
     uint32_t n_rays;          // poses * B
+    uint32_t n_tasks;         // ceil(n_rays / 64): one task = 64 consecutive rays
+    uint32_t tasks_per_wave;  // consecutive tasks each wave walks
     int32_t n_poses;
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
     const double *pose_x, *pose_y, *dir_start;  // [n_poses]
@@ -169,32 +172,46 @@ struct RayJob {
 template <int LAYOUT, bool POW2, bool IDENT, bool STEP>
 __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
 {
-    const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ray >= j.n_rays) return;
-    const uint32_t B = (uint32_t)k.num_beams;
-    const uint32_t p = j.div_magic ? (__umulhi(ray, j.div_magic) >> j.div_shift) : ray / B;
-    const int b = (int)(ray - p * B);
-    const int idx = beam_dir_index(k, j.dir_start[p], b);
-    const double2 cs = k.cs[idx];
-    int hr, hc, nl;
-    double r = march_ray<LAYOUT, POW2, IDENT>(k, j.pose_x[p], j.pose_y[p], cs.x, cs.y, hr, hc, nl);
-    if (STEP) {
-        if (j.noise) {
-            int row = j.step_count[p];
-            if (row >= j.noise_rows) row %= j.noise_rows;  // only when the table wraps
-            r += j.noise[(size_t)row * B + b];
-        }
-        const double vel = j.vel[p];
-        // check_ttc_jit is an any-over-beams: every hitting lane raises the agent's flag
-        if (vel != 0.0 && ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh)) j.wall_flag[p] = 1;
-    } else {
-        if (j.hit_rc) {
-            j.hit_rc[(size_t)ray * 2] = hr;
-            j.hit_rc[(size_t)ray * 2 + 1] = hc;
-        }
-        if (j.lookups) atomicAdd(&j.lookups[p], (unsigned long long)nl);
+    __shared__ double lut_lds[LAYOUT == LAYOUT_CODE8 ? 256 : 1];
+    if (LAYOUT == LAYOUT_CODE8) {
+        // stage the 2 KB value LUT once per workgroup; every wave then walks j.tasks_per_wave
+        // consecutive 64-ray tasks so the fill is amortised
+        for (int t = threadIdx.x; t < kLutEntries; t += blockDim.x) lut_lds[t] = k.lut[t];
+        __syncthreads();
     }
-    j.ranges[ray] = r;
+    const uint32_t B = (uint32_t)k.num_beams;
+    const uint32_t tpw = j.tasks_per_wave;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t t = 0; t < tpw; ++t) {
+        const uint32_t task = wave * tpw + t;
+        if (task >= j.n_tasks) break;  // wave-uniform
+        const uint32_t ray = task * 64u + lane;
+        if (ray >= j.n_rays) break;
+        const uint32_t p = j.div_magic ? (__umulhi(ray, j.div_magic) >> j.div_shift) : ray / B;
+        const int b = (int)(ray - p * B);
+        const int idx = beam_dir_index(k, j.dir_start[p], b);
+        const double2 cs = k.cs[idx];
+        int hr, hc, nl;
+        double r = march_ray<LAYOUT, POW2, IDENT>(k, lut_lds, j.pose_x[p], j.pose_y[p], cs.x, cs.y, hr, hc, nl);
+        if (STEP) {
+            if (j.noise) {
+                int row = j.step_count[p];
+                if (row >= j.noise_rows) row %= j.noise_rows;  // only when the table wraps
+                r += j.noise[(size_t)row * B + b];
+            }
+            const double vel = j.vel[p];
+            // check_ttc_jit is an any-over-beams: every hitting lane raises the agent's flag
+            if (vel != 0.0 && ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh)) j.wall_flag[p] = 1;
+        } else {
+            if (j.hit_rc) {
+                j.hit_rc[(size_t)ray * 2] = hr;
+                j.hit_rc[(size_t)ray * 2 + 1] = hc;
+            }
+            if (j.lookups) atomicAdd(&j.lookups[p], (unsigned long long)nl);
+        }
+        j.ranges[ray] = r;
+    }
 }
 
 // ---- K3: finalize ---------------------------------------------------------------------------
@@ -553,6 +570,35 @@ __global__ void k_retile(const double *__restrict__ rowmajor, int H, int W, int 
     tiled[t] = (r < H && c < W) ? rowmajor[(size_t)r * W + c] : 0.0;
 }
 
+// CODE8 layout: code = rank of the cell's value among the 255 smallest distinct table values
+// (binary search in the ascending LUT), 255 when it is not one of them; 16x8-cell tiles.
+__global__ void k_build_codes(const double *__restrict__ rowmajor, int H, int W, int ctiles_w, int ctiles_h,
+                              const double *__restrict__ lut, int n_lut, uint8_t *__restrict__ codes)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)ctiles_w * ctiles_h * 128;
+    if (t >= total) return;
+    const size_t tile = t >> 7;
+    const int within = (int)(t & 127);
+    const int r = (int)(tile / ctiles_w) * 8 + (within >> 4);
+    const int c = (int)(tile % ctiles_w) * 16 + (within & 15);
+    uint8_t code = 255;
+    if (r < H && c < W) {
+        const double v = rowmajor[(size_t)r * W + c];
+        int lo = 0, hi = n_lut - 1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const double m = lut[mid];
+            if (m == v) {
+                code = (uint8_t)mid;
+                break;
+            }
+            if (m < v) lo = mid + 1; else hi = mid - 1;
+        }
+    }
+    codes[t] = code;
+}
+
 __global__ void k_interleave_cs(const double *__restrict__ sines, const double *__restrict__ cosines, int n, double2 *__restrict__ cs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,6 +615,9 @@ struct f110_sim {
     ScanConst k{};
     bool has_map = false;
     uint32_t step_magic = 0, step_shift = 0;  // ray -> agent division constants of the step launch
+    int scan_tasks_per_wave = 1, num_cus = 256;  // consecutive 64-ray tasks per wave
+    uint8_t *d_codes = nullptr;
+    double *d_lut = nullptr;
     int scan_block = 64;
     double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
     double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_actions = nullptr, *d_poses = nullptr;
@@ -689,8 +738,18 @@ static scan_rays_fn pick_rays(const ScanConst &k, int layout)
 {
 #define SEL(L) (k.res_pow2 ? (k.ident_rot ? k_scan_rays<L, true, true, STEP> : k_scan_rays<L, true, false, STEP>) \
                            : (k.ident_rot ? k_scan_rays<L, false, true, STEP> : k_scan_rays<L, false, false, STEP>))
+    if (layout == F110_MAP_CODE8) return SEL(LAYOUT_CODE8);
     return layout == F110_MAP_TILED_F64 ? SEL(LAYOUT_TILED) : SEL(LAYOUT_ROWMAJOR);
 #undef SEL
+}
+
+static dim3 rays_grid(RayJob &j, int block, int tasks_per_wave)
+{
+    j.n_tasks = (j.n_rays + 63u) / 64u;
+    j.tasks_per_wave = tasks_per_wave > 0 ? (uint32_t)tasks_per_wave : 1u;
+    const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave;
+    const uint32_t wpb = (uint32_t)block / 64u;
+    return dim3((waves + wpb - 1) / wpb);
 }
 
 extern "C" {
@@ -742,7 +801,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         return fail(nullptr, F110_ERR_INVALID, "f110_create: num_envs/num_agents >= 1, num_beams/theta_dis >= 2 required");
     if (cfg->integrator != F110_INTEGRATOR_RK4 && cfg->integrator != F110_INTEGRATOR_EULER)
         return fail(nullptr, F110_ERR_INVALID, "Invalid Integrator Specified. Please choose RK4 or Euler");
-    if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_TILED_F64)
+    if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_TILED_F64 && cfg->map_layout != F110_MAP_CODE8)
         return fail(nullptr, F110_ERR_INVALID, "unknown map_layout %d", cfg->map_layout);
     if ((long long)cfg->num_envs * cfg->num_agents * (long long)cfg->num_beams > 0xFFFFFF00LL) return fail(nullptr, F110_ERR_INVALID, "num_envs*num_agents*num_beams must stay below 2^32");
     int ndev = 0;
@@ -759,10 +818,18 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     h->N = cfg->num_envs * cfg->num_agents;
     const int N = h->N, B = cfg->num_beams;
     h->scan_block = cfg->scan_block > 0 ? cfg->scan_block : 64;
+    h->scan_tasks_per_wave = cfg->scan_tasks_per_wave > 0 ? cfg->scan_tasks_per_wave
+                             : (cfg->map_layout == F110_MAP_CODE8 ? 4 : 1);
+    if (cfg->scan_block <= 0 && cfg->map_layout == F110_MAP_CODE8) h->scan_block = 256;
     if (h->scan_block % 64 != 0 || h->scan_block > 256) { delete h; return fail(nullptr, F110_ERR_INVALID, "scan_block must be 64, 128, 192 or 256"); }
 #define CK(expr) do { int rc_ = (expr); if (rc_ != F110_OK) { snprintf(g_err, sizeof g_err, "%s", h->err); f110_destroy(h); return rc_; } } while (0)
 #define CKH(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(nullptr, F110_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); f110_destroy(h); return F110_ERR_HIP; } } while (0)
     CKH(hipSetDevice(cfg->device_id));
+    {
+        hipDeviceProp_t prop;
+        CKH(hipGetDeviceProperties(&prop, cfg->device_id));
+        h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CKH(hipEventCreate(&h->ev_begin));
     CKH(hipEventCreate(&h->ev_end));
@@ -864,7 +931,7 @@ void f110_destroy(f110_sim *h)
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
-                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_actions, h->d_poses, h->d_cs, h->d_mask};
+                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_codes, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -914,6 +981,29 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
         k.table = h->d_dt_tiled;
     } else {
         k.table = h->d_dt_row;
+    }
+    if (h->cfg.map_layout == F110_MAP_CODE8) {
+        // the 255 smallest distinct table values (one-time host sort of the downloaded table)
+        std::vector<double> vals((size_t)H * W);
+        HIPCHK(h, hipMemcpyAsync(vals.data(), h->d_dt_row, vals.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        vals.erase(std::remove_if(vals.begin(), vals.end(), [](double v) { return v != v; }), vals.end());
+        std::sort(vals.begin(), vals.end());
+        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+        std::vector<double> lut(256, INFINITY);
+        const int n_lut = (int)std::min<size_t>(vals.size(), (size_t)kLutEntries);
+        for (int i = 0; i < n_lut; ++i) lut[i] = vals[i];
+        const int ctw = (W + 15) / 16, cth = (H + 7) / 8;
+        if (h->d_codes) { (void)hipFree(h->d_codes); h->d_codes = nullptr; }
+        if (!h->d_lut) TRY(dmalloc(h, &h->d_lut, (size_t)256));
+        const size_t total = (size_t)ctw * cth * 128;
+        TRY(dmalloc(h, &h->d_codes, total));
+        HIPCHK(h, hipMemcpyAsync(h->d_lut, lut.data(), 256 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_build_codes, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_row, H, W, ctw, cth, h->d_lut, n_lut, h->d_codes);
+        HIPCHK(h, hipGetLastError());
+        k.codes = h->d_codes;
+        k.lut = h->d_lut;
+        k.code_tile_row_bytes = ctw * 128;
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->has_map = true;
@@ -1102,7 +1192,8 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         j.div_magic = h->step_magic;
         j.div_shift = h->step_shift;
         scan_rays_fn fn = pick_rays<true>(h->k, h->cfg.map_layout);
-        hipLaunchKernelGGL(fn, grid1d(j.n_rays, h->scan_block), dim3(h->scan_block), 0, h->stream, j, h->k);
+        const dim3 grid = rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
+        hipLaunchKernelGGL(fn, grid, dim3(h->scan_block), 0, h->stream, j, h->k);
     }
     if (prof) HIPCHK(h, hipEventRecord(e2, h->stream));
     if (h->cfg.num_agents > 1)
@@ -1320,7 +1411,8 @@ int f110_scan_batch(f110_sim *h, const double *poses, int32_t m, double *ranges,
     j.lookups = dl;
     set_div_magic(j, (uint32_t)B);
     scan_rays_fn fn = pick_rays<false>(h->k, h->cfg.map_layout);
-    hipLaunchKernelGGL(fn, grid1d(j.n_rays, h->scan_block), dim3(h->scan_block), 0, h->stream, j, h->k);
+    const dim3 grid = rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
+    hipLaunchKernelGGL(fn, grid, dim3(h->scan_block), 0, h->stream, j, h->k);
     HIPCHK(h, hipGetLastError());
     TRY(s.down(ranges, dr, (size_t)m * B));
     if (hit_rc) TRY(s.down(hit_rc, dh, (size_t)m * B * 2));

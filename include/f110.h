@@ -51,7 +51,9 @@ enum { F110_INTEGRATOR_RK4 = 1, F110_INTEGRATOR_EULER = 2 }; /* base_classes.py:
 /* distance-table layouts in HBM (DESIGN.md §data layout) */
 enum {
     F110_MAP_ROWMAJOR_F64 = 0, /* dt[r][c] as the reference stores it */
-    F110_MAP_TILED_F64 = 1     /* 4x4-cell tiles, one 128-byte line per tile */
+    F110_MAP_TILED_F64 = 1,    /* 4x4-cell tiles, one 128-byte line per tile */
+    F110_MAP_CODE8 = 2         /* 1-byte code per cell (16x8-cell tiles) + 255-entry exact float64
+                                  value LUT staged in LDS; code 255 escapes to the row-major table */
 };
 
 /* Simulator(params, num_agents, seed, time_step, ego_idx, integrator, lidar_dist)
@@ -67,7 +69,7 @@ typedef struct f110_config {
     int32_t device_id;     /* HIP device ordinal */
     int32_t map_layout;    /* F110_MAP_* */
     int32_t scan_block;    /* threads per scan workgroup (0 = default) */
-    int32_t reserved0;
+    int32_t scan_tasks_per_wave; /* consecutive 64-ray tasks each wave walks (0 = default) */
     double fov, eps, max_range;
     double time_step, lidar_dist, ttc_thresh;
     double params[F110_NPARAMS]; /* initial vehicle params for every agent slot */

@@ -5,6 +5,7 @@
 // functions into a small shared library that tests/test_host_math.py compares with the
 // oracle.  It catches arithmetic/ordering mistakes before GPU minutes are spent; the GPU
 // parity tests (-m gpu) remain the parity proof for the device instantiation.
+#include <algorithm>
 #include <vector>
 
 #include "../../f1tenth_gym_amd/csrc/f110_math.hpp"
@@ -58,7 +59,28 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
     const double g = 64.0 * (double)B * 2.2737367544323206e-13;
     k.dir_guard = g > 1e-8 ? g : 1e-8;
     k.inv_theta_dis = 1.0 / (double)theta_dis;
-    if (layout == 1) {
+    std::vector<double> lut(256, INFINITY);
+    std::vector<uint8_t> codes;
+    if (layout == 2) {  // CODE8: same construction as finish_map() + k_build_codes
+        std::vector<double> vals(dt, dt + (size_t)H * W);
+        std::sort(vals.begin(), vals.end());
+        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+        const int n_lut = (int)std::min<size_t>(vals.size(), (size_t)kLutEntries);
+        for (int i = 0; i < n_lut; ++i) lut[i] = vals[i];
+        const int ctw = (W + 15) / 16, cth = (H + 7) / 8;
+        codes.assign((size_t)ctw * cth * 128, 255);
+        for (int r = 0; r < H; ++r)
+            for (int c = 0; c < W; ++c) {
+                const double v = dt[(size_t)r * W + c];
+                const auto it = std::lower_bound(lut.begin(), lut.begin() + n_lut, v);
+                if (it != lut.begin() + n_lut && *it == v)
+                    codes[((size_t)(r >> 3) * ctw + (c >> 4)) * 128 + ((r & 7) << 4) + (c & 15)] = (uint8_t)(it - lut.begin());
+            }
+        k.codes = codes.data();
+        k.lut = lut.data();
+        k.code_tile_row_bytes = ctw * 128;
+        k.table = dt;
+    } else if (layout == 1) {
         const int th = (H + 3) / 4;
         tiled.assign((size_t)k.tiles_w * th * 16, 0.0);
         for (int r = 0; r < H; ++r)
@@ -75,8 +97,11 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
         dir_idx[b] = idx;
         int hr, hc, nl;
         double r;
-#define RUN(L, P, I) r = march_ray<L, P, I>(k, pose[0], pose[1], cs[idx].x, cs[idx].y, hr, hc, nl)
-        if (layout == 1) {
+#define RUN(L, P, I) r = march_ray<L, P, I>(k, lut.data(), pose[0], pose[1], cs[idx].x, cs[idx].y, hr, hc, nl)
+        if (layout == 2) {
+            if (k.res_pow2) { if (k.ident_rot) RUN(2, true, true); else RUN(2, true, false); }
+            else { if (k.ident_rot) RUN(2, false, true); else RUN(2, false, false); }
+        } else if (layout == 1) {
             if (k.res_pow2) { if (k.ident_rot) RUN(1, true, true); else RUN(1, true, false); }
             else { if (k.ident_rot) RUN(1, false, true); else RUN(1, false, false); }
         } else {
@@ -113,7 +138,7 @@ void hh_scan_generic(const double *dt, int H, int W, double res, double ox, doub
     for (int b = 0; b < B; ++b) {
         const int idx = beam_dir_index(k, start, b);
         int hr, hc, nl;
-        ranges[b] = march_ray<0, false, false>(k, pose[0], pose[1], cs[idx].x, cs[idx].y, hr, hc, nl);
+        ranges[b] = march_ray<0, false, false>(k, nullptr, pose[0], pose[1], cs[idx].x, cs[idx].y, hr, hc, nl);
     }
 }
 

@@ -105,7 +105,7 @@ def test_bad_integrator_raises(amd, unit):
 
 
 # ---------------------------------------------------------------------------- scan (a8-a12)
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("fixture,mapname,beams,fov", [
     ("scan_example_map", "example_map", 1080, 4.7), ("scan_berlin", "berlin", 1080, 4.7),
     ("scan_example_map_4096", "example_map", 4096, 4.7), ("scan_example_map_271", "example_map", 271, 6.0)])
@@ -127,7 +127,7 @@ def test_scan_generic_paths_vs_oracle(amd, orc):
     dt, res, origin = oracle_map_dt("example_map")
     sub = np.ascontiguousarray(dt[600:1000, 900:1300])
     rng = np.random.default_rng(11)
-    for layout in (0, 1):
+    for layout in (0, 1, 2):
         for res2, org in [(0.05, [-3.0, -4.0, 0.3]), (0.0625, [1.0, 2.0, -1.1]), (0.07, [0.0, 0.0, 0.0])]:
             so = orc.ScanOracle(1080, 4.7)
             so.set_map_dt(sub * (res2 / res), res2, org)
@@ -242,7 +242,7 @@ def _noise(T, B=1080, seed=12345):
     return np.random.default_rng(seed).normal(0., 0.01, size=(T, B))
 
 
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 def test_sim_rollout_vs_golden(amd, layout):
     g = gold("sim_rollout")
     img, res, origin = load_map_image("example_map")
@@ -337,7 +337,7 @@ def _drive(amd, orc, E, A, T, layout=0, seed=0, beams=1080, reset_every=None, ch
     return stats
 
 
-@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 def test_step_vs_oracle_64_envs_200_steps(amd, orc, layout):
     """the parity gate that accompanies every timing: first 64 envs x 200 steps"""
     st = _drive(amd, orc, 64, 2, 200, layout=layout, reset_every=10, check_every=5)
