@@ -31,7 +31,7 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("num_envs", C.c_int32), ("num_agents", C.c_int32),
                 ("num_beams", C.c_int32), ("theta_dis", C.c_int32), ("integrator", C.c_int32),
                 ("device_id", C.c_int32), ("map_layout", C.c_int32), ("scan_block", C.c_int32),
-                ("scan_tasks_per_wave", C.c_int32), ("fov", C.c_double), ("eps", C.c_double),
+                ("scan_tasks_per_wave", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32), ("fov", C.c_double), ("eps", C.c_double),
                 ("max_range", C.c_double), ("time_step", C.c_double), ("lidar_dist", C.c_double),
                 ("ttc_thresh", C.c_double), ("params", C.c_double * NPARAMS)]
 

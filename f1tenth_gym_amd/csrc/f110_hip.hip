@@ -33,6 +33,19 @@ using namespace f110;
 
 // ============================================================================ device side
 
+// What one ray needs to know about its agent, written by k_integrate: read through the scalar
+// cache by k_scan_rays (a wave's 64 consecutive rays belong to at most two agents).
+struct RayHdr {
+    double x, y;        // lidar position (base_classes.py:407-408)
+    double start;       // wrapped theta_index of beam 0 (laser_models.py:166-172)
+    double vel;         // post-integration longitudinal velocity (iTTC)
+    double d0;          // first table sample, shared by every beam of the scan (:129)
+    int32_t noise_row;  // row of the noise table for this step, -1 = no noise
+    int32_t hr0, hc0;   // cell of that first sample
+    int32_t pad[3];
+};
+static_assert(sizeof(RayHdr) == 64, "RayHdr is read as four 16-byte scalar loads");
+
 struct AgentArrays {
     int32_t n_agents_total;  // N
     int32_t agents_per_env;  // A
@@ -42,6 +55,7 @@ struct AgentArrays {
     double *scan_pose;       // [3][N]  lidar pose after integration
     double *snap_pose;       // [3][N]  Simulator.agent_poses (:574)
     double *dir_start;       // [N]     wrapped theta_index of beam 0
+    RayHdr *ray_hdr;         // [N]     per-agent constants of this step's scan
     double *scans;           // [N][B]
     double *collisions;      // [N]
     double *collision_idx;   // [N]
@@ -90,7 +104,28 @@ __global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, c
     a.snap_pose[i] = st[0];
     a.snap_pose[(size_t)N + i] = st[1];
     a.snap_pose[2 * (size_t)N + i] = st[4];
-    a.dir_start[i] = scan_start_index(k, sp[2]);
+    const double start = scan_start_index(k, sp[2]);
+    a.dir_start[i] = start;
+    {
+        // everything the ray kernel needs per agent, incl. the first table sample that all
+        // beams share (trace_ray :129 evaluated at the lidar position; generic exact path)
+        RayHdr hd;
+        ScanConst kr = k;
+        kr.table = k.table_rm;
+        hd.x = sp[0];
+        hd.y = sp[1];
+        hd.start = start;
+        hd.vel = st[3];
+        hd.d0 = sample_distance<LAYOUT_ROWMAJOR, false, false>(kr, nullptr, sp[0], sp[1], hd.hr0, hd.hc0);
+        int row = -1;
+        if (a.noise_rows > 0) {
+            row = a.step_count[i];
+            if (row >= a.noise_rows) row %= a.noise_rows;
+        }
+        hd.noise_row = row;
+        hd.pad[0] = hd.pad[1] = hd.pad[2] = 0;
+        a.ray_hdr[i] = hd;
+    }
     a.in_collision[i] = 0;  // raised by k_scan_rays when any beam's iTTC is under the threshold
 }
 
@@ -154,20 +189,27 @@ struct RayJob {
     uint32_t tasks_per_wave;  // consecutive tasks each wave walks
     int32_t n_poses;
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
-    const double *pose_x, *pose_y, *dir_start;  // [n_poses]
+    const double *pose_x, *pose_y, *dir_start;  // [n_poses] (unit path)
     double *ranges;           // [n_poses][B]
     // STEP only
-    const double *vel;        // [n_poses] post-integration longitudinal velocity
-    const int32_t *step_count;
+    const RayHdr *hdr;        // [n_poses] written by k_integrate
     const double *noise;      // [noise_rows][B] or nullptr
     const double *beam_cos, *side_dist;
     int32_t *wall_flag;       // [n_poses], zeroed by k_integrate
-    int32_t noise_rows;
     double ttc_thresh;
+    double ttc_side_max, ttc_k;  // r > ttc_side_max + ttc_k*|v| cannot satisfy the iTTC predicate
     // unit only
     int32_t *hit_rc;                 // [n_poses][B][2] or nullptr
     unsigned long long *lookups;     // [n_poses] or nullptr
 };
+
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 template <int LAYOUT, bool POW2, bool IDENT, bool STEP>
 __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
@@ -190,20 +232,56 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
         if (ray >= j.n_rays) break;
         const uint32_t p = j.div_magic ? (__umulhi(ray, j.div_magic) >> j.div_shift) : ray / B;
         const int b = (int)(ray - p * B);
-        const int idx = beam_dir_index(k, j.dir_start[p], b);
-        const double2 cs = k.cs[idx];
         int hr, hc, nl;
-        double r = march_ray<LAYOUT, POW2, IDENT>(k, lut_lds, j.pose_x[p], j.pose_y[p], cs.x, cs.y, hr, hc, nl);
+        double r;
         if (STEP) {
-            if (j.noise) {
-                int row = j.step_count[p];
-                if (row >= j.noise_rows) row %= j.noise_rows;  // only when the table wraps
-                r += j.noise[(size_t)row * B + b];
+            // per-agent constants through the scalar cache: the 64 rays of this wave belong to
+            // agent p0 (the first lane's) or p0+1, so two uniform 64-byte headers cover the wave
+            // and no vector-memory instruction is spent on them (B < 64: a wave may span more
+            // agents -> per-lane loads).
+            double hx, hy, hstart, hvel, hd0;
+            int hrow;
+            if (B >= 64u) {
+                typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
+                const uint32_t p0 = __builtin_amdgcn_readfirstlane(p);
+                const uint32_t p1 = (p0 + 1u < (uint32_t)j.n_poses) ? p0 + 1u : p0;
+                const chdr_t h0 = (chdr_t)(j.hdr) + p0;
+                const chdr_t h1 = (chdr_t)(j.hdr) + p1;
+                const bool first = (p == p0);
+                // uniform_*(): pin each header field to SGPRs so the compiler keeps two scalar
+                // loads + a per-lane select instead of one divergent vector load
+                const double x0 = uniform_f64(h0->x), y0 = uniform_f64(h0->y), s0 = uniform_f64(h0->start);
+                const double v0 = uniform_f64(h0->vel), d00 = uniform_f64(h0->d0);
+                const int n0 = uniform_i32(h0->noise_row), r0 = uniform_i32(h0->hr0), c0 = uniform_i32(h0->hc0);
+                const double x1 = uniform_f64(h1->x), y1 = uniform_f64(h1->y), s1 = uniform_f64(h1->start);
+                const double v1 = uniform_f64(h1->vel), d01 = uniform_f64(h1->d0);
+                const int n1 = uniform_i32(h1->noise_row), r1 = uniform_i32(h1->hr0), c1 = uniform_i32(h1->hc0);
+                hx = first ? x0 : x1;
+                hy = first ? y0 : y1;
+                hstart = first ? s0 : s1;
+                hvel = first ? v0 : v1;
+                hd0 = first ? d00 : d01;
+                hrow = first ? n0 : n1;
+                hr = first ? r0 : r1;
+                hc = first ? c0 : c1;
+            } else {
+                const RayHdr hd = j.hdr[p];
+                hx = hd.x; hy = hd.y; hstart = hd.start; hvel = hd.vel; hd0 = hd.d0; hrow = hd.noise_row;
+                hr = hd.hr0; hc = hd.hc0;
             }
-            const double vel = j.vel[p];
-            // check_ttc_jit is an any-over-beams: every hitting lane raises the agent's flag
-            if (vel != 0.0 && ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh)) j.wall_flag[p] = 1;
+            const double2 cs = k.cs[beam_dir_index(k, hstart, b)];
+            r = march_from_first<LAYOUT, POW2, IDENT>(k, lut_lds, hx, hy, cs.x, cs.y, hd0, hr, hc, nl);
+            if (hrow >= 0) r += j.noise[(size_t)hrow * B + b];
+            // check_ttc_jit is an any-over-beams: every hitting lane raises the agent's flag.
+            // r > max(side) + thresh*(1+1e-9)*max|cos|*|v|  implies  r - side_distances[b] >
+            // thresh*(1+1e-12)*|v*cosines[b]|, i.e. the "no hit" branch of ttc_beam_hit, so the
+            // per-beam tables are only read for the few beams that are that close.
+            if (hvel != 0.0 && !(r > j.ttc_side_max + j.ttc_k * fabs(hvel)) &&
+                ttc_beam_hit(r, j.side_dist[b], hvel, j.beam_cos[b], j.ttc_thresh))
+                j.wall_flag[p] = 1;
         } else {
+            const double2 cs = k.cs[beam_dir_index(k, j.dir_start[p], b)];
+            r = march_ray<LAYOUT, POW2, IDENT>(k, lut_lds, j.pose_x[p], j.pose_y[p], cs.x, cs.y, hr, hc, nl);
             if (j.hit_rc) {
                 j.hit_rc[(size_t)ray * 2] = hr;
                 j.hit_rc[(size_t)ray * 2 + 1] = hc;
@@ -616,6 +694,7 @@ struct f110_sim {
     bool has_map = false;
     uint32_t step_magic = 0, step_shift = 0;  // ray -> agent division constants of the step launch
     int scan_tasks_per_wave = 1, num_cus = 256;  // consecutive 64-ray tasks per wave
+    double ttc_side_max = INFINITY, ttc_cos_max = INFINITY;  // see f110_set_beam_tables
     uint8_t *d_codes = nullptr;
     double *d_lut = nullptr;
     int scan_block = 64;
@@ -842,6 +921,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     CK(dmalloc(h, &d.scan_pose, (size_t)3 * N));
     CK(dmalloc(h, &d.snap_pose, (size_t)3 * N));
     CK(dmalloc(h, &d.dir_start, (size_t)N));
+    CK(dmalloc(h, &d.ray_hdr, (size_t)N));
     CK(dmalloc(h, &d.scans, (size_t)N * B));
     CK(dmalloc(h, &d.collisions, (size_t)N));
     CK(dmalloc(h, &d.collision_idx, (size_t)N));
@@ -929,7 +1009,7 @@ void f110_destroy(f110_sim *h)
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     AgentArrays &d = h->dev;
-    void *ptrs[] = {d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
+    void *ptrs[] = {d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
                     h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_codes, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask};
     for (void *p : ptrs)
@@ -979,8 +1059,10 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
         hipLaunchKernelGGL(k_retile, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_row, H, W, k.tiles_w, tiles_h, h->d_dt_tiled);
         HIPCHK(h, hipGetLastError());
         k.table = h->d_dt_tiled;
+        k.table_rm = h->d_dt_row;
     } else {
         k.table = h->d_dt_row;
+        k.table_rm = h->d_dt_row;
     }
     if (h->cfg.map_layout == F110_MAP_CODE8) {
         // the 255 smallest distinct table values (one-time host sort of the downloaded table)
@@ -1088,6 +1170,19 @@ int f110_set_beam_tables(f110_sim *h, const double *sa, const double *co, const 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     // beam spacing of THIS table (seed of the nearest-beam search in the opponent ray-cast)
     h->dev.angle_inc = (sa[B - 1] - sa[0]) / (B - 1);
+    // iTTC early-out of k_scan_rays: with s = max|side|, c = max|cos|, a beam with
+    // r > s + thresh*(1+1e-9)*c*|v| has (r - side_b) > thresh*(1+1e-12)*|v*cos_b| and cannot hit.
+    {
+        double smax = 0.0, cmax = 0.0;
+        bool finite = true;
+        for (int i = 0; i < B; ++i) {
+            if (!(sd[i] == sd[i]) || !(co[i] == co[i])) finite = false;
+            smax = std::max(smax, std::fabs(sd[i]));
+            cmax = std::max(cmax, std::fabs(co[i]));
+        }
+        h->ttc_side_max = finite ? smax : INFINITY;
+        h->ttc_cos_max = finite ? cmax : INFINITY;
+    }
     return F110_OK;
 }
 
@@ -1181,10 +1276,10 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         j.pose_y = h->dev.scan_pose + N;
         j.dir_start = h->dev.dir_start;
         j.ranges = h->dev.scans;
-        j.vel = h->dev.state + 3 * (size_t)N;
-        j.step_count = h->dev.step_count;
+        j.hdr = h->dev.ray_hdr;
         j.noise = h->dev.noise;
-        j.noise_rows = h->dev.noise_rows;
+        j.ttc_side_max = h->ttc_side_max;
+        j.ttc_k = h->dev.ttc_thresh * (1.0 + 1e-9) * h->ttc_cos_max;
         j.beam_cos = h->dev.beam_cos;
         j.side_dist = h->dev.side_dist;
         j.wall_flag = h->dev.in_collision;

@@ -172,6 +172,7 @@ constexpr int kLutEntries = 255;   // codes 0..254 index the LUT, 255 = escape t
 
 struct ScanConst {
     const double *table;   // distance table in the chosen layout (CODE8: the row-major table)
+    const double *table_rm;  // the row-major float64 table (always present)
     const uint8_t *codes;  // CODE8: one byte per cell, 16x8-cell tiles (one 128-byte line each)
     const double *lut;     // CODE8: the 255 smallest distinct table values, ascending (HBM copy)
     const double2 *cs;     // (cos, sin) of linspace(0, 2pi, theta_dis), interleaved
@@ -267,12 +268,14 @@ F110_HD double sample_distance(const ScanConst &k, const double *lut, double x, 
     return d;
 }
 
-// trace_ray :106-146 (sphere tracing over the distance table)
+// trace_ray :133-146 — the marching loop, entered with the first sample (:129-130) already taken.
+// Every ray of one scan starts at the same lidar position, so that first sample is shared by
+// all beams of an agent: the step kernel receives it from k_integrate instead of gathering it
+// once per ray.
 template <int LAYOUT, bool POW2, bool IDENT>
-F110_HD double march_ray(const ScanConst &k, const double *lut, double x, double y, double c, double s,
-                         int &hit_r, int &hit_c, int &lookups)
+F110_HD double march_from_first(const ScanConst &k, const double *lut, double x, double y, double c, double s,
+                                double d, int &hit_r, int &hit_c, int &lookups)
 {
-    double d = sample_distance<LAYOUT, POW2, IDENT>(k, lut, x, y, hit_r, hit_c);
     double total = d;
     int n = 1;
     while (d > k.eps && total <= k.max_range) {
@@ -284,6 +287,15 @@ F110_HD double march_ray(const ScanConst &k, const double *lut, double x, double
     }
     lookups = n;
     return (total > k.max_range) ? k.max_range : total;
+}
+
+// trace_ray :106-146 (sphere tracing over the distance table)
+template <int LAYOUT, bool POW2, bool IDENT>
+F110_HD double march_ray(const ScanConst &k, const double *lut, double x, double y, double c, double s,
+                         int &hit_r, int &hit_c, int &lookups)
+{
+    const double d = sample_distance<LAYOUT, POW2, IDENT>(k, lut, x, y, hit_r, hit_c);
+    return march_from_first<LAYOUT, POW2, IDENT>(k, lut, x, y, c, s, d, hit_r, hit_c, lookups);
 }
 
 // get_scan :166-172

@@ -70,6 +70,7 @@ typedef struct f110_config {
     int32_t map_layout;    /* F110_MAP_* */
     int32_t scan_block;    /* threads per scan workgroup (0 = default) */
     int32_t scan_tasks_per_wave; /* consecutive 64-ray tasks each wave walks (0 = default) */
+    int32_t reserved0, reserved1;
     double fov, eps, max_range;
     double time_step, lidar_dist, ttc_thresh;
     double params[F110_NPARAMS]; /* initial vehicle params for every agent slot */

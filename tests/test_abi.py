@@ -32,10 +32,10 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     """f110_config is passed by pointer: the ctypes mirror must have the C layout
-    (9 int32 + pad + 6 double + 18 double)."""
+    (12 int32 + 6 double + 18 double)."""
     from f1tenth_gym_amd import _ffi
-    assert C.sizeof(_ffi.Config) == 10 * 4 + 6 * 8 + 18 * 8
-    assert _ffi.Config.fov.offset == 40 and _ffi.Config.params.offset == 88
+    assert C.sizeof(_ffi.Config) == 12 * 4 + 6 * 8 + 18 * 8
+    assert _ffi.Config.fov.offset == 48 and _ffi.Config.params.offset == 96
     assert C.sizeof(_ffi.ObsHost) == 12 * 8 and C.sizeof(_ffi.DeviceViews) == 8 * 8
 
 

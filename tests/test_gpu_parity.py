@@ -452,3 +452,31 @@ def test_vec_env_auto_reset(amd):
             assert st["step_count"][idx * 2] == 0 and np.array_equal(st["state"][idx * 2][[0, 1, 4]], poses[idx, 0])
             break
     assert seen_done
+
+
+@pytest.mark.parametrize("layout,tasks,block", [(0, 1, 64), (0, 3, 128), (1, 2, 256), (2, 4, 64), (2, 1, 256)])
+def test_scan_launch_geometries_bit_exact(amd, orc, layout, tasks, block):
+    """map layout / tasks-per-wave / workgroup size only change scheduling and storage:
+    unit scans equal the golden vectors and a stepped batch equals the oracle bit-for-bit on scans"""
+    g = gold("scan_example_map")
+    img, res, origin = load_map_image("example_map")
+    s = amd.BatchSim(num_envs=1, num_agents=1, map_layout=layout, scan_tasks_per_wave=tasks, scan_block=block)
+    s.set_map_image(img, res, origin)
+    ranges, hits, lk = s.scan_batch(g["poses"], want_hits=True, want_lookups=True)
+    assert np.array_equal(hits, g["hit_rc"]) and np.array_equal(ranges, g["scans"]) and np.array_equal(lk, g["lookups"])
+    s.close()
+    dt, _, _ = oracle_map_dt("example_map")
+    E, A, T = 37, 2, 12
+    noise = _noise(T + 1)
+    s = amd.BatchSim(num_envs=E, num_agents=A, map_layout=layout, scan_tasks_per_wave=tasks, scan_block=block)
+    s.set_map_image(img, res, origin); s.set_noise_table(noise)
+    ref = orc.SimOracle(E, A); ref.set_map_dt(dt, res, origin); ref.set_noise(noise)
+    poses = bench_start_poses(E, A); s.reset(poses); ref.reset(poses)
+    rng = np.random.default_rng(4)
+    for t in range(T):
+        act = np.stack([rng.uniform(-0.3, 0.3, E * A), rng.uniform(1.0, 7.0, E * A)], axis=1)
+        s.step(act); ref.step(act, 8)
+    o = s.get("scans", "state", "collisions", "in_collision")
+    assert np.array_equal(o["collisions"], ref.collisions) and np.array_equal(o["in_collision"], ref.in_collision)
+    assert rel_err(o["state"], ref.state) < FTOL and rel_err(o["scans"], ref.scans) < FTOL
+    s.close()
