@@ -61,7 +61,9 @@ struct AgentArrays {
     double *collision_idx;   // [N]
     int32_t *in_collision;   // [N]
     int32_t *step_count;     // [N]
-    int32_t *opp_window;     // [N][A][2] beam range each opponent can occupy (no-wall-hit heading)
+    int32_t *opp_window;     // [N][A][4] beam range each opponent can occupy: {lo, hi} for the live
+                             //           heading and {lo0, hi0} for heading 0 (after a wall hit)
+    double *opp_verts;       // [N][A][8] the opponent's box drawn with the ego's length/width
     const double *params;    // [A][18]
     const double *noise;     // [noise_rows][B] or nullptr
     const double *scan_angles, *beam_cos, *side_dist;  // [B]
@@ -164,14 +166,21 @@ __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
                 partner = j;  // j ascending -> ends at the largest colliding index
             }
         }
-        // beam window this opponent can occupy in my scan, for the common case that my iTTC
-        // check does not fire (then my live heading is the snapshot heading); k_finalize
-        // recomputes it with heading 0 for agents that did hit a wall.
+        // beam window this opponent can occupy in my scan: once for my post-integration heading
+        // (no wall hit) and once for heading 0 (RaceCar.check_ttc zeroes it on a wall hit, and the
+        // ray-cast reads the live state, base_classes.py:225,246-249); k_finalize picks one.
         int ref_lo, ref_hi, lo, hi;
         box_vertices(ox, oy, oth, blen, bwid, other);
+        int32_t *win = a.opp_window + ((size_t)i * A + j) * 4;
         opponent_beam_window(mx, my, mth, other, ox, oy, disc_r, a.scan_angles, B, a.angle_inc, ref_lo, ref_hi, lo, hi);
-        a.opp_window[((size_t)i * A + j) * 2] = lo;
-        a.opp_window[((size_t)i * A + j) * 2 + 1] = hi;
+        win[0] = lo;
+        win[1] = hi;
+        opponent_beam_window(mx, my, 0.0, other, ox, oy, disc_r, a.scan_angles, B, a.angle_inc, ref_lo, ref_hi, lo, hi);
+        win[2] = lo;
+        win[3] = hi;
+        double *ov = a.opp_verts + ((size_t)i * A + j) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ov[c] = other[c];
     }
     a.collisions[i] = hit ? 1.0 : 0.0;
     a.collision_idx[i] = (double)partner;
@@ -296,7 +305,7 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
 // One wave per agent.  RaceCar.check_ttc's side effects (:246-252), Simulator's collision OR
 // (:588-589), then RaceCar.ray_cast_agents (:206-227): opponents from the :574 snapshot, ego
 // pose = live state (heading already zeroed on a wall hit), box = the ego's own params.
-__global__ void __launch_bounds__(64) k_finalize(AgentArrays a, int32_t B)
+__global__ void __launch_bounds__(64, 5) k_finalize(AgentArrays a, int32_t B)
 {
     const int i = blockIdx.x, tid = threadIdx.x;
     const int N = a.n_agents_total, A = a.agents_per_env;
@@ -313,24 +322,17 @@ __global__ void __launch_bounds__(64) k_finalize(AgentArrays a, int32_t B)
         }
         a.step_count[i] += 1;
     }
-    const int env = i / A, me = i - env * A;
-    const double blen = a.params[(size_t)me * NPARAMS + P_LENGTH];
-    const double bwid = a.params[(size_t)me * NPARAMS + P_WIDTH];
+    const int me = i % A;
     double *sc = a.scans + (size_t)i * B;
     for (int jj = 0; jj < A; ++jj) {
         if (jj == me) continue;
-        const int o = env * A + jj;
-        int lo = a.opp_window[((size_t)i * A + jj) * 2];
-        int hi = a.opp_window[((size_t)i * A + jj) * 2 + 1];
-        if (!wall && hi < lo) continue;  // nothing of this opponent is visible
-        const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o];
+        const int32_t *win = a.opp_window + ((size_t)i * A + jj) * 4 + (wall ? 2 : 0);
+        const int lo = win[0], hi = win[1];
+        if (hi < lo) continue;  // nothing of this opponent can be hit
+        const double *ov = a.opp_verts + ((size_t)i * A + jj) * 8;
         double v[8];
-        box_vertices(ox, oy, a.snap_pose[2 * (size_t)N + o], blen, bwid, v);
-        if (wall) {  // heading was zeroed: the window of k_collide does not apply (rare path)
-            int ref_lo, ref_hi;
-            opponent_beam_window(ex, ey, eth, v, ox, oy, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B,
-                                 a.angle_inc, ref_lo, ref_hi, lo, hi);
-        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = ov[c];
         for (int b = lo + tid; b <= hi; b += 64) {
             const double bt = eth + a.scan_angles[b];
             const double v3x = cos(bt + kPi / 2.), v3y = sin(bt + kPi / 2.);
@@ -897,8 +899,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     h->N = cfg->num_envs * cfg->num_agents;
     const int N = h->N, B = cfg->num_beams;
     h->scan_block = cfg->scan_block > 0 ? cfg->scan_block : 64;
-    h->scan_tasks_per_wave = cfg->scan_tasks_per_wave > 0 ? cfg->scan_tasks_per_wave
-                             : (cfg->map_layout == F110_MAP_CODE8 ? 4 : 1);
+    h->scan_tasks_per_wave = cfg->scan_tasks_per_wave > 0 ? cfg->scan_tasks_per_wave : 4;
     if (cfg->scan_block <= 0 && cfg->map_layout == F110_MAP_CODE8) h->scan_block = 256;
     if (h->scan_block % 64 != 0 || h->scan_block > 256) { delete h; return fail(nullptr, F110_ERR_INVALID, "scan_block must be 64, 128, 192 or 256"); }
 #define CK(expr) do { int rc_ = (expr); if (rc_ != F110_OK) { snprintf(g_err, sizeof g_err, "%s", h->err); f110_destroy(h); return rc_; } } while (0)
@@ -927,7 +928,8 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     CK(dmalloc(h, &d.collision_idx, (size_t)N));
     CK(dmalloc(h, &d.in_collision, (size_t)N));
     CK(dmalloc(h, &d.step_count, (size_t)N));
-    CK(dmalloc(h, &d.opp_window, (size_t)N * cfg->num_agents * 2));
+    CK(dmalloc(h, &d.opp_window, (size_t)N * cfg->num_agents * 4));
+    CK(dmalloc(h, &d.opp_verts, (size_t)N * cfg->num_agents * 8));
     CK(dmalloc(h, &h->d_params, (size_t)cfg->num_agents * NPARAMS));
     CK(dmalloc(h, &h->d_scan_angles, (size_t)B));
     CK(dmalloc(h, &h->d_beam_cos, (size_t)B));
@@ -1009,7 +1011,7 @@ void f110_destroy(f110_sim *h)
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     AgentArrays &d = h->dev;
-    void *ptrs[] = {d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
+    void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
                     h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_codes, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask};
     for (void *p : ptrs)

@@ -34,20 +34,15 @@ prof)
   PB="python $R/bench.py $SHORT --no-profile-events"
   timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats -o stats -- $PB --steps 100 --warmup 10 > $OUT/prof_stats.log 2>&1
   python $R/tools/summarize_prof.py stats $OUT/prof_stats $OUT/kernel_stats.txt
-  timeout 400 rocprofv3 --pmc FETCH_SIZE -T -f csv -d $OUT/pmc_fetch -o fetch -- $PB --steps 20 --warmup 3 > $OUT/pmc_fetch.log 2>&1
-  python $R/tools/summarize_prof.py pmc $OUT/pmc_fetch $OUT/pmc_fetch.json
-  timeout 400 rocprofv3 --pmc WRITE_SIZE -T -f csv -d $OUT/pmc_write -o write -- $PB --steps 20 --warmup 3 > $OUT/pmc_write.log 2>&1
-  python $R/tools/summarize_prof.py pmc $OUT/pmc_write $OUT/pmc_write.json
-  timeout 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -T -f csv -d $OUT/pmc_sq -o sq -- $PB --steps 20 --warmup 3 > $OUT/pmc_sq.log 2>&1
-  python $R/tools/summarize_prof.py pmc $OUT/pmc_sq $OUT/pmc_sq.json
-  timeout 400 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -T -f csv -d $OUT/pmc_sq2 -o sq2 -- $PB --steps 20 --warmup 3 > $OUT/pmc_sq2.log 2>&1
-  python $R/tools/summarize_prof.py pmc $OUT/pmc_sq2 $OUT/pmc_sq2.json
-  timeout 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -T -f csv -d $OUT/pmc_tcc -o tcc -- $PB --steps 20 --warmup 3 > $OUT/pmc_tcc.log 2>&1
-  python $R/tools/summarize_prof.py pmc $OUT/pmc_tcc $OUT/pmc_tcc.json
-  timeout 400 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum TA_BUSY_avr TA_TA_BUSY_sum -T -f csv -d $OUT/pmc_tcp -o tcp -- $PB --steps 20 --warmup 3 > $OUT/pmc_tcp.log 2>&1
-  python $R/tools/summarize_prof.py pmc $OUT/pmc_tcp $OUT/pmc_tcp.json
+  i=0
+  for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_TA_BUSY GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "MeanOccupancyPerCU VALUBusy MemUnitStalled"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays|k_finalize|k_integrate|k_collide" -T -f csv -d $OUT/pmc_$i -o p -- $PB --steps 12 --warmup 2 > $OUT/pmc_$i.log 2>&1
+    python $R/tools/summarize_prof.py pmc $OUT/pmc_$i $OUT/pmc_pass$i.json
+    rm -rf $OUT/pmc_$i
+  done
   cd "$R"
-  rm -rf $OUT/prof_stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_tcc $OUT/pmc_tcp
+  rm -rf $OUT/prof_stats
   ;;
 esac
 done
