@@ -63,6 +63,8 @@ class Rendezvous(object):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if "F110_BENCH_DEVICE" in os.environ:   # testing aid: several ranks on one GPU
+            self.local_rank = int(os.environ["F110_BENCH_DEVICE"])
         self.dist = None
         if self.world > 1:
             import torch  # imported BEFORE libf110_hip.so so both share one libamdhip64
@@ -287,10 +289,11 @@ def main():
         "metric": "agent-steps/s (1080-beam scan + ST dynamics)", "value": value, "unit": "agent-steps/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%d agents per GPU (%d envs x %d), example_map 1600x1600 @0.0625 m, %d-beam lidar, "
-                               "ST dynamics RK4 dt=0.01, scan noise %s, in-place resets %s (BASELINE configs[2])"
-                               % (args.agents, args.agents // args.agents_per_env, args.agents_per_env, args.beams,
-                                  "off" if args.no_noise else "on", "off" if args.no_reset else "on"),
+        "config": {"workload": ("%d agents per GPU (%d envs x %d), example_map 1600x1600 @0.0625 m, %d-beam lidar, "
+                                "ST dynamics RK4 dt=0.01, scan noise %s, in-place resets %s"
+                                % (args.agents, args.agents // args.agents_per_env, args.agents_per_env, args.beams,
+                                   "off" if args.no_noise else "on", "off" if args.no_reset else "on"))
+                               + (" (BASELINE configs[2])" if args.agents == 65536 and args.beams == 1080 else ""),
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
                    "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut"}[args.layout],
                    "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks,

@@ -691,6 +691,8 @@ struct f110_sim {
     f110_config cfg{};
     int N = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;          // k_collide runs here, concurrently with k_scan_rays
+    hipEvent_t ev_integrated = nullptr, ev_collided = nullptr;
     AgentArrays dev{};
     ScanConst k{};
     bool has_map = false;
@@ -911,6 +913,9 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CKH(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    CKH(hipEventCreateWithFlags(&h->ev_integrated, hipEventDisableTiming));
+    CKH(hipEventCreateWithFlags(&h->ev_collided, hipEventDisableTiming));
     CKH(hipEventCreate(&h->ev_begin));
     CKH(hipEventCreate(&h->ev_end));
     AgentArrays &d = h->dev;
@@ -1010,6 +1015,7 @@ void f110_destroy(f110_sim *h)
 {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
@@ -1017,6 +1023,9 @@ void f110_destroy(f110_sim *h)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    if (h->ev_integrated) (void)hipEventDestroy(h->ev_integrated);
+    if (h->ev_collided) (void)hipEventDestroy(h->ev_collided);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1268,7 +1277,15 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
     hipLaunchKernelGGL(k_integrate, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->k, d_actions);
-    if (h->cfg.num_agents > 1) hipLaunchKernelGGL(k_collide, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
+    // k_collide only feeds k_finalize, k_scan_rays only needs k_integrate: run the two side by
+    // side (second stream, event fork/join) so the pair test + window set-up hides under the scan
+    const bool multi = h->cfg.num_agents > 1;
+    if (multi) {
+        HIPCHK(h, hipEventRecord(h->ev_integrated, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_integrated, 0));
+        hipLaunchKernelGGL(k_collide, grid1d(N, 256), dim3(256), 0, h->side_stream, h->dev, h->k.num_beams);
+        HIPCHK(h, hipEventRecord(h->ev_collided, h->side_stream));
+    }
     if (prof) HIPCHK(h, hipEventRecord(e1, h->stream));
     {
         RayJob j{};
@@ -1293,7 +1310,8 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         hipLaunchKernelGGL(fn, grid, dim3(h->scan_block), 0, h->stream, j, h->k);
     }
     if (prof) HIPCHK(h, hipEventRecord(e2, h->stream));
-    if (h->cfg.num_agents > 1)
+    if (multi) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_collided, 0));
+    if (multi)
         hipLaunchKernelGGL(k_finalize, dim3(N), dim3(64), 0, h->stream, h->dev, h->k.num_beams);
     else
         hipLaunchKernelGGL(k_finalize_solo, grid1d(N, 256), dim3(256), 0, h->stream, h->dev);
