@@ -43,6 +43,16 @@ class ObsHost(C.Structure):
                 ("in_collision", _i32p), ("step_count", _i32p)]
 
 
+class EpisodeHost(C.Structure):
+    _fields_ = [("lap_times", _dp), ("lap_counts", _dp), ("toggles", _dp), ("current_time", _dp),
+                ("near_starts", _u8p), ("done", _u8p), ("checkpoint_done", _u8p)]
+
+
+class EpisodeViews(C.Structure):
+    _fields_ = [("done", C.c_void_p), ("checkpoint_done", C.c_void_p), ("lap_times", C.c_void_p),
+                ("lap_counts", C.c_void_p), ("toggles", C.c_void_p), ("current_time", C.c_void_p)]
+
+
 class DeviceViews(C.Structure):
     _fields_ = [("scans", C.c_void_p), ("state", C.c_void_p), ("agent_poses", C.c_void_p),
                 ("collisions", C.c_void_p), ("collision_idx", C.c_void_p),
@@ -68,6 +78,12 @@ PROTOTYPES = {
     "f110_reset": (C.c_int, [C.c_void_p, _dp, _u8p]),
     "f110_reset_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "f110_reset_collided_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "f110_episode_init": (C.c_int, [C.c_void_p, C.c_int32]),
+    "f110_episode_reset": (C.c_int, [C.c_void_p, _dp, _dp, _u8p]),
+    "f110_episode_step_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "f110_episode_reset_done_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "f110_episode_get": (C.c_int, [C.c_void_p, C.POINTER(EpisodeHost)]),
+    "f110_episode_device_views": (C.c_int, [C.c_void_p, C.POINTER(EpisodeViews)]),
     "f110_step": (C.c_int, [C.c_void_p, _dp]),
     "f110_step_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_get_obs": (C.c_int, [C.c_void_p, C.POINTER(ObsHost)]),

@@ -236,6 +236,58 @@ class BatchSim(object):
         c = None if d_count is None else (d_count.ptr if isinstance(d_count, DeviceArray) else int(d_count))
         check(_ffi.lib().f110_reset_collided_device(self._h, p, int(ego_idx), c), self._h, IndexError)
 
+    # ------------------------------------------------------------------ episode logic on the device
+    def episode_init(self, ego_idx=0):
+        check(_ffi.lib().f110_episode_init(self._h, int(ego_idx)), self._h, IndexError)
+        self._ep_ego = int(ego_idx)
+
+    def episode_reset(self, poses, env_mask=None):
+        """F110Env.reset's state part (f110_env.py:319-334) for the masked envs: lap bookkeeping
+        cleared, start poses + start_rot stored, simulator state reset."""
+        poses = as_f64(poses, (self.N, 3))
+        th = -poses.reshape(self.E, self.A, 3)[:, self._ep_ego, 2]
+        rot = np.stack([np.cos(th), -np.sin(th), np.sin(th), np.cos(th)], axis=1)   # start_rot :331
+        rot = np.ascontiguousarray(rot, dtype=np.float64)
+        mptr = None
+        if env_mask is not None:
+            m = np.ascontiguousarray(env_mask, dtype=np.uint8)
+            mptr = m.ctypes.data_as(_ffi._u8p)
+        check(_ffi.lib().f110_episode_reset(self._h, dptr(poses), dptr(rot), mptr), self._h)
+
+    _ep_ego = 0
+
+    def episode_step_device(self, d_actions):
+        ptr = d_actions.ptr if isinstance(d_actions, DeviceArray) else int(d_actions)
+        check(_ffi.lib().f110_episode_step_device(self._h, ptr), self._h)
+
+    def episode_reset_done_device(self, d_count=None):
+        c = None if d_count is None else (d_count.ptr if isinstance(d_count, DeviceArray) else int(d_count))
+        check(_ffi.lib().f110_episode_reset_done_device(self._h, c), self._h)
+
+    def episode_get(self):
+        N, E = self.N, self.E
+        out = {"lap_times": np.empty(N), "lap_counts": np.empty(N), "toggles": np.empty(N),
+               "current_time": np.empty(E), "near_starts": np.empty(N, dtype=np.uint8),
+               "done": np.empty(E, dtype=np.uint8), "checkpoint_done": np.empty(N, dtype=np.uint8)}
+        o = _ffi.EpisodeHost()
+        for k in ("lap_times", "lap_counts", "toggles", "current_time"):
+            setattr(o, k, dptr(out[k]))
+        for k in ("near_starts", "done", "checkpoint_done"):
+            setattr(o, k, out[k].ctypes.data_as(_ffi._u8p))
+        check(_ffi.lib().f110_episode_get(self._h, C.byref(o)), self._h)
+        return out
+
+    def episode_device_views(self):
+        v = _ffi.EpisodeViews()
+        check(_ffi.lib().f110_episode_device_views(self._h, C.byref(v)), self._h)
+        N, E = self.N, self.E
+        return {"done": DeviceArray(self, (E,), np.uint8, v.done),
+                "checkpoint_done": DeviceArray(self, (N,), np.uint8, v.checkpoint_done),
+                "lap_times": DeviceArray(self, (N,), np.float64, v.lap_times),
+                "lap_counts": DeviceArray(self, (N,), np.float64, v.lap_counts),
+                "toggles": DeviceArray(self, (N,), np.float64, v.toggles),
+                "current_time": DeviceArray(self, (E,), np.float64, v.current_time)}
+
     def device_array(self, shape, dtype=np.float64):
         return DeviceArray(self, shape, dtype)
 

@@ -416,6 +416,122 @@ __global__ void k_reset_collided(AgentArrays a, const double *__restrict__ start
     if (n_reset && i - env * A == ego_idx) atomicAdd(n_reset, 1);
 }
 
+// ---- episode logic on the device ------------------------------------------------
+// F110Env._check_done (f110_env.py:204-246): start/finish-zone toggles, lap counts and times, done
+// = ego collided or every agent has 4 toggles — one lane per env, so an RL loop that keeps its
+// policy on the GPU never has to read poses back to decide `done`.
+struct EpisodeArrays {
+    int32_t ego_idx, pad;
+    double timestep;
+    double *start_poses;   // [N][3]
+    double *rot;           // [E][4] start_rot row-major (f110_env.py:331), computed by the host
+    double *current_time;  // [E]
+    uint8_t *near_start;   // [N]
+    double *toggle;        // [N]
+    double *lap_count;     // [N]
+    double *lap_time;      // [N]
+    uint8_t *done;         // [E]
+    uint8_t *checkpoint;   // [N] toggle >= 4
+};
+
+__global__ void __launch_bounds__(256) k_episode(AgentArrays a, EpisodeArrays ep, int num_envs)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= num_envs) return;
+    const int N = a.n_agents_total, A = a.agents_per_env;
+    const double ct = ep.current_time[e] + ep.timestep;  // f110_env.py:295
+    ep.current_time[e] = ct;
+    const double r00 = ep.rot[4 * e], r01 = ep.rot[4 * e + 1], r10 = ep.rot[4 * e + 2], r11 = ep.rot[4 * e + 3];
+    const double left_t = 2, right_t = 2;
+    bool all4 = true;
+    for (int s = 0; s < A; ++s) {
+        const int i = e * A + s;
+        const double px = a.state[i] - ep.start_poses[3 * (size_t)i];
+        const double py = a.state[(size_t)N + i] - ep.start_poses[3 * (size_t)i + 1];
+        const double dx = r00 * px + r01 * py;  // np.dot(start_rot, [px; py]) :223
+        double ty = r10 * px + r11 * py;
+        if (ty > left_t)
+            ty -= left_t;
+        else if (ty < -right_t)
+            ty = -right_t - ty;
+        else
+            ty = 0;
+        const double dist2 = dx * dx + ty * ty;
+        const bool closes = dist2 <= 0.1;
+        bool near = ep.near_start[i] != 0;
+        double tog = ep.toggle[i];
+        if (closes && !near) {
+            near = true;
+            tog += 1;
+        } else if (!closes && near) {
+            near = false;
+            tog += 1;
+        }
+        ep.near_start[i] = near ? 1 : 0;
+        ep.toggle[i] = tog;
+        ep.lap_count[i] = floor(tog / 2);  // toggle_list // 2
+        if (tog < 4) ep.lap_time[i] = ct;
+        ep.checkpoint[i] = tog >= 4 ? 1 : 0;
+        all4 = all4 && (tog >= 4);
+    }
+    ep.done[e] = (a.collisions[e * A + ep.ego_idx] != 0.0 || all4) ? 1 : 0;  // :244
+}
+
+// re-seat every env whose done flag is set (F110Env.reset :319-334 without its zero-action step)
+__global__ void __launch_bounds__(256) k_episode_reset_done(AgentArrays a, EpisodeArrays ep, int32_t *__restrict__ n_reset)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.n_agents_total, A = a.agents_per_env;
+    if (i >= N) return;
+    const int e = i / A;
+    if (!ep.done[e]) return;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = 0.;
+    a.state[i] = ep.start_poses[3 * (size_t)i];
+    a.state[(size_t)N + i] = ep.start_poses[3 * (size_t)i + 1];
+    a.state[4 * (size_t)N + i] = ep.start_poses[3 * (size_t)i + 2];
+    a.steer_buf[i] = 0.;
+    a.steer_buf[(size_t)N + i] = 0.;
+    a.buf_cnt[i] = 0;
+    a.in_collision[i] = 0;
+    a.step_count[i] = 0;
+    ep.near_start[i] = 1;
+    ep.toggle[i] = 0.;
+    if (i - e * A == 0) {
+        ep.current_time[e] = 0.;
+        if (n_reset) atomicAdd(n_reset, 1);
+    }
+}
+
+// done[] is read by every lane of the env above and cleared here, in a separate launch
+__global__ void k_episode_clear_done(EpisodeArrays ep, int num_envs)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < num_envs) ep.done[e] = 0;
+}
+
+__global__ void k_episode_reset(AgentArrays a, EpisodeArrays ep, const double *__restrict__ poses,
+                                const double *__restrict__ rot, const uint8_t *__restrict__ env_mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.n_agents_total, A = a.agents_per_env;
+    if (i >= N) return;
+    const int e = i / A;
+    if (env_mask && !env_mask[e]) return;
+    ep.start_poses[3 * (size_t)i] = poses[3 * (size_t)i];
+    ep.start_poses[3 * (size_t)i + 1] = poses[3 * (size_t)i + 1];
+    ep.start_poses[3 * (size_t)i + 2] = poses[3 * (size_t)i + 2];
+    ep.near_start[i] = 1;
+    ep.toggle[i] = 0.;
+    ep.checkpoint[i] = 0;
+    if (i - e * A == 0) {
+        ep.current_time[e] = 0.;
+        ep.done[e] = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ep.rot[4 * e + c] = rot[4 * e + c];
+    }
+}
+
 // ---- unit kernels (one per reference function; parity tests) ------------------------------
 __global__ void k_dir_index_unit(ScanConst k, const double *__restrict__ thetas, int m, int32_t *__restrict__ idx)
 {
@@ -706,6 +822,9 @@ struct f110_sim {
     double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_actions = nullptr, *d_poses = nullptr;
     double2 *d_cs = nullptr;
     uint8_t *d_mask = nullptr;
+    EpisodeArrays ep{};
+    bool has_episode = false;
+    double *d_rot_stage = nullptr;
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool profiling = false;
@@ -776,6 +895,7 @@ struct Scratch {
 static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 typedef void (*scan_rays_fn)(RayJob, ScanConst);
+static int copy_col(f110_sim *h, double *dst, const double *src, size_t n);
 
 // ray / B by multiply-high: find (magic, shift) with umulhi(x, magic) >> shift == x / B for every
 // x < n (verified at every multiple of B and its predecessor, which is sufficient because both
@@ -1022,6 +1142,12 @@ void f110_destroy(f110_sim *h)
                     h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_codes, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    {
+        void *eptrs[] = {h->ep.start_poses, h->ep.rot, h->ep.current_time, h->ep.near_start, h->ep.toggle,
+                         h->ep.lap_count, h->ep.lap_time, h->ep.done, h->ep.checkpoint, h->d_rot_stage};
+        for (void *p : eptrs)
+            if (p) (void)hipFree(p);
+    }
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     if (h->ev_integrated) (void)hipEventDestroy(h->ev_integrated);
     if (h->ev_collided) (void)hipEventDestroy(h->ev_collided);
@@ -1241,6 +1367,106 @@ int f110_reset_collided_device(f110_sim *h, const double *d_start_poses, int32_t
     if (ego_idx < 0 || ego_idx >= h->cfg.num_agents) return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
     hipLaunchKernelGGL(k_reset_collided, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, d_start_poses, ego_idx, d_count);
     HIPCHK(h, hipGetLastError());
+    return F110_OK;
+}
+
+// ---- episode logic (f110_env.py:204-246,306-338) -----------------------------------------------
+int f110_episode_init(f110_sim *h, int32_t ego_idx)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    if (ego_idx < 0 || ego_idx >= h->cfg.num_agents) return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
+    const size_t N = (size_t)h->N, E = (size_t)h->cfg.num_envs;
+    EpisodeArrays &ep = h->ep;
+    if (!h->has_episode) {
+        TRY(dmalloc(h, &ep.start_poses, 3 * N));
+        TRY(dmalloc(h, &ep.rot, 4 * E));
+        TRY(dmalloc(h, &ep.current_time, E));
+        TRY(dmalloc(h, &ep.near_start, N));
+        TRY(dmalloc(h, &ep.toggle, N));
+        TRY(dmalloc(h, &ep.lap_count, N));
+        TRY(dmalloc(h, &ep.lap_time, N));
+        TRY(dmalloc(h, &ep.done, E));
+        TRY(dmalloc(h, &ep.checkpoint, N));
+        TRY(dmalloc(h, &h->d_rot_stage, 4 * E));
+        HIPCHK(h, hipMemsetAsync(ep.start_poses, 0, 3 * N * sizeof(double), h->stream));
+        HIPCHK(h, hipMemsetAsync(ep.rot, 0, 4 * E * sizeof(double), h->stream));
+        HIPCHK(h, hipMemsetAsync(ep.current_time, 0, E * sizeof(double), h->stream));
+        HIPCHK(h, hipMemsetAsync(ep.near_start, 1, N, h->stream));
+        HIPCHK(h, hipMemsetAsync(ep.toggle, 0, N * sizeof(double), h->stream));
+        HIPCHK(h, hipMemsetAsync(ep.lap_count, 0, N * sizeof(double), h->stream));
+        HIPCHK(h, hipMemsetAsync(ep.lap_time, 0, N * sizeof(double), h->stream));
+        HIPCHK(h, hipMemsetAsync(ep.done, 0, E, h->stream));
+        HIPCHK(h, hipMemsetAsync(ep.checkpoint, 0, N, h->stream));
+        h->has_episode = true;
+    }
+    ep.ego_idx = ego_idx;
+    ep.timestep = h->cfg.time_step;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_episode_reset(f110_sim *h, const double *poses, const double *rot, const uint8_t *env_mask)
+{
+    if (!h || !poses || !rot) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
+    HIPCHK(h, hipMemcpyAsync(h->d_poses, poses, sizeof(double) * 3 * h->N, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_rot_stage, rot, sizeof(double) * 4 * h->cfg.num_envs, hipMemcpyHostToDevice, h->stream));
+    if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->cfg.num_envs, hipMemcpyHostToDevice, h->stream));
+    const uint8_t *dm = env_mask ? h->d_mask : nullptr;
+    hipLaunchKernelGGL(k_episode_reset, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, h->ep, h->d_poses, h->d_rot_stage, dm);
+    hipLaunchKernelGGL(k_reset, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, h->d_poses, dm);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_episode_step_device(f110_sim *h, const double *d_actions)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
+    TRY(f110_step_device(h, d_actions));
+    hipLaunchKernelGGL(k_episode, grid1d(h->cfg.num_envs, 256), dim3(256), 0, h->stream, h->dev, h->ep, h->cfg.num_envs);
+    HIPCHK(h, hipGetLastError());
+    return F110_OK;
+}
+
+int f110_episode_reset_done_device(f110_sim *h, int32_t *d_count)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
+    hipLaunchKernelGGL(k_episode_reset_done, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, h->ep, d_count);
+    hipLaunchKernelGGL(k_episode_clear_done, grid1d(h->cfg.num_envs, 256), dim3(256), 0, h->stream, h->ep, h->cfg.num_envs);
+    HIPCHK(h, hipGetLastError());
+    return F110_OK;
+}
+
+int f110_episode_get(f110_sim *h, const f110_episode_host *o)
+{
+    if (!h || !o) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
+    const size_t N = (size_t)h->N, E = (size_t)h->cfg.num_envs;
+    const EpisodeArrays &ep = h->ep;
+    TRY(copy_col(h, o->lap_times, ep.lap_time, N));
+    TRY(copy_col(h, o->lap_counts, ep.lap_count, N));
+    TRY(copy_col(h, o->toggles, ep.toggle, N));
+    TRY(copy_col(h, o->current_time, ep.current_time, E));
+    if (o->near_starts) HIPCHK(h, hipMemcpyAsync(o->near_starts, ep.near_start, N, hipMemcpyDeviceToHost, h->stream));
+    if (o->done) HIPCHK(h, hipMemcpyAsync(o->done, ep.done, E, hipMemcpyDeviceToHost, h->stream));
+    if (o->checkpoint_done) HIPCHK(h, hipMemcpyAsync(o->checkpoint_done, ep.checkpoint, N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_episode_device_views(f110_sim *h, f110_episode_views *v)
+{
+    if (!h || !v) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
+    v->done = h->ep.done;
+    v->checkpoint_done = h->ep.checkpoint;
+    v->lap_times = h->ep.lap_time;
+    v->lap_counts = h->ep.lap_count;
+    v->toggles = h->ep.toggle;
+    v->current_time = h->ep.current_time;
     return F110_OK;
 }
 

@@ -169,9 +169,16 @@ class F110VecEnv(object):
     with array observations (leading env axis).  `auto_reset=True` re-seats finished envs at
     their start poses inside step() (mask reset in place) — like the reference's
     reset() that costs them one zero-action step, taken on the next call.
+
+    device_logic=True runs the lap / done bookkeeping (F110Env._check_done) and the auto-reset on
+    the GPU (f110_episode_*): per step only `done`, the lap arrays and the requested observation
+    fields cross PCIe.  obs_fields selects what is read back ('scans' is 8.6 KB per agent);
+    everything stays available in HBM through `device_views()`.
     """
 
-    def __init__(self, num_envs, auto_reset=False, **kwargs):
+    _ALL = ("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions")
+
+    def __init__(self, num_envs, auto_reset=False, device_logic=False, obs_fields=None, **kwargs):
         self.num_envs = int(num_envs)
         self.seed = kwargs.get('seed', 12345)
         self.map_name, self.map_path = _resolve_map_path(kwargs)
@@ -181,6 +188,8 @@ class F110VecEnv(object):
         self.timestep = kwargs.get('timestep', 0.01)
         self.ego_idx = kwargs.get('ego_idx', 0)
         self.auto_reset = auto_reset
+        self.device_logic = bool(device_logic)
+        self.obs_fields = tuple(self._ALL if obs_fields is None else obs_fields)
         self._lap = _LapLogic(self.num_envs, self.num_agents, self.ego_idx)
         self.sim = Simulator(self.params, self.num_agents, self.seed, time_step=self.timestep,
                              ego_idx=self.ego_idx, integrator=kwargs.get('integrator', Integrator.RK4),
@@ -191,21 +200,64 @@ class F110VecEnv(object):
                              map_layout=kwargs.get('map_layout', _ffi.MAP_ROWMAJOR_F64))
         self.sim.set_map(self.map_path, self.map_ext)
         self._start_poses = None
+        self._d_actions = None
+        if self.device_logic:
+            self.sim.batch.episode_init(self.ego_idx)
+            self._d_actions = self.sim.batch.device_array((self.num_envs * self.num_agents, 2))
+
+    def device_views(self):
+        v = self.sim.batch.device_views()
+        if self.device_logic:
+            v.update(self.sim.batch.episode_device_views())
+        return v
 
     def reset(self, poses, env_mask=None):
         poses = np.asarray(poses, dtype=np.float64).reshape(self.num_envs, self.num_agents, 3)
         self._start_poses = poses.copy() if self._start_poses is None or env_mask is None else \
             np.where(np.asarray(env_mask, dtype=bool)[:, None, None], poses, self._start_poses)
-        self.sim.reset(poses, env_mask)
-        self._lap.reset(poses, env_mask)
+        if self.device_logic:
+            self.sim.batch.episode_reset(poses.reshape(-1, 3), env_mask)
+            if env_mask is None or np.all(env_mask):
+                self.sim._steps_since_full_reset = 0
+        else:
+            self.sim.reset(poses, env_mask)
+            self._lap.reset(poses, env_mask)
         return self.step(np.zeros((self.num_envs, self.num_agents, 2)))
 
+    def _step_device(self, actions):
+        E, A = self.num_envs, self.num_agents
+        b = self.sim.batch
+        if self.sim._noise is not None:
+            self.sim._noise.ensure(b, self.sim._steps_since_full_reset + 1)
+        self._d_actions.upload(np.asarray(actions, dtype=np.float64).reshape(E * A, 2))
+        b.episode_step_device(self._d_actions)
+        self.sim._steps_since_full_reset += 1
+        names = {"poses_x": "poses_x", "poses_y": "poses_y", "poses_theta": "poses_theta",
+                 "linear_vels_x": "linear_vels_x", "ang_vels_z": "ang_vels_z", "collisions": "collisions",
+                 "scans": "scans"}
+        o = b.get(*[names[f] for f in self.obs_fields]) if self.obs_fields else {}
+        obs = {'ego_idx': self.ego_idx}
+        for f in self.obs_fields:
+            obs[f] = o[f].reshape(E, A, -1) if f == "scans" else o[f].reshape(E, A)
+        ep = b.episode_get()
+        obs['lap_times'] = ep["lap_times"].reshape(E, A)
+        obs['lap_counts'] = ep["lap_counts"].reshape(E, A)
+        done = ep["done"].astype(bool)
+        info = {'checkpoint_done': ep["checkpoint_done"].reshape(E, A).astype(bool),
+                'toggle_list': ep["toggles"].reshape(E, A), 'near_starts': ep["near_starts"].reshape(E, A).astype(bool)}
+        if self.auto_reset:
+            b.episode_reset_done_device()
+        return obs, self.timestep, done, info
+
     def step(self, actions):
+        if self.device_logic:
+            return self._step_device(actions)
         obs = self.sim.step(actions)
         done, toggles = self._lap.update(obs['poses_x'], obs['poses_y'], obs['collisions'], self.timestep)
         obs['lap_times'] = self._lap.lap_times
         obs['lap_counts'] = self._lap.lap_counts
-        info = {'checkpoint_done': toggles}
+        info = {'checkpoint_done': toggles, 'toggle_list': self._lap.toggle_list.copy(),
+                'near_starts': self._lap.near_starts.copy()}
         if self.auto_reset and done.any():
             self.sim.reset(self._start_poses, done)
             self._lap.reset(self._start_poses, done)

@@ -121,6 +121,30 @@ int f110_reset_device(f110_sim *h, const double *d_poses, const uint8_t *d_env_m
 int f110_reset_collided_device(f110_sim *h, const double *d_start_poses, int32_t ego_idx,
                                int32_t *d_count);
 
+/* ---- F110Env episode logic on the device: _check_done f110_env.py:204-246 (start/finish-zone
+ * toggles, lap counts / times, done = ego collided or all agents have 4 toggles) and the state part
+ * of reset() :319-334, so GPU-resident RL loops never read poses back to decide `done`.
+ * f110_episode_reset also performs f110_reset for the masked envs.  h_rot [num_envs][4] is
+ * start_rot (:331) row-major, computed by the host like the reference does. */
+typedef struct f110_episode_host {
+    double *lap_times, *lap_counts, *toggles; /* [N] */
+    double *current_time;                     /* [num_envs] */
+    uint8_t *near_starts;                     /* [N] */
+    uint8_t *done;                            /* [num_envs] */
+    uint8_t *checkpoint_done;                 /* [N] toggle_list >= 4 */
+} f110_episode_host;
+typedef struct f110_episode_views {
+    uint8_t *done, *checkpoint_done;
+    double *lap_times, *lap_counts, *toggles, *current_time;
+} f110_episode_views;
+int f110_episode_init(f110_sim *h, int32_t ego_idx);
+int f110_episode_reset(f110_sim *h, const double *h_poses, const double *h_rot,
+                       const uint8_t *h_env_mask);
+int f110_episode_step_device(f110_sim *h, const double *d_actions); /* f110_step_device + _check_done */
+int f110_episode_reset_done_device(f110_sim *h, int32_t *d_count);  /* re-seat envs whose done flag is set */
+int f110_episode_get(f110_sim *h, const f110_episode_host *out);
+int f110_episode_device_views(f110_sim *h, f110_episode_views *out);
+
 /* Simulator.step base_classes.py:553-612.  actions [N][2] = (steer, speed).
  * Asynchronous on the handle's stream; outputs are read with f110_get_* (which sync). */
 int f110_step(f110_sim *h, const double *h_actions);

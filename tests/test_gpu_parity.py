@@ -480,3 +480,42 @@ def test_scan_launch_geometries_bit_exact(amd, orc, layout, tasks, block):
     assert np.array_equal(o["collisions"], ref.collisions) and np.array_equal(o["in_collision"], ref.in_collision)
     assert rel_err(o["state"], ref.state) < FTOL and rel_err(o["scans"], ref.scans) < FTOL
     s.close()
+
+
+def test_device_episode_logic_matches_host_and_golden(amd):
+    """(f)-1: lap / done bookkeeping and auto-reset on the device == the host _LapLogic (which is
+    pinned to the reference episode in test_host_logic.py) and == the golden F110Env episode"""
+    import os
+    from _util import MAPS
+    kw = dict(map=os.path.join(MAPS, "example_map"), map_ext='.png', num_agents=2, seed=12345)
+    E = 24
+    host = amd.F110VecEnv(E, auto_reset=True, **kw)
+    dev = amd.F110VecEnv(E, auto_reset=True, device_logic=True, **kw)
+    poses = bench_start_poses(E, 2).reshape(E, 2, 3)
+    oh, _, dh, ih = host.reset(poses); od, _, dd, idv = dev.reset(poses)
+    rng = np.random.default_rng(9)
+    n_done = 0
+    for t in range(160):
+        if t % 20 == 0:
+            act = np.stack([rng.uniform(-0.3, 0.3, (E, 2)), rng.uniform(-1.0, 6.0, (E, 2))], axis=2)
+        oh, _, dh, ih = host.step(act); od, _, dd, idv = dev.step(act)
+        assert np.array_equal(dh, dd), t
+        for k in ("poses_x", "poses_y", "poses_theta", "linear_vels_x", "collisions", "lap_counts", "scans"):
+            assert np.array_equal(oh[k], od[k]), (t, k)
+        assert np.allclose(oh["lap_times"], od["lap_times"], rtol=0, atol=1e-12)
+        assert np.array_equal(ih["checkpoint_done"], idv["checkpoint_done"])
+        assert np.array_equal(ih["toggle_list"], idv["toggle_list"]) and np.array_equal(ih["near_starts"], idv["near_starts"])
+        n_done += int(dd.sum())
+    assert n_done > 0
+    # golden single-agent lap episode through the device logic
+    e = gold("env_episode")
+    env = amd.F110VecEnv(1, device_logic=True, obs_fields=("poses_x", "poses_y", "collisions"),
+                         map=os.path.join(MAPS, "example_map"), map_ext='.png', num_agents=1, seed=12345)
+    obs, r, done, info = env.reset(e["start"].reshape(1, 1, 3))
+    for t, a in enumerate(e["actions"]):
+        obs, r, done, info = env.step(a.reshape(1, 1, 2))
+        k = t + 1
+        assert float(info['toggle_list'][0, 0]) == e["toggle"][k] and bool(info['near_starts'][0, 0]) == bool(e["near"][k])
+        assert float(obs['lap_counts'][0, 0]) == e["lap_count"][k] and bool(done[0]) == bool(e["done"][k])
+        assert abs(float(obs['lap_times'][0, 0]) - e["lap_time"][k]) < 1e-12
+    assert bool(done[0]) and "scans" not in obs
