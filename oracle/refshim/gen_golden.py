@@ -432,9 +432,52 @@ def gen_env(ns):
     save("env_episode", start=start, actions=np.array(acts), **{k: np.array(v) for k, v in rec.items()})
 
 
+# ------------------------------------------------------------------------- waypoint_follow
+def gen_waypoint_follow(ns):
+    """BASELINE configs[0]: examples/waypoint_follow.py — the reference's PurePursuitPlanner drives
+    one car around example_map in the reference F110Env until done (two laps).  Records the
+    planner's actions (so the replay needs no planner) and the resulting trajectory."""
+    import importlib.util
+    import types
+    from argparse import Namespace
+    import yaml
+    ns = ref_loader.load_reference(with_env=True)
+    sys.modules["pyglet.gl"].GL_POINTS = 0
+    spec = importlib.util.spec_from_file_location("waypoint_follow_ref", os.path.join(REF, "examples", "waypoint_follow.py"))
+    wf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wf)
+    with open(os.path.join(REF, "examples", "config_example_map.yaml")) as f:
+        conf = Namespace(**yaml.safe_load(f))
+    conf.wpt_path = os.path.join(GOLD, "maps", "example_waypoints.csv")
+    planner = wf.PurePursuitPlanner(conf, (0.17145 + 0.15875))
+    work = {'tlad': 0.82461887897713965, 'vgain': 1.375}
+    ref_loader.fresh_racecar_class(ns)
+    env = ns.f110_env.F110Env(map=EXAMPLE_MAP, map_ext='.png', num_agents=1, timestep=0.01,
+                              integrator=ns.base_classes.Integrator.RK4)
+    start = np.array([[conf.sx, conf.sy, conf.stheta]])
+    obs, r, done, info = env.reset(start)
+    acts, rec = [], []
+    t = 0
+    while not done and t < 7000:
+        speed, steer = planner.plan(obs['poses_x'][0], obs['poses_y'][0], obs['poses_theta'][0], work['tlad'], work['vgain'])
+        a = np.array([[steer, speed]])
+        obs, r, done, info = env.step(a)
+        acts.append(a[0].copy())
+        rec.append([obs['poses_x'][0], obs['poses_y'][0], obs['poses_theta'][0], obs['linear_vels_x'][0],
+                    obs['ang_vels_z'][0], float(obs['lap_times'][0]), float(obs['lap_counts'][0]),
+                    float(obs['collisions'][0]), float(done), float(np.sum(obs['scans'][0]))])
+        t += 1
+    rec = np.array(rec)
+    print("    waypoint_follow: %d steps, laps %.0f, lap time %.2f, collided %s, max v %.2f"
+          % (t, rec[-1, 6], rec[-1, 5], bool(rec[:, 7].any()), rec[:, 3].max()))
+    ref_loader.fresh_racecar_class(ns)
+    save("waypoint_follow", start=start, actions=np.array(acts), traj=rec,
+         columns=np.array(["x", "y", "theta", "v", "yaw_rate", "lap_time", "lap_count", "collision", "done", "scan_sum"]))
+
+
 GROUPS = {"data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
-          "sim": gen_sim, "env": gen_env}
+          "sim": gen_sim, "env": gen_env, "waypoint_follow": gen_waypoint_follow}
 
 
 def main(argv):

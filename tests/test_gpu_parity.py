@@ -519,3 +519,26 @@ def test_device_episode_logic_matches_host_and_golden(amd):
         assert float(obs['lap_counts'][0, 0]) == e["lap_count"][k] and bool(done[0]) == bool(e["done"][k])
         assert abs(float(obs['lap_times'][0, 0]) - e["lap_time"][k]) < 1e-12
     assert bool(done[0]) and "scans" not in obs
+
+
+def test_waypoint_follow_two_laps_through_f110env(amd):
+    """BASELINE configs[0]: the reference's waypoint_follow.py run (its planner's actions recorded
+    from the reference) replayed through the drop-in F110Env for two laps, 3329 steps"""
+    import os
+    from _util import MAPS
+    g = gold("waypoint_follow")
+    env = amd.F110Env(map=os.path.join(MAPS, "example_map"), map_ext='.png', num_agents=1, timestep=0.01,
+                      integrator=amd.Integrator.RK4)
+    obs, r, done, info = env.reset(g["start"])
+    worst = 0.0
+    for t, a in enumerate(g["actions"]):
+        obs, r, done, info = env.step(a.reshape(1, 2))
+        row = g["traj"][t]
+        worst = max(worst, rel_err([obs['poses_x'][0], obs['poses_y'][0], obs['poses_theta'][0], obs['linear_vels_x'][0],
+                                    obs['ang_vels_z'][0]], row[:5]))
+        assert float(obs['lap_counts'][0]) == row[6] and float(obs['collisions'][0]) == row[7] and done == bool(row[8]), t
+        assert abs(float(obs['lap_times'][0]) - row[5]) < 1e-9
+        if t % 32 == 0:
+            assert abs(np.sum(obs['scans'][0]) - row[9]) / row[9] < NORTH_STAR
+    assert worst < NORTH_STAR, worst
+    assert done and float(obs['lap_counts'][0]) == 2.0
