@@ -198,6 +198,7 @@ struct RayJob {
     uint32_t tasks_per_wave;  // consecutive tasks each wave walks
     int32_t n_poses;
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
+    int32_t xcd_remap;
     const double *pose_x, *pose_y, *dir_start;  // [n_poses] (unit path)
     double *ranges;           // [n_poses][B]
     // STEP only
@@ -233,7 +234,15 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
     const uint32_t B = (uint32_t)k.num_beams;
     const uint32_t tpw = j.tasks_per_wave;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md).  Re-map so that each
+    // XCD walks one contiguous eighth of the rays: all beams of an agent, and agents that are
+    // neighbours in the batch, then share one XCD's L2 instead of being spread over all eight.
+    uint32_t blk = blockIdx.x;
+    if (j.xcd_remap) {
+        const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
+        blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // bijective for any nb
+    }
+    const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
     for (uint32_t t = 0; t < tpw; ++t) {
         const uint32_t task = wave * tpw + t;
         if (task >= j.n_tasks) break;  // wave-uniform
@@ -950,6 +959,7 @@ static dim3 rays_grid(RayJob &j, int block, int tasks_per_wave)
 {
     j.n_tasks = (j.n_rays + 63u) / 64u;
     j.tasks_per_wave = tasks_per_wave > 0 ? (uint32_t)tasks_per_wave : 1u;
+    j.xcd_remap = 1;  // measured neutral on MI355X (the table's hot set is L2-resident either way)
     const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave;
     const uint32_t wpb = (uint32_t)block / 64u;
     return dim3((waves + wpb - 1) / wpb);
