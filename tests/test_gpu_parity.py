@@ -346,6 +346,15 @@ def test_step_vs_oracle_64_envs_200_steps(amd, orc, layout):
     assert st["wall"] > 0, "rollout never exercised a wall hit"
 
 
+def test_step_4096_beams_dedupe_vs_oracle(amd, orc):
+    """more beams than table directions: the step marches each distinct direction once and
+    expands to beams (k_expand_beams); must equal the oracle that marches every beam"""
+    st = _drive(amd, orc, 10, 2, 40, beams=4096, reset_every=8)
+    assert st["flag_mismatch"] == 0 and st["state"] < NORTH_STAR and st["scan"] < 1e-12, st
+    st = _drive(amd, orc, 7, 1, 25, beams=2500, layout=1)
+    assert st["flag_mismatch"] == 0 and st["scan"] < 1e-12, st
+
+
 def test_step_many_agents_per_env(amd, orc):
     st = _drive(amd, orc, 6, 5, 60)
     assert st["flag_mismatch"] == 0 and st["state"] < NORTH_STAR and st["scan"] < NORTH_STAR, st
