@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--scan-block", type=int, default=int(os.environ.get("F110_SCAN_BLOCK", "0")))
     ap.add_argument("--scan-tasks", type=int, default=int(os.environ.get("F110_SCAN_TASKS", "0")),
                     help="consecutive 64-ray tasks per wave (0 = default)")
+    ap.add_argument("--gather", action="store_true",
+                    help="RCCL all-gather of every rank's scans after each step (BASELINE config 4; off by default)")
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--no-reset", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,6 +92,16 @@ class Rendezvous(object):
         t = self.torch.tensor([x], dtype=self.torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t[0])
+
+    def broadcast_bytes(self, payload, n):
+        """rank 0's `payload` (n bytes) to every rank"""
+        if not self.dist:
+            return payload
+        t = self.torch.zeros(n, dtype=self.torch.uint8)
+        if self.rank == 0:
+            t = self.torch.tensor(list(payload), dtype=self.torch.uint8)
+        self.dist.broadcast(t, src=0)
+        return bytes(t.tolist())
 
     def close(self):
         if self.dist:
@@ -144,11 +156,18 @@ def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
     for s in sets:
         d = sim.device_array((E * A, 2)); d.upload(s); d_sets.append(d)
     d_count = sim.device_array((1,), dtype=np.int32); d_count.upload(np.zeros(1, dtype=np.int32))
+    d_all = None
+    if args.gather:
+        uid = BatchSim.comm_unique_id() if rdv.rank == 0 else b"\0" * 128
+        sim.comm_init(rdv.world, rdv.rank, rdv.broadcast_bytes(uid, 128))
+        d_all = sim.device_array((rdv.world, E * A, args.beams))
     sim.reset_device(d_start)
     sim.sync()
 
     def one(t):
         sim.step_device(d_sets[t // 20])
+        if d_all is not None:
+            sim.comm_all_gather_scans(d_all)
         if not args.no_reset:
             sim.reset_collided_device(d_start, 0, d_count)
 
@@ -175,6 +194,11 @@ def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
                     "fin_ms_avg": fin_ms / max(n, 1), "n_prof": n})
         sim.profile_kernels(False)
     out["final"] = sim.get("collisions", "in_collision", "step_count")
+    if d_all is not None:   # the gathered block of this rank must equal its own scans
+        mine = sim.get("scans")["scans"]
+        got = d_all.download()[rdv.rank]
+        out["gather_ok"] = bool((mine == got).all())
+        d_all.free()
     for d in d_sets + [d_start, d_count]:
         d.free()
     sim.close()
@@ -297,9 +321,12 @@ def main():
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
                    "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut"}[args.layout],
                    "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks,
-                   "parallelism": "env-sharded x%d, no data-path collective" % n_gpus,
+                   "parallelism": "env-sharded x%d, %s" % (n_gpus, "RCCL all-gather of scans after every step" if args.gather
+                                                           else "no data-path collective"),
                    "env_resets_in_timed_region": int(n_reset)},
     }
+    if args.gather:
+        line["config"]["gather_ok"] = res.get("gather_ok")
     if rdv.rank == 0:
         lbar = None
         if n_gpus == 1 and not args.no_cpu_baseline:

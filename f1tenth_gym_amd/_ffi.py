@@ -93,6 +93,10 @@ PROTOTYPES = {
     "f110_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "f110_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "f110_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "f110_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "f110_comm_all_gather_scans": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "f110_comm_destroy": (C.c_int, [C.c_void_p]),
     "f110_timer_begin": (C.c_int, [C.c_void_p]),
     "f110_timer_end_ms": (C.c_int, [C.c_void_p, _dp]),
     "f110_profile_kernels": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -236,6 +236,24 @@ class BatchSim(object):
         c = None if d_count is None else (d_count.ptr if isinstance(d_count, DeviceArray) else int(d_count))
         check(_ffi.lib().f110_reset_collided_device(self._h, p, int(ego_idx), c), self._h, IndexError)
 
+    # ------------------------------------------------------------------ optional RCCL observation gather
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        check(_ffi.lib().f110_comm_unique_id(buf), None)
+        return buf.raw
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(_ffi.lib().f110_comm_init(self._h, int(n_ranks), int(rank), buf), self._h)
+        self.comm_ranks = int(n_ranks)
+
+    def comm_all_gather_scans(self, d_recv):
+        ptr = d_recv.ptr if isinstance(d_recv, DeviceArray) else int(d_recv)
+        check(_ffi.lib().f110_comm_all_gather_scans(self._h, ptr), self._h)
+
     # ------------------------------------------------------------------ episode logic on the device
     def episode_init(self, ego_idx=0):
         check(_ffi.lib().f110_episode_init(self._h, int(ego_idx)), self._h, IndexError)

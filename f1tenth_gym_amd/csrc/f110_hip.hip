@@ -16,6 +16,9 @@
 // Compiled with -ffp-contract=off: float64, reference operation order, no FMA contraction.
 // There is no CPU fallback in this library.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -904,6 +907,8 @@ struct f110_sim {
     double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_actions = nullptr, *d_poses = nullptr;
     double2 *d_cs = nullptr;
     uint8_t *d_mask = nullptr;
+    ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
+    int comm_ranks = 0;
     EpisodeArrays ep{};
     bool has_episode = false;
     double *d_rot_stage = nullptr;
@@ -1234,6 +1239,7 @@ void f110_destroy(f110_sim *h)
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    (void)f110_comm_destroy(h);
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
@@ -1465,6 +1471,100 @@ int f110_reset_collided_device(f110_sim *h, const double *d_start_poses, int32_t
     if (ego_idx < 0 || ego_idx >= h->cfg.num_agents) return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
     hipLaunchKernelGGL(k_reset_collided, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, d_start_poses, ego_idx, d_count);
     HIPCHK(h, hipGetLastError());
+    return F110_OK;
+}
+
+// ---- optional observation gather over RCCL / xGMI (BASELINE config 4) ---------------------------
+// The step path has no collective: environments never interact and each rank's policy consumes
+// its observations on the owning GPU.  For consumers that want every rank's scans on every GPU,
+// this all-gathers them; RCCL is resolved at run time (dlopen) so the library has no link-time
+// dependency on it and, inside a process that already loaded torch's RCCL, shares that copy.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (api.lib) {
+            api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+            api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.lib, "ncclAllGather"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+        }
+    }
+    const bool ok = api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy && api.GetErrorString;
+    return ok ? &api : nullptr;
+}
+}  // namespace
+
+int f110_comm_unique_id(void *out_id128)
+{
+    if (!out_id128) return fail(nullptr, F110_ERR_INVALID, "null argument");
+    RcclApi *r = rccl_api();
+    if (!r) return fail(nullptr, F110_ERR_STATE, "RCCL (librccl.so) could not be loaded");
+    ncclUniqueId id;
+    const ncclResult_t rc = r->GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail(nullptr, F110_ERR_HIP, "ncclGetUniqueId failed: %s", r->GetErrorString(rc));
+    static_assert(sizeof(id) == F110_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(out_id128, &id, sizeof(id));
+    return F110_OK;
+}
+
+int f110_comm_init(f110_sim *h, int32_t n_ranks, int32_t rank, const void *id128)
+{
+    if (!h || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(h, F110_ERR_INVALID, "f110_comm_init: bad argument");
+    RcclApi *r = rccl_api();
+    if (!r) return fail(h, F110_ERR_STATE, "RCCL (librccl.so) could not be loaded");
+    if (h->comm) return fail(h, F110_ERR_STATE, "communicator already initialised");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    const ncclResult_t rc = r->CommInitRank(&h->comm, n_ranks, id, rank);
+    if (rc != ncclSuccess) {
+        h->comm = nullptr;
+        return fail(h, F110_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString(rc));
+    }
+    h->comm_ranks = n_ranks;
+    return F110_OK;
+}
+
+int f110_comm_all_gather_scans(f110_sim *h, void *d_recv)
+{
+    if (!h || !d_recv) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->comm) return fail(h, F110_ERR_STATE, "f110_comm_init has not been called");
+    RcclApi *r = rccl_api();
+    const size_t count = (size_t)h->N * h->cfg.num_beams;
+    const ncclResult_t rc = r->AllGather(h->dev.scans, d_recv, count, ncclFloat64, h->comm, h->stream);
+    if (rc != ncclSuccess) return fail(h, F110_ERR_HIP, "ncclAllGather failed: %s", r->GetErrorString(rc));
+    return F110_OK;
+}
+
+int f110_comm_destroy(f110_sim *h)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    if (h->comm) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        RcclApi *r = rccl_api();
+        if (r) (void)r->CommDestroy(h->comm);
+        h->comm = nullptr;
+        h->comm_ranks = 0;
+    }
     return F110_OK;
 }
 

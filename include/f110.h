@@ -188,6 +188,18 @@ int f110_device_free(f110_sim *h, void *d_ptr);
 int f110_memcpy_h2d(f110_sim *h, void *d_dst, const void *h_src, size_t bytes);
 int f110_memcpy_d2h(f110_sim *h, void *h_dst, const void *d_src, size_t bytes);
 
+/* ---- optional observation gather over RCCL / xGMI (BASELINE config 4; off the step path) ----
+ * Environments never interact, so stepping needs no collective.  A consumer that wants every
+ * rank's scans on every GPU creates one communicator (rank 0 makes the id, the launcher's control
+ * plane broadcasts its 128 bytes) and calls f110_comm_all_gather_scans after a step: an
+ * ncclAllGather of [N][B] float64 per rank, enqueued on the handle's stream.
+ * d_recv: device buffer of n_ranks*N*B doubles. */
+#define F110_COMM_ID_BYTES 128
+int f110_comm_unique_id(void *out_id128);
+int f110_comm_init(f110_sim *h, int32_t n_ranks, int32_t rank, const void *id128);
+int f110_comm_all_gather_scans(f110_sim *h, void *d_recv);
+int f110_comm_destroy(f110_sim *h);
+
 /* HIP-event timing on the handle's stream (bench.py roofline leg).
  * f110_timer_begin/_end bracket a region; f110_profile_kernels(1) additionally brackets
  * every scan-kernel launch inside f110_step with its own event pair. */
