@@ -423,12 +423,17 @@ F110_HD void disc_beam_range(double ex, double ey, double eth, double cx, double
 {
     const double dx = cx - ex, dy = cy - ey;
     const double dist = sqrt(dx * dx + dy * dy);
-    if (!(dist > R * 1.000001 + 1e-9)) {  // lidar inside / on the disc (or NaN): no cull
+    // No cull when the lidar is inside / on the disc (or anything is NaN), and none when the
+    // heading is astronomically large: the reference wraps yaw by a single 2*pi per step
+    // (base_classes.py:400-404), so a diverged yaw rate leaves |yaw| ~ 1e15, where
+    // pose[2] + scan_angles[i] (:343) is rounded to a grid coarser than the beam spacing and the
+    // beams no longer point where their index says.  Below 1e6 that rounding is < 1e-10 rad.
+    if (!(dist > R * 1.000001 + 1e-9) || !(fabs(eth) < 1e6)) {
         cl = 0;
         ch = num_beams - 1;
         return;
     }
-    double phi = atan2(dy, dx) - eth;
+    double phi = atan2(dy, dx) - atan2(sin(eth), cos(eth));
     phi -= kTwoPi * rint(phi / kTwoPi);  // (-pi, pi]
     const double psi = asin(R / dist) + 3.0 * angle_inc + 1e-6;
     const double sa0 = scan_angles[0];

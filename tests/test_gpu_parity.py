@@ -551,3 +551,38 @@ def test_waypoint_follow_two_laps_through_f110env(amd):
             assert abs(np.sum(obs['scans'][0]) - row[9]) / row[9] < NORTH_STAR
     assert worst < NORTH_STAR, worst
     assert done and float(obs['lap_counts'][0]) == 2.0
+
+
+def test_step_other_maps_params_euler_lidar_offset(amd, orc):
+    """step-level parity away from the bench defaults: berlin / skirk (resolution 0.05 is not a
+    power of two -> guarded-division cell index; dt[-1,-1] = 0 -> rays end where they leave the
+    map), Euler integrator, lidar offset, per-agent vehicle params, noise table shorter than the
+    episode (wraps)"""
+    rng = np.random.default_rng(17)
+    for mapname, integ, ld, layout in [("berlin", 1, 0.0, 0), ("skirk", 2, 0.275, 1), ("berlin", 1, 0.275, 2)]:
+        img, res, origin = load_map_image(mapname)
+        dt, _, _ = oracle_map_dt(mapname)
+        E, A, T = 9, 3, 50
+        noise = _noise(7)                      # 7 rows only: step counts wrap modulo 7
+        p2 = dict(amd.DEFAULT_PARAMS); p2.update({'mu': 0.8, 'm': 3.2, 'length': 0.50, 'width': 0.28, 'a_max': 7.0})
+        s = amd.BatchSim(num_envs=E, num_agents=A, integrator=integ, lidar_dist=ld, map_layout=layout)
+        s.set_map_image(img, res, origin); s.set_noise_table(noise); s.set_params(p2, 1)
+        ref = orc.SimOracle(E, A, integrator=integ, lidar_dist=ld)
+        ref.set_map_dt(dt, res, origin); ref.set_noise(noise); ref.set_params(p2, 1)
+        with pytest.raises(IndexError):
+            s.set_params(p2, 3)
+        # cars start near the map's (0,0), which is free space on both maps, in a loose cluster
+        poses = np.stack([rng.uniform(-0.6, 0.6, E * A), rng.uniform(-0.6, 0.6, E * A), rng.uniform(0, 2 * np.pi, E * A)], axis=1)
+        s.reset(poses); ref.reset(poses)
+        mism, es, er = 0, 0.0, 0.0
+        for t in range(T):
+            if t % 10 == 0:
+                act = np.stack([rng.uniform(-0.4, 0.4, E * A), rng.uniform(-2.0, 5.0, E * A)], axis=1)
+            s.step(act); ref.step(act, 8)
+            o = s.get("scans", "state", "collisions", "collision_idx", "in_collision", "step_count")
+            mism += int(np.sum(o["collisions"] != ref.collisions) + np.sum(o["in_collision"] != ref.in_collision)
+                        + np.sum(o["collision_idx"] != ref.collision_idx))
+            es = max(es, rel_err(o["state"], ref.state)); er = max(er, rel_err(o["scans"], ref.scans))
+        assert mism == 0 and es < NORTH_STAR and er < NORTH_STAR, (mapname, mism, es, er)
+        assert ref.collisions.sum() > 0          # the cluster does produce body collisions
+        s.close()

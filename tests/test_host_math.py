@@ -201,6 +201,8 @@ def test_disc_cull_is_result_preserving(hh):
     culled_total = ref_total = 0
     for i in range(1500):
         ego = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(0, 2 * np.pi) if i % 7 else 0.0])
+        if i % 11 == 0:      # diverged yaw (a reversing car can blow the yaw rate up): huge headings
+            ego[2] = rng.choice([1.16059365e+15, -3.3e12, 7.7e8, 1e300])
         dist = rng.uniform(0.0, 0.5) if i % 10 == 0 else rng.uniform(0.3, 12.0)
         bearing = rng.uniform(-np.pi, np.pi) if i % 3 else np.pi + rng.uniform(-0.5, 0.5)
         opp = np.array([ego[0] + dist * np.cos(ego[2] + bearing), ego[1] + dist * np.sin(ego[2] + bearing), rng.uniform(0, 2 * np.pi)])
