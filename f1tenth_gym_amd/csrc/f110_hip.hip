@@ -433,13 +433,16 @@ __global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = a.n_agents_total;
     if (i >= N) return;
-    if (a.in_collision[i]) {
+    const int wall = a.in_collision[i];
+    if (wall) {
         a.state[3 * (size_t)N + i] = 0.;
         a.state[4 * (size_t)N + i] = 0.;
         a.state[5 * (size_t)N + i] = 0.;
         a.state[6 * (size_t)N + i] = 0.;
-        a.collisions[i] = 1.0;
     }
+    // collision_multiple on a single body returns zeros every step (collision_models.py:196-197);
+    // k_collide is not launched for A = 1, so the flag is (re)written here
+    a.collisions[i] = wall ? 1.0 : 0.0;
     a.step_count[i] += 1;
 }
 

@@ -358,8 +358,11 @@ def test_step_4096_beams_dedupe_vs_oracle(amd, orc):
 def test_step_many_agents_per_env(amd, orc):
     st = _drive(amd, orc, 6, 5, 60)
     assert st["flag_mismatch"] == 0 and st["state"] < NORTH_STAR and st["scan"] < NORTH_STAR, st
-    st = _drive(amd, orc, 9, 1, 40)
+    # single-agent envs, long enough for wall hits AND the steps after them (collisions must drop
+    # back to 0: collision_multiple returns zeros for one body, collision_models.py:196-197)
+    st = _drive(amd, orc, 24, 1, 220)
     assert st["flag_mismatch"] == 0 and st["state"] < NORTH_STAR and st["scan"] < NORTH_STAR, st
+    assert st["wall"] > 0
 
 
 def test_config5_4096_beams_tiled_big_map(amd, orc):
