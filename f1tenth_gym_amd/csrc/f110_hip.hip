@@ -1,20 +1,8 @@
-// f110_hip.hip — gfx950 kernels + the C ABI (include/f110.h) of the batched F1TENTH hot path.
-//
-// One handle owns one MI355X and one HIP stream.  A step is four launches on that stream:
-//   k_integrate   1 lane / agent   pid + steering delay + RK4|Euler + yaw wrap + lidar pose
-//                                  (base_classes.py:256-409), SoA columns, coalesced
-//   k_collide     1 lane / agent   get_vertices + GJK against the env's other agents
-//                                  (collision_models.py:113-260, base_classes.py:536-550)
-//   k_scan_rays   1 lane / ray, rays numbered agent*B + beam so a wave holds 64 consecutive
-//                                  beams: sphere-trace the distance table (laser_models.py:106-186),
-//                                  add the noise row (:450-452), evaluate the iTTC predicate
-//                                  (:188-217) and write the range once, coalesced.  Kept free of
-//                                  everything else so it runs at 8 waves/SIMD.
-//   k_finalize    1 wave / agent   wall-hit state zeroing (base_classes.py:246-249), collision
-//                                  flags (:588-589), opponent ray-cast on the beams each opponent
-//                                  blocks (laser_models.py:282-346).
-// Compiled with -ffp-contract=off: float64, reference operation order, no FMA contraction.
-// There is no CPU fallback in this library.
+// f110_hip.hip — host side of libf110_hip.so: the handle (one MI355X, one HIP stream + a side
+// stream), device-memory ownership, kernel launches and the C ABI declared in include/f110.h.
+// The kernels live in f110_kernels.hpp, the scalar float64 building blocks in f110_math.hpp.
+// A step is k_integrate -> { k_scan_rays || k_collide (side stream) } -> k_finalize.
+// Compiled with -ffp-contract=off.  There is no CPU fallback in this library.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -30,861 +18,8 @@
 #include <vector>
 
 #include "../../include/f110.h"
-#include "f110_math.hpp"
+#include "f110_kernels.hpp"
 
-using namespace f110;
-
-// ============================================================================ device side
-
-// What one ray needs to know about its agent, written by k_integrate: read through the scalar
-// cache by k_scan_rays (a wave's 64 consecutive rays belong to at most two agents).
-struct RayHdr {
-    double x, y;        // lidar position (base_classes.py:407-408)
-    double start;       // wrapped theta_index of beam 0 (laser_models.py:166-172)
-    double vel;         // post-integration longitudinal velocity (iTTC)
-    double d0;          // first table sample, shared by every beam of the scan (:129)
-    int32_t noise_row;  // row of the noise table for this step, -1 = no noise
-    int32_t hr0, hc0;   // cell of that first sample
-    int32_t i0;         // table index of beam 0
-    int32_t n_dirs;     // distinct table indices the scan's beams use (dedupe mode), else 0
-    int32_t pad;
-};
-static_assert(sizeof(RayHdr) == 64, "RayHdr is read as four 16-byte scalar loads");
-
-struct AgentArrays {
-    int32_t n_agents_total;  // N
-    int32_t agents_per_env;  // A
-    double *state;           // [7][N]
-    double *steer_buf;       // [2][N]
-    int32_t *buf_cnt;        // [N]
-    double *scan_pose;       // [3][N]  lidar pose after integration
-    double *snap_pose;       // [3][N]  Simulator.agent_poses (:574)
-    double *dir_start;       // [N]     wrapped theta_index of beam 0
-    RayHdr *ray_hdr;         // [N]     per-agent constants of this step's scan
-    double *scans;           // [N][B]
-    double *collisions;      // [N]
-    double *collision_idx;   // [N]
-    int32_t *in_collision;   // [N]
-    int32_t *step_count;     // [N]
-    int32_t *opp_window;     // [N][A][4] beam range each opponent can occupy: {lo, hi} for the live
-                             //           heading and {lo0, hi0} for heading 0 (after a wall hit)
-    double *opp_verts;       // [N][A][8] the opponent's box drawn with the ego's length/width
-    const double *params;    // [A][18]
-    const double *noise;     // [noise_rows][B] or nullptr
-    const double *scan_angles, *beam_cos, *side_dist;  // [B]
-    int32_t noise_rows, integrator;
-    double time_step, lidar_dist, ttc_thresh, angle_inc;
-    double box_length, box_width;  // Simulator.params used by check_collision (:549)
-};
-
-__device__ __forceinline__ VehicleParams load_params(const double *p)
-{
-    VehicleParams vp;
-#pragma unroll
-    for (int i = 0; i < NPARAMS; ++i) vp.v[i] = p[i];
-    return vp;
-}
-
-// ---- K1: integrate every agent one time step ------------------------------------------
-__global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, const double *__restrict__ actions)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = a.n_agents_total;
-    if (i >= N) return;
-    const VehicleParams vp = load_params(a.params + (size_t)(i % a.agents_per_env) * NPARAMS);
-    double st[7];
-#pragma unroll
-    for (int c = 0; c < 7; ++c) st[c] = a.state[(size_t)c * N + i];
-    double b0 = a.steer_buf[i], b1 = a.steer_buf[(size_t)N + i];
-    int cnt = a.buf_cnt[i];
-    const double2 act = reinterpret_cast<const double2 *>(actions)[i];
-    double sp[3];
-    advance_vehicle(st, b0, b1, cnt, act.x, act.y, vp, a.time_step, a.integrator, a.lidar_dist, sp);
-#pragma unroll
-    for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = st[c];
-    a.steer_buf[i] = b0;
-    a.steer_buf[(size_t)N + i] = b1;
-    a.buf_cnt[i] = cnt;
-    a.scan_pose[i] = sp[0];
-    a.scan_pose[(size_t)N + i] = sp[1];
-    a.scan_pose[2 * (size_t)N + i] = sp[2];
-    a.snap_pose[i] = st[0];
-    a.snap_pose[(size_t)N + i] = st[1];
-    a.snap_pose[2 * (size_t)N + i] = st[4];
-    const double start = scan_start_index(k, sp[2]);
-    a.dir_start[i] = start;
-    {
-        // everything the ray kernel needs per agent, incl. the first table sample that all
-        // beams share (trace_ray :129 evaluated at the lidar position; generic exact path)
-        RayHdr hd;
-        ScanConst kr = k;
-        kr.table = k.table_rm;
-        hd.x = sp[0];
-        hd.y = sp[1];
-        hd.start = start;
-        hd.vel = st[3];
-        hd.d0 = sample_distance<LAYOUT_ROWMAJOR, false, false>(kr, nullptr, sp[0], sp[1], hd.hr0, hd.hc0);
-        int row = -1;
-        if (a.noise_rows > 0) {
-            row = a.step_count[i];
-            if (row >= a.noise_rows) row %= a.noise_rows;
-        }
-        hd.noise_row = row;
-        hd.i0 = beam_dir_index(k, start, 0);
-        hd.n_dirs = 0;
-        if (k.theta_inc < 1.0) {  // consecutive beams advance the table index by 0 or 1 (mod theta_dis)
-            int span = beam_dir_index(k, start, k.num_beams - 1) - hd.i0;
-            if (span < 0) span += k.theta_dis;
-            hd.n_dirs = span + 1;
-        }
-        hd.pad = 0;
-        a.ray_hdr[i] = hd;
-    }
-    a.in_collision[i] = 0;  // raised by k_scan_rays when any beam's iTTC is under the threshold
-}
-
-// ---- K1b: pairwise body collisions inside each env ------------------------------------
-// collision_multiple visits pairs (i<j) ascending and overwrites collision_idx, so an agent's
-// final index is the largest colliding partner; flags are symmetric.  Each lane evaluates the
-// GJK of its pairs in the reference's (lower, higher) argument order.
-__global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = a.n_agents_total, A = a.agents_per_env;
-    if (i >= N) return;
-    const int env = i / A, me = i - env * A;
-    double mine[8];
-    const double mx = a.snap_pose[i], my = a.snap_pose[(size_t)N + i], mth = a.snap_pose[2 * (size_t)N + i];
-    box_vertices(mx, my, mth, a.box_length, a.box_width, mine);
-    // bodies whose centres are further apart than a box diagonal (+1 mm) cannot overlap
-    const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
-    // RaceCar.ray_cast_agents draws the opponents with the EGO's length/width (:223)
-    const double blen = a.params[(size_t)me * NPARAMS + P_LENGTH];
-    const double bwid = a.params[(size_t)me * NPARAMS + P_WIDTH];
-    const double disc_r = 0.5 * sqrt(blen * blen + bwid * bwid);
-    bool hit = false;
-    int partner = -1;
-    for (int j = 0; j < A; ++j) {
-        if (j == me) continue;
-        const int o = env * A + j;
-        const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
-        const double dx = ox - mx, dy = oy - my;
-        double other[8];
-        if (dx * dx + dy * dy <= reach * reach) {
-            box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
-            const bool c = (me < j) ? gjk_overlap(mine, other) : gjk_overlap(other, mine);
-            if (c) {
-                hit = true;
-                partner = j;  // j ascending -> ends at the largest colliding index
-            }
-        }
-        // beam window this opponent can occupy in my scan: once for my post-integration heading
-        // (no wall hit) and once for heading 0 (RaceCar.check_ttc zeroes it on a wall hit, and the
-        // ray-cast reads the live state, base_classes.py:225,246-249); k_finalize picks one.
-        int ref_lo, ref_hi, lo, hi;
-        box_vertices(ox, oy, oth, blen, bwid, other);
-        int32_t *win = a.opp_window + ((size_t)i * A + j) * 4;
-        opponent_beam_window(mx, my, mth, other, ox, oy, disc_r, a.scan_angles, B, a.angle_inc, ref_lo, ref_hi, lo, hi);
-        win[0] = lo;
-        win[1] = hi;
-        opponent_beam_window(mx, my, 0.0, other, ox, oy, disc_r, a.scan_angles, B, a.angle_inc, ref_lo, ref_hi, lo, hi);
-        win[2] = lo;
-        win[3] = hi;
-        double *ov = a.opp_verts + ((size_t)i * A + j) * 8;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) ov[c] = other[c];
-    }
-    a.collisions[i] = hit ? 1.0 : 0.0;
-    a.collision_idx[i] = (double)partner;
-}
-
-// ---- K2: ray march -------------------------------------------------------------------------
-// Rays are numbered ray = pose*B + beam, one lane per ray, so the 64 lanes of a wave are
-// consecutive beams of (at most two) poses: neighbouring beams touch neighbouring cells and
-// have correlated lengths.  STEP=true is the env.step() form (SoA poses written by
-// k_integrate, noise row, iTTC predicate); STEP=false is ScanSimulator2D.scan for the unit
-// entry point (also reports terminating cells and lookup counts).
-struct RayJob {
-    uint32_t n_rays;          // poses * B
-    uint32_t n_tasks;         // ceil(n_rays / 64): one task = 64 consecutive rays
-    uint32_t tasks_per_wave;  // consecutive tasks each wave walks
-    int32_t n_poses;
-    uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
-    int32_t xcd_remap;
-    int32_t dir_mode, dir_stride;   // dedupe pass: rays are (agent, distinct direction), dir_stride per agent
-    const double *dir_ranges;       // k_expand_beams: [n_poses][dir_stride] raw ranges of the dedupe pass
-    const double *pose_x, *pose_y, *dir_start;  // [n_poses] (unit path)
-    double *ranges;           // [n_poses][B]
-    // STEP only
-    const RayHdr *hdr;        // [n_poses] written by k_integrate
-    const double *noise;      // [noise_rows][B] or nullptr
-    const double *beam_cos, *side_dist;
-    int32_t *wall_flag;       // [n_poses], zeroed by k_integrate
-    double ttc_thresh;
-    double ttc_side_max, ttc_k;  // r > ttc_side_max + ttc_k*|v| cannot satisfy the iTTC predicate
-    // unit only
-    int32_t *hit_rc;                 // [n_poses][B][2] or nullptr
-    unsigned long long *lookups;     // [n_poses] or nullptr
-};
-
-__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ double uniform_f64(double v)
-{
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-// Per-agent ray constants for the lane's agent p.  With >= 64 rays per agent the 64 rays of a wave
-// belong to agent p0 (the first lane's) or p0+1, so two uniform 64-byte headers fetched through
-// the scalar cache cover the wave and no vector-memory instruction is spent on them; uniform_*()
-// pins each field to SGPRs so the compiler keeps two scalar loads + a per-lane select instead of
-// one divergent vector load.  Fewer rays per agent: a wave may span more agents -> per-lane load.
-struct LaneHdr {
-    double x, y, start, vel, d0;
-    int row, hr, hc, i0, n_dirs;
-};
-
-__device__ __forceinline__ LaneHdr load_lane_hdr(const RayHdr *hdr, uint32_t p, uint32_t n_poses, bool wide)
-{
-    LaneHdr o;
-    if (wide) {
-        typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
-        const uint32_t p0 = __builtin_amdgcn_readfirstlane(p);
-        const uint32_t p1 = (p0 + 1u < n_poses) ? p0 + 1u : p0;
-        const chdr_t h0 = (chdr_t)(hdr) + p0;
-        const chdr_t h1 = (chdr_t)(hdr) + p1;
-        const bool first = (p == p0);
-        const double x0 = uniform_f64(h0->x), y0 = uniform_f64(h0->y), s0 = uniform_f64(h0->start);
-        const double v0 = uniform_f64(h0->vel), d00 = uniform_f64(h0->d0);
-        const int n0 = uniform_i32(h0->noise_row), r0 = uniform_i32(h0->hr0), c0 = uniform_i32(h0->hc0);
-        const int i00 = uniform_i32(h0->i0), nd0 = uniform_i32(h0->n_dirs);
-        const double x1 = uniform_f64(h1->x), y1 = uniform_f64(h1->y), s1 = uniform_f64(h1->start);
-        const double v1 = uniform_f64(h1->vel), d01 = uniform_f64(h1->d0);
-        const int n1 = uniform_i32(h1->noise_row), r1 = uniform_i32(h1->hr0), c1 = uniform_i32(h1->hc0);
-        const int i01 = uniform_i32(h1->i0), nd1 = uniform_i32(h1->n_dirs);
-        o.x = first ? x0 : x1;
-        o.y = first ? y0 : y1;
-        o.start = first ? s0 : s1;
-        o.vel = first ? v0 : v1;
-        o.d0 = first ? d00 : d01;
-        o.row = first ? n0 : n1;
-        o.hr = first ? r0 : r1;
-        o.hc = first ? c0 : c1;
-        o.i0 = first ? i00 : i01;
-        o.n_dirs = first ? nd0 : nd1;
-    } else {
-        const RayHdr hd = hdr[p];
-        o.x = hd.x; o.y = hd.y; o.start = hd.start; o.vel = hd.vel; o.d0 = hd.d0; o.row = hd.noise_row;
-        o.hr = hd.hr0; o.hc = hd.hc0; o.i0 = hd.i0; o.n_dirs = hd.n_dirs;
-    }
-    return o;
-}
-
-// noise + iTTC + store for one beam (shared by k_scan_rays and k_expand_beams).
-// check_ttc_jit is an any-over-beams: every hitting lane raises the agent's flag.
-// r > max(side) + thresh*(1+1e-9)*max|cos|*|v| implies r - side_distances[b] >
-// thresh*(1+1e-12)*|v*cosines[b]|, i.e. the "no hit" branch of ttc_beam_hit, so the per-beam
-// tables are only read for the few beams that are that close.
-struct RayJob;
-__device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_t p, int b, uint32_t ray, double r,
-                                            int row, double vel);
-
-template <int LAYOUT, bool POW2, bool IDENT, bool STEP>
-__global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
-{
-    __shared__ double lut_lds[LAYOUT == LAYOUT_CODE8 ? 256 : 1];
-    if (LAYOUT == LAYOUT_CODE8) {
-        // stage the 2 KB value LUT once per workgroup; every wave then walks j.tasks_per_wave
-        // consecutive 64-ray tasks so the fill is amortised
-        for (int t = threadIdx.x; t < kLutEntries; t += blockDim.x) lut_lds[t] = k.lut[t];
-        __syncthreads();
-    }
-    const uint32_t B = (STEP && j.dir_mode) ? (uint32_t)j.dir_stride : (uint32_t)k.num_beams;
-    const uint32_t tpw = j.tasks_per_wave;
-    const uint32_t lane = threadIdx.x & 63u;
-    // Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md).  Re-map so that each
-    // XCD walks one contiguous eighth of the rays: all beams of an agent, and agents that are
-    // neighbours in the batch, then share one XCD's L2 instead of being spread over all eight.
-    uint32_t blk = blockIdx.x;
-    if (j.xcd_remap) {
-        const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
-        blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // bijective for any nb
-    }
-    const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
-    for (uint32_t t = 0; t < tpw; ++t) {
-        const uint32_t task = wave * tpw + t;
-        if (task >= j.n_tasks) break;  // wave-uniform
-        const uint32_t ray = task * 64u + lane;
-        if (ray >= j.n_rays) break;
-        const uint32_t p = j.div_magic ? (__umulhi(ray, j.div_magic) >> j.div_shift) : ray / B;
-        const int b = (int)(ray - p * B);
-        int hr, hc, nl;
-        double r;
-        if (STEP) {
-            const LaneHdr hd = load_lane_hdr(j.hdr, p, (uint32_t)j.n_poses, B >= 64u);
-            hr = hd.hr;
-            hc = hd.hc;
-            if (j.dir_mode) {
-                // dedupe pass: "beam" b is the b-th distinct table direction of agent p's scan;
-                // raw range only (noise / iTTC / beam expansion happen in k_expand_beams)
-                if (b < hd.n_dirs) {
-                    int didx = hd.i0 + b;
-                    if (didx >= k.theta_dis) didx -= k.theta_dis;
-                    const double2 cs = k.cs[didx];
-                    j.ranges[ray] = march_from_first<LAYOUT, POW2, IDENT>(k, lut_lds, hd.x, hd.y, cs.x, cs.y, hd.d0, hr, hc, nl);
-                }
-                continue;
-            }
-            const double2 cs = k.cs[beam_dir_index(k, hd.start, b)];
-            r = march_from_first<LAYOUT, POW2, IDENT>(k, lut_lds, hd.x, hd.y, cs.x, cs.y, hd.d0, hr, hc, nl);
-            finish_beam(j, B, p, b, ray, r, hd.row, hd.vel);
-            continue;
-        } else {
-            const double2 cs = k.cs[beam_dir_index(k, j.dir_start[p], b)];
-            r = march_ray<LAYOUT, POW2, IDENT>(k, lut_lds, j.pose_x[p], j.pose_y[p], cs.x, cs.y, hr, hc, nl);
-            if (j.hit_rc) {
-                j.hit_rc[(size_t)ray * 2] = hr;
-                j.hit_rc[(size_t)ray * 2 + 1] = hc;
-            }
-            if (j.lookups) atomicAdd(&j.lookups[p], (unsigned long long)nl);
-        }
-        j.ranges[ray] = r;
-    }
-}
-
-__device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_t p, int b, uint32_t ray, double r,
-                                            int row, double vel)
-{
-    if (row >= 0) r += j.noise[(size_t)row * B + b];
-    if (vel != 0.0 && !(r > j.ttc_side_max + j.ttc_k * fabs(vel)) &&
-        ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh))
-        j.wall_flag[p] = 1;
-    j.ranges[ray] = r;
-}
-
-// ---- K2b: beam expansion of the dedupe pass ---------------------------------------------------
-// More beams than table directions (BASELINE config 5: 4096 beams, theta_dis = 2000 -> 1497
-// distinct directions per scan): beams that share a table index from the same origin are the same
-// ray.  k_scan_rays (dir_mode) marches each distinct direction once; here every beam picks its
-// direction's range, then gets its own noise sample and iTTC test.  Bit-identical to marching
-// every beam, ~2.7x fewer table gathers.
-__global__ void __launch_bounds__(256) k_expand_beams(RayJob j, ScanConst k)
-{
-    const uint32_t B = (uint32_t)k.num_beams;
-    const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ray >= j.n_rays) return;
-    const uint32_t p = j.div_magic ? (__umulhi(ray, j.div_magic) >> j.div_shift) : ray / B;
-    const int b = (int)(ray - p * B);
-    const LaneHdr hd = load_lane_hdr(j.hdr, p, (uint32_t)j.n_poses, B >= 64u);
-    int s = beam_dir_index(k, hd.start, b) - hd.i0;
-    if (s < 0) s += k.theta_dis;
-    const double r = j.dir_ranges[(size_t)p * j.dir_stride + s];
-    finish_beam(j, B, p, b, ray, r, hd.row, hd.vel);
-}
-
-// ---- K3: finalize ---------------------------------------------------------------------------
-// One wave per agent.  RaceCar.check_ttc's side effects (:246-252), Simulator's collision OR
-// (:588-589), then RaceCar.ray_cast_agents (:206-227): opponents from the :574 snapshot, ego
-// pose = live state (heading already zeroed on a wall hit), box = the ego's own params.
-__global__ void __launch_bounds__(64, 5) k_finalize(AgentArrays a, int32_t B)
-{
-    const int i = blockIdx.x, tid = threadIdx.x;
-    const int N = a.n_agents_total, A = a.agents_per_env;
-    const int wall = a.in_collision[i];
-    const double ex = a.state[i], ey = a.state[(size_t)N + i];
-    const double eth = wall ? 0.0 : a.state[4 * (size_t)N + i];
-    if (tid == 0) {
-        if (wall) {
-            a.state[3 * (size_t)N + i] = 0.;
-            a.state[4 * (size_t)N + i] = 0.;
-            a.state[5 * (size_t)N + i] = 0.;
-            a.state[6 * (size_t)N + i] = 0.;
-            a.collisions[i] = 1.0;
-        }
-        a.step_count[i] += 1;
-    }
-    const int me = i % A;
-    double *sc = a.scans + (size_t)i * B;
-    for (int jj = 0; jj < A; ++jj) {
-        if (jj == me) continue;
-        const int32_t *win = a.opp_window + ((size_t)i * A + jj) * 4 + (wall ? 2 : 0);
-        const int lo = win[0], hi = win[1];
-        if (hi < lo) continue;  // nothing of this opponent can be hit
-        const double *ov = a.opp_verts + ((size_t)i * A + jj) * 8;
-        double v[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = ov[c];
-        for (int b = lo + tid; b <= hi; b += 64) {
-            const double bt = eth + a.scan_angles[b];
-            const double v3x = cos(bt + kPi / 2.), v3y = sin(bt + kPi / 2.);
-            const double r0 = sc[b];
-            const double r = box_range(ex, ey, v3x, v3y, v, r0);
-            if (r < r0) sc[b] = r;
-        }
-        // the next opponent may touch the same beams: make this wave's stores visible to it
-        __threadfence_block();
-    }
-}
-
-// single-agent envs: no opponents, one lane per agent is enough
-__global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = a.n_agents_total;
-    if (i >= N) return;
-    const int wall = a.in_collision[i];
-    if (wall) {
-        a.state[3 * (size_t)N + i] = 0.;
-        a.state[4 * (size_t)N + i] = 0.;
-        a.state[5 * (size_t)N + i] = 0.;
-        a.state[6 * (size_t)N + i] = 0.;
-    }
-    // collision_multiple on a single body returns zeros every step (collision_models.py:196-197);
-    // k_collide is not launched for A = 1, so the flag is (re)written here
-    a.collisions[i] = wall ? 1.0 : 0.0;
-    a.step_count[i] += 1;
-}
-
-// unit-path helper: AoS poses [M][3] -> pose_x, pose_y, dir_start
-__global__ void k_prepare_poses(ScanConst k, const double *__restrict__ poses, int m, double *__restrict__ px,
-                                double *__restrict__ py, double *__restrict__ start)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    px[i] = poses[3 * i];
-    py[i] = poses[3 * i + 1];
-    start[i] = scan_start_index(k, poses[3 * i + 2]);
-}
-
-// ---- reset ------------------------------------------------------------------------------
-__global__ void k_reset(AgentArrays a, const double *__restrict__ poses, const uint8_t *__restrict__ env_mask)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = a.n_agents_total;
-    if (i >= N) return;
-    if (env_mask && !env_mask[i / a.agents_per_env]) return;
-#pragma unroll
-    for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = 0.;
-    a.state[i] = poses[3 * (size_t)i];
-    a.state[(size_t)N + i] = poses[3 * (size_t)i + 1];
-    a.state[4 * (size_t)N + i] = poses[3 * (size_t)i + 2];
-    a.steer_buf[i] = 0.;
-    a.steer_buf[(size_t)N + i] = 0.;
-    a.buf_cnt[i] = 0;
-    a.in_collision[i] = 0;
-    a.step_count[i] = 0;
-}
-
-// in-place re-seat of finished environments (SURVEY §8d "mask reset"): an env whose ego agent
-// has collisions != 0 is reset to its start poses, exactly as k_reset would with that env masked.
-__global__ void k_reset_collided(AgentArrays a, const double *__restrict__ start_poses, int ego_idx,
-                                 int32_t *__restrict__ n_reset)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = a.n_agents_total, A = a.agents_per_env;
-    if (i >= N) return;
-    const int env = i / A;
-    if (a.collisions[env * A + ego_idx] == 0.0) return;
-    // every lane of the env reads the ego flag before any lane of the env can have cleared it:
-    // collisions[] is not written here (it keeps the step's value, as Simulator.collisions does)
-#pragma unroll
-    for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = 0.;
-    a.state[i] = start_poses[3 * (size_t)i];
-    a.state[(size_t)N + i] = start_poses[3 * (size_t)i + 1];
-    a.state[4 * (size_t)N + i] = start_poses[3 * (size_t)i + 2];
-    a.steer_buf[i] = 0.;
-    a.steer_buf[(size_t)N + i] = 0.;
-    a.buf_cnt[i] = 0;
-    a.in_collision[i] = 0;
-    a.step_count[i] = 0;
-    if (n_reset && i - env * A == ego_idx) atomicAdd(n_reset, 1);
-}
-
-// ---- episode logic on the device ------------------------------------------------
-// F110Env._check_done (f110_env.py:204-246): start/finish-zone toggles, lap counts and times, done
-// = ego collided or every agent has 4 toggles — one lane per env, so an RL loop that keeps its
-// policy on the GPU never has to read poses back to decide `done`.
-struct EpisodeArrays {
-    int32_t ego_idx, pad;
-    double timestep;
-    double *start_poses;   // [N][3]
-    double *rot;           // [E][4] start_rot row-major (f110_env.py:331), computed by the host
-    double *current_time;  // [E]
-    uint8_t *near_start;   // [N]
-    double *toggle;        // [N]
-    double *lap_count;     // [N]
-    double *lap_time;      // [N]
-    uint8_t *done;         // [E]
-    uint8_t *checkpoint;   // [N] toggle >= 4
-};
-
-__global__ void __launch_bounds__(256) k_episode(AgentArrays a, EpisodeArrays ep, int num_envs)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= num_envs) return;
-    const int N = a.n_agents_total, A = a.agents_per_env;
-    const double ct = ep.current_time[e] + ep.timestep;  // f110_env.py:295
-    ep.current_time[e] = ct;
-    const double r00 = ep.rot[4 * e], r01 = ep.rot[4 * e + 1], r10 = ep.rot[4 * e + 2], r11 = ep.rot[4 * e + 3];
-    const double left_t = 2, right_t = 2;
-    bool all4 = true;
-    for (int s = 0; s < A; ++s) {
-        const int i = e * A + s;
-        const double px = a.state[i] - ep.start_poses[3 * (size_t)i];
-        const double py = a.state[(size_t)N + i] - ep.start_poses[3 * (size_t)i + 1];
-        const double dx = r00 * px + r01 * py;  // np.dot(start_rot, [px; py]) :223
-        double ty = r10 * px + r11 * py;
-        if (ty > left_t)
-            ty -= left_t;
-        else if (ty < -right_t)
-            ty = -right_t - ty;
-        else
-            ty = 0;
-        const double dist2 = dx * dx + ty * ty;
-        const bool closes = dist2 <= 0.1;
-        bool near = ep.near_start[i] != 0;
-        double tog = ep.toggle[i];
-        if (closes && !near) {
-            near = true;
-            tog += 1;
-        } else if (!closes && near) {
-            near = false;
-            tog += 1;
-        }
-        ep.near_start[i] = near ? 1 : 0;
-        ep.toggle[i] = tog;
-        ep.lap_count[i] = floor(tog / 2);  // toggle_list // 2
-        if (tog < 4) ep.lap_time[i] = ct;
-        ep.checkpoint[i] = tog >= 4 ? 1 : 0;
-        all4 = all4 && (tog >= 4);
-    }
-    ep.done[e] = (a.collisions[e * A + ep.ego_idx] != 0.0 || all4) ? 1 : 0;  // :244
-}
-
-// re-seat every env whose done flag is set (F110Env.reset :319-334 without its zero-action step)
-__global__ void __launch_bounds__(256) k_episode_reset_done(AgentArrays a, EpisodeArrays ep, int32_t *__restrict__ n_reset)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = a.n_agents_total, A = a.agents_per_env;
-    if (i >= N) return;
-    const int e = i / A;
-    if (!ep.done[e]) return;
-#pragma unroll
-    for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = 0.;
-    a.state[i] = ep.start_poses[3 * (size_t)i];
-    a.state[(size_t)N + i] = ep.start_poses[3 * (size_t)i + 1];
-    a.state[4 * (size_t)N + i] = ep.start_poses[3 * (size_t)i + 2];
-    a.steer_buf[i] = 0.;
-    a.steer_buf[(size_t)N + i] = 0.;
-    a.buf_cnt[i] = 0;
-    a.in_collision[i] = 0;
-    a.step_count[i] = 0;
-    ep.near_start[i] = 1;
-    ep.toggle[i] = 0.;
-    if (i - e * A == 0) {
-        ep.current_time[e] = 0.;
-        if (n_reset) atomicAdd(n_reset, 1);
-    }
-}
-
-// done[] is read by every lane of the env above and cleared here, in a separate launch
-__global__ void k_episode_clear_done(EpisodeArrays ep, int num_envs)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < num_envs) ep.done[e] = 0;
-}
-
-__global__ void k_episode_reset(AgentArrays a, EpisodeArrays ep, const double *__restrict__ poses,
-                                const double *__restrict__ rot, const uint8_t *__restrict__ env_mask)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int N = a.n_agents_total, A = a.agents_per_env;
-    if (i >= N) return;
-    const int e = i / A;
-    if (env_mask && !env_mask[e]) return;
-    ep.start_poses[3 * (size_t)i] = poses[3 * (size_t)i];
-    ep.start_poses[3 * (size_t)i + 1] = poses[3 * (size_t)i + 1];
-    ep.start_poses[3 * (size_t)i + 2] = poses[3 * (size_t)i + 2];
-    ep.near_start[i] = 1;
-    ep.toggle[i] = 0.;
-    ep.checkpoint[i] = 0;
-    if (i - e * A == 0) {
-        ep.current_time[e] = 0.;
-        ep.done[e] = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) ep.rot[4 * e + c] = rot[4 * e + c];
-    }
-}
-
-// ---- unit kernels (one per reference function; parity tests) ------------------------------
-__global__ void k_dir_index_unit(ScanConst k, const double *__restrict__ thetas, int m, int32_t *__restrict__ idx)
-{
-    const int p = blockIdx.x;
-    const double start = scan_start_index(k, thetas[p]);
-    for (int b = threadIdx.x; b < k.num_beams; b += blockDim.x) idx[(size_t)p * k.num_beams + b] = beam_dir_index(k, start, b);
-}
-
-__global__ void k_dynamics_unit(const double *__restrict__ x, const double *__restrict__ u, const double *__restrict__ params,
-                                int m, double *__restrict__ f_st, double *__restrict__ f_ks)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const VehicleParams vp = load_params(params);
-    double xs[7], f[7];
-#pragma unroll
-    for (int c = 0; c < 7; ++c) xs[c] = x[7 * (size_t)i + c];
-    rhs_single_track(xs, u[2 * i], u[2 * i + 1], vp, f);
-#pragma unroll
-    for (int c = 0; c < 7; ++c) f_st[7 * (size_t)i + c] = f[c];
-    rhs_kinematic(xs, u[2 * i], u[2 * i + 1], vp, f);
-#pragma unroll
-    for (int c = 0; c < 5; ++c) f_ks[5 * (size_t)i + c] = f[c];
-}
-
-__global__ void k_pid_unit(const double *__restrict__ in, const double *__restrict__ params, int m, double *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const VehicleParams vp = load_params(params);
-    double accl, sv;
-    speed_steer_controller(in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3], vp, accl, sv);
-    out[2 * i] = accl;
-    out[2 * i + 1] = sv;
-}
-
-__global__ void k_update_pose_unit(const double *__restrict__ s0, const double *__restrict__ buf0, const int32_t *__restrict__ cnt0,
-                                   const double *__restrict__ act, const double *__restrict__ params, double dt, int integ,
-                                   double lidar_dist, int m, double *__restrict__ s1, double *__restrict__ buf1,
-                                   int32_t *__restrict__ cnt1, double *__restrict__ spose)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const VehicleParams vp = load_params(params);
-    double st[7], sp[3];
-#pragma unroll
-    for (int c = 0; c < 7; ++c) st[c] = s0[7 * (size_t)i + c];
-    double b0 = buf0[2 * i], b1 = buf0[2 * i + 1];
-    int cnt = cnt0[i];
-    advance_vehicle(st, b0, b1, cnt, act[2 * i], act[2 * i + 1], vp, dt, integ, lidar_dist, sp);
-#pragma unroll
-    for (int c = 0; c < 7; ++c) s1[7 * (size_t)i + c] = st[c];
-    buf1[2 * i] = b0;
-    buf1[2 * i + 1] = b1;
-    cnt1[i] = cnt;
-    spose[3 * i] = sp[0];
-    spose[3 * i + 1] = sp[1];
-    spose[3 * i + 2] = sp[2];
-}
-
-__global__ void k_vertices_unit(const double *__restrict__ poses, double length, double width, int m, double *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    double v[8];
-    box_vertices(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2], length, width, v);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) out[8 * (size_t)i + c] = v[c];
-}
-
-__global__ void k_gjk_unit(const double *__restrict__ va, const double *__restrict__ vb, int m, int32_t *__restrict__ flags)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    double a[8], b[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        a[c] = va[8 * (size_t)i + c];
-        b[c] = vb[8 * (size_t)i + c];
-    }
-    flags[i] = gjk_overlap(a, b) ? 1 : 0;
-}
-
-// collision_multiple :184-212 — one lane per body, same last-writer rule as k_collide
-__global__ void k_collision_multiple_unit(const double *__restrict__ verts, int groups, int n, double *__restrict__ col,
-                                          double *__restrict__ idx)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= groups * n) return;
-    const int g = t / n, me = t - g * n;
-    double mine[8], other[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) mine[c] = verts[8 * (size_t)t + c];
-    bool hit = false;
-    int partner = -1;
-    for (int j = 0; j < n; ++j) {
-        if (j == me) continue;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) other[c] = verts[8 * ((size_t)g * n + j) + c];
-        const bool cc = (me < j) ? gjk_overlap(mine, other) : gjk_overlap(other, mine);
-        if (cc) {
-            hit = true;
-            partner = j;
-        }
-    }
-    col[t] = hit ? 1.0 : 0.0;
-    idx[t] = (double)partner;
-}
-
-__global__ void k_ttc_unit(const double *__restrict__ scans, const double *__restrict__ vels, int m, int B,
-                           const double *__restrict__ beam_cos, const double *__restrict__ side, double thresh,
-                           int32_t *__restrict__ flags)
-{
-    const int p = blockIdx.x;
-    const double vel = vels[p];
-    int hit = 0;
-    if (vel != 0.0)
-        for (int b = threadIdx.x; b < B; b += blockDim.x)
-            if (ttc_beam_hit(scans[(size_t)p * B + b], side[b], vel, beam_cos[b], thresh)) hit = 1;
-    const int any = __syncthreads_or(hit);
-    if (threadIdx.x == 0) flags[p] = any;
-}
-
-__global__ void k_raycast_unit(const double *__restrict__ ego, const double *__restrict__ verts, int m, int B,
-                               const double *__restrict__ scan_angles, double angle_inc, double *__restrict__ scans,
-                               int32_t *__restrict__ minmax)
-{
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const double ex = ego[3 * p], ey = ego[3 * p + 1], eth = ego[3 * p + 2];
-    double v[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) v[c] = verts[8 * (size_t)p + c];
-    // circumscribed disc of the quadrilateral: centroid + largest vertex distance
-    const double cx = (((v[0] + v[2]) + v[4]) + v[6]) / 4, cy = (((v[1] + v[3]) + v[5]) + v[7]) / 4;
-    double r2 = 0.0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const double dx = v[2 * c] - cx, dy = v[2 * c + 1] - cy;
-        r2 = fmax(r2, dx * dx + dy * dy);
-    }
-    int ref_lo, ref_hi, lo, hi;
-    opponent_beam_window(ex, ey, eth, v, cx, cy, sqrt(r2) * 1.000001, scan_angles, B, angle_inc, ref_lo, ref_hi, lo, hi);
-    if (minmax && tid == 0) {
-        minmax[2 * p] = ref_lo;
-        minmax[2 * p + 1] = ref_hi;
-    }
-    double *sc = scans + (size_t)p * B;
-    for (int b = lo + tid; b <= hi; b += blockDim.x) {
-        const double bt = eth + scan_angles[b];
-        const double r0 = sc[b];
-        const double r = box_range(ex, ey, cos(bt + kPi / 2.), sin(bt + kPi / 2.), v, r0);
-        if (r < r0) sc[b] = r;
-    }
-}
-
-__global__ void k_get_range_unit(const double *__restrict__ in, int m, double *__restrict__ out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const double *r = in + 8 * (size_t)i;
-    const double bt = r[3];
-    out[i] = edge_range(r[0], r[1], cos(bt + kPi / 2.), sin(bt + kPi / 2.), r[4], r[5], r[6], r[7]);
-}
-
-// ---- map pipeline: flip + threshold + exact EDT + dt = res*sqrt(d2) ------------------------
-// laser_models.py:398-404
-__global__ void k_flip_threshold(const uint8_t *__restrict__ img_top_first, int H, int W, uint8_t *__restrict__ bin)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)H * W) return;
-    const int r = (int)(t / W), c = (int)(t - (size_t)r * W);
-    bin[t] = img_top_first[(size_t)(H - 1 - r) * W + c] > 128 ? 1 : 0;
-}
-
-constexpr uint32_t kEdtInf = 0x00007FFFu;  // "no obstacle in this column": larger than any map side
-
-// phase 1: per column, distance to the nearest obstacle cell in that column (lane = column)
-__global__ void k_edt_columns(const uint8_t *__restrict__ bin, int H, int W, uint32_t *__restrict__ g)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= W) return;
-    uint32_t run = kEdtInf;
-    for (int y = 0; y < H; ++y) {
-        run = bin[(size_t)y * W + x] ? (run >= kEdtInf ? kEdtInf : run + 1) : 0;
-        g[(size_t)y * W + x] = run;
-    }
-    run = kEdtInf;
-    for (int y = H - 1; y >= 0; --y) {
-        const uint32_t cur = g[(size_t)y * W + x];
-        run = (cur == 0) ? 0 : (run >= kEdtInf ? kEdtInf : run + 1);
-        if (run < cur) g[(size_t)y * W + x] = run;
-    }
-}
-
-// phase 2: per row, d2[u] = min_i (u-i)^2 + g[i]^2 — exact integer lower envelope by brute
-// force; the row of g^2 is staged in LDS and every lane walks it (LDS broadcast reads).
-__global__ void __launch_bounds__(256) k_edt_rows(const uint32_t *__restrict__ g, int H, int W, uint32_t *__restrict__ d2)
-{
-    extern __shared__ uint32_t g2[];
-    const int y = blockIdx.x;
-    for (int i = threadIdx.x; i < W; i += blockDim.x) {
-        const uint32_t v = g[(size_t)y * W + i];
-        g2[i] = v * v;  // <= 0x7FFF^2 < 2^30
-    }
-    __syncthreads();
-    for (int u = threadIdx.x; u < W; u += blockDim.x) {
-        uint32_t best = 0xFFFFFFFFu;
-        for (int i = 0; i < W; ++i) {
-            const int d = u - i;
-            const uint32_t cand = (uint32_t)(d * d) + g2[i];
-            best = cand < best ? cand : best;
-        }
-        d2[(size_t)y * W + u] = best;
-    }
-}
-
-__global__ void k_dt_from_d2(const uint32_t *__restrict__ d2, size_t n, double res, double *__restrict__ dt)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) dt[t] = res * sqrt((double)d2[t]);  // laser_models.py:52
-}
-
-__global__ void k_retile(const double *__restrict__ rowmajor, int H, int W, int tiles_w, int tiles_h, double *__restrict__ tiled)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)tiles_w * tiles_h * 16;
-    if (t >= total) return;
-    const size_t tile = t >> 4;
-    const int within = (int)(t & 15);
-    const int r = (int)(tile / tiles_w) * 4 + (within >> 2);
-    const int c = (int)(tile % tiles_w) * 4 + (within & 3);
-    tiled[t] = (r < H && c < W) ? rowmajor[(size_t)r * W + c] : 0.0;
-}
-
-// CODE8 layout: code = rank of the cell's value among the 255 smallest distinct table values
-// (binary search in the ascending LUT), 255 when it is not one of them; 16x8-cell tiles.
-__global__ void k_build_codes(const double *__restrict__ rowmajor, int H, int W, int ctiles_w, int ctiles_h,
-                              const double *__restrict__ lut, int n_lut, uint8_t *__restrict__ codes)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)ctiles_w * ctiles_h * 128;
-    if (t >= total) return;
-    const size_t tile = t >> 7;
-    const int within = (int)(t & 127);
-    const int r = (int)(tile / ctiles_w) * 8 + (within >> 4);
-    const int c = (int)(tile % ctiles_w) * 16 + (within & 15);
-    uint8_t code = 255;
-    if (r < H && c < W) {
-        const double v = rowmajor[(size_t)r * W + c];
-        int lo = 0, hi = n_lut - 1;
-        while (lo <= hi) {
-            const int mid = (lo + hi) >> 1;
-            const double m = lut[mid];
-            if (m == v) {
-                code = (uint8_t)mid;
-                break;
-            }
-            if (m < v) lo = mid + 1; else hi = mid - 1;
-        }
-    }
-    codes[t] = code;
-}
-
-__global__ void k_interleave_cs(const double *__restrict__ sines, const double *__restrict__ cosines, int n, double2 *__restrict__ cs)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) cs[i] = make_double2(cosines[i], sines[i]);
-}
 
 // ============================================================================ host side
 
