@@ -43,7 +43,8 @@ def parse_args():
     ap.add_argument("--agents", type=int, default=65536, help="agents per GPU (envs x 2)")
     ap.add_argument("--agents-per-env", type=int, default=2)
     ap.add_argument("--beams", type=int, default=1080)
-    ap.add_argument("--layout", type=int, default=int(os.environ.get("F110_MAP_LAYOUT", "0")), help="0 row-major f64, 1 tiled 4x4 f64, 2 byte codes + LDS LUT")
+    ap.add_argument("--layout", type=int, default=int(os.environ.get("F110_MAP_LAYOUT", "3")),
+                    help="0 row-major f64, 1 tiled 4x4 f64, 2 byte codes + LDS LUT, 3 row-major f64 with an out-of-bounds border + fixed-point addressing")
     ap.add_argument("--scan-block", type=int, default=int(os.environ.get("F110_SCAN_BLOCK", "0")))
     ap.add_argument("--scan-tasks", type=int, default=int(os.environ.get("F110_SCAN_TASKS", "0")),
                     help="consecutive 64-ray tasks per wave (0 = default)")
@@ -319,7 +320,7 @@ def main():
                                    "off" if args.no_noise else "on", "off" if args.no_reset else "on"))
                                + (" (BASELINE configs[2])" if args.agents == 65536 and args.beams == 1080 else ""),
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
-                   "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut"}[args.layout],
+                   "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64"}[args.layout],
                    "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks,
                    "parallelism": "env-sharded x%d, %s" % (n_gpus, "RCCL all-gather of scans after every step" if args.gather
                                                            else "no data-path collective"),

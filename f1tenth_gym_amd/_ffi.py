@@ -17,7 +17,8 @@ PARAM_KEYS = ['mu', 'C_Sf', 'C_Sr', 'lf', 'lr', 'h', 'm', 'I', 's_min', 's_max',
               'sv_max', 'v_switch', 'a_max', 'v_min', 'v_max', 'width', 'length']
 
 OK, ERR_INVALID, ERR_NO_MAP, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
-MAP_ROWMAJOR_F64, MAP_TILED_F64, MAP_CODE8 = 0, 1, 2
+MAP_ROWMAJOR_F64, MAP_TILED_F64, MAP_CODE8, MAP_PADDED_F64 = 0, 1, 2, 3
+MAP_DEFAULT = MAP_PADDED_F64   # fastest; falls back to row-major for maps too large for it
 INTEGRATOR_RK4, INTEGRATOR_EULER = 1, 2
 
 _dp = C.POINTER(C.c_double)
@@ -102,6 +103,7 @@ PROTOTYPES = {
     "f110_profile_kernels": (C.c_int, [C.c_void_p, C.c_int32]),
     "f110_profile_read": (C.c_int, [C.c_void_p, _i32p, _dp, _dp, _dp]),
     "f110_scan_batch": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp, _i32p, _i64p]),
+    "f110_scan_path_stats": (C.c_int, [C.c_void_p, C.c_int32, _i64p]),
     "f110_dynamics_batch": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int32, _dp, _dp]),
     "f110_pid_batch": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp]),
     "f110_update_pose_batch": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _dp, _dp, C.c_double, C.c_int32,

@@ -109,7 +109,7 @@ class DeviceArray(object):
 class BatchSim(object):
     def __init__(self, params=None, num_envs=1, num_agents=2, num_beams=1080, fov=4.7, eps=0.0001,
                  theta_dis=2000, max_range=30.0, time_step=0.01, integrator=_ffi.INTEGRATOR_RK4,
-                 lidar_dist=0.0, ttc_thresh=0.005, device_id=0, map_layout=_ffi.MAP_ROWMAJOR_F64,
+                 lidar_dist=0.0, ttc_thresh=0.005, device_id=0, map_layout=_ffi.MAP_DEFAULT,
                  scan_block=0, scan_tasks_per_wave=0):
         self._h = None
         L = _ffi.lib()
@@ -387,6 +387,14 @@ class BatchSim(object):
         if want_lookups:
             res.append(lk)
         return res[0] if len(res) == 1 else tuple(res)
+
+    def scan_path_stats(self, enable=None, read=True):
+        """diagnostics: rays marched as dict(fast, guard, exact) since the last read; enable=True/False
+        switches the counting (off by default)"""
+        out = np.zeros(3, dtype=np.int64)
+        check(_ffi.lib().f110_scan_path_stats(self._h, -1 if enable is None else int(bool(enable)),
+                                              out.ctypes.data_as(_ffi._i64p) if read else None), self._h)
+        return dict(fast=int(out[0]), guard=int(out[1]), exact=int(out[2]))
 
     def beam_dir_index_batch(self, thetas):
         thetas = as_f64(thetas).reshape(-1)

@@ -42,7 +42,9 @@ struct f110_sim {
     double *d_lut = nullptr;
     int scan_block = 64;
     double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
-    double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_actions = nullptr, *d_poses = nullptr;
+    unsigned long long *d_path_stats = nullptr;  // [3], see f110_scan_path_stats
+    bool path_stats_on = false;
+    double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_dt_pad = nullptr, *d_actions = nullptr, *d_poses = nullptr;
     double2 *d_cs = nullptr;
     uint8_t *d_mask = nullptr;
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
@@ -167,6 +169,7 @@ static scan_rays_fn pick_rays(const ScanConst &k, int layout)
 #define SEL(L) (k.res_pow2 ? (k.ident_rot ? k_scan_rays<L, true, true, STEP> : k_scan_rays<L, true, false, STEP>) \
                            : (k.ident_rot ? k_scan_rays<L, false, true, STEP> : k_scan_rays<L, false, false, STEP>))
     if (layout == F110_MAP_CODE8) return SEL(LAYOUT_CODE8);
+    if (layout == F110_MAP_PADDED_F64 && k.pad) return SEL(LAYOUT_PADDED);
     return layout == F110_MAP_TILED_F64 ? SEL(LAYOUT_TILED) : SEL(LAYOUT_ROWMAJOR);
 #undef SEL
 }
@@ -175,7 +178,6 @@ static dim3 rays_grid(RayJob &j, int block, int tasks_per_wave)
 {
     j.n_tasks = (j.n_rays + 63u) / 64u;
     j.tasks_per_wave = tasks_per_wave > 0 ? (uint32_t)tasks_per_wave : 1u;
-    j.xcd_remap = 1;  // measured neutral on MI355X (the table's hot set is L2-resident either way)
     const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave;
     const uint32_t wpb = (uint32_t)block / 64u;
     return dim3((waves + wpb - 1) / wpb);
@@ -230,7 +232,8 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         return fail(nullptr, F110_ERR_INVALID, "f110_create: num_envs/num_agents >= 1, num_beams/theta_dis >= 2 required");
     if (cfg->integrator != F110_INTEGRATOR_RK4 && cfg->integrator != F110_INTEGRATOR_EULER)
         return fail(nullptr, F110_ERR_INVALID, "Invalid Integrator Specified. Please choose RK4 or Euler");
-    if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_TILED_F64 && cfg->map_layout != F110_MAP_CODE8)
+    if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_TILED_F64 && cfg->map_layout != F110_MAP_CODE8 &&
+        cfg->map_layout != F110_MAP_PADDED_F64)
         return fail(nullptr, F110_ERR_INVALID, "unknown map_layout %d", cfg->map_layout);
     if ((long long)cfg->num_envs * cfg->num_agents * (long long)cfg->num_beams > 0xFFFFFF00LL) return fail(nullptr, F110_ERR_INVALID, "num_envs*num_agents*num_beams must stay below 2^32");
     int ndev = 0;
@@ -381,7 +384,7 @@ void f110_destroy(f110_sim *h)
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
-                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_codes, h->d_dir_ranges, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask};
+                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_dt_pad, h->d_codes, h->d_dir_ranges, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     {
@@ -442,6 +445,19 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
     } else {
         k.table = h->d_dt_row;
         k.table_rm = h->d_dt_row;
+    }
+    k.pad = nullptr;
+    if (h->d_dt_pad) { (void)hipFree(h->d_dt_pad); h->d_dt_pad = nullptr; }
+    if (h->cfg.map_layout == F110_MAP_PADDED_F64 && setup_padded(k)) {
+        // the table again with a border of out-of-bounds cells wide enough for any ray of a lidar
+        // that is on (or within kPadSlack cells of) the map; maps too large for 16-bit cell
+        // coordinates keep k.pad == nullptr and run the plain row-major kernel
+        const size_t total = (size_t)k.pad_width * k.pad_height;
+        TRY(dmalloc(h, &h->d_dt_pad, total));
+        hipLaunchKernelGGL(k_build_padded, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_row, H, W, k.pad_border, k.pad_width, k.pad_height,
+                           h->d_dt_pad);
+        HIPCHK(h, hipGetLastError());
+        k.pad = h->d_dt_pad;
     }
     if (h->cfg.map_layout == F110_MAP_CODE8) {
         // the 255 smallest distinct table values (one-time host sort of the downloaded table)
@@ -838,6 +854,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         if (!e0 || !e1 || !e2 || !e3) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
+    h->dev.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;
     hipLaunchKernelGGL(k_integrate, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->k, d_actions);
     // k_collide only feeds k_finalize, k_scan_rays only needs k_integrate: run the two side by
     // side (second stream, event fork/join) so the pair test + window set-up hides under the scan
@@ -1101,15 +1118,34 @@ int f110_scan_batch(f110_sim *h, const double *poses, int32_t m, double *ranges,
     j.ranges = dr;
     j.hit_rc = dh;
     j.lookups = dl;
+    j.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;
     set_div_magic(j, (uint32_t)B);
     scan_rays_fn fn = pick_rays<false>(h->k, h->cfg.map_layout);
     const dim3 grid = rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
     hipLaunchKernelGGL(fn, grid, dim3(h->scan_block), 0, h->stream, j, h->k);
     HIPCHK(h, hipGetLastError());
+
     TRY(s.down(ranges, dr, (size_t)m * B));
     if (hit_rc) TRY(s.down(hit_rc, dh, (size_t)m * B * 2));
     if (lookups) TRY(s.down(reinterpret_cast<unsigned long long *>(lookups), dl, (size_t)m));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_scan_path_stats(f110_sim *h, int32_t enable, int64_t *out3)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (!h->d_path_stats) {
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_path_stats), 3 * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemsetAsync(h->d_path_stats, 0, 3 * sizeof(unsigned long long), h->stream));
+    }
+    if (out3) {
+        HIPCHK(h, hipMemcpyAsync(out3, h->d_path_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_path_stats, 0, 3 * sizeof(unsigned long long), h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    if (enable >= 0) h->path_stats_on = enable != 0;
     return F110_OK;
 }
 

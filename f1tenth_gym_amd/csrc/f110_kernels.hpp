@@ -34,9 +34,9 @@ struct RayHdr {
     int32_t hr0, hc0;   // cell of that first sample
     int32_t i0;         // table index of beam 0
     int32_t n_dirs;     // distinct table indices the scan's beams use (dedupe mode), else 0
-    int32_t pad;
+    int32_t fast;       // PADDED: every sample of every ray of this scan lands inside the padded table
 };
-static_assert(sizeof(RayHdr) == 64, "RayHdr is read as four 16-byte scalar loads");
+static_assert(sizeof(RayHdr) == 64, "RayHdr is read as 16-byte scalar loads");
 
 struct AgentArrays {
     int32_t n_agents_total;  // N
@@ -53,6 +53,7 @@ struct AgentArrays {
     double *collision_idx;   // [N]
     int32_t *in_collision;   // [N]
     int32_t *step_count;     // [N]
+    unsigned long long *path_stats;  // diagnostics or nullptr: rays of fast scans [0] / of exact scans [2]
     int32_t *opp_window;     // [N][A][4] beam range each opponent can occupy: {lo, hi} for the live
                              //           heading and {lo0, hi0} for heading 0 (after a wall hit)
     double *opp_verts;       // [N][A][8] the opponent's box drawn with the ego's length/width
@@ -118,13 +119,19 @@ __global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, c
         }
         hd.noise_row = row;
         hd.i0 = beam_dir_index(k, start, 0);
+        hd.fast = 0;
+        if (k.pad) {
+            double ux, uy;
+            padded_position<false>(k, sp[0], sp[1], ux, uy);
+            hd.fast = padded_start_ok(k, ux, uy) ? 1 : 0;
+        }
+        if (a.path_stats) atomicAdd(&a.path_stats[hd.fast ? 0 : 2], (unsigned long long)k.num_beams);
         hd.n_dirs = 0;
         if (k.theta_inc < 1.0) {  // consecutive beams advance the table index by 0 or 1 (mod theta_dis)
             int span = beam_dir_index(k, start, k.num_beams - 1) - hd.i0;
             if (span < 0) span += k.theta_dis;
             hd.n_dirs = span + 1;
         }
-        hd.pad = 0;
         a.ray_hdr[i] = hd;
     }
     a.in_collision[i] = 0;  // raised by k_scan_rays when any beam's iTTC is under the threshold
@@ -197,7 +204,7 @@ struct RayJob {
     uint32_t tasks_per_wave;  // consecutive tasks each wave walks
     int32_t n_poses;
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
-    int32_t xcd_remap;
+    int32_t reserved_remap;
     int32_t dir_mode, dir_stride;   // dedupe pass: rays are (agent, distinct direction), dir_stride per agent
     const double *dir_ranges;       // k_expand_beams: [n_poses][dir_stride] raw ranges of the dedupe pass
     const double *pose_x, *pose_y, *dir_start;  // [n_poses] (unit path)
@@ -212,6 +219,9 @@ struct RayJob {
     // unit only
     int32_t *hit_rc;                 // [n_poses][B][2] or nullptr
     unsigned long long *lookups;     // [n_poses] or nullptr
+    // diagnostics (unit form; the step form counts per scan in k_integrate), nullptr unless enabled:
+    // rays marched {fixed-point only, with a guard-band sample resolved exactly, exact throughout}
+    unsigned long long *path_stats;
 };
 
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -222,48 +232,40 @@ __device__ __forceinline__ double uniform_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
-// Per-agent ray constants for the lane's agent p.  With >= 64 rays per agent the 64 rays of a wave
-// belong to agent p0 (the first lane's) or p0+1, so two uniform 64-byte headers fetched through
-// the scalar cache cover the wave and no vector-memory instruction is spent on them; uniform_*()
-// pins each field to SGPRs so the compiler keeps two scalar loads + a per-lane select instead of
-// one divergent vector load.  Fewer rays per agent: a wave may span more agents -> per-lane load.
+// Per-agent ray constants for the lane's agent p.  A wave holds 64 consecutive rays, so with >= 64
+// rays per agent all its lanes belong to one agent except in the one wave per agent that
+// straddles a boundary (1 in 17 at 1080 beams).  Uniform wave: the 64-byte header comes through
+// the scalar cache (no vector-memory instruction, no per-lane select); uniform_*() pins the
+// fields to SGPRs so the compiler does not turn them back into a divergent vector load.
+// Straddling wave: plain per-lane loads.
 struct LaneHdr {
     double x, y, start, vel, d0;
-    int row, hr, hc, i0, n_dirs;
+    int row, hr, hc, i0, n_dirs, fast;
 };
 
-__device__ __forceinline__ LaneHdr load_lane_hdr(const RayHdr *hdr, uint32_t p, uint32_t n_poses, bool wide)
+__device__ __forceinline__ LaneHdr load_lane_hdr(const RayHdr *hdr, uint32_t p)
 {
     LaneHdr o;
-    if (wide) {
+    const uint32_t p0 = __builtin_amdgcn_readfirstlane(p);
+    if (__ballot(p != p0) == 0ull) {  // wave-uniform branch
         typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
-        const uint32_t p0 = __builtin_amdgcn_readfirstlane(p);
-        const uint32_t p1 = (p0 + 1u < n_poses) ? p0 + 1u : p0;
         const chdr_t h0 = (chdr_t)(hdr) + p0;
-        const chdr_t h1 = (chdr_t)(hdr) + p1;
-        const bool first = (p == p0);
-        const double x0 = uniform_f64(h0->x), y0 = uniform_f64(h0->y), s0 = uniform_f64(h0->start);
-        const double v0 = uniform_f64(h0->vel), d00 = uniform_f64(h0->d0);
-        const int n0 = uniform_i32(h0->noise_row), r0 = uniform_i32(h0->hr0), c0 = uniform_i32(h0->hc0);
-        const int i00 = uniform_i32(h0->i0), nd0 = uniform_i32(h0->n_dirs);
-        const double x1 = uniform_f64(h1->x), y1 = uniform_f64(h1->y), s1 = uniform_f64(h1->start);
-        const double v1 = uniform_f64(h1->vel), d01 = uniform_f64(h1->d0);
-        const int n1 = uniform_i32(h1->noise_row), r1 = uniform_i32(h1->hr0), c1 = uniform_i32(h1->hc0);
-        const int i01 = uniform_i32(h1->i0), nd1 = uniform_i32(h1->n_dirs);
-        o.x = first ? x0 : x1;
-        o.y = first ? y0 : y1;
-        o.start = first ? s0 : s1;
-        o.vel = first ? v0 : v1;
-        o.d0 = first ? d00 : d01;
-        o.row = first ? n0 : n1;
-        o.hr = first ? r0 : r1;
-        o.hc = first ? c0 : c1;
-        o.i0 = first ? i00 : i01;
-        o.n_dirs = first ? nd0 : nd1;
+        o.x = uniform_f64(h0->x);
+        o.y = uniform_f64(h0->y);
+        o.start = uniform_f64(h0->start);
+        o.vel = uniform_f64(h0->vel);
+        o.d0 = uniform_f64(h0->d0);
+        o.row = uniform_i32(h0->noise_row);
+        o.hr = uniform_i32(h0->hr0);
+        o.hc = uniform_i32(h0->hc0);
+        o.i0 = uniform_i32(h0->i0);
+        o.n_dirs = uniform_i32(h0->n_dirs);
+        o.fast = uniform_i32(h0->fast);
     } else {
         const RayHdr hd = hdr[p];
         o.x = hd.x; o.y = hd.y; o.start = hd.start; o.vel = hd.vel; o.d0 = hd.d0; o.row = hd.noise_row;
         o.hr = hd.hr0; o.hc = hd.hc0; o.i0 = hd.i0; o.n_dirs = hd.n_dirs;
+        o.fast = hd.fast;
     }
     return o;
 }
@@ -276,6 +278,22 @@ __device__ __forceinline__ LaneHdr load_lane_hdr(const RayHdr *hdr, uint32_t p, 
 struct RayJob;
 __device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_t p, int b, uint32_t ray, double r,
                                             int row, double vel);
+
+// One ray from its (shared) first sample d0 on.  path: 0 fixed-point march, 1 fixed-point march with
+// some guard-band sample resolved exactly, 2 exact arithmetic throughout.
+template <int LAYOUT, bool POW2, bool IDENT, bool WANT_CELL>
+__device__ __forceinline__ double trace_from_first(const ScanConst &k, const double *lut, double x, double y, bool fast, double c,
+                                                   double s, double d0, int &hr, int &hc, int &nl, int &path)
+{
+    if (LAYOUT == LAYOUT_PADDED) {
+        bool resolved;
+        const double r = march_padded<IDENT, WANT_CELL>(k, x, y, c, s, d0, fast, hr, hc, nl, resolved);
+        path = fast ? (resolved ? 1 : 0) : 2;
+        return r;
+    }
+    path = 2;
+    return march_from_first<LAYOUT, POW2, IDENT>(k, lut, x, y, c, s, d0, hr, hc, nl);
+}
 
 template <int LAYOUT, bool POW2, bool IDENT, bool STEP>
 __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
@@ -294,7 +312,7 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
     // XCD walks one contiguous eighth of the rays: all beams of an agent, and agents that are
     // neighbours in the batch, then share one XCD's L2 instead of being spread over all eight.
     uint32_t blk = blockIdx.x;
-    if (j.xcd_remap) {
+    {
         const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
         blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // bijective for any nb
     }
@@ -306,10 +324,10 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
         if (ray >= j.n_rays) break;
         const uint32_t p = j.div_magic ? (__umulhi(ray, j.div_magic) >> j.div_shift) : ray / B;
         const int b = (int)(ray - p * B);
-        int hr, hc, nl;
+        int hr, hc, nl, path;
         double r;
         if (STEP) {
-            const LaneHdr hd = load_lane_hdr(j.hdr, p, (uint32_t)j.n_poses, B >= 64u);
+            const LaneHdr hd = load_lane_hdr(j.hdr, p);
             hr = hd.hr;
             hc = hd.hc;
             if (j.dir_mode) {
@@ -319,17 +337,27 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
                     int didx = hd.i0 + b;
                     if (didx >= k.theta_dis) didx -= k.theta_dis;
                     const double2 cs = k.cs[didx];
-                    j.ranges[ray] = march_from_first<LAYOUT, POW2, IDENT>(k, lut_lds, hd.x, hd.y, cs.x, cs.y, hd.d0, hr, hc, nl);
+                    j.ranges[ray] = trace_from_first<LAYOUT, POW2, IDENT, false>(k, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl,
+                                                                                 path);
                 }
                 continue;
             }
             const double2 cs = k.cs[beam_dir_index(k, hd.start, b)];
-            r = march_from_first<LAYOUT, POW2, IDENT>(k, lut_lds, hd.x, hd.y, cs.x, cs.y, hd.d0, hr, hc, nl);
+            r = trace_from_first<LAYOUT, POW2, IDENT, false>(k, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl, path);
             finish_beam(j, B, p, b, ray, r, hd.row, hd.vel);
             continue;
         } else {
             const double2 cs = k.cs[beam_dir_index(k, j.dir_start[p], b)];
-            r = march_ray<LAYOUT, POW2, IDENT>(k, lut_lds, j.pose_x[p], j.pose_y[p], cs.x, cs.y, hr, hc, nl);
+            const double x = j.pose_x[p], y = j.pose_y[p];
+            const double d0 = sample_distance<LAYOUT, POW2, IDENT>(k, lut_lds, x, y, hr, hc);
+            bool fast = false;
+            if (LAYOUT == LAYOUT_PADDED) {
+                double ux, uy;
+                padded_position<IDENT>(k, x, y, ux, uy);
+                fast = padded_start_ok(k, ux, uy);
+            }
+            r = trace_from_first<LAYOUT, POW2, IDENT, true>(k, lut_lds, x, y, fast, cs.x, cs.y, d0, hr, hc, nl, path);
+            if (j.path_stats) atomicAdd(&j.path_stats[path], 1ull);
             if (j.hit_rc) {
                 j.hit_rc[(size_t)ray * 2] = hr;
                 j.hit_rc[(size_t)ray * 2 + 1] = hc;
@@ -363,7 +391,7 @@ __global__ void __launch_bounds__(256) k_expand_beams(RayJob j, ScanConst k)
     if (ray >= j.n_rays) return;
     const uint32_t p = j.div_magic ? (__umulhi(ray, j.div_magic) >> j.div_shift) : ray / B;
     const int b = (int)(ray - p * B);
-    const LaneHdr hd = load_lane_hdr(j.hdr, p, (uint32_t)j.n_poses, B >= 64u);
+    const LaneHdr hd = load_lane_hdr(j.hdr, p);
     int s = beam_dir_index(k, hd.start, b) - hd.i0;
     if (s < 0) s += k.theta_dis;
     const double r = j.dir_ranges[(size_t)p * j.dir_stride + s];
@@ -824,6 +852,17 @@ __global__ void k_dt_from_d2(const uint32_t *__restrict__ d2, size_t n, double r
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) dt[t] = res * sqrt((double)d2[t]);  // laser_models.py:52
+}
+
+// PADDED layout: the table inside a border of `b` cells that read dt[-1,-1], what the reference
+// returns for any out-of-bounds sample (laser_models.py:80-81,103)
+__global__ void k_build_padded(const double *__restrict__ rowmajor, int H, int W, int b, int Wp, int Hp, double *__restrict__ pad)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Wp * Hp) return;
+    const int r = (int)(i / Wp) - b, c = (int)(i % Wp) - b;
+    const bool inside = (r >= 0) & (r < H) & (c >= 0) & (c < W);
+    pad[i] = inside ? rowmajor[(size_t)r * W + c] : rowmajor[(size_t)H * W - 1];
 }
 
 __global__ void k_retile(const double *__restrict__ rowmajor, int H, int W, int tiles_w, int tiles_h, double *__restrict__ tiled)

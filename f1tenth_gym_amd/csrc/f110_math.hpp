@@ -167,7 +167,7 @@ F110_HD void advance_vehicle(double *st, double &buf0, double &buf1, int &buf_cn
 }
 
 // ------------------------------------------------------------------ laser_models.py
-enum { LAYOUT_ROWMAJOR = 0, LAYOUT_TILED = 1, LAYOUT_CODE8 = 2 };
+enum { LAYOUT_ROWMAJOR = 0, LAYOUT_TILED = 1, LAYOUT_CODE8 = 2, LAYOUT_PADDED = 3 };
 constexpr int kLutEntries = 255;   // codes 0..254 index the LUT, 255 = escape to the float64 table
 
 struct ScanConst {
@@ -183,7 +183,71 @@ struct ScanConst {
     double w_res, h_res;   // width*resolution, height*resolution (xy_2_rc :79)
     double oob_value;      // dt[-1,-1]: what an out-of-bounds sample reads (:80-81,:103)
     double eps, max_range, fov, theta_inc, dir_guard, inv_theta_dis;
+    // PADDED: the row-major table surrounded by `pad_border` cells of oob_value on every side,
+    // addressed in fixed point (see march_padded).  pad == nullptr: not available for this map.
+    const double *pad;
+    int32_t pad_border, pad_row_bytes, pad_width, pad_height;
+    double pad_lo, pad_hi_x, pad_hi_y;  // lidar positions (padded cell units) whose rays stay inside
+    double pad_cx, pad_cy;              // padded_position: u = x*axx + y*axy + cx  (IDENT: axx = inv_res, axy = 0)
+    double pad_axx, pad_axy, pad_ayx, pad_ayy;
 };
+
+// The PADDED fast path maps a sample position to padded-table cell units u (approximate on
+// purpose, |error| < 1e-9 cells) and reads the cell as the integer part of the fixed-point word
+// that adding kFixBig = 1.5 * 2^36 leaves in the low mantissa bits (ulp = 2^-16 cells):
+//   lo32(u + kFixBig) = round(u * 65536),  cell = word >> 16,  fraction = word & 0xffff.
+// The addition rounds to nearest, so a position within 2^-17 cells of a cell boundary (either
+// side) comes out with fraction == 0: that is the guard band in which the cheap decision could
+// differ from the reference's int(x_rot / resolution) / range tests (laser_models.py:79-84),
+// and for such a sample (about 1 in 30 000) the cell is recomputed with the reference's exact
+// arithmetic.  Everything else provably picks the reference's cell: all quantities that differ
+// from the reference's are smaller than 1e-9 cells.  Out-of-range samples need no test at all:
+// the border cells hold the value the reference reads for them.
+constexpr double kFixBig = 103079215104.0;  // 1.5 * 2^36
+constexpr int kFixFracBits = 16;
+constexpr int kPadSlack = 64;               // extra border cells so a lidar slightly outside the map stays fast
+
+F110_HD uint32_t low_word(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__double2loint(v);
+#else
+    uint64_t b;
+    __builtin_memcpy(&b, &v, 8);
+    return (uint32_t)b;
+#endif
+}
+
+// border width in cells for a map: rays sample at most max_range (+ rounding) away from the lidar
+F110_HD int padded_border_cells(double max_range, double inv_res)
+{
+    return (int)ceil(max_range * inv_res) + 2 + kPadSlack;
+}
+
+// fills the PADDED constants of k (k.pad itself is set by the caller); false when the map is too
+// large for 16-bit cell coordinates / 32-bit byte offsets and the exact path must be used
+F110_HD bool setup_padded(ScanConst &k)
+{
+    const int b = padded_border_cells(k.max_range, k.inv_res);
+    const long long wp = (long long)k.width + 2 * b, hp = (long long)k.height + 2 * b;
+    k.pad = nullptr;
+    k.pad_border = b;
+    if (wp >= 65536 || hp >= 65536 || wp * 8 >= (1 << 24) || wp * hp * 8 >= (1ll << 32)) return false;
+    k.pad_width = (int)wp;
+    k.pad_height = (int)hp;
+    k.pad_row_bytes = (int)(wp * 8);
+    const double reach = ceil(k.max_range * k.inv_res) + 2.0;
+    k.pad_lo = reach + 1.0;
+    k.pad_hi_x = (double)wp - reach - 2.0;
+    k.pad_hi_y = (double)hp - reach - 2.0;
+    k.pad_axx = k.orig_c * k.inv_res;
+    k.pad_axy = k.orig_s * k.inv_res;
+    k.pad_ayx = -k.orig_s * k.inv_res;
+    k.pad_ayy = k.orig_c * k.inv_res;
+    k.pad_cx = (double)b - (k.orig_x * k.orig_c + k.orig_y * k.orig_s) * k.inv_res;
+    k.pad_cy = (double)b - (k.orig_y * k.orig_c - k.orig_x * k.orig_s) * k.inv_res;
+    return true;
+}
 
 // 24-bit multiply (v_mul_u32_u24 / v_mad_u32_u24 are full-rate; the 32-bit v_mul_lo_u32 is not).
 // Rows, columns and row pitches of any realistic map are far below 2^24.
@@ -215,7 +279,7 @@ F110_HD double table_fetch(const ScanConst &k, int r, int c, const double *lut)
     // 32-bit BYTE offset from the (wave-uniform) table base: lets the compiler use the
     // scalar-base + 32-bit-VGPR-offset form of global_load (tables are < 4 GiB, checked on upload)
     uint32_t off;
-    if (LAYOUT == LAYOUT_ROWMAJOR) {
+    if (LAYOUT == LAYOUT_ROWMAJOR || LAYOUT == LAYOUT_PADDED) {  // PADDED: k.table is the plain table (exact path)
         off = mul24((uint32_t)r, (uint32_t)k.row_bytes) + ((uint32_t)c << 3);
     } else {
         const uint32_t tile = mul24((uint32_t)(r >> 2), (uint32_t)k.tiles_w) + (uint32_t)(c >> 2);
@@ -296,6 +360,102 @@ F110_HD double march_ray(const ScanConst &k, const double *lut, double x, double
 {
     const double d = sample_distance<LAYOUT, POW2, IDENT>(k, lut, x, y, hit_r, hit_c);
     return march_from_first<LAYOUT, POW2, IDENT>(k, lut, x, y, c, s, d, hit_r, hit_c, lookups);
+}
+
+// ---- PADDED fast path ---------------------------------------------------------------------
+// world position -> padded-table cell units (xy_2_rc :68-77 then / resolution, + border), with
+// the rotation, the 1/resolution and the offsets folded into six constants (setup_padded).
+// Approximate on purpose: |error| < 1e-9 cells, see the comment at kFixBig.
+template <bool IDENT>
+F110_HD void padded_position(const ScanConst &k, double x, double y, double &ux, double &uy)
+{
+    if (IDENT) {
+        ux = fma(x, k.inv_res, k.pad_cx);
+        uy = fma(y, k.inv_res, k.pad_cy);
+    } else {
+        ux = fma(x, k.pad_axx, fma(y, k.pad_axy, k.pad_cx));
+        uy = fma(y, k.pad_ayy, fma(x, k.pad_ayx, k.pad_cy));
+    }
+}
+
+// true when every sample of every ray from this lidar position lands inside the padded table
+// (false for NaN): samples are taken at most max_range (+ rounding) from the lidar
+F110_HD bool padded_start_ok(const ScanConst &k, double ux, double uy)
+{
+    return (ux >= k.pad_lo) & (ux <= k.pad_hi_x) & (uy >= k.pad_lo) & (uy <= k.pad_hi_y);
+}
+
+// xy_2_rc :55-86 with the reference's own arithmetic (true divisions; width*resolution formed
+// here from the integers, as :79 does), as a byte offset into the padded table.  An
+// out-of-bounds position reads border cell (0,0), which holds dt[-1,-1] like every border cell.
+// Rarely executed, so it is written to need few constants rather than few instructions.
+template <bool IDENT>
+F110_HD uint32_t padded_offset_exact(const ScanConst &k, double x, double y, int &r, int &c)
+{
+    const double xt = x - k.orig_x;
+    const double yt = y - k.orig_y;
+    double xr = xt, yr = yt;
+    if (!IDENT) {
+        xr = xt * k.orig_c + yt * k.orig_s;
+        yr = -xt * k.orig_s + yt * k.orig_c;
+    }
+    const bool inside = (xr >= 0) & (xr < (double)k.width * k.res) & (yr >= 0) & (yr < (double)k.height * k.res);
+    r = -1;
+    c = -1;
+    uint32_t off = 0;
+    if (inside) {
+        c = (int)(xr / k.res);
+        r = (int)(yr / k.res);
+        off = mul24((uint32_t)(r + k.pad_border), (uint32_t)k.pad_row_bytes) + ((uint32_t)(c + k.pad_border) << 3);
+    }
+    return off;
+}
+
+// trace_ray :133-146 on the padded table, entered with the first sample d taken.  The ray's
+// position is advanced exactly as the reference does (x += d*c, :140-141); the cell of a sample
+// comes from the fixed-point word unless the sample is in the guard band (or the scan's lidar
+// position is not `fast`), in which case it is recomputed with the reference's arithmetic.
+// r/c: cell of the last sample in the reference's convention (-1,-1 out of bounds); untouched when
+// the loop takes no sample.  resolved: some sample needed the exact arithmetic (diagnostics).
+template <bool IDENT, bool WANT_CELL>
+F110_HD double march_padded(const ScanConst &k, double x, double y, double c, double s, double d, bool fast, int &hit_r,
+                            int &hit_c, int &lookups, bool &resolved)
+{
+    double total = d;
+    int n = 1;
+    resolved = false;
+    const char *base = reinterpret_cast<const char *>(k.pad);
+    while ((d > k.eps) & (total <= k.max_range)) {
+        x += d * c;
+        y += d * s;
+        double ux, uy;
+        padded_position<IDENT>(k, x, y, ux, uy);
+        const uint32_t wx = low_word(ux + kFixBig);
+        const uint32_t wy = low_word(uy + kFixBig);
+        uint32_t off = mul24(wy >> kFixFracBits, (uint32_t)k.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
+        if (WANT_CELL) {
+            hit_c = (int)(wx >> kFixFracBits) - k.pad_border;
+            hit_r = (int)(wy >> kFixFracBits) - k.pad_border;
+            if (hit_c < 0 || hit_c >= k.width || hit_r < 0 || hit_r >= k.height) {
+                hit_r = -1;
+                hit_c = -1;
+            }
+        }
+        if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u) | !fast) {
+            int er, ec;
+            resolved = true;
+            off = padded_offset_exact<IDENT>(k, x, y, er, ec);
+            if (WANT_CELL) {
+                hit_r = er;
+                hit_c = ec;
+            }
+        }
+        d = *reinterpret_cast<const double *>(base + off);
+        total += d;
+        ++n;
+    }
+    lookups = n;
+    return (total > k.max_range) ? k.max_range : total;
 }
 
 // get_scan :166-172

@@ -112,7 +112,7 @@ class F110Env(_EnvBase):
         self.sim = Simulator(self.params, self.num_agents, self.seed, time_step=self.timestep,
                              ego_idx=self.ego_idx, integrator=self.integrator, lidar_dist=self.lidar_dist,
                              device_id=kwargs.get('device_id', 0),
-                             map_layout=kwargs.get('map_layout', _ffi.MAP_ROWMAJOR_F64))
+                             map_layout=kwargs.get('map_layout', _ffi.MAP_DEFAULT))
         self.sim.set_map(self.map_path, self.map_ext)
         self.render_obs = None
         self.current_obs = None
@@ -197,7 +197,7 @@ class F110VecEnv(object):
                              num_beams=kwargs.get('num_beams', 1080), fov=kwargs.get('fov', 4.7),
                              scan_noise_std=kwargs.get('scan_noise_std', 0.01),
                              device_id=kwargs.get('device_id', 0),
-                             map_layout=kwargs.get('map_layout', _ffi.MAP_ROWMAJOR_F64))
+                             map_layout=kwargs.get('map_layout', _ffi.MAP_DEFAULT))
         self.sim.set_map(self.map_path, self.map_ext)
         self._start_poses = None
         self._d_actions = None

@@ -10,7 +10,7 @@ from .core import BatchSim, load_map_files
 
 class ScanSimulator2D(object):
     def __init__(self, num_beams, fov, eps=0.0001, theta_dis=2000, max_range=30.0, device_id=0,
-                 map_layout=_ffi.MAP_ROWMAJOR_F64):
+                 map_layout=_ffi.MAP_DEFAULT):
         self.num_beams = num_beams
         self.fov = fov
         self.eps = eps

@@ -74,7 +74,7 @@ class AgentView(object):
 class Simulator(object):
     def __init__(self, params, num_agents, seed, time_step=0.01, ego_idx=0, integrator=Integrator.RK4,
                  lidar_dist=0.0, num_envs=1, num_beams=1080, fov=4.7, scan_noise_std=0.01, device_id=0,
-                 map_layout=_ffi.MAP_ROWMAJOR_F64, scan_block=0):
+                 map_layout=_ffi.MAP_DEFAULT, scan_block=0):
         self.num_agents = num_agents
         self.num_envs = num_envs
         self.seed = seed

@@ -52,8 +52,12 @@ enum { F110_INTEGRATOR_RK4 = 1, F110_INTEGRATOR_EULER = 2 }; /* base_classes.py:
 enum {
     F110_MAP_ROWMAJOR_F64 = 0, /* dt[r][c] as the reference stores it */
     F110_MAP_TILED_F64 = 1,    /* 4x4-cell tiles, one 128-byte line per tile */
-    F110_MAP_CODE8 = 2         /* 1-byte code per cell (16x8-cell tiles) + 255-entry exact float64
+    F110_MAP_CODE8 = 2,        /* 1-byte code per cell (16x8-cell tiles) + 255-entry exact float64
                                   value LUT staged in LDS; code 255 escapes to the row-major table */
+    F110_MAP_PADDED_F64 = 3    /* dt[r][c] inside a border of out-of-bounds cells (max_range wide), so
+                                  the march loop needs no range test, with fixed-point cell addressing
+                                  and an exact re-march for samples in the guard band (the fastest
+                                  layout; maps too large for it run as F110_MAP_ROWMAJOR_F64) */
 };
 
 /* Simulator(params, num_agents, seed, time_step, ego_idx, integrator, lidar_dist)
@@ -215,6 +219,11 @@ int f110_profile_read(f110_sim *h, int32_t *n_launches, double *scan_ms_total,
  * h_lookups [M] table lookups per pose or NULL. */
 int f110_scan_batch(f110_sim *h, const double *h_poses, int32_t m, double *h_ranges,
                     int32_t *h_hit_rc, int64_t *h_lookups);
+/* Diagnostics of the scan kernels (step and unit form): with enable = 1 every marched ray is counted
+ * as {fixed-point march on the padded table, re-marched exactly after a guard-band sample, exact
+ * because the lidar is off the padded table / the layout has no fast path}.  out3 (or NULL) receives
+ * and clears the counters; enable = -1 leaves the switch as it is.  Off by default (atomics). */
+int f110_scan_path_stats(f110_sim *h, int32_t enable, int64_t *out3);
 /* vehicle_dynamics_st / vehicle_dynamics_ks  dynamic_models.py:90-176; x [M][7], u [M][2] */
 int f110_dynamics_batch(f110_sim *h, const double *h_x, const double *h_u,
                         const double *h_params18, int32_t m, double *h_f_st, double *h_f_ks);

@@ -37,7 +37,15 @@ void hh_advance(double *st, double *buf, int *cnt, double steer, double speed, c
     advance_vehicle(st, buf[0], buf[1], *cnt, steer, speed, vp, dt, integ, lidar_dist, scan_pose);
 }
 
-// layout: 0 row-major, 1 tiled 4x4
+// guard-band re-marches of the PADDED layout since the last call to hh_padded_stats
+static long long g_pad_fast = 0, g_pad_guard = 0, g_pad_far = 0;
+void hh_padded_stats(long long *out)
+{
+    out[0] = g_pad_fast; out[1] = g_pad_guard; out[2] = g_pad_far;
+    g_pad_fast = g_pad_guard = g_pad_far = 0;
+}
+
+// layout: 0 row-major, 1 tiled 4x4, 2 byte codes + LUT, 3 padded + fixed-point addressing
 void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, double oy, double oc, double os,
              const double *sines, const double *cosines, int theta_dis, int B, double fov, double eps,
              double max_range, const double *pose, double *ranges, int *hit_rc, int *dir_idx, long long *lookups)
@@ -90,6 +98,14 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
     } else {
         k.table = dt;
     }
+    k.table_rm = dt;
+    std::vector<double> padded;
+    if (layout == 3 && setup_padded(k)) {  // same construction as finish_map() + k_build_padded
+        padded.assign((size_t)k.pad_width * k.pad_height, k.oob_value);
+        for (int r = 0; r < H; ++r)
+            std::copy(dt + (size_t)r * W, dt + (size_t)(r + 1) * W, padded.begin() + (size_t)(r + k.pad_border) * k.pad_width + k.pad_border);
+        k.pad = padded.data();
+    }
     const double start = scan_start_index(k, pose[2]);
     long long total = 0;
     for (int b = 0; b < B; ++b) {
@@ -98,7 +114,22 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
         int hr, hc, nl;
         double r;
 #define RUN(L, P, I) r = march_ray<L, P, I>(k, lut.data(), pose[0], pose[1], cs[idx].x, cs[idx].y, hr, hc, nl)
-        if (layout == 2) {
+        if (layout == 3) {
+            // what k_scan_rays<LAYOUT_PADDED, ..., STEP=false> does per ray
+            const double d0 = k.ident_rot ? sample_distance<3, false, true>(k, nullptr, pose[0], pose[1], hr, hc)
+                                          : sample_distance<3, false, false>(k, nullptr, pose[0], pose[1], hr, hc);
+            if (k.pad) {
+                double ux, uy;
+                bool resolved;
+                if (k.ident_rot) padded_position<true>(k, pose[0], pose[1], ux, uy); else padded_position<false>(k, pose[0], pose[1], ux, uy);
+                const bool fast = padded_start_ok(k, ux, uy);
+                r = k.ident_rot ? march_padded<true, true>(k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, fast, hr, hc, nl, resolved)
+                                : march_padded<false, true>(k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, fast, hr, hc, nl, resolved);
+                if (!fast) ++g_pad_far; else if (resolved) ++g_pad_guard; else ++g_pad_fast;
+            } else {
+                r = march_from_first<3, false, false>(k, nullptr, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, hr, hc, nl);
+            }
+        } else if (layout == 2) {
             if (k.res_pow2) { if (k.ident_rot) RUN(2, true, true); else RUN(2, true, false); }
             else { if (k.ident_rot) RUN(2, false, true); else RUN(2, false, false); }
         } else if (layout == 1) {

@@ -105,7 +105,7 @@ def test_bad_integrator_raises(amd, unit):
 
 
 # ---------------------------------------------------------------------------- scan (a8-a12)
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
 @pytest.mark.parametrize("fixture,mapname,beams,fov", [
     ("scan_example_map", "example_map", 1080, 4.7), ("scan_berlin", "berlin", 1080, 4.7),
     ("scan_example_map_4096", "example_map", 4096, 4.7), ("scan_example_map_271", "example_map", 271, 6.0)])
@@ -127,7 +127,7 @@ def test_scan_generic_paths_vs_oracle(amd, orc):
     dt, res, origin = oracle_map_dt("example_map")
     sub = np.ascontiguousarray(dt[600:1000, 900:1300])
     rng = np.random.default_rng(11)
-    for layout in (0, 1, 2):
+    for layout in (0, 1, 2, 3):
         for res2, org in [(0.05, [-3.0, -4.0, 0.3]), (0.0625, [1.0, 2.0, -1.1]), (0.07, [0.0, 0.0, 0.0])]:
             so = orc.ScanOracle(1080, 4.7)
             so.set_map_dt(sub * (res2 / res), res2, org)
@@ -242,7 +242,7 @@ def _noise(T, B=1080, seed=12345):
     return np.random.default_rng(seed).normal(0., 0.01, size=(T, B))
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
 def test_sim_rollout_vs_golden(amd, layout):
     g = gold("sim_rollout")
     img, res, origin = load_map_image("example_map")
@@ -337,7 +337,7 @@ def _drive(amd, orc, E, A, T, layout=0, seed=0, beams=1080, reset_every=None, ch
     return stats
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
 def test_step_vs_oracle_64_envs_200_steps(amd, orc, layout):
     """the parity gate that accompanies every timing: first 64 envs x 200 steps"""
     st = _drive(amd, orc, 64, 2, 200, layout=layout, reset_every=10, check_every=5)
@@ -466,7 +466,7 @@ def test_vec_env_auto_reset(amd):
     assert seen_done
 
 
-@pytest.mark.parametrize("layout,tasks,block", [(0, 1, 64), (0, 3, 128), (1, 2, 256), (2, 4, 64), (2, 1, 256)])
+@pytest.mark.parametrize("layout,tasks,block", [(0, 1, 64), (0, 3, 128), (1, 2, 256), (2, 4, 64), (2, 1, 256), (3, 4, 64), (3, 1, 256)])
 def test_scan_launch_geometries_bit_exact(amd, orc, layout, tasks, block):
     """map layout / tasks-per-wave / workgroup size only change scheduling and storage:
     unit scans equal the golden vectors and a stepped batch equals the oracle bit-for-bit on scans"""
@@ -562,7 +562,7 @@ def test_step_other_maps_params_euler_lidar_offset(amd, orc):
     map), Euler integrator, lidar offset, per-agent vehicle params, noise table shorter than the
     episode (wraps)"""
     rng = np.random.default_rng(17)
-    for mapname, integ, ld, layout in [("berlin", 1, 0.0, 0), ("skirk", 2, 0.275, 1), ("berlin", 1, 0.275, 2)]:
+    for mapname, integ, ld, layout in [("berlin", 1, 0.0, 0), ("skirk", 2, 0.275, 1), ("berlin", 1, 0.275, 2), ("skirk", 1, 0.275, 3), ("berlin", 2, 0.0, 3)]:
         img, res, origin = load_map_image(mapname)
         dt, _, _ = oracle_map_dt(mapname)
         E, A, T = 9, 3, 50
@@ -588,4 +588,41 @@ def test_step_other_maps_params_euler_lidar_offset(amd, orc):
             es = max(es, rel_err(o["state"], ref.state)); er = max(er, rel_err(o["scans"], ref.scans))
         assert mism == 0 and es < NORTH_STAR and er < NORTH_STAR, (mapname, mism, es, er)
         assert ref.collisions.sum() > 0          # the cluster does produce body collisions
+        s.close()
+
+
+@pytest.mark.gpu
+def test_padded_layout_guard_band_and_far_poses(amd, orc):
+    """PADDED layout on the device: lidars on cell corners with axis-aligned beams (guard band),
+    on / just off / far off the map (border, then the exact fallback), all bit-equal to the oracle"""
+    so = orc.ScanOracle(1080, 4.7)
+    rng = np.random.default_rng(21)
+    for mapname in ("berlin", "example_map", "skirk"):
+        dt, res, origin = oracle_map_dt(mapname)
+        so.set_map_dt(dt, res, origin)
+        H, W = dt.shape
+        free = np.argwhere(dt > 0.3)
+        poses = []
+        for r, c in free[rng.choice(len(free), 40, replace=False)]:
+            poses.append([origin[0] + c * res, origin[1] + r * res, rng.choice([0.0, np.pi / 2, np.pi, -np.pi / 2])])
+            poses.append([origin[0] + c * res, origin[1] + (r + 0.5) * res, 0.0])
+            poses.append([origin[0] + (c + rng.uniform()) * res, origin[1] + (r + rng.uniform()) * res, rng.uniform(-7, 7)])
+        poses += [[origin[0], origin[1], 0.3], [origin[0] - 1.0, origin[1] + H * res / 2, 0.0],
+                  [origin[0] + W * res + 2.5, origin[1] + H * res + 2.5, 3.9], [origin[0] - 40.0, origin[1] - 40.0, 0.8],
+                  [origin[0] + W * res / 2, origin[1] + H * res + 29.0, -1.6], [1e9, -1e9, 1.0], [1e300, 0.0, 0.0]]
+        poses = np.asarray(poses)
+        s = amd.BatchSim(num_envs=1, num_agents=1, map_layout=3)
+        s.set_map_dt(dt, res, origin)
+        s.scan_path_stats(enable=True)
+        ranges, hits, lk = s.scan_batch(poses, want_hits=True, want_lookups=True)
+        st = s.scan_path_stats()
+        # the fixed-point march is what runs (no silent fallback); a few rays in 10^4 sample in the
+        # guard band and are re-marched; the 4 far-off lidars take the exact march
+        assert st["fast"] + st["guard"] + st["exact"] == poses.shape[0] * 1080
+        assert st["fast"] >= 120 * 1080 * 0.99 and 0 < st["guard"] < 2e-3 * st["fast"] and st["exact"] >= 4 * 1080, st
+        for k, pose in enumerate(poses):
+            ref, ref_hits = so.scan(pose, want_hits=True)
+            assert np.array_equal(hits[k], ref_hits), (mapname, pose)
+            assert np.array_equal(ranges[k], ref), (mapname, pose)
+            assert lk[k] == so.last_lookups
         s.close()

@@ -94,7 +94,7 @@ def _hh_scan(hh, layout, dt, res, origin, sines, cosines, B, fov, pose, theta_di
 @pytest.mark.parametrize("fixture,mapname,beams,fov", [
     ("scan_example_map", "example_map", 1080, 4.7), ("scan_berlin", "berlin", 1080, 4.7),
     ("scan_example_map_4096", "example_map", 4096, 4.7), ("scan_example_map_271", "example_map", 271, 6.0)])
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
 def test_scan_matches_golden(hh, fixture, mapname, beams, fov, layout):
     g = gold(fixture)
     dt, res, origin = oracle_map_dt(mapname)
@@ -121,10 +121,51 @@ def test_scan_generic_path_and_rotated_origin(hh):
             u, v = rng.uniform(5, 15, 2) * res2 / 0.05
             pose = [org[0] + c * u - s * v, org[1] + s * u + c * v, rng.uniform(0, 6.28)]
             ref, ref_hits = so.scan(pose, want_hits=True)
-            ranges, hits, idx, lk = _hh_scan(hh, 0, so.dt, res2, org, so.sines, so.cosines, 1080, 4.7, pose)
-            assert np.array_equal(hits, ref_hits)
-            assert np.array_equal(ranges, ref)
+            for layout in (0, 3):
+                ranges, hits, idx, lk = _hh_scan(hh, layout, so.dt, res2, org, so.sines, so.cosines, 1080, 4.7, pose)
+                assert np.array_equal(hits, ref_hits)
+                assert np.array_equal(ranges, ref)
+                assert lk == so.last_lookups
+
+
+def _padded_stats(hh):
+    out = (C.c_longlong * 3)()
+    hh.hh_padded_stats(out)
+    return dict(fast=out[0], guard=out[1], far=out[2])
+
+
+def test_padded_layout_guard_band_and_far_poses(hh):
+    """PADDED layout (border of out-of-bounds cells + fixed-point cell addressing): bit-equal to
+    the oracle where the cheap decision is taken, where a sample falls in the guard band (rays
+    running along cell boundaries) and where the lidar is too far off the map for the border."""
+    so = orc.ScanOracle(1080, 4.7)
+    rng = np.random.default_rng(21)
+    _padded_stats(hh)
+    for mapname in ("berlin", "example_map", "skirk"):
+        dt, res, origin = oracle_map_dt(mapname)
+        so.set_map_dt(dt, res, origin)
+        H, W = dt.shape
+        free = np.argwhere(dt > 0.3)
+        poses = []
+        for r, c in free[rng.choice(len(free), 6, replace=False)]:
+            # lidar exactly on a cell corner / edge, headings along the axes: samples land on
+            # cell boundaries over and over
+            poses.append([origin[0] + c * res, origin[1] + r * res, rng.choice([0.0, np.pi / 2, np.pi, -np.pi / 2]) + 4.7 / 2 * 0])
+            poses.append([origin[0] + c * res, origin[1] + (r + 0.5) * res, 0.0])
+            poses.append([origin[0] + (c + rng.uniform()) * res, origin[1] + (r + rng.uniform()) * res, rng.uniform(-7, 7)])
+        # on the border of the map, just outside, far outside, absurd
+        poses += [[origin[0], origin[1], 0.3], [origin[0] - 1.0, origin[1] + H * res / 2, 0.0],
+                  [origin[0] + W * res + 2.5, origin[1] + H * res + 2.5, 3.9], [origin[0] - 40.0, origin[1] - 40.0, 0.8],
+                  [origin[0] + W * res / 2, origin[1] + H * res + 29.0, -1.6], [1e9, -1e9, 1.0], [1e300, 0.0, 0.0]]
+        for pose in poses:
+            ref, ref_hits = so.scan(pose, want_hits=True)
+            ranges, hits, idx, lk = _hh_scan(hh, 3, dt, res, origin, so.sines, so.cosines, 1080, 4.7, pose)
+            assert np.array_equal(hits, ref_hits), (mapname, pose)
+            assert np.array_equal(ranges, ref), (mapname, pose)
             assert lk == so.last_lookups
+    st = _padded_stats(hh)
+    # a few rays in 10^4 are re-marched; the far-off lidars never use the border
+    assert st["fast"] > 20000 and 10 < st["guard"] < 2e-3 * st["fast"] and st["far"] >= 3 * 2 * 1080, st
 
 
 def test_dir_index_exact_replay(hh):
