@@ -42,6 +42,8 @@ struct f110_sim {
     double *d_lut = nullptr;
     int scan_block = 64;
     double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
+    ScanConst *d_k = nullptr;  // HBM copy of k (RayJob::k_cold), refreshed by cold_consts()
+    ScanConst k_uploaded{};
     unsigned long long *d_path_stats = nullptr;  // [3], see f110_scan_path_stats
     bool path_stats_on = false;
     double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_dt_pad = nullptr, *d_actions = nullptr, *d_poses = nullptr;
@@ -162,6 +164,17 @@ static void set_div_magic(RayJob &j, uint32_t B)
     }
 }
 
+
+// the device copy of h->k, brought up to date (stream-ordered) if any field changed
+static const ScanConst *cold_consts(f110_sim *h)
+{
+    if (!h->d_k && hipMalloc(reinterpret_cast<void **>(&h->d_k), sizeof(ScanConst)) != hipSuccess) return nullptr;
+    if (std::memcmp(&h->k, &h->k_uploaded, sizeof(ScanConst)) != 0) {
+        std::memcpy(&h->k_uploaded, &h->k, sizeof(ScanConst));
+        if (hipMemcpyAsync(h->d_k, &h->k_uploaded, sizeof(ScanConst), hipMemcpyHostToDevice, h->stream) != hipSuccess) return nullptr;
+    }
+    return h->d_k;
+}
 
 template <bool STEP>
 static scan_rays_fn pick_rays(const ScanConst &k, int layout)
@@ -384,7 +397,7 @@ void f110_destroy(f110_sim *h)
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
-                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_dt_pad, h->d_codes, h->d_dir_ranges, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats};
+                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_dt_pad, h->d_codes, h->d_dir_ranges, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     {
@@ -884,6 +897,8 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         j.ttc_thresh = h->dev.ttc_thresh;
         j.div_magic = h->step_magic;
         j.div_shift = h->step_shift;
+        j.k_cold = cold_consts(h);
+        if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
         scan_rays_fn fn = pick_rays<true>(h->k, h->cfg.map_layout);
         if (h->dir_stride > 0) {
             RayJob jd = j;  // pass 1: one ray per (agent, distinct direction)
@@ -1119,6 +1134,8 @@ int f110_scan_batch(f110_sim *h, const double *poses, int32_t m, double *ranges,
     j.hit_rc = dh;
     j.lookups = dl;
     j.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;
+    j.k_cold = cold_consts(h);
+    if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_scan_batch: constant upload failed");
     set_div_magic(j, (uint32_t)B);
     scan_rays_fn fn = pick_rays<false>(h->k, h->cfg.map_layout);
     const dim3 grid = rays_grid(j, h->scan_block, h->scan_tasks_per_wave);

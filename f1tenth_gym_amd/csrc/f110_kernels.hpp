@@ -222,6 +222,9 @@ struct RayJob {
     // diagnostics (unit form; the step form counts per scan in k_integrate), nullptr unless enabled:
     // rays marched {fixed-point only, with a guard-band sample resolved exactly, exact throughout}
     unsigned long long *path_stats;
+    // HBM copy of the ScanConst the kernel also receives by value: the (very rare) exact re-march of
+    // the PADDED layout reads its constants from here, so they cost the fast kernel no registers
+    const ScanConst *k_cold;
 };
 
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -279,16 +282,24 @@ struct RayJob;
 __device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_t p, int b, uint32_t ray, double r,
                                             int row, double vel);
 
-// One ray from its (shared) first sample d0 on.  path: 0 fixed-point march, 1 fixed-point march with
-// some guard-band sample resolved exactly, 2 exact arithmetic throughout.
+// One ray from its (shared) first sample d0 on.  path: 0 fixed-point march, 1 fixed-point march
+// given up and re-marched exactly, 2 exact arithmetic throughout.
 template <int LAYOUT, bool POW2, bool IDENT, bool WANT_CELL>
-__device__ __forceinline__ double trace_from_first(const ScanConst &k, const double *lut, double x, double y, bool fast, double c,
-                                                   double s, double d0, int &hr, int &hc, int &nl, int &path)
+__device__ __forceinline__ double trace_from_first(const ScanConst &k, const ScanConst *k_cold, const double *lut, double x, double y,
+                                                   bool fast, double c, double s, double d0, int &hr, int &hc, int &nl,
+                                                   int &path)
 {
     if (LAYOUT == LAYOUT_PADDED) {
-        bool resolved;
-        const double r = march_padded<IDENT, WANT_CELL>(k, x, y, c, s, d0, fast, hr, hc, nl, resolved);
-        path = fast ? (resolved ? 1 : 0) : 2;
+        double r = 0.;
+        bool exact = !fast;
+        if (fast) {
+            double ux, uy, cux, cuy;
+            padded_position<IDENT>(k, x, y, ux, uy);
+            padded_rate<IDENT>(k, c, s, cux, cuy);
+            exact = !march_padded<WANT_CELL>(k, ux, uy, cux, cuy, d0, r, hr, hc, nl);
+        }
+        path = fast ? (exact ? 1 : 0) : 2;
+        if (exact) r = march_exact_cold<IDENT>(k_cold, x, y, c, s, d0, hr, hc, nl);
         return r;
     }
     path = 2;
@@ -337,13 +348,13 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
                     int didx = hd.i0 + b;
                     if (didx >= k.theta_dis) didx -= k.theta_dis;
                     const double2 cs = k.cs[didx];
-                    j.ranges[ray] = trace_from_first<LAYOUT, POW2, IDENT, false>(k, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl,
+                    j.ranges[ray] = trace_from_first<LAYOUT, POW2, IDENT, false>(k, j.k_cold, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl,
                                                                                  path);
                 }
                 continue;
             }
             const double2 cs = k.cs[beam_dir_index(k, hd.start, b)];
-            r = trace_from_first<LAYOUT, POW2, IDENT, false>(k, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl, path);
+            r = trace_from_first<LAYOUT, POW2, IDENT, false>(k, j.k_cold, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl, path);
             finish_beam(j, B, p, b, ray, r, hd.row, hd.vel);
             continue;
         } else {
@@ -356,7 +367,7 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
                 padded_position<IDENT>(k, x, y, ux, uy);
                 fast = padded_start_ok(k, ux, uy);
             }
-            r = trace_from_first<LAYOUT, POW2, IDENT, true>(k, lut_lds, x, y, fast, cs.x, cs.y, d0, hr, hc, nl, path);
+            r = trace_from_first<LAYOUT, POW2, IDENT, true>(k, j.k_cold, lut_lds, x, y, fast, cs.x, cs.y, d0, hr, hc, nl, path);
             if (j.path_stats) atomicAdd(&j.path_stats[path], 1ull);
             if (j.hit_rc) {
                 j.hit_rc[(size_t)ray * 2] = hr;

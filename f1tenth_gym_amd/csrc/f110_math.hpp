@@ -190,22 +190,25 @@ struct ScanConst {
     double pad_lo, pad_hi_x, pad_hi_y;  // lidar positions (padded cell units) whose rays stay inside
     double pad_cx, pad_cy;              // padded_position: u = x*axx + y*axy + cx  (IDENT: axx = inv_res, axy = 0)
     double pad_axx, pad_axy, pad_ayx, pad_ayy;
+    int32_t pad_max_samples, pad_reserved;  // samples per ray the fixed-point error bound covers
 };
 
-// The PADDED fast path maps a sample position to padded-table cell units u (approximate on
-// purpose, |error| < 1e-9 cells) and reads the cell as the integer part of the fixed-point word
-// that adding kFixBig = 1.5 * 2^36 leaves in the low mantissa bits (ulp = 2^-16 cells):
+// The PADDED fast path keeps a ray's position in padded-table cell units u (approximate on
+// purpose: it differs from the reference's float64 position by less than kPadGuard / 4 cells,
+// setup_padded) and reads the cell as the integer part of the fixed-point word that adding
+// kFixBig = 1.5 * 2^36 leaves in the low mantissa bits (ulp = 2^-16 cells):
 //   lo32(u + kFixBig) = round(u * 65536),  cell = word >> 16,  fraction = word & 0xffff.
-// The addition rounds to nearest, so a position within 2^-17 cells of a cell boundary (either
-// side) comes out with fraction == 0: that is the guard band in which the cheap decision could
-// differ from the reference's int(x_rot / resolution) / range tests (laser_models.py:79-84),
-// and for such a sample (about 1 in 30 000) the cell is recomputed with the reference's exact
-// arithmetic.  Everything else provably picks the reference's cell: all quantities that differ
-// from the reference's are smaller than 1e-9 cells.  Out-of-range samples need no test at all:
-// the border cells hold the value the reference reads for them.
+// The addition rounds to nearest, so only a position within 2^-17 cells of a cell boundary can
+// come out with fraction == 0; for those (1 sample in 30 000) the distance to the boundary is
+// looked at in full precision: further than kPadGuard = 2^-27 cells -> the cell is floor(u), the
+// same cell the reference's int(x_rot / resolution) and range tests (laser_models.py:79-84) pick,
+// because everything that differs from the reference is smaller than kPadGuard / 4; closer -> the
+// ray is re-marched with the reference's arithmetic (about one ray in 10^7).  Out-of-range
+// samples need no test at all: the border cells hold the value the reference reads for them.
 constexpr double kFixBig = 103079215104.0;  // 1.5 * 2^36
 constexpr int kFixFracBits = 16;
 constexpr int kPadSlack = 64;               // extra border cells so a lidar slightly outside the map stays fast
+constexpr double kPadGuard = 7.450580596923828e-09;  // 2^-27 cells: closer to a cell boundary than this -> exact march
 
 F110_HD uint32_t low_word(double v)
 {
@@ -246,6 +249,17 @@ F110_HD bool setup_padded(ScanConst &k)
     k.pad_ayy = k.orig_c * k.inv_res;
     k.pad_cx = (double)b - (k.orig_x * k.orig_c + k.orig_y * k.orig_s) * k.inv_res;
     k.pad_cy = (double)b - (k.orig_y * k.orig_c - k.orig_x * k.orig_s) * k.inv_res;
+    // Error budget of march_padded against the reference's float64 positions, in cells.  Per
+    // sample: the reference rounds x += d*c (<= 1 ulp of the largest coordinate), the fixed-point
+    // side rounds one fma (<= 1/2 ulp of the padded width) and carries the 2^-52 relative error of
+    // cu.  Once: the start position, the offsets, the rotation and the final division.
+    const double xmax = fabs(k.orig_x) + fabs(k.orig_y) + ((double)k.width + (double)k.height) * k.res + 2.0 * k.max_range + 1.0;
+    const double ulp_x = xmax * 2.220446049250313e-16, ulp_u = (double)(wp > hp ? wp : hp) * 2.220446049250313e-16;
+    const double per_sample = ulp_x * k.inv_res + ulp_u + 4.0 * 2.220446049250313e-16 * k.max_range * k.inv_res;
+    const double once = 8.0 * (ulp_x * k.inv_res + ulp_u);
+    const double n_max = floor((0.25 * kPadGuard - once) / per_sample);
+    if (!(n_max >= 256.0)) return false;  // coordinates too large for the bound to be useful
+    k.pad_max_samples = n_max > 1e6 ? 1000000 : (int)n_max;
     return true;
 }
 
@@ -364,8 +378,7 @@ F110_HD double march_ray(const ScanConst &k, const double *lut, double x, double
 
 // ---- PADDED fast path ---------------------------------------------------------------------
 // world position -> padded-table cell units (xy_2_rc :68-77 then / resolution, + border), with
-// the rotation, the 1/resolution and the offsets folded into six constants (setup_padded).
-// Approximate on purpose: |error| < 1e-9 cells, see the comment at kFixBig.
+// the rotation, the 1/resolution and the offsets folded into six constants (setup_padded)
 template <bool IDENT>
 F110_HD void padded_position(const ScanConst &k, double x, double y, double &ux, double &uy)
 {
@@ -378,6 +391,19 @@ F110_HD void padded_position(const ScanConst &k, double x, double y, double &ux,
     }
 }
 
+// ray direction -> padded cells advanced per metre of range
+template <bool IDENT>
+F110_HD void padded_rate(const ScanConst &k, double c, double s, double &cux, double &cuy)
+{
+    if (IDENT) {
+        cux = c * k.inv_res;
+        cuy = s * k.inv_res;
+    } else {
+        cux = fma(c, k.pad_axx, s * k.pad_axy);
+        cuy = fma(s, k.pad_ayy, c * k.pad_ayx);
+    }
+}
+
 // true when every sample of every ray from this lidar position lands inside the padded table
 // (false for NaN): samples are taken at most max_range (+ rounding) from the lidar
 F110_HD bool padded_start_ok(const ScanConst &k, double ux, double uy)
@@ -385,77 +411,100 @@ F110_HD bool padded_start_ok(const ScanConst &k, double ux, double uy)
     return (ux >= k.pad_lo) & (ux <= k.pad_hi_x) & (uy >= k.pad_lo) & (uy <= k.pad_hi_y);
 }
 
-// xy_2_rc :55-86 with the reference's own arithmetic (true divisions; width*resolution formed
-// here from the integers, as :79 does), as a byte offset into the padded table.  An
-// out-of-bounds position reads border cell (0,0), which holds dt[-1,-1] like every border cell.
-// Rarely executed, so it is written to need few constants rather than few instructions.
-template <bool IDENT>
-F110_HD uint32_t padded_offset_exact(const ScanConst &k, double x, double y, int &r, int &c)
-{
-    const double xt = x - k.orig_x;
-    const double yt = y - k.orig_y;
-    double xr = xt, yr = yt;
-    if (!IDENT) {
-        xr = xt * k.orig_c + yt * k.orig_s;
-        yr = -xt * k.orig_s + yt * k.orig_c;
-    }
-    const bool inside = (xr >= 0) & (xr < (double)k.width * k.res) & (yr >= 0) & (yr < (double)k.height * k.res);
-    r = -1;
-    c = -1;
-    uint32_t off = 0;
-    if (inside) {
-        c = (int)(xr / k.res);
-        r = (int)(yr / k.res);
-        off = mul24((uint32_t)(r + k.pad_border), (uint32_t)k.pad_row_bytes) + ((uint32_t)(c + k.pad_border) << 3);
-    }
-    return off;
-}
-
-// trace_ray :133-146 on the padded table, entered with the first sample d taken.  The ray's
-// position is advanced exactly as the reference does (x += d*c, :140-141); the cell of a sample
-// comes from the fixed-point word unless the sample is in the guard band (or the scan's lidar
-// position is not `fast`), in which case it is recomputed with the reference's arithmetic.
+// trace_ray :133-146 on the padded table, entered with the first sample d taken.  (ux, uy) is
+// the lidar in padded cell units and (cux, cuy) the cells advanced per metre, so sample n is at
+// u_n = u_0 + (d_0 + ... + d_{n-1}) * cu: the same point as the reference's x_n of :140-141 up to
+// rounding, |u_n - reference| < kPadGuard / 4 for n <= k.pad_max_samples (setup_padded).
+// Returns false when the ray must be re-marched with the reference's arithmetic: a sample within
+// kPadGuard of a cell boundary, or more samples than the error bound covers (about one ray in
+// 10^7); the outputs are then meaningless.
 // r/c: cell of the last sample in the reference's convention (-1,-1 out of bounds); untouched when
-// the loop takes no sample.  resolved: some sample needed the exact arithmetic (diagnostics).
-template <bool IDENT, bool WANT_CELL>
-F110_HD double march_padded(const ScanConst &k, double x, double y, double c, double s, double d, bool fast, int &hit_r,
-                            int &hit_c, int &lookups, bool &resolved)
+// the loop takes no sample.
+template <bool WANT_CELL>
+F110_HD bool march_padded(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
+                          int &hit_r, int &hit_c, int &lookups)
 {
     double total = d;
     int n = 1;
-    resolved = false;
+    bool redo = false;
     const char *base = reinterpret_cast<const char *>(k.pad);
-    while ((d > k.eps) & (total <= k.max_range)) {
-        x += d * c;
-        y += d * s;
-        double ux, uy;
-        padded_position<IDENT>(k, x, y, ux, uy);
+    while ((d > k.eps) & (total <= k.max_range) & !redo) {
+        ux = fma(d, cux, ux);
+        uy = fma(d, cuy, uy);
         const uint32_t wx = low_word(ux + kFixBig);
         const uint32_t wy = low_word(uy + kFixBig);
         uint32_t off = mul24(wy >> kFixFracBits, (uint32_t)k.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
         if (WANT_CELL) {
-            hit_c = (int)(wx >> kFixFracBits) - k.pad_border;
-            hit_r = (int)(wy >> kFixFracBits) - k.pad_border;
-            if (hit_c < 0 || hit_c >= k.width || hit_r < 0 || hit_r >= k.height) {
-                hit_r = -1;
-                hit_c = -1;
-            }
+            hit_c = (int)(wx >> kFixFracBits);
+            hit_r = (int)(wy >> kFixFracBits);
         }
-        if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u) | !fast) {
-            int er, ec;
-            resolved = true;
-            off = padded_offset_exact<IDENT>(k, x, y, er, ec);
+        if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {
+            // within 2^-17 of a cell boundary, where the word (rounded to nearest) may name the
+            // cell above: take the floor, and give the ray up if it is closer than kPadGuard
+            redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
+            const int fc = (int)floor(ux), fr = (int)floor(uy);
+            off = mul24((uint32_t)fr, (uint32_t)k.pad_row_bytes) + ((uint32_t)fc << 3);
             if (WANT_CELL) {
-                hit_r = er;
-                hit_c = ec;
+                hit_c = fc;
+                hit_r = fr;
             }
         }
         d = *reinterpret_cast<const double *>(base + off);
         total += d;
         ++n;
     }
+    if (WANT_CELL && n > 1) {
+        hit_c -= k.pad_border;
+        hit_r -= k.pad_border;
+        if (hit_c < 0 || hit_c >= k.width || hit_r < 0 || hit_r >= k.height) {
+            hit_r = -1;
+            hit_c = -1;
+        }
+    }
     lookups = n;
-    return (total > k.max_range) ? k.max_range : total;
+    range = (total > k.max_range) ? k.max_range : total;
+    return !(redo | (n > k.pad_max_samples));
+}
+
+// The exact march for the rays march_padded gives up on, written to keep the fast kernel's
+// register footprint: its constants are fetched from the HBM copy of ScanConst when (if ever) it
+// runs, and it uses the reference's own arithmetic (true divisions, width*resolution formed from
+// the integers as laser_models.py:79 does) on the plain row-major table.
+template <bool IDENT>
+F110_HD double march_exact_cold(const ScanConst *kc_in, double x, double y, double c, double s, double d, int &hit_r,
+                                int &hit_c, int &lookups)
+{
+    // volatile: every constant is re-read where it is used instead of living in a register for the
+    // whole loop; this path runs for about one ray in 10^7, its footprint matters, its speed does not
+    const volatile ScanConst *kc = kc_in;
+    double total = d;
+    int n = 1;
+    while (d > kc->eps && total <= kc->max_range) {
+        x += d * c;
+        y += d * s;
+        const double xt = x - kc->orig_x, yt = y - kc->orig_y;
+        double xr = xt, yr = yt;
+        if (!IDENT) {
+            const double oc = kc->orig_c, os = kc->orig_s;
+            xr = xt * oc + yt * os;
+            yr = -xt * os + yt * oc;
+        }
+        const double res = kc->res;
+        hit_r = -1;
+        hit_c = -1;
+        d = kc->oob_value;
+        if ((xr >= 0) & (xr < (double)kc->width * res) & (yr >= 0) & (yr < (double)kc->height * res)) {
+            hit_c = (int)(xr / res);
+            hit_r = (int)(yr / res);
+            const char *base = reinterpret_cast<const char *>(kc->table_rm);
+            d = *reinterpret_cast<const double *>(base + (mul24((uint32_t)hit_r, (uint32_t)kc->row_bytes) + ((uint32_t)hit_c << 3)));
+        }
+        total += d;
+        ++n;
+    }
+    lookups = n;
+    const double max_range = kc->max_range;
+    return (total > max_range) ? max_range : total;
 }
 
 // get_scan :166-172

@@ -118,17 +118,17 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
             // what k_scan_rays<LAYOUT_PADDED, ..., STEP=false> does per ray
             const double d0 = k.ident_rot ? sample_distance<3, false, true>(k, nullptr, pose[0], pose[1], hr, hc)
                                           : sample_distance<3, false, false>(k, nullptr, pose[0], pose[1], hr, hc);
+            bool fast = false, exact = true;
             if (k.pad) {
-                double ux, uy;
-                bool resolved;
-                if (k.ident_rot) padded_position<true>(k, pose[0], pose[1], ux, uy); else padded_position<false>(k, pose[0], pose[1], ux, uy);
-                const bool fast = padded_start_ok(k, ux, uy);
-                r = k.ident_rot ? march_padded<true, true>(k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, fast, hr, hc, nl, resolved)
-                                : march_padded<false, true>(k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, fast, hr, hc, nl, resolved);
-                if (!fast) ++g_pad_far; else if (resolved) ++g_pad_guard; else ++g_pad_fast;
-            } else {
-                r = march_from_first<3, false, false>(k, nullptr, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, hr, hc, nl);
+                double ux, uy, cux, cuy;
+                if (k.ident_rot) { padded_position<true>(k, pose[0], pose[1], ux, uy); padded_rate<true>(k, cs[idx].x, cs[idx].y, cux, cuy); }
+                else { padded_position<false>(k, pose[0], pose[1], ux, uy); padded_rate<false>(k, cs[idx].x, cs[idx].y, cux, cuy); }
+                fast = padded_start_ok(k, ux, uy);
+                if (fast) exact = !march_padded<true>(k, ux, uy, cux, cuy, d0, r, hr, hc, nl);
+                if (!fast) ++g_pad_far; else if (exact) ++g_pad_guard; else ++g_pad_fast;
             }
+            if (exact) r = k.ident_rot ? march_exact_cold<true>(&k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, hr, hc, nl)
+                                       : march_exact_cold<false>(&k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, hr, hc, nl);
         } else if (layout == 2) {
             if (k.res_pow2) { if (k.ident_rot) RUN(2, true, true); else RUN(2, true, false); }
             else { if (k.ident_rot) RUN(2, false, true); else RUN(2, false, false); }
