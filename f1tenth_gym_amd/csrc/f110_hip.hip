@@ -921,7 +921,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     if (prof) HIPCHK(h, hipEventRecord(e2, h->stream));
     if (multi) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_collided, 0));
     if (multi)
-        hipLaunchKernelGGL(k_finalize, dim3(N), dim3(64), 0, h->stream, h->dev, h->k.num_beams);
+        hipLaunchKernelGGL(k_finalize, dim3((N + kFinalizeAgents - 1) / kFinalizeAgents), dim3(64 * kFinalizeAgents), 0, h->stream, h->dev, h->k.num_beams);
     else
         hipLaunchKernelGGL(k_finalize_solo, grid1d(N, 256), dim3(256), 0, h->stream, h->dev);
     if (prof) HIPCHK(h, hipEventRecord(e3, h->stream));

@@ -410,16 +410,24 @@ __global__ void __launch_bounds__(256) k_expand_beams(RayJob j, ScanConst k)
 }
 
 // ---- K3: finalize ---------------------------------------------------------------------------
-// One wave per agent.  RaceCar.check_ttc's side effects (:246-252), Simulator's collision OR
-// (:588-589), then RaceCar.ray_cast_agents (:206-227): opponents from the :574 snapshot, ego
-// pose = live state (heading already zeroed on a wall hit), box = the ego's own params.
-__global__ void __launch_bounds__(64, 5) k_finalize(AgentArrays a, int32_t B)
+// One wave per agent, kFinalizeAgents agents per workgroup (the kernel is a swarm of short waves:
+// with one-wave workgroups it was bound by the workgroup dispatch rate, not by its work).
+// RaceCar.check_ttc's side effects (:246-252), Simulator's collision OR (:588-589), then
+// RaceCar.ray_cast_agents (:206-227): opponents from the :574 snapshot, ego pose = live state
+// (heading already zeroed on a wall hit), box = the ego's own params.
+constexpr int kFinalizeAgents = 4;
+
+__global__ void __launch_bounds__(64 * kFinalizeAgents) k_finalize(AgentArrays a, int32_t B)
 {
-    const int i = blockIdx.x, tid = threadIdx.x;
+    const int i = blockIdx.x * kFinalizeAgents + (threadIdx.x >> 6), tid = threadIdx.x & 63;
     const int N = a.n_agents_total, A = a.agents_per_env;
+    if (i >= N) return;  // whole wave
+    // everything the wave may need is requested up front (one round trip), not behind the flag
     const int wall = a.in_collision[i];
     const double ex = a.state[i], ey = a.state[(size_t)N + i];
-    const double eth = wall ? 0.0 : a.state[4 * (size_t)N + i];
+    const double th_live = a.state[4 * (size_t)N + i];
+    const int me = i % A;
+    const double eth = wall ? 0.0 : th_live;
     if (tid == 0) {
         if (wall) {
             a.state[3 * (size_t)N + i] = 0.;
@@ -430,21 +438,21 @@ __global__ void __launch_bounds__(64, 5) k_finalize(AgentArrays a, int32_t B)
         }
         a.step_count[i] += 1;
     }
-    const int me = i % A;
     double *sc = a.scans + (size_t)i * B;
     for (int jj = 0; jj < A; ++jj) {
         if (jj == me) continue;
-        const int32_t *win = a.opp_window + ((size_t)i * A + jj) * 4 + (wall ? 2 : 0);
-        const int lo = win[0], hi = win[1];
-        if (hi < lo) continue;  // nothing of this opponent can be hit
+        const int4 w4 = *reinterpret_cast<const int4 *>(a.opp_window + ((size_t)i * A + jj) * 4);
         const double *ov = a.opp_verts + ((size_t)i * A + jj) * 8;
         double v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = ov[c];
+        const int lo = wall ? w4.z : w4.x, hi = wall ? w4.w : w4.y;
+        if (hi < lo) continue;  // nothing of this opponent can be hit
         for (int b = lo + tid; b <= hi; b += 64) {
             const double bt = eth + a.scan_angles[b];
-            const double v3x = cos(bt + kPi / 2.), v3y = sin(bt + kPi / 2.);
             const double r0 = sc[b];
+            double v3x, v3y;
+            sincos(bt + kPi / 2., &v3y, &v3x);  // one argument reduction for both (get_range :259-260)
             const double r = box_range(ex, ey, v3x, v3y, v, r0);
             if (r < r0) sc[b] = r;
         }

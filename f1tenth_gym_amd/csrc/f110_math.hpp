@@ -134,26 +134,30 @@ F110_HD void advance_vehicle(double *st, double &buf0, double &buf1, int &buf_cn
     double accl, sv;
     speed_steer_controller(speed_cmd, steer, st[3], st[2], p, accl, sv);  // :282
 
-    if (integrator == 1) {  // Integrator.RK4 :284-373
-        double k1[7], k2[7], k3[7], k4[7], tmp[7];
-        rhs_single_track(st, sv, accl, p, k1);
+    {
+        // Integrator.RK4 :284-373 (k1..k4, state + dt/6 * (k1 + 2 k2 + 2 k3 + k4)) and Integrator.Euler
+        // :375-395 as ONE loop over the stages, not unrolled: the right-hand side is the bulk of this
+        // kernel's code, and a kernel that runs one wave per SIMD pays for every instruction byte it
+        // has to fetch.  Same operations in the same order as the reference's straight-line code:
+        // acc = ((k1 + 2*k2) + 2*k3) + 1*k4, stage inputs st + dt*(k/2), st + dt*(k/2), st + dt*k.
+        const int stages = (integrator == 1) ? 4 : 1;
+        double acc[7], tmp[7], kk[7];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) tmp[i] = st[i] + dt * (k1[i] / 2);
-        rhs_single_track(tmp, sv, accl, p, k2);
+        for (int i = 0; i < 7; ++i) tmp[i] = st[i];
+#pragma unroll 1
+        for (int sidx = 0; sidx < stages; ++sidx) {
+            rhs_single_track(tmp, sv, accl, p, kk);
+            const double wgt = (sidx == 1 || sidx == 2) ? 2.0 : 1.0;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) tmp[i] = st[i] + dt * (k2[i] / 2);
-        rhs_single_track(tmp, sv, accl, p, k3);
+            for (int i = 0; i < 7; ++i) {
+                acc[i] = (sidx == 0) ? kk[i] : acc[i] + wgt * kk[i];
+                const double h = (sidx < 2) ? kk[i] / 2 : kk[i];
+                tmp[i] = st[i] + dt * h;
+            }
+        }
+        const double w = (integrator == 1) ? dt * (1. / 6.) : dt;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) tmp[i] = st[i] + dt * k3[i];
-        rhs_single_track(tmp, sv, accl, p, k4);
-        const double w = dt * (1. / 6.);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) st[i] = st[i] + w * (((k1[i] + 2 * k2[i]) + 2 * k3[i]) + k4[i]);
-    } else {  // Integrator.Euler :375-395
-        double f[7];
-        rhs_single_track(st, sv, accl, p, f);
-#pragma unroll
-        for (int i = 0; i < 7; ++i) st[i] = st[i] + dt * f[i];
+        for (int i = 0; i < 7; ++i) st[i] = st[i] + w * acc[i];
     }
     // :400-404
     if (st[4] > kTwoPi)
