@@ -52,6 +52,7 @@ def parse_args():
                     help="RCCL all-gather of every rank's scans after each step (BASELINE config 4; off by default)")
     ap.add_argument("--no-noise", action="store_true")
     ap.add_argument("--no-reset", action="store_true")
+    ap.add_argument("--separate-reset", action="store_true", help="re-seat finished envs with a separate launch per step instead of inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--secondary", type=int, default=4096, help="also time this many agents (configs[1]); 0 = skip")
@@ -164,12 +165,17 @@ def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
         d_all = sim.device_array((rdv.world, E * A, args.beams))
     sim.reset_device(d_start)
     sim.sync()
+    # finished envs (ego collided) are re-seated in place every step: folded into the step's last
+    # kernel (f110_set_auto_reseat), or as the separate f110_reset_collided_device launch
+    fused_reset = not args.no_reset and not args.separate_reset
+    if fused_reset:
+        sim.set_auto_reseat(d_start, 0, d_count)
 
     def one(t):
         sim.step_device(d_sets[t // 20])
         if d_all is not None:
             sim.comm_all_gather_scans(d_all)
-        if not args.no_reset:
+        if not args.no_reset and not fused_reset:
             sim.reset_collided_device(d_start, 0, d_count)
 
     for t in range(warmup):

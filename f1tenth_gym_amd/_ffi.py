@@ -79,6 +79,7 @@ PROTOTYPES = {
     "f110_reset": (C.c_int, [C.c_void_p, _dp, _u8p]),
     "f110_reset_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "f110_reset_collided_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "f110_set_auto_reseat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "f110_episode_init": (C.c_int, [C.c_void_p, C.c_int32]),
     "f110_episode_reset": (C.c_int, [C.c_void_p, _dp, _dp, _u8p]),
     "f110_episode_step_device": (C.c_int, [C.c_void_p, C.c_void_p]),

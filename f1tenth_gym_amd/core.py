@@ -236,6 +236,13 @@ class BatchSim(object):
         c = None if d_count is None else (d_count.ptr if isinstance(d_count, DeviceArray) else int(d_count))
         check(_ffi.lib().f110_reset_collided_device(self._h, p, int(ego_idx), c), self._h, IndexError)
 
+    def set_auto_reseat(self, d_start_poses, ego_idx=0, d_count=None):
+        """fold reset_collided_device into the end of every following step (None disarms it)"""
+        p = None if d_start_poses is None else (d_start_poses.ptr if isinstance(d_start_poses, DeviceArray) else int(d_start_poses))
+        c = None if d_count is None else (d_count.ptr if isinstance(d_count, DeviceArray) else int(d_count))
+        check(_ffi.lib().f110_set_auto_reseat(self._h, p, int(ego_idx), c), self._h, IndexError)
+        self._reseat_refs = (d_start_poses, d_count)   # keep the device buffers alive while armed
+
     # ------------------------------------------------------------------ optional RCCL observation gather
     @staticmethod
     def comm_unique_id():

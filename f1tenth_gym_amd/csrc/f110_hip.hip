@@ -632,6 +632,17 @@ int f110_reset_device(f110_sim *h, const double *d_poses, const uint8_t *d_env_m
     return F110_OK;
 }
 
+int f110_set_auto_reseat(f110_sim *h, const double *d_start_poses, int32_t ego_idx, int32_t *d_count)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    if (d_start_poses && (ego_idx < 0 || ego_idx >= h->cfg.num_agents))
+        return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
+    h->dev.reseat_poses = d_start_poses;
+    h->dev.reseat_ego = d_start_poses ? ego_idx : 0;
+    h->dev.reseat_count = d_start_poses ? d_count : nullptr;
+    return F110_OK;
+}
+
 int f110_reset_collided_device(f110_sim *h, const double *d_start_poses, int32_t ego_idx, int32_t *d_count)
 {
     if (!h || !d_start_poses) return fail(h, F110_ERR_INVALID, "null argument");

@@ -54,6 +54,10 @@ struct AgentArrays {
     int32_t *in_collision;   // [N]
     int32_t *step_count;     // [N]
     unsigned long long *path_stats;  // diagnostics or nullptr: rays of fast scans [0] / of exact scans [2]
+    // armed by f110_set_auto_reseat: k_finalize ends with the in-place re-seat of finished envs
+    const double *reseat_poses;      // [N][3] or nullptr
+    int32_t *reseat_count;           // device counter or nullptr
+    int32_t reseat_ego, pad_reseat;
     int32_t *opp_window;     // [N][A][4] beam range each opponent can occupy: {lo, hi} for the live
                              //           heading and {lo0, hi0} for heading 0 (after a wall hit)
     double *opp_verts;       // [N][A][8] the opponent's box drawn with the ego's length/width
@@ -409,6 +413,25 @@ __global__ void __launch_bounds__(256) k_expand_beams(RayJob j, ScanConst k)
     finish_beam(j, B, p, b, ray, r, hd.row, hd.vel);
 }
 
+// In-place re-seat of one agent of a finished env (f110_reset_collided_device / auto re-seat): what
+// k_reset does for a masked env.  collisions[] keeps the step's value, as Simulator.collisions does,
+// and so does in_collision[] here (k_integrate clears it at the next step; other waves of this
+// kernel may still be reading the ego's flag).
+__device__ __forceinline__ void reseat_agent(const AgentArrays &a, int i, bool count)
+{
+    const int N = a.n_agents_total;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = 0.;
+    a.state[i] = a.reseat_poses[3 * (size_t)i];
+    a.state[(size_t)N + i] = a.reseat_poses[3 * (size_t)i + 1];
+    a.state[4 * (size_t)N + i] = a.reseat_poses[3 * (size_t)i + 2];
+    a.steer_buf[i] = 0.;
+    a.steer_buf[(size_t)N + i] = 0.;
+    a.buf_cnt[i] = 0;
+    a.step_count[i] = 0;
+    if (count && a.reseat_count) atomicAdd(a.reseat_count, 1);
+}
+
 // ---- K3: finalize ---------------------------------------------------------------------------
 // One wave per agent, kFinalizeAgents agents per workgroup (the kernel is a swarm of short waves:
 // with one-wave workgroups it was bound by the workgroup dispatch rate, not by its work).
@@ -459,6 +482,12 @@ __global__ void __launch_bounds__(64 * kFinalizeAgents) k_finalize(AgentArrays a
         // the next opponent may touch the same beams: make this wave's stores visible to it
         __threadfence_block();
     }
+    if (a.reseat_poses && tid == 0) {
+        // the ego's collisions value of this step = pair test (k_collide, complete) OR its wall flag
+        // (k_scan_rays, complete); neither input is written by this kernel's re-seat
+        const int ego = (i / A) * A + a.reseat_ego;
+        if (a.collisions[ego] != 0.0 || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
+    }
 }
 
 // single-agent envs: no opponents, one lane per agent is enough
@@ -478,6 +507,7 @@ __global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
     // k_collide is not launched for A = 1, so the flag is (re)written here
     a.collisions[i] = wall ? 1.0 : 0.0;
     a.step_count[i] += 1;
+    if (a.reseat_poses && wall) reseat_agent(a, i, true);
 }
 
 // unit-path helper: AoS poses [M][3] -> pose_x, pose_y, dir_start

@@ -124,6 +124,11 @@ int f110_reset_device(f110_sim *h, const double *d_poses, const uint8_t *d_env_m
  * *d_count (device int32, may be NULL) is incremented once per env reset. */
 int f110_reset_collided_device(f110_sim *h, const double *d_start_poses, int32_t ego_idx,
                                int32_t *d_count);
+/* The same re-seat folded into the end of every following f110_step / f110_step_device (one kernel
+ * boundary less per step), until called again with d_start_poses = NULL.  State, delay buffer and
+ * step counters end up exactly as after step + f110_reset_collided_device; in_collision keeps the
+ * step's value (the separate call clears it). */
+int f110_set_auto_reseat(f110_sim *h, const double *d_start_poses, int32_t ego_idx, int32_t *d_count);
 
 /* ---- F110Env episode logic on the device: _check_done f110_env.py:204-246 (start/finish-zone
  * toggles, lap counts / times, done = ego collided or all agents have 4 toggles) and the state part

@@ -6,7 +6,7 @@ for unit inputs).  Nothing here reads /root/reference.
 import numpy as np
 import pytest
 
-from _util import gold, load_map_image, oracle_map_dt, bench_start_poses, rel_err
+from _util import gold, load_map_image, oracle_map_dt, bench_start_poses, raceline, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -627,4 +627,45 @@ def test_padded_layout_guard_band_and_far_poses(amd, orc):
             assert np.array_equal(hits[k], ref_hits), (mapname, pose)
             assert np.array_equal(ranges[k], ref), (mapname, pose)
             assert lk[k] == so.last_lookups
+        s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A", [1, 2, 3])
+def test_auto_reseat_equals_step_plus_reset_collided(amd, A):
+    """f110_set_auto_reseat (re-seat folded into the step's last kernel) leaves exactly the state
+    that step + f110_reset_collided_device leaves, step after step, with envs finishing all the time"""
+    E, T = 96, 120
+    img, res, origin = load_map_image("example_map")
+    w = raceline()
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, w.shape[0], E)
+    base = np.stack([w[k, 1], w[k, 2], w[k, 3] + np.pi / 2], axis=1)
+    poses = np.repeat(base, A, axis=0) + np.stack([rng.uniform(-0.6, 0.6, E * A), rng.uniform(-0.6, 0.6, E * A), rng.uniform(-0.4, 0.4, E * A)], axis=1)
+    sims, starts, counts = [], [], []
+    for fused in (False, True):
+        s = amd.BatchSim(num_envs=E, num_agents=A)
+        s.set_map_image(img, res, origin)
+        s.set_noise_table(np.random.default_rng(9).normal(0., 0.01, size=(T + 2, 1080)))
+        d_start = s.device_array((E * A, 3)); d_start.upload(poses)
+        d_count = s.device_array((1,), dtype=np.int32); d_count.upload(np.zeros(1, dtype=np.int32))
+        s.reset_device(d_start)
+        if fused:
+            s.set_auto_reseat(d_start, A - 1, d_count)
+        sims.append(s); starts.append(d_start); counts.append(d_count)
+    d_act = [s.device_array((E * A, 2)) for s in sims]
+    for t in range(T):
+        act = np.stack([rng.uniform(-0.45, 0.45, E * A), rng.uniform(1.0, 9.0, E * A)], axis=1)
+        for s, da, ds, dc, fused in zip(sims, d_act, starts, counts, (False, True)):
+            da.upload(act)
+            s.step_device(da)
+            if not fused:
+                s.reset_collided_device(ds, A - 1, dc)
+        a, b = (s.get("scans", "state", "collisions", "collision_idx", "step_count") for s in sims)
+        for key in a:
+            assert np.array_equal(a[key], b[key]), (t, key)
+    n = [int(c.download()[0]) for c in counts]
+    assert n[0] == n[1] and n[0] > 10, n
+    sims[1].set_auto_reseat(None)
+    for s in sims:
         s.close()
