@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--gather", action="store_true",
                     help="RCCL all-gather of every rank's scans after each step (BASELINE config 4; off by default)")
     ap.add_argument("--no-noise", action="store_true")
+    ap.add_argument("--policy", choices=["random", "pure_pursuit"], default="random",
+                    help="random: pre-drawn device-resident action sets (the default workload); pure_pursuit: the reference's "
+                         "example planner (examples/waypoint_follow.py) evaluated on the device every step, closed loop")
     ap.add_argument("--no-reset", action="store_true")
     ap.add_argument("--separate-reset", action="store_true", help="re-seat finished envs with a separate launch per step instead of inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,8 +174,20 @@ def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
     if fused_reset:
         sim.set_auto_reseat(d_start, 0, d_count)
 
+    planner, d_plan = None, None
+    if args.policy == "pure_pursuit":
+        from f1tenth_gym_amd import PurePursuitPlanner
+        from _util import raceline
+        w = raceline()
+        planner = PurePursuitPlanner(np.ascontiguousarray(np.stack([w[:, 1], w[:, 2], w[:, 5]], axis=1)), 0.17145 + 0.15875, sim=sim)
+        d_plan = sim.device_array((E * A, 2))
+
     def one(t):
-        sim.step_device(d_sets[t // 20])
+        if planner is not None:
+            planner.plan_device(sim, d_plan, 0.82461887897713965, 1.375 * 0.8)   # the example's look-ahead; 80 % of its speed gain
+            sim.step_device(d_plan)
+        else:
+            sim.step_device(d_sets[t // 20])
         if d_all is not None:
             sim.comm_all_gather_scans(d_all)
         if not args.no_reset and not fused_reset:
@@ -206,7 +221,7 @@ def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
         got = d_all.download()[rdv.rank]
         out["gather_ok"] = bool((mine == got).all())
         d_all.free()
-    for d in d_sets + [d_start, d_count]:
+    for d in d_sets + [d_start, d_count] + ([d_plan] if d_plan is not None else []):
         d.free()
     sim.close()
     return out
@@ -325,6 +340,8 @@ def main():
                                 % (args.agents, args.agents // args.agents_per_env, args.agents_per_env, args.beams,
                                    "off" if args.no_noise else "on", "off" if args.no_reset else "on"))
                                + (" (BASELINE configs[2])" if args.agents == 65536 and args.beams == 1080 else ""),
+                   "policy": ("pre-drawn random actions, device resident" if args.policy == "random" else
+                              "reference pure-pursuit planner evaluated on the device every step (closed loop, planner time included)"),
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
                    "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64"}[args.layout],
                    "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks,

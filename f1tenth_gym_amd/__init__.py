@@ -8,6 +8,7 @@ from .core import BatchSim, DeviceArray, DEFAULT_PARAMS  # noqa: F401
 from .sim import Integrator, Simulator  # noqa: F401
 from .laser import ScanSimulator2D  # noqa: F401
 from .env import F110Env, F110VecEnv  # noqa: F401
+from .planner import PurePursuitPlanner  # noqa: F401
 from .functional import (vehicle_dynamics_st, vehicle_dynamics_ks, pid, get_vertices, collision,  # noqa: F401
                          collision_multiple, check_ttc_jit, ray_cast)
 

@@ -395,6 +395,25 @@ class BatchSim(object):
             res.append(lk)
         return res[0] if len(res) == 1 else tuple(res)
 
+    # ------------------------------------------------------------------ the reference's example policy
+    def pure_pursuit_batch(self, waypoints, poses, lookahead, vgain, wheelbase, max_reacquire=20.0):
+        """PurePursuitPlanner.plan (examples/waypoint_follow.py:203-217) for host poses [m][3];
+        waypoints [M][3] = (x, y, speed).  Returns actions [m][2] = (steer, speed)."""
+        wp = as_f64(waypoints); poses = as_f64(poses)
+        if wp.ndim != 2 or wp.shape[1] != 3 or poses.ndim != 2 or poses.shape[1] != 3:
+            raise ValueError("waypoints must be [M][3] = (x, y, speed) and poses [m][3]")
+        out = np.empty((poses.shape[0], 2))
+        check(_ffi.lib().f110_pure_pursuit_batch(self._h, dptr(wp), wp.shape[0], dptr(poses), poses.shape[0], float(lookahead),
+                                                 float(vgain), float(wheelbase), float(max_reacquire), dptr(out)), self._h)
+        return out
+
+    def pure_pursuit_device(self, d_waypoints, num_waypoints, d_actions, lookahead, vgain, wheelbase, max_reacquire=20.0):
+        """the same policy on the live poses of all N agents, device buffers, no host round trip"""
+        w = d_waypoints.ptr if isinstance(d_waypoints, DeviceArray) else int(d_waypoints)
+        a = d_actions.ptr if isinstance(d_actions, DeviceArray) else int(d_actions)
+        check(_ffi.lib().f110_pure_pursuit_device(self._h, w, int(num_waypoints), float(lookahead), float(vgain), float(wheelbase),
+                                                  float(max_reacquire), a), self._h)
+
     def scan_path_stats(self, enable=None, read=True):
         """diagnostics: rays marched as dict(fast, guard, exact) since the last read; enable=True/False
         switches the counting (off by default)"""

@@ -1160,6 +1160,48 @@ int f110_scan_batch(f110_sim *h, const double *poses, int32_t m, double *ranges,
     return F110_OK;
 }
 
+// ---- the reference's example policy (examples/waypoint_follow.py) -----------------------------
+static int check_planner_args(f110_sim *h, const void *wp, int32_t M, double lookahead)
+{
+    if (!h || !wp) return fail(h, F110_ERR_INVALID, "pure pursuit: null argument");
+    if (M < 2) return fail(h, F110_ERR_INVALID, "pure pursuit: need at least 2 waypoints (got %d)", M);
+    if (!(lookahead > 0)) return fail(h, F110_ERR_INVALID, "pure pursuit: lookahead distance must be positive");
+    return F110_OK;
+}
+
+int f110_pure_pursuit_batch(f110_sim *h, const double *h_waypoints, int32_t M, const double *h_poses, int32_t m, double lookahead,
+                            double vgain, double wheelbase, double max_reacquire, double *h_actions)
+{
+    TRY(check_planner_args(h, h_waypoints, M, lookahead));
+    if (!h_poses || !h_actions || m < 0) return fail(h, F110_ERR_INVALID, "pure pursuit: bad argument");
+    if (m == 0) return F110_OK;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    Scratch s(h);
+    double *dw = nullptr, *dp = nullptr, *da = nullptr;
+    TRY(s.up(h_waypoints, (size_t)3 * M, &dw));
+    TRY(s.up(h_poses, (size_t)3 * m, &dp));
+    TRY(s.up<double>(nullptr, (size_t)2 * m, &da));
+    hipLaunchKernelGGL(k_pure_pursuit, grid1d((size_t)m * kPlanLanes, 256), dim3(256), 0, h->stream, dw, M, dp, dp + 1, dp + 2, 3, m, lookahead, vgain, wheelbase,
+                       max_reacquire, da);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(h_actions, da, (size_t)2 * m));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_pure_pursuit_device(f110_sim *h, const double *d_waypoints, int32_t M, double lookahead, double vgain, double wheelbase,
+                             double max_reacquire, double *d_actions)
+{
+    TRY(check_planner_args(h, d_waypoints, M, lookahead));
+    if (!d_actions) return fail(h, F110_ERR_INVALID, "pure pursuit: null actions buffer");
+    const int N = h->N;
+    const double *st = h->dev.state;
+    hipLaunchKernelGGL(k_pure_pursuit, grid1d((size_t)N * kPlanLanes, 256), dim3(256), 0, h->stream, d_waypoints, M, st, st + N, st + 4 * (size_t)N, 1, N, lookahead,
+                       vgain, wheelbase, max_reacquire, d_actions);
+    HIPCHK(h, hipGetLastError());
+    return F110_OK;
+}
+
 int f110_scan_path_stats(f110_sim *h, int32_t enable, int64_t *out3)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");

@@ -955,6 +955,99 @@ __global__ void k_build_codes(const double *__restrict__ rowmajor, int H, int W,
     codes[t] = code;
 }
 
+// examples/waypoint_follow.py: PurePursuitPlanner.plan, 16 lanes per pose (4 poses per wave).  The
+// lanes of a group split the segments of the waypoint polyline: the nearest-point search is a
+// per-lane first-minimum followed by a (distance, index) lexicographic min across the group — the
+// same winner as np.argmin's first minimum — and the look-ahead search tests 16 segments at a
+// time and takes the lowest hit.  Per-segment arithmetic is f110_math.hpp's, unchanged.
+// actions [n][2] = (steer, speed).
+constexpr int kPlanLanes = 16;
+
+__global__ void __launch_bounds__(256) k_pure_pursuit(const double *__restrict__ wp, int M, const double *__restrict__ px_,
+                                                      const double *__restrict__ py_, const double *__restrict__ pth_, int stride, int n,
+                                                      double lookahead, double vgain, double wheelbase, double max_reacquire,
+                                                      double *__restrict__ actions)
+{
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / kPlanLanes;   // pose
+    const int sub = threadIdx.x & (kPlanLanes - 1);
+    const int grp_shift = (threadIdx.x & 63) & ~(kPlanLanes - 1);            // first lane of my group in the wave
+    const bool live = gid < n;
+    const int g = live ? gid : n - 1;   // idle groups shadow the last pose so the wave stays convergent
+    const double px = px_[(size_t)g * stride], py = py_[(size_t)g * stride], theta = pth_[(size_t)g * stride];
+    // ---- nearest_point_on_trajectory :15-50
+    double dist = INFINITY, tb = 0.0;
+    int best = 0x7fffffff;
+    for (int k = sub; k + 1 < M; k += kPlanLanes) {
+        const double ax = wp[3 * k], ay = wp[3 * k + 1];
+        const double dx = wp[3 * k + 3] - ax, dy = wp[3 * k + 4] - ay;
+        double t = ((px - ax) * dx + (py - ay) * dy) / (dx * dx + dy * dy);
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double rx = px - (ax + t * dx), ry = py - (ay + t * dy);
+        const double d = sqrt(rx * rx + ry * ry);
+        if (d < dist) {
+            dist = d;
+            tb = t;
+            best = k;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < kPlanLanes; m <<= 1) {
+        const double od = __shfl_xor(dist, m, kPlanLanes), ot = __shfl_xor(tb, m, kPlanLanes);
+        const int ob = __shfl_xor(best, m, kPlanLanes);
+        if (od < dist || (od == dist && ob < best)) {
+            dist = od;
+            tb = ot;
+            best = ob;
+        }
+    }
+    if (best == 0x7fffffff) best = 0;   // all distances NaN: np.argmin -> 0
+    // ---- _get_current_waypoint :183-201
+    int goal = best;
+    bool have = true;
+    if (dist < lookahead) {
+        // first_point_on_trajectory_intersecting_circle :52-132, wrap=True
+        const double start = (double)best + tb;
+        const int start_i = (int)start;
+        const double start_t = fmod(start, 1.0);
+        goal = -1;
+        for (int base = start_i; base + 1 < M && goal < 0; base += kPlanLanes) {
+            const int i = base + sub;
+            const bool hit = (i + 1 < M) &&
+                             lookahead_cuts(wp[3 * i], wp[3 * i + 1], wp[3 * i + 3], wp[3 * i + 4], px, py, lookahead, i == start_i ? start_t : 0.0);
+            const unsigned m16 = (unsigned)((__ballot(hit) >> grp_shift) & 0xffffull);
+            if (m16) goal = base + __ffs(m16) - 1;
+        }
+        for (int base = -1; base < start_i && goal < 0; base += kPlanLanes) {
+            const int i = base + sub;
+            bool hit = false;
+            if (i < start_i) {
+                const int k0 = i < 0 ? M - 1 : i, k1 = i + 1;
+                hit = lookahead_cuts(wp[3 * k0], wp[3 * k0 + 1], wp[3 * k1], wp[3 * k1 + 1], px, py, lookahead, 0.0);
+            }
+            const unsigned m16 = (unsigned)((__ballot(hit) >> grp_shift) & 0xffffull);
+            if (m16) {
+                const int i0 = base + __ffs(m16) - 1;
+                goal = i0 < 0 ? M - 1 : i0;
+            }
+        }
+        have = goal >= 0;
+    } else if (!(dist < max_reacquire)) {
+        have = false;
+    }
+    if (sub != 0 || !live) return;
+    // ---- get_actuation :134-145, plan :203-217
+    double steer = 0.0, speed = 4.0;
+    if (have) {
+        const double wy = sin(-theta) * (wp[3 * goal] - px) + cos(-theta) * (wp[3 * goal + 1] - py);
+        speed = vgain * wp[3 * best + 2];
+        if (!(fabs(wy) < 1e-6)) {
+            const double radius = 1 / (2.0 * wy / (lookahead * lookahead));
+            steer = atan(wheelbase / radius);
+        }
+    }
+    reinterpret_cast<double2 *>(actions)[gid] = make_double2(steer, speed);
+}
+
 __global__ void k_interleave_cs(const double *__restrict__ sines, const double *__restrict__ cosines, int n, double2 *__restrict__ cs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

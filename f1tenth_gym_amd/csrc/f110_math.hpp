@@ -805,4 +805,86 @@ F110_HD bool gjk_overlap(const double *v1, const double *v2)
     return false;
 }
 
+// ------------------------------------------------------------------ examples/waypoint_follow.py
+// The reference's example policy (PurePursuitPlanner), so a closed loop can stay on the GPU.
+// waypoints [M][3] = (x, y, speed).
+
+// nearest_point_on_trajectory :15-50: projection on every segment, parameter clipped to [0,1],
+// first segment with the smallest distance (np.argmin)
+F110_HD int nearest_on_trajectory(const double *wp, int M, double px, double py, double &dist, double &t_best)
+{
+    int best = 0;
+    dist = INFINITY;
+    t_best = 0.0;
+    for (int k = 0; k + 1 < M; ++k) {
+        const double ax = wp[3 * k], ay = wp[3 * k + 1];
+        const double dx = wp[3 * k + 3] - ax, dy = wp[3 * k + 4] - ay;
+        double t = ((px - ax) * dx + (py - ay) * dy) / (dx * dx + dy * dy);
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double rx = px - (ax + t * dx), ry = py - (ay + t * dy);
+        const double d = sqrt(rx * rx + ry * ry);
+        if (d < dist) {
+            dist = d;
+            t_best = t;
+            best = k;
+        }
+    }
+    return best;
+}
+
+// does the look-ahead circle cut the segment s -> e (+1e-6 on e, :70)?  In the segment the search
+// starts in only parameters >= t_min count (:86-96); elsewhere t_min = 0.
+F110_HD bool lookahead_cuts(double sx, double sy, double ex, double ey, double px, double py, double radius, double t_min)
+{
+    const double vx = (ex + 1e-6) - sx, vy = (ey + 1e-6) - sy;
+    const double a = vx * vx + vy * vy;
+    const double b = 2.0 * (vx * (sx - px) + vy * (sy - py));
+    const double c = (sx * sx + sy * sy) + (px * px + py * py) - 2.0 * (sx * px + sy * py) - radius * radius;
+    const double disc = b * b - 4 * a * c;
+    if (disc < 0) return false;
+    const double root = sqrt(disc);
+    const double t1 = (-b - root) / (2.0 * a), t2 = (-b + root) / (2.0 * a);
+    return (t1 >= 0.0 && t1 <= 1.0 && t1 >= t_min) || (t2 >= 0.0 && t2 <= 1.0 && t2 >= t_min);
+}
+
+// first_point_on_trajectory_intersecting_circle :52-132 (wrap=True) -> index of the waypoint the
+// planner then steers to (the segment's first waypoint; M-1 for the closing segment, which the
+// reference reaches as wpts[-1]), or -1
+F110_HD int first_waypoint_on_circle(const double *wp, int M, double px, double py, double radius, double start)
+{
+    const int start_i = (int)start;
+    const double start_t = fmod(start, 1.0);
+    for (int i = start_i; i + 1 < M; ++i)
+        if (lookahead_cuts(wp[3 * i], wp[3 * i + 1], wp[3 * i + 3], wp[3 * i + 4], px, py, radius, i == start_i ? start_t : 0.0))
+            return i;
+    for (int i = -1; i < start_i; ++i) {
+        const int k0 = i < 0 ? M - 1 : i, k1 = i + 1;   // i in [-1, M-2]: Python's (i % M), ((i+1) % M)
+        if (lookahead_cuts(wp[3 * k0], wp[3 * k0 + 1], wp[3 * k1], wp[3 * k1 + 1], px, py, radius, 0.0)) return k0;
+    }
+    return -1;
+}
+
+// PurePursuitPlanner.plan :203-217 with _get_current_waypoint :183-201 and get_actuation :134-145
+F110_HD void pure_pursuit_plan(const double *wp, int M, double px, double py, double theta, double lookahead, double vgain,
+                               double wheelbase, double max_reacquire, double &steer, double &speed)
+{
+    steer = 0.0;
+    speed = 4.0;  // "no waypoint" action :213-214
+    double dist, t;
+    const int i = nearest_on_trajectory(wp, M, px, py, dist, t);
+    int goal = i;
+    if (dist < lookahead) {
+        goal = first_waypoint_on_circle(wp, M, px, py, lookahead, (double)i + t);
+        if (goal < 0) return;
+    } else if (!(dist < max_reacquire)) {
+        return;
+    }
+    // steer to the WAYPOINT `goal` (:193) at the speed of the NEAREST index (:195)
+    const double wy = sin(-theta) * (wp[3 * goal] - px) + cos(-theta) * (wp[3 * goal + 1] - py);
+    speed = vgain * wp[3 * i + 2];
+    if (fabs(wy) < 1e-6) return;
+    const double radius = 1 / (2.0 * wy / (lookahead * lookahead));
+    steer = atan(wheelbase / radius);
+}
+
 }  // namespace f110

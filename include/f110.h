@@ -224,6 +224,17 @@ int f110_profile_read(f110_sim *h, int32_t *n_launches, double *scan_ms_total,
  * h_lookups [M] table lookups per pose or NULL. */
 int f110_scan_batch(f110_sim *h, const double *h_poses, int32_t m, double *h_ranges,
                     int32_t *h_hit_rc, int64_t *h_lookups);
+/* examples/waypoint_follow.py:15-217 — PurePursuitPlanner.plan (nearest point on the waypoint
+ * polyline, first look-ahead-circle cut with wrap-around, get_actuation), the reference's example
+ * policy, so that a closed loop can stay on the GPU.  waypoints [M][3] = (x, y, speed) as the
+ * planner reads them through conf.wpt_xind / wpt_yind / wpt_vind; actions [.][2] = (steer, speed),
+ * the layout f110_step takes.  _batch: host poses [m][3]; _device: the live poses of all N agents
+ * (observation poses_x / poses_y / poses_theta), device pointers, asynchronous on the handle's stream. */
+int f110_pure_pursuit_batch(f110_sim *h, const double *h_waypoints, int32_t M, const double *h_poses,
+                            int32_t m, double lookahead, double vgain, double wheelbase,
+                            double max_reacquire, double *h_actions);
+int f110_pure_pursuit_device(f110_sim *h, const double *d_waypoints, int32_t M, double lookahead,
+                             double vgain, double wheelbase, double max_reacquire, double *d_actions);
 /* Diagnostics of the scan kernels (step and unit form): with enable = 1 every marched ray is counted
  * as {fixed-point march on the padded table, re-marched exactly after a guard-band sample, exact
  * because the lidar is off the padded table / the layout has no fast path}.  out3 (or NULL) receives

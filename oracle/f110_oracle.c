@@ -894,3 +894,109 @@ int32_t *orc_sim_in_collision(orc_sim *s) { return s->in_collision; }
 int32_t *orc_sim_step_count(orc_sim *s) { return s->step_count; }
 int32_t *orc_sim_hit_rc(orc_sim *s) { return s->hit_rc; }
 int64_t orc_sim_lookups(orc_sim *s) { return s->lookups; }
+
+/* ------------------------------------------------------------------ examples/waypoint_follow.py */
+
+/* waypoint_follow.py:15-50.  Segment k joins waypoint k and k+1; the projection parameter is
+ * clipped to [0,1]; the first segment with the smallest distance wins (np.argmin). */
+int orc_nearest_on_trajectory(const double *wp, int M, double px, double py, double *dist,
+                              double *t_out)
+{
+    int best = 0;
+    double best_d = INFINITY, best_t = 0.0;
+    for (int k = 0; k + 1 < M; ++k) {
+        const double ax = wp[3 * k], ay = wp[3 * k + 1];
+        const double dx = wp[3 * (k + 1)] - ax, dy = wp[3 * (k + 1) + 1] - ay;
+        const double l2 = dx * dx + dy * dy;
+        const double dot = (px - ax) * dx + (py - ay) * dy;
+        double t = dot / l2;
+        if (t < 0.0) t = 0.0;
+        if (t > 1.0) t = 1.0;
+        const double qx = ax + t * dx, qy = ay + t * dy;
+        const double ex = px - qx, ey = py - qy;
+        const double d = sqrt(ex * ex + ey * ey);
+        if (d < best_d) {
+            best_d = d;
+            best_t = t;
+            best = k;
+        }
+    }
+    *dist = best_d;
+    *t_out = best_t;
+    return best;
+}
+
+/* one segment of :52-132: does the circle cut start -> end (+1e-6 on both end coordinates, :70)?
+ * first = the segment the search starts in, where only parameters >= start_t count (:86-96) */
+static int circle_hits_segment(double sx, double sy, double ex, double ey, double px, double py,
+                               double radius, int first, double start_t)
+{
+    const double vx = (ex + 1e-6) - sx, vy = (ey + 1e-6) - sy;
+    const double a = vx * vx + vy * vy;
+    const double b = 2.0 * (vx * (sx - px) + vy * (sy - py));
+    const double c = (sx * sx + sy * sy) + (px * px + py * py) - 2.0 * (sx * px + sy * py) - radius * radius;
+    double disc = b * b - 4 * a * c;
+    if (disc < 0) return 0;
+    disc = sqrt(disc);
+    const double t1 = (-b - disc) / (2.0 * a);
+    const double t2 = (-b + disc) / (2.0 * a);
+    if (first) {
+        if (t1 >= 0.0 && t1 <= 1.0 && t1 >= start_t) return 1;
+        if (t2 >= 0.0 && t2 <= 1.0 && t2 >= start_t) return 1;
+        return 0;
+    }
+    return (t1 >= 0.0 && t1 <= 1.0) || (t2 >= 0.0 && t2 <= 1.0);
+}
+
+int orc_first_point_on_circle(const double *wp, int M, double px, double py, double radius,
+                              double start)
+{
+    const int start_i = (int)start;
+    const double start_t = fmod(start, 1.0);
+    for (int i = start_i; i + 1 < M; ++i)
+        if (circle_hits_segment(wp[3 * i], wp[3 * i + 1], wp[3 * (i + 1)], wp[3 * (i + 1) + 1], px, py, radius,
+                                i == start_i, start_t))
+            return i;
+    /* wrap=True :108-130: segments -1 .. start_i-1 with Python's modulo indexing; the index that is
+     * reported is the loop variable itself (-1 for the closing segment), and the caller then reads
+     * wpts[-1] */
+    for (int i = -1; i < start_i; ++i) {
+        const int k0 = ((i % M) + M) % M, k1 = (((i + 1) % M) + M) % M;
+        if (circle_hits_segment(wp[3 * k0], wp[3 * k0 + 1], wp[3 * k1], wp[3 * k1 + 1], px, py, radius, 0, 0.0))
+            return i < 0 ? M + i : i;   /* as an index into the waypoint array */
+    }
+    return -1;
+}
+
+void orc_pure_pursuit_plan(const double *wp, int M, const double pose[3], double lookahead,
+                           double vgain, double wheelbase, double max_reacquire,
+                           double action[2])
+{
+    double dist, t;
+    const int i = orc_nearest_on_trajectory(wp, M, pose[0], pose[1], &dist, &t);
+    double gx, gy, speed;
+    if (dist < lookahead) {
+        const int i2 = orc_first_point_on_circle(wp, M, pose[0], pose[1], lookahead, (double)i + t);
+        if (i2 < 0) { action[0] = 0.0; action[1] = 4.0; return; }     /* :213-214 */
+        gx = wp[3 * i2];                                              /* the waypoint, not the cut (:193) */
+        gy = wp[3 * i2 + 1];
+        speed = wp[3 * i + 2];                                        /* speed of the NEAREST index (:195) */
+    } else if (dist < max_reacquire) {
+        gx = wp[3 * i];
+        gy = wp[3 * i + 1];
+        speed = wp[3 * i + 2];
+    } else {
+        action[0] = 0.0;
+        action[1] = 4.0;
+        return;
+    }
+    /* get_actuation :134-145 */
+    const double wy = sin(-pose[2]) * (gx - pose[0]) + cos(-pose[2]) * (gy - pose[1]);
+    double steer = 0.0;
+    if (!(fabs(wy) < 1e-6)) {
+        const double radius = 1 / (2.0 * wy / (lookahead * lookahead));
+        steer = atan(wheelbase / radius);
+    }
+    action[0] = steer;
+    action[1] = vgain * speed;
+}

@@ -97,6 +97,12 @@ def lib():
             fn.argtypes = [C.c_void_p]
         L.orc_sim_lookups.restype = C.c_int64
         L.orc_sim_lookups.argtypes = [C.c_void_p]
+        L.orc_nearest_on_trajectory.restype = C.c_int
+        L.orc_nearest_on_trajectory.argtypes = [_dp, C.c_int, C.c_double, C.c_double, _dp, _dp]
+        L.orc_first_point_on_circle.restype = C.c_int
+        L.orc_first_point_on_circle.argtypes = [_dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_pure_pursuit_plan.restype = None
+        L.orc_pure_pursuit_plan.argtypes = [_dp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_double, _dp]
         _lib = L
     return _lib
 
@@ -329,3 +335,24 @@ class SimOracle(object):
     def hit_rc(self): return self._view("hit_rc", (self.N, self.B, 2))
     @property
     def lookups(self): return lib().orc_sim_lookups(self._h)
+
+
+# ---- examples/waypoint_follow.py (pure-pursuit planner) ----
+def nearest_on_trajectory(waypoints, px, py):
+    w, wp = _d(waypoints)
+    dist = C.c_double(0.0); t = C.c_double(0.0)
+    i = lib().orc_nearest_on_trajectory(wp, w.shape[0], px, py, C.byref(dist), C.byref(t))
+    return i, dist.value, t.value
+
+
+def first_point_on_circle(waypoints, px, py, radius, start):
+    w, wp = _d(waypoints)
+    return lib().orc_first_point_on_circle(wp, w.shape[0], px, py, radius, start)
+
+
+def pure_pursuit_plan(waypoints, pose, lookahead, vgain, wheelbase, max_reacquire=20.0):
+    """-> (steer, speed)"""
+    w, wp = _d(waypoints); p, pp = _d(pose)
+    out = np.empty(2)
+    lib().orc_pure_pursuit_plan(wp, w.shape[0], pp, lookahead, vgain, wheelbase, max_reacquire, out.ctypes.data_as(_dp))
+    return out

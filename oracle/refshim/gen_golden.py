@@ -475,7 +475,60 @@ def gen_waypoint_follow(ns):
          columns=np.array(["x", "y", "theta", "v", "yaw_rate", "lap_time", "lap_count", "collision", "done", "scan_sum"]))
 
 
-GROUPS = {"data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
+# ------------------------------------------------------------------------- planner
+def gen_planner(ns):
+    """examples/waypoint_follow.py:15-217 — PurePursuitPlanner.plan and its helpers as functions of
+    the pose: nearest point (index, distance, t), look-ahead waypoint index and the (speed, steer)
+    the planner returns.  Poses: the golden lap's trajectory (every 7th step), the same poses pushed
+    off the raceline (re-acquire branch, 0.82 m < distance < 20 m), far away (> 20 m: default
+    action) and exactly on waypoints."""
+    import importlib.util
+    from argparse import Namespace
+    import yaml
+    ref_loader.load_reference(with_env=True)
+    sys.modules["pyglet.gl"].GL_POINTS = 0
+    spec = importlib.util.spec_from_file_location("waypoint_follow_ref2", os.path.join(REF, "examples", "waypoint_follow.py"))
+    wf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wf)
+    with open(os.path.join(REF, "examples", "config_example_map.yaml")) as f:
+        conf = Namespace(**yaml.safe_load(f))
+    conf.wpt_path = os.path.join(GOLD, "maps", "example_waypoints.csv")
+    wheelbase = 0.17145 + 0.15875
+    planner = wf.PurePursuitPlanner(conf, wheelbase)
+    tlad, vgain = 0.82461887897713965, 1.375
+    lap = np.load(os.path.join(GOLD, "waypoint_follow.npz"))["traj"][::7, :3]
+    rng = np.random.default_rng(2024)
+    off = lap[::3].copy()
+    off[:, 0] += rng.uniform(-4, 4, off.shape[0]); off[:, 1] += rng.uniform(-4, 4, off.shape[0]); off[:, 2] += rng.uniform(-1, 1, off.shape[0])
+    far = lap[::40].copy() + np.array([60.0, -45.0, 0.3])
+    wp = planner.waypoints
+    onwp = np.stack([wp[::25, conf.wpt_xind], wp[::25, conf.wpt_yind], wp[::25, 3] + np.pi / 2], axis=1)
+    near = lap[::5].copy()
+    near[:, 0] += rng.uniform(-0.5, 0.5, near.shape[0]); near[:, 1] += rng.uniform(-0.5, 0.5, near.shape[0]); near[:, 2] += rng.uniform(-0.6, 0.6, near.shape[0])
+    poses = np.concatenate([lap, off, far, onwp, near], axis=0)
+    wpts = np.vstack((wp[:, conf.wpt_xind], wp[:, conf.wpt_yind])).T
+    out, near_rec, look_rec = [], [], []
+    for x, y, th in poses:
+        speed, steer = planner.plan(x, y, th, tlad, vgain)
+        out.append([steer, speed])
+        pos = np.array([x, y])
+        npnt, ndist, t, i = wf.nearest_point_on_trajectory(pos, wpts)
+        near_rec.append([float(i), float(ndist), float(t)])
+        i2 = -2          # -2: not searched / nothing found; -1 is a real answer (the closing segment)
+        if ndist < tlad:
+            _, i2_, _ = wf.first_point_on_trajectory_intersecting_circle(pos, tlad, wpts, i + t, wrap=True)
+            i2 = -2 if i2_ is None else int(i2_)
+        look_rec.append(i2)
+    out = np.array(out)
+    print("    planner: %d poses; default-action %d, re-acquire %d, look-ahead %d" % (
+        len(poses), int(np.sum((out[:, 1] == 4.0) & (out[:, 0] == 0.0))),
+        int(np.sum((np.array(near_rec)[:, 1] >= tlad) & (np.array(near_rec)[:, 1] < 20.0))), int(np.sum(np.array(look_rec) >= -1))))
+    save("planner", poses=poses, actions=out, nearest=np.array(near_rec), lookahead_index=np.array(look_rec, dtype=np.int64),
+         waypoints=np.stack([wp[:, conf.wpt_xind], wp[:, conf.wpt_yind], wp[:, conf.wpt_vind]], axis=1),
+         tlad=np.array([tlad]), vgain=np.array([vgain]), wheelbase=np.array([wheelbase]), max_reacquire=np.array([20.0]))
+
+
+GROUPS = {"planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
           "sim": gen_sim, "env": gen_env, "waypoint_follow": gen_waypoint_follow}
 

@@ -148,6 +148,18 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
     *lookups = total;
 }
 
+// examples/waypoint_follow.py planner pieces (host instantiation of the device code)
+void hh_pure_pursuit(const double *wp, int M, const double *pose, double lookahead, double vgain, double wheelbase,
+                     double max_reacquire, double *action, int *nearest_i, double *nearest_dt, int *goal)
+{
+    double dist, t;
+    *nearest_i = nearest_on_trajectory(wp, M, pose[0], pose[1], dist, t);
+    nearest_dt[0] = dist;
+    nearest_dt[1] = t;
+    *goal = dist < lookahead ? first_waypoint_on_circle(wp, M, pose[0], pose[1], lookahead, (double)*nearest_i + t) : -2;
+    pure_pursuit_plan(wp, M, pose[0], pose[1], pose[2], lookahead, vgain, wheelbase, max_reacquire, action[0], action[1]);
+}
+
 // force the generic (non-pow2 / rotated) code path on any map: used to cross-check the
 // specialisations against each other
 void hh_scan_generic(const double *dt, int H, int W, double res, double ox, double oy, double oc, double os,

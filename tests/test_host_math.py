@@ -291,3 +291,30 @@ def test_ttc_predicate_guard_band(hh):
         assert got == ref, (v, scan[:4])
         n_hit += ref
     assert 100 < n_hit < len(cases) - 100
+
+
+def test_pure_pursuit_planner(hh):
+    """examples/waypoint_follow.py planner: host instantiation of the device code == oracle (bit for
+    bit: same libm) == the reference's outputs (golden; NumPy's dot / arctan differ by <= 1 ulp)"""
+    g = gold("planner")
+    wp, wpp = d(g["waypoints"]); M = wp.shape[0]
+    L, vg, wb = float(g["tlad"][0]), float(g["vgain"][0]), float(g["wheelbase"][0])
+    rng = np.random.default_rng(31)
+    extra = np.stack([rng.uniform(-60, 20, 300), rng.uniform(-30, 30, 300), rng.uniform(-7, 7, 300)], axis=1)
+    poses = np.concatenate([g["poses"], extra])
+    for k, pose in enumerate(poses):
+        p_, pp = d(pose)
+        act = np.empty(2); ndt = np.empty(2); ni = C.c_int(0); goal = C.c_int(0)
+        hh.hh_pure_pursuit(wpp, M, pp, C.c_double(L), C.c_double(vg), C.c_double(wb), C.c_double(20.0), act.ctypes.data_as(_dp),
+                           C.byref(ni), ndt.ctypes.data_as(_dp), C.byref(goal))
+        oi, od, ot = orc.nearest_on_trajectory(wp, pose[0], pose[1])
+        assert ni.value == oi and ndt[0] == od and ndt[1] == ot
+        if od < L:
+            assert goal.value == orc.first_point_on_circle(wp, pose[0], pose[1], L, oi + ot)
+        assert np.array_equal(act, orc.pure_pursuit_plan(wp, pose, L, vg, wb)), (k, pose)
+        if k < len(g["poses"]):
+            assert ni.value == int(g["nearest"][k, 0]) and abs(ndt[0] - g["nearest"][k, 1]) < 1e-12 and abs(ndt[1] - g["nearest"][k, 2]) < 1e-12
+            li = int(g["lookahead_index"][k])
+            if li >= -1:
+                assert goal.value == (li if li >= 0 else M + li)
+            assert np.max(np.abs(act - g["actions"][k])) < 1e-14
