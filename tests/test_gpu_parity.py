@@ -771,3 +771,21 @@ def test_closed_loop_pure_pursuit_on_device(amd, orc):
     assert racing.sum() >= 0.9 * E
     pl.close()
     s.close()
+
+
+@pytest.mark.gpu
+def test_example_waypoint_follow_reproduces_the_reference_run():
+    """examples/waypoint_follow.py (drop-in F110Env + the device planner, closed loop, nothing
+    replayed) ends where the reference's own run of its example ended: same number of steps, two
+    laps, same lap time, no collision (golden: tests/golden/waypoint_follow.npz)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("amd_waypoint_follow", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "waypoint_follow.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    res = ex.run(ex.load_conf())
+    g = gold("waypoint_follow")
+    assert res["done"] and not res["collided"]
+    assert res["steps"] == g["actions"].shape[0]
+    assert res["lap_count"] == g["traj"][-1, 6] == 2.0
+    assert abs(res["lap_time"] - g["traj"][-1, 5]) < 1e-9
