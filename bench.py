@@ -51,13 +51,15 @@ def parse_args():
     ap.add_argument("--gather", action="store_true",
                     help="RCCL all-gather of every rank's scans after each step (BASELINE config 4; off by default)")
     ap.add_argument("--no-noise", action="store_true")
-    ap.add_argument("--policy", choices=["random", "pure_pursuit"], default="random",
+    ap.add_argument("--policy", choices=["random", "pure_pursuit", "parked"], default="random",
                     help="random: pre-drawn device-resident action sets (the default workload); pure_pursuit: the reference's "
-                         "example planner (examples/waypoint_follow.py) evaluated on the device every step, closed loop")
+                         "example planner (examples/waypoint_follow.py) evaluated on the device every step, closed loop; "
+                         "parked: zero actions, every car stays on its start pose (SURVEY 8d fixed-pose variant, a pure scan number)")
     ap.add_argument("--no-reset", action="store_true")
     ap.add_argument("--separate-reset", action="store_true", help="re-seat finished envs with a separate launch per step instead of inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--fixed-pose-steps", type=int, default=100, help="also time this many steps with all cars parked (0 = skip)")
     ap.add_argument("--secondary", type=int, default=4096, help="also time this many agents (configs[1]); 0 = skip")
     ap.add_argument("--no-profile-events", action="store_true")
     return ap.parse_args()
@@ -182,8 +184,14 @@ def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
         planner = PurePursuitPlanner(np.ascontiguousarray(np.stack([w[:, 1], w[:, 2], w[:, 5]], axis=1)), 0.17145 + 0.15875, sim=sim)
         d_plan = sim.device_array((E * A, 2))
 
+    d_zero = None
+    if args.policy == "parked":
+        d_zero = sim.device_array((E * A, 2)); d_zero.upload(np.zeros((E * A, 2)))
+
     def one(t):
-        if planner is not None:
+        if d_zero is not None:
+            sim.step_device(d_zero)
+        elif planner is not None:
             planner.plan_device(sim, d_plan, 0.82461887897713965, 1.375 * 0.8)   # the example's look-ahead; 80 % of its speed gain
             sim.step_device(d_plan)
         else:
@@ -221,19 +229,19 @@ def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
         got = d_all.download()[rdv.rank]
         out["gather_ok"] = bool((mine == got).all())
         d_all.free()
-    for d in d_sets + [d_start, d_count] + ([d_plan] if d_plan is not None else []):
+    for d in d_sets + [d_start, d_count] + [x for x in (d_plan, d_zero) if x is not None]:
         d.free()
     sim.close()
     return out
 
 
 def parity_gate(args, rdv):
-    """first 64 envs x 40 steps of the bench inputs: HIP vs oracle (flags exact, floats <= 1e-5)"""
+    """first 64 envs x 200 steps of the bench inputs: HIP vs oracle (flags exact, floats <= 1e-5)"""
     import numpy as np
     from _util import load_map_image, oracle_map_dt
     from oracle import orc
     from f1tenth_gym_amd import BatchSim
-    A, E, T = args.agents_per_env, 64, 40
+    A, E, T = args.agents_per_env, 64, 200
     img, res, origin = load_map_image("example_map")
     dt, _, _ = oracle_map_dt("example_map")
     noise = None if args.no_noise else np.random.default_rng(12345).normal(0., 0.01, size=(T + 2, args.beams))
@@ -246,7 +254,7 @@ def parity_gate(args, rdv):
         sim.set_noise_table(noise); ref.set_noise(noise)
     poses = start_poses_for(shard_envs(E, 0), A)
     sim.reset(poses); ref.reset(poses)
-    sets = action_sets(2, E * A, seed=1000)
+    sets = action_sets((T + 19) // 20, E * A, seed=1000)
     flag_mismatch, es, er = 0, 0.0, 0.0
     threads = min(os.cpu_count() or 1, 32)
     for t in range(T):
@@ -340,8 +348,9 @@ def main():
                                 % (args.agents, args.agents // args.agents_per_env, args.agents_per_env, args.beams,
                                    "off" if args.no_noise else "on", "off" if args.no_reset else "on"))
                                + (" (BASELINE configs[2])" if args.agents == 65536 and args.beams == 1080 else ""),
-                   "policy": ("pre-drawn random actions, device resident" if args.policy == "random" else
-                              "reference pure-pursuit planner evaluated on the device every step (closed loop, planner time included)"),
+                   "policy": {"random": "pre-drawn random actions, device resident",
+                              "pure_pursuit": "reference pure-pursuit planner evaluated on the device every step (closed loop, planner time included)",
+                              "parked": "zero actions: every car stays on its start pose"}[args.policy],
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
                    "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64"}[args.layout],
                    "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks,
@@ -377,6 +386,14 @@ def main():
         line["config"]["secondary"] = {"workload": "%d agents (BASELINE configs[1])" % args.secondary,
                                        "value": args.secondary * max(args.steps, 200) / r2["elapsed_s"],
                                        "ms_per_step": 1e3 * r2["elapsed_s"] / max(args.steps, 200)}
+    if n_gpus == 1 and args.fixed_pose_steps > 0 and args.policy == "random" and rdv.rank == 0:
+        import copy
+        a3 = copy.copy(args)
+        a3.policy, a3.no_reset = "parked", True
+        r3 = run_gpu(a3, rdv, args.agents, args.fixed_pose_steps, 10, profile_events=False)
+        line["config"]["fixed_pose_variant"] = {"workload": "same agents parked on their start poses (speed 0, no resets)",
+                                                "value": args.agents * args.fixed_pose_steps / r3["elapsed_s"],
+                                                "ms_per_step": 1e3 * r3["elapsed_s"] / args.fixed_pose_steps}
     if rdv.rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()

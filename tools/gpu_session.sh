@@ -11,7 +11,7 @@ OUT=$R/gpurun_out; mkdir -p $OUT
 MODES="${*:-test}"
 { rocminfo | grep -E "Marketing Name|gfx9|Compute Unit" | head -8; nproc; lscpu | grep "Model name" | head -1; } > $OUT/box.txt 2>&1
 python -c "import __graft_entry__ as g; print(g.build())" > $OUT/build.log 2>&1
-SHORT="--no-cpu-baseline --secondary 0"
+SHORT="--no-cpu-baseline --secondary 0 --fixed-pose-steps 0"
 for MODE in $MODES; do
 case $MODE in
 test)

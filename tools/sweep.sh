@@ -2,7 +2,7 @@
 # quick perf sweep of scan launch geometry:  gpurun -- 'bash tools/sweep.sh'
 cd "${GRAFT_REPO_ROOT:-.}"; OUT=gpurun_out; mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
-SHORT="--no-cpu-baseline --secondary 0 --steps 150 --warmup 15"
+SHORT="--no-cpu-baseline --secondary 0 --fixed-pose-steps 0 --steps 150 --warmup 15"
 for cfg in "$@"; do
   set -- $cfg
   echo "== $cfg"
