@@ -161,6 +161,11 @@ class BatchSim(object):
         img, res, origin = load_map_files(map_path, map_ext)
         self.set_map_image(img, res, origin)
 
+    def add_map(self, map_path, map_ext):
+        """register another track from its yaml + image files; returns its slot (set_env_maps)"""
+        img, res, origin = load_map_files(map_path, map_ext)
+        return self.add_map_image(img, res, origin)
+
     def set_map_image(self, img_top_first, resolution, origin):
         img = np.ascontiguousarray(img_top_first, dtype=np.uint8)
         if img.ndim != 2:
@@ -180,6 +185,36 @@ class BatchSim(object):
                                          float(np.sin(origin[2]))), self._h)
         self.has_map = True
         self.map_resolution, self.map_origin = float(resolution), list(origin)
+
+    # ---- a different track per env (extension; slot 0 is the map of set_map_*)
+    def add_map_image(self, img_top_first, resolution, origin):
+        """register another map (same pipeline as set_map_image); returns its slot"""
+        img = np.ascontiguousarray(img_top_first, dtype=np.uint8)
+        if img.ndim != 2:
+            raise ValueError("map image must be 2-D")
+        slot = C.c_int32(0)
+        check(_ffi.lib().f110_add_map_image(self._h, img.ctypes.data_as(_ffi._u8p), img.shape[0], img.shape[1], float(resolution),
+                                            float(origin[0]), float(origin[1]), float(origin[2]), C.byref(slot)), self._h)
+        return int(slot.value)
+
+    def add_map_dt(self, dt, resolution, origin):
+        dt = as_f64(dt)
+        if dt.ndim != 2:
+            raise ValueError("distance table must be 2-D")
+        slot = C.c_int32(0)
+        check(_ffi.lib().f110_add_map_dt(self._h, dptr(dt), dt.shape[0], dt.shape[1], float(resolution), float(origin[0]),
+                                         float(origin[1]), float(np.cos(origin[2])), float(np.sin(origin[2])), C.byref(slot)), self._h)
+        return int(slot.value)
+
+    def set_env_maps(self, env_map):
+        """env_map [num_envs] of slots (None: every env back on slot 0)"""
+        if env_map is None:
+            check(_ffi.lib().f110_set_env_maps(self._h, None), self._h)
+            return
+        m = np.ascontiguousarray(env_map, dtype=np.int32).reshape(-1)
+        if m.shape[0] != self.E:
+            raise ValueError("env_map must have num_envs=%d entries (got %d)" % (self.E, m.shape[0]))
+        check(_ffi.lib().f110_set_env_maps(self._h, m.ctypes.data_as(_ffi._i32p)), self._h)
 
     def get_map_dt(self):
         h, w = C.c_int32(), C.c_int32()

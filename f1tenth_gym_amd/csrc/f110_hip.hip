@@ -42,6 +42,17 @@ struct f110_sim {
     double *d_lut = nullptr;
     int scan_block = 64;
     double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
+    // a different track per env: slot 0 is the map of f110_set_map_*, further slots come from
+    // f110_add_map_*; f110_set_env_maps assigns them and builds the device tables
+    struct MapSlot {
+        double *d_dt_row = nullptr, *d_dt_pad = nullptr;
+        ScanConst k{};
+    };
+    std::vector<MapSlot> extra_maps;
+    MapFast *d_maps_fast = nullptr;
+    ScanConst *d_maps_full = nullptr;
+    int32_t *d_env_map = nullptr;
+    bool multi_map = false;
     ScanConst *d_k = nullptr;  // HBM copy of k (RayJob::k_cold), refreshed by cold_consts()
     ScanConst k_uploaded{};
     unsigned long long *d_path_stats = nullptr;  // [3], see f110_scan_path_stats
@@ -174,6 +185,16 @@ static const ScanConst *cold_consts(f110_sim *h)
         if (hipMemcpyAsync(h->d_k, &h->k_uploaded, sizeof(ScanConst), hipMemcpyHostToDevice, h->stream) != hipSuccess) return nullptr;
     }
     return h->d_k;
+}
+
+// The step's scan runs agent-aligned (k_scan_rays_agent) with the PADDED layout unless that would
+// leave more than 3 % of the lanes idle (few beams); F110_SCAN_FLAT=1 forces the flat kernel (A/B).
+static bool agent_aligned(const f110_sim *h)
+{
+    static const bool force_flat = std::getenv("F110_SCAN_FLAT") != nullptr;
+    if (force_flat || h->cfg.map_layout != F110_MAP_PADDED_F64 || !h->k.pad || h->dir_stride > 0) return false;
+    const int B = h->k.num_beams, lanes = (B + 63) / 64 * 64;
+    return (lanes - B) * 100 <= 3 * B;
 }
 
 template <bool STEP>
@@ -400,6 +421,13 @@ void f110_destroy(f110_sim *h)
                     h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_dt_pad, h->d_codes, h->d_dir_ranges, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto &ms : h->extra_maps) {
+        if (ms.d_dt_row) (void)hipFree(ms.d_dt_row);
+        if (ms.d_dt_pad) (void)hipFree(ms.d_dt_pad);
+    }
+    if (h->d_maps_fast) (void)hipFree(h->d_maps_fast);
+    if (h->d_maps_full) (void)hipFree(h->d_maps_full);
+    if (h->d_env_map) (void)hipFree(h->d_env_map);
     {
         void *eptrs[] = {h->ep.start_poses, h->ep.rot, h->ep.current_time, h->ep.near_start, h->ep.toggle,
                          h->ep.lap_count, h->ep.lap_time, h->ep.done, h->ep.checkpoint, h->d_rot_stage};
@@ -424,9 +452,9 @@ int f110_sync(f110_sim *h)
 }
 
 // ---- map ---------------------------------------------------------------------------------
-static int finish_map(f110_sim *h, int H, int W, double res, double ox, double oy, double oc, double os)
+// the per-map fields of ScanConst that do not involve device memory
+static void fill_map_fields(ScanConst &k, int H, int W, double res, double ox, double oy, double oc, double os)
 {
-    ScanConst &k = h->k;
     k.height = H;
     k.width = W;
     k.tiles_w = (W + 3) / 4;
@@ -445,6 +473,15 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
     k.ident_rot = (oc == 1.0 && os == 0.0) ? 1 : 0;
     k.w_res = W * res;  // width * resolution, laser_models.py:79
     k.h_res = H * res;
+}
+
+static int finish_map(f110_sim *h, int H, int W, double res, double ox, double oy, double oc, double os)
+{
+    ScanConst &k = h->k;
+    h->multi_map = false;       // slot 0 changed: f110_set_env_maps has to be called again
+    h->dev.maps_full = nullptr;
+    h->dev.env_map = nullptr;
+    fill_map_fields(k, H, W, res, ox, oy, oc, os);
     HIPCHK(h, hipMemcpyAsync(&k.oob_value, h->d_dt_row + ((size_t)H * W - 1), sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (h->cfg.map_layout == F110_MAP_TILED_F64) {
         const int tiles_h = (H + 3) / 4;
@@ -534,6 +571,127 @@ int f110_set_map_dt(f110_sim *h, const double *h_dt, int32_t H, int32_t W, doubl
     TRY(dmalloc(h, &h->d_dt_row, n));
     HIPCHK(h, hipMemcpyAsync(h->d_dt_row, h_dt, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return finish_map(h, H, W, res, ox, oy, oc, os);
+}
+
+// ---- a different track per env ---------------------------------------------------------------------
+// the exact-EDT pipeline of f110_set_map_image into a fresh row-major table
+static int edt_table_from_image(f110_sim *h, const uint8_t *h_img, int H, int W, double res, double **d_dt_row)
+{
+    const size_t n = (size_t)H * W;
+    uint8_t *d_img = nullptr, *d_bin = nullptr;
+    uint32_t *d_g = nullptr, *d_d2 = nullptr;
+    Scratch s(h);
+    TRY(s.up(h_img, n, &d_img));
+    TRY(s.up<uint8_t>(nullptr, n, &d_bin));
+    TRY(s.up<uint32_t>(nullptr, n, &d_g));
+    TRY(s.up<uint32_t>(nullptr, n, &d_d2));
+    TRY(dmalloc(h, d_dt_row, n));
+    hipLaunchKernelGGL(k_flip_threshold, grid1d(n, 256), dim3(256), 0, h->stream, d_img, H, W, d_bin);
+    hipLaunchKernelGGL(k_edt_columns, grid1d(W, 64), dim3(64), 0, h->stream, d_bin, H, W, d_g);
+    hipLaunchKernelGGL(k_edt_rows, dim3(H), dim3(256), (size_t)W * sizeof(uint32_t), h->stream, d_g, H, W, d_d2);
+    hipLaunchKernelGGL(k_dt_from_d2, grid1d(n, 256), dim3(256), 0, h->stream, d_d2, n, res, *d_dt_row);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+static int add_map_slot(f110_sim *h, double *d_dt_row, int H, int W, double res, double ox, double oy, double oc, double os, int32_t *slot)
+{
+    f110_sim::MapSlot ms;
+    ms.d_dt_row = d_dt_row;
+    ms.k = h->k;   // beam / trig / range constants are shared; the map fields follow
+    fill_map_fields(ms.k, H, W, res, ox, oy, oc, os);
+    ms.k.table = ms.k.table_rm = d_dt_row;
+    ms.k.codes = nullptr;
+    ms.k.lut = nullptr;
+    HIPCHK(h, hipMemcpyAsync(&ms.k.oob_value, d_dt_row + ((size_t)H * W - 1), sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!setup_padded(ms.k)) {
+        (void)hipFree(d_dt_row);
+        return fail(h, F110_ERR_INVALID, "f110_add_map: a per-env map must fit the padded layout (16-bit cell coordinates, < 4 GiB)");
+    }
+    const size_t total = (size_t)ms.k.pad_width * ms.k.pad_height;
+    if (dmalloc(h, &ms.d_dt_pad, total) != F110_OK) {
+        (void)hipFree(d_dt_row);
+        return F110_ERR_NOMEM;
+    }
+    hipLaunchKernelGGL(k_build_padded, grid1d(total, 256), dim3(256), 0, h->stream, d_dt_row, H, W, ms.k.pad_border, ms.k.pad_width,
+                       ms.k.pad_height, ms.d_dt_pad);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    ms.k.pad = ms.d_dt_pad;
+    h->extra_maps.push_back(ms);
+    if (slot) *slot = (int32_t)h->extra_maps.size();   // slot 0 is the map of f110_set_map_*
+    return F110_OK;
+}
+
+int f110_add_map_image(f110_sim *h, const uint8_t *h_img, int32_t H, int32_t W, double res, double ox, double oy, double oyaw, int32_t *slot)
+{
+    if (!h || !h_img) return fail(h, F110_ERR_INVALID, "f110_add_map_image: null argument");
+    if (H < 1 || W < 1 || H > 16384 || W > 16384 || !(res > 0)) return fail(h, F110_ERR_INVALID, "f110_add_map_image: bad shape %dx%d or resolution", H, W);
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    double *d_dt_row = nullptr;
+    TRY(edt_table_from_image(h, h_img, H, W, res, &d_dt_row));
+    return add_map_slot(h, d_dt_row, H, W, res, ox, oy, std::cos(oyaw), std::sin(oyaw), slot);
+}
+
+int f110_add_map_dt(f110_sim *h, const double *h_dt, int32_t H, int32_t W, double res, double ox, double oy, double oc, double os, int32_t *slot)
+{
+    if (!h || !h_dt) return fail(h, F110_ERR_INVALID, "f110_add_map_dt: null argument");
+    if (H < 1 || W < 1 || !(res > 0)) return fail(h, F110_ERR_INVALID, "f110_add_map_dt: bad shape or resolution");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    double *d_dt_row = nullptr;
+    TRY(dmalloc(h, &d_dt_row, (size_t)H * W));
+    HIPCHK(h, hipMemcpyAsync(d_dt_row, h_dt, (size_t)H * W * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return add_map_slot(h, d_dt_row, H, W, res, ox, oy, oc, os, slot);
+}
+
+int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (!h_env_map) {   // back to one map for everybody
+        h->multi_map = false;
+        h->dev.maps_full = nullptr;
+        h->dev.env_map = nullptr;
+        return F110_OK;
+    }
+    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    if (h->cfg.map_layout != F110_MAP_PADDED_F64 || !h->k.pad)
+        return fail(h, F110_ERR_STATE, "f110_set_env_maps needs map_layout = F110_MAP_PADDED_F64 and a slot-0 map that fits it");
+    if (h->dir_stride > 0) return fail(h, F110_ERR_STATE, "f110_set_env_maps is not available with more beams than table directions");
+    const int E = h->cfg.num_envs, M = 1 + (int)h->extra_maps.size();
+    for (int e = 0; e < E; ++e)
+        if (h_env_map[e] < 0 || h_env_map[e] >= M) return fail(h, F110_ERR_INVALID, "f110_set_env_maps: env %d -> slot %d, but %d maps are registered", e, h_env_map[e], M);
+    std::vector<ScanConst> full(M);
+    std::vector<MapFast> fast(M);
+    for (int m = 0; m < M; ++m) {
+        full[m] = m == 0 ? h->k : h->extra_maps[m - 1].k;
+        // constants that may have changed since a slot was added (trig / beam tables) are global
+        full[m].cs = h->k.cs;
+        fast[m].pad = full[m].pad;
+        fast[m].pad_cx = full[m].pad_cx;
+        fast[m].pad_cy = full[m].pad_cy;
+        fast[m].pad_axx = full[m].pad_axx;
+        fast[m].pad_axy = full[m].pad_axy;
+        fast[m].pad_ayx = full[m].pad_ayx;
+        fast[m].pad_ayy = full[m].pad_ayy;
+        fast[m].pad_row_bytes = (uint32_t)full[m].pad_row_bytes;
+        fast[m].pad_max_samples = full[m].pad_max_samples;
+    }
+    if (h->d_maps_fast) { (void)hipFree(h->d_maps_fast); h->d_maps_fast = nullptr; }
+    if (h->d_maps_full) { (void)hipFree(h->d_maps_full); h->d_maps_full = nullptr; }
+    if (!h->d_env_map) HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_env_map), sizeof(int32_t) * E));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_maps_fast), sizeof(MapFast) * M));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_maps_full), sizeof(ScanConst) * M));
+    HIPCHK(h, hipMemcpyAsync(h->d_maps_fast, fast.data(), sizeof(MapFast) * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_maps_full, full.data(), sizeof(ScanConst) * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_env_map, h_env_map, sizeof(int32_t) * E, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->dev.maps_full = h->d_maps_full;
+    h->dev.env_map = h->d_env_map;
+    h->multi_map = true;
+    return F110_OK;
 }
 
 int f110_get_map_dt(f110_sim *h, double *out)
@@ -924,6 +1082,19 @@ int f110_step_device(f110_sim *h, const double *d_actions)
             j.dir_stride = h->dir_stride;  // pass 2: every beam picks its direction's range
             j.dir_ranges = h->d_dir_ranges;
             hipLaunchKernelGGL(k_expand_beams, grid1d(j.n_rays, 256), dim3(256), 0, h->stream, j, h->k);
+        } else if (h->multi_map || agent_aligned(h)) {
+            // whole 64-ray tasks per agent, so every wave belongs to one agent (and one map)
+            const uint32_t tpa = ((uint32_t)h->k.num_beams + 63u) / 64u;
+            (void)rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
+            j.n_tasks = (uint32_t)N * tpa;
+            const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave, wpb = (uint32_t)h->scan_block / 64u;
+            const dim3 grid((waves + wpb - 1) / wpb), block(h->scan_block);
+            if (h->multi_map)
+                hipLaunchKernelGGL((k_scan_rays_agent<true, false>), grid, block, 0, h->stream, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+            else if (h->k.ident_rot)
+                hipLaunchKernelGGL((k_scan_rays_agent<false, true>), grid, block, 0, h->stream, j, h->k, nullptr, nullptr, tpa);
+            else
+                hipLaunchKernelGGL((k_scan_rays_agent<false, false>), grid, block, 0, h->stream, j, h->k, nullptr, nullptr, tpa);
         } else {
             const dim3 grid = rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
             hipLaunchKernelGGL(fn, grid, dim3(h->scan_block), 0, h->stream, j, h->k);

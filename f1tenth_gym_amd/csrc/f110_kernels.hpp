@@ -31,7 +31,8 @@ struct RayHdr {
     double vel;         // post-integration longitudinal velocity (iTTC)
     double d0;          // first table sample, shared by every beam of the scan (:129)
     int32_t noise_row;  // row of the noise table for this step, -1 = no noise
-    int32_t hr0, hc0;   // cell of that first sample
+    int32_t map_slot;   // which registered map this agent's env runs on (0 unless f110_set_env_maps)
+    int32_t pad_hdr;
     int32_t i0;         // table index of beam 0
     int32_t n_dirs;     // distinct table indices the scan's beams use (dedupe mode), else 0
     int32_t fast;       // PADDED: every sample of every ray of this scan lands inside the padded table
@@ -54,6 +55,9 @@ struct AgentArrays {
     int32_t *in_collision;   // [N]
     int32_t *step_count;     // [N]
     unsigned long long *path_stats;  // diagnostics or nullptr: rays of fast scans [0] / of exact scans [2]
+    // a different track per env (f110_set_env_maps), else both nullptr
+    const ScanConst *maps_full;      // [n_maps] every field of every registered map (exact paths)
+    const int32_t *env_map;          // [num_envs] slot of each env
     // armed by f110_set_auto_reseat: k_finalize ends with the in-place re-seat of finished envs
     const double *reseat_poses;      // [N][3] or nullptr
     int32_t *reseat_count;           // device counter or nullptr
@@ -115,7 +119,13 @@ __global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, c
         hd.y = sp[1];
         hd.start = start;
         hd.vel = st[3];
-        hd.d0 = sample_distance<LAYOUT_ROWMAJOR, false, false>(kr, nullptr, sp[0], sp[1], hd.hr0, hd.hc0);
+        // a different track per env (f110_set_env_maps): this agent's map constants come from the
+        // registered slot instead of the kernel argument
+        hd.map_slot = a.env_map ? a.env_map[i / a.agents_per_env] : 0;
+        hd.pad_hdr = 0;
+        const ScanConst *km = a.env_map ? a.maps_full + hd.map_slot : &kr;
+        int r0, c0;
+        hd.d0 = sample_distance<LAYOUT_ROWMAJOR, false, false>(*km, nullptr, sp[0], sp[1], r0, c0);
         int row = -1;
         if (a.noise_rows > 0) {
             row = a.step_count[i];
@@ -124,10 +134,10 @@ __global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, c
         hd.noise_row = row;
         hd.i0 = beam_dir_index(k, start, 0);
         hd.fast = 0;
-        if (k.pad) {
+        if (km->pad) {
             double ux, uy;
-            padded_position<false>(k, sp[0], sp[1], ux, uy);
-            hd.fast = padded_start_ok(k, ux, uy) ? 1 : 0;
+            padded_position<false>(*km, sp[0], sp[1], ux, uy);
+            hd.fast = padded_start_ok(*km, ux, uy) ? 1 : 0;
         }
         if (a.path_stats) atomicAdd(&a.path_stats[hd.fast ? 0 : 2], (unsigned long long)k.num_beams);
         hd.n_dirs = 0;
@@ -198,7 +208,7 @@ __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
 
 // ---- K2: ray march -------------------------------------------------------------------------
 // Rays are numbered ray = pose*B + beam, one lane per ray, so the 64 lanes of a wave are
-// consecutive beams of (at most two) poses: neighbouring beams touch neighbouring cells and
+// consecutive beams of (almost always) one pose: neighbouring beams touch neighbouring cells and
 // have correlated lengths.  STEP=true is the env.step() form (SoA poses written by
 // k_integrate, noise row, iTTC predicate); STEP=false is ScanSimulator2D.scan for the unit
 // entry point (also reports terminating cells and lookup counts).
@@ -208,7 +218,6 @@ struct RayJob {
     uint32_t tasks_per_wave;  // consecutive tasks each wave walks
     int32_t n_poses;
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
-    int32_t reserved_remap;
     int32_t dir_mode, dir_stride;   // dedupe pass: rays are (agent, distinct direction), dir_stride per agent
     const double *dir_ranges;       // k_expand_beams: [n_poses][dir_stride] raw ranges of the dedupe pass
     const double *pose_x, *pose_y, *dir_start;  // [n_poses] (unit path)
@@ -224,7 +233,7 @@ struct RayJob {
     int32_t *hit_rc;                 // [n_poses][B][2] or nullptr
     unsigned long long *lookups;     // [n_poses] or nullptr
     // diagnostics (unit form; the step form counts per scan in k_integrate), nullptr unless enabled:
-    // rays marched {fixed-point only, with a guard-band sample resolved exactly, exact throughout}
+    // rays marched {fixed-point only, given up and re-marched exactly, exact throughout}
     unsigned long long *path_stats;
     // HBM copy of the ScanConst the kernel also receives by value: the (very rare) exact re-march of
     // the PADDED layout reads its constants from here, so they cost the fast kernel no registers
@@ -247,7 +256,7 @@ __device__ __forceinline__ double uniform_f64(double v)
 // Straddling wave: plain per-lane loads.
 struct LaneHdr {
     double x, y, start, vel, d0;
-    int row, hr, hc, i0, n_dirs, fast;
+    int row, map_slot, i0, n_dirs, fast;
 };
 
 __device__ __forceinline__ LaneHdr load_lane_hdr(const RayHdr *hdr, uint32_t p)
@@ -263,15 +272,14 @@ __device__ __forceinline__ LaneHdr load_lane_hdr(const RayHdr *hdr, uint32_t p)
         o.vel = uniform_f64(h0->vel);
         o.d0 = uniform_f64(h0->d0);
         o.row = uniform_i32(h0->noise_row);
-        o.hr = uniform_i32(h0->hr0);
-        o.hc = uniform_i32(h0->hc0);
+        o.map_slot = uniform_i32(h0->map_slot);
         o.i0 = uniform_i32(h0->i0);
         o.n_dirs = uniform_i32(h0->n_dirs);
         o.fast = uniform_i32(h0->fast);
     } else {
         const RayHdr hd = hdr[p];
         o.x = hd.x; o.y = hd.y; o.start = hd.start; o.vel = hd.vel; o.d0 = hd.d0; o.row = hd.noise_row;
-        o.hr = hd.hr0; o.hc = hd.hc0; o.i0 = hd.i0; o.n_dirs = hd.n_dirs;
+        o.map_slot = hd.map_slot; o.i0 = hd.i0; o.n_dirs = hd.n_dirs;
         o.fast = hd.fast;
     }
     return o;
@@ -343,8 +351,8 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
         double r;
         if (STEP) {
             const LaneHdr hd = load_lane_hdr(j.hdr, p);
-            hr = hd.hr;
-            hc = hd.hc;
+            hr = -1;
+            hc = -1;
             if (j.dir_mode) {
                 // dedupe pass: "beam" b is the b-th distinct table direction of agent p's scan;
                 // raw range only (noise / iTTC / beam expansion happen in k_expand_beams)
@@ -380,6 +388,79 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
             if (j.lookups) atomicAdd(&j.lookups[p], (unsigned long long)nl);
         }
         j.ranges[ray] = r;
+    }
+}
+
+// ---- K2a: the step's ray march, agent-aligned ----------------------------------------------------
+// Same march as k_scan_rays<LAYOUT_PADDED, ..., STEP>, with every agent's beams laid out on whole
+// 64-ray tasks (ceil(B/64) tasks per agent, the last one partly idle: 0.7 % of the lanes at 1080
+// beams).  A wave then always belongs to ONE agent: the header is scalar in every wave (no per-lane
+// header path, no per-lane ray -> (agent, beam) division, lidar position and first sample stay in
+// SGPRs) — and the agent's map can be a per-env property (f110_set_env_maps): its constants, one
+// 64-byte MapFast record, arrive through the scalar cache next to the header and the loop runs
+// with scalar constants exactly as with one map.
+struct MapFast {
+    const double *pad;                       // the map's padded table
+    double pad_cx, pad_cy;                   // padded_position constants (general, rotated form)
+    double pad_axx, pad_axy, pad_ayx, pad_ayy;
+    uint32_t pad_row_bytes;
+    int32_t pad_max_samples;
+};
+static_assert(sizeof(MapFast) == 64, "MapFast is read as one 64-byte scalar load");
+
+template <bool PER_ENV_MAP, bool IDENT>
+__global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
+                                                          const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
+{
+    const uint32_t B = (uint32_t)k.num_beams;
+    const uint32_t tpw = j.tasks_per_wave;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t blk = blockIdx.x;
+    {
+        const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
+        blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // XCD-contiguous, as k_scan_rays
+    }
+    const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
+    for (uint32_t t = 0; t < tpw; ++t) {
+        const uint32_t task = __builtin_amdgcn_readfirstlane(wave * tpw + t);
+        if (task >= j.n_tasks) break;
+        const uint32_t p = task / tasks_per_agent;                  // scalar
+        const int b = (int)((task - p * tasks_per_agent) * 64u + lane);
+        if (b >= (int)B) continue;
+        typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
+        typedef const __attribute__((address_space(4))) MapFast *cmap_t;
+        const chdr_t h0 = (chdr_t)(j.hdr) + p;
+        const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
+        const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
+        const int row = uniform_i32(h0->noise_row), slot = uniform_i32(h0->map_slot), fast = uniform_i32(h0->fast);
+        ScanConst km = k;   // PER_ENV_MAP: only the fields set here differ
+        const ScanConst *cold = j.k_cold;
+        if (PER_ENV_MAP) {
+            const cmap_t m0 = (cmap_t)(maps_fast) + slot;
+            cold = maps_full + slot;
+            const uint64_t pa = (uint64_t)m0->pad;
+            km.pad = (const double *)(((uint64_t)(uint32_t)uniform_i32((int)(pa >> 32)) << 32) | (uint32_t)uniform_i32((int)pa));
+            km.pad_cx = uniform_f64(m0->pad_cx);
+            km.pad_cy = uniform_f64(m0->pad_cy);
+            km.pad_axx = uniform_f64(m0->pad_axx);
+            km.pad_axy = uniform_f64(m0->pad_axy);
+            km.pad_ayx = uniform_f64(m0->pad_ayx);
+            km.pad_ayy = uniform_f64(m0->pad_ayy);
+            km.pad_row_bytes = uniform_i32((int)m0->pad_row_bytes);
+            km.pad_max_samples = uniform_i32(m0->pad_max_samples);
+        }
+        const double2 cs = k.cs[beam_dir_index(k, start, b)];
+        int hr = -1, hc = -1, nl;
+        double r = 0.;
+        bool exact = fast == 0;
+        if (fast) {
+            double ux, uy, cux, cuy;
+            padded_position<IDENT>(km, x, y, ux, uy);
+            padded_rate<IDENT>(km, cs.x, cs.y, cux, cuy);
+            exact = !march_padded<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl);
+        }
+        if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
+        finish_beam(j, B, p, b, p * B + (uint32_t)b, r, row, vel);
     }
 }
 

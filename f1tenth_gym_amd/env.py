@@ -174,6 +174,10 @@ class F110VecEnv(object):
     the GPU (f110_episode_*): per step only `done`, the lap arrays and the requested observation
     fields cross PCIe.  obs_fields selects what is read back ('scans' is 8.6 KB per agent);
     everything stays available in HBM through `device_views()`.
+
+    Domain randomisation over tracks: `extra_maps=[(yaml_path, ext), ...]` registers further maps
+    (slots 1, 2, ...; `map` is slot 0) and `env_map=[slot per env]` assigns them; `set_env_maps()`
+    re-assigns later.
     """
 
     _ALL = ("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions")
@@ -199,11 +203,22 @@ class F110VecEnv(object):
                              device_id=kwargs.get('device_id', 0),
                              map_layout=kwargs.get('map_layout', _ffi.MAP_DEFAULT))
         self.sim.set_map(self.map_path, self.map_ext)
+        self.map_slots = [(self.map_path, self.map_ext)]
+        for path, ext in kwargs.get('extra_maps', ()):
+            self.sim.batch.add_map(path, ext)
+            self.map_slots.append((path, ext))
+        if kwargs.get('env_map') is not None:
+            self.set_env_maps(kwargs['env_map'])
         self._start_poses = None
         self._d_actions = None
         if self.device_logic:
             self.sim.batch.episode_init(self.ego_idx)
             self._d_actions = self.sim.batch.device_array((self.num_envs * self.num_agents, 2))
+
+    def set_env_maps(self, env_map):
+        """env_map [num_envs]: which registered track each env runs on (None: all on slot 0)"""
+        self.sim.batch.set_env_maps(env_map)
+        self.env_map = None if env_map is None else np.asarray(env_map, dtype=np.int32).copy()
 
     def device_views(self):
         v = self.sim.batch.device_views()

@@ -109,6 +109,20 @@ int f110_set_trig_tables(f110_sim *h, const double *h_sines, const double *h_cos
 /* RaceCar class-level per-beam tables, base_classes.py:125-158 */
 int f110_set_beam_tables(f110_sim *h, const double *h_scan_angles, const double *h_cosines,
                          const double *h_side_distances, int32_t num_beams);
+/* Extension (domain randomisation): a different track per env.  The map of
+ * f110_set_map_* is slot 0; f110_add_map_* registers further maps (same arguments, same exact-EDT
+ * pipeline) and returns their slot; f110_set_env_maps assigns a slot to every env (h_env_map
+ * [num_envs]; NULL = everybody back on slot 0).  Needs map_layout = F110_MAP_PADDED_F64 with every
+ * map fitting it and num_beams below the dedupe threshold.  Changing slot 0 or adding maps takes
+ * effect at the next f110_set_env_maps.  Unit entry points (f110_scan_batch ...) keep using slot 0. */
+int f110_add_map_image(f110_sim *h, const uint8_t *h_img, int32_t height, int32_t width,
+                       double resolution, double origin_x, double origin_y, double origin_yaw,
+                       int32_t *slot);
+int f110_add_map_dt(f110_sim *h, const double *h_dt, int32_t height, int32_t width,
+                    double resolution, double origin_x, double origin_y, double origin_c,
+                    double origin_s, int32_t *slot);
+int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map);
+
 /* Simulator.update_params base_classes.py:514-534 (agent_idx<0: all slots) */
 int f110_set_params(f110_sim *h, int32_t agent_idx, const double *h_params18);
 /* scan noise, laser_models.py:450-452 with base_classes.py:204: row k is added to every

@@ -789,3 +789,81 @@ def test_example_waypoint_follow_reproduces_the_reference_run():
     assert res["steps"] == g["actions"].shape[0]
     assert res["lap_count"] == g["traj"][-1, 6] == 2.0
     assert abs(res["lap_time"] - g["traj"][-1, 5]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_per_env_maps_equal_single_map_sims(amd, orc):
+    """f110_set_env_maps (a different track per env): every env group of a 3-map batch evolves bit
+    for bit like a single-map simulator of that track, and like the oracle"""
+    names = ["example_map", "berlin", "skirk"]
+    maps = [load_map_image(n) for n in names]
+    E, A, T = 30, 2, 60
+    env_map = np.arange(E) % 3
+    rng = np.random.default_rng(8)
+    w = raceline()
+    poses = np.zeros((E, A, 3))
+    for e in range(E):
+        if env_map[e] == 0:
+            k = rng.integers(0, w.shape[0]); base = np.array([w[k, 1], w[k, 2], w[k, 3] + np.pi / 2])
+        else:
+            base = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(0, 6.28)])
+        for a in range(A):
+            poses[e, a] = base + np.array([rng.uniform(-0.7, 0.7), rng.uniform(-0.7, 0.7), rng.uniform(-0.4, 0.4)])
+    poses = poses.reshape(E * A, 3)
+    noise = np.random.default_rng(4).normal(0., 0.01, size=(T + 2, 1080))
+    multi = amd.BatchSim(num_envs=E, num_agents=A)
+    multi.set_map_image(*maps[0])
+    assert multi.add_map_image(*maps[1]) == 1 and multi.add_map_image(*maps[2]) == 2
+    multi.set_env_maps(env_map)
+    multi.set_noise_table(noise)
+    multi.reset(poses)
+    singles, refs, sel = [], [], []
+    for m in range(3):
+        idx = np.where(env_map == m)[0]
+        ag = (idx[:, None] * A + np.arange(A)[None, :]).reshape(-1)
+        s = amd.BatchSim(num_envs=len(idx), num_agents=A)
+        s.set_map_image(*maps[m]); s.set_noise_table(noise); s.reset(poses[ag])
+        dt, res, origin = oracle_map_dt(names[m])
+        r = orc.SimOracle(len(idx), A); r.set_map_dt(dt, res, origin); r.set_noise(noise); r.reset(poses[ag])
+        singles.append(s); refs.append(r); sel.append(ag)
+    for t in range(T):
+        act = np.stack([rng.uniform(-0.4, 0.4, E * A), rng.uniform(0.5, 8.0, E * A)], axis=1)
+        multi.step(act)
+        for s, r, ag in zip(singles, refs, sel):
+            s.step(act[ag]); r.step(act[ag])
+        if t % 6 == 5 or t == T - 1:
+            o = multi.get("scans", "state", "collisions", "in_collision", "collision_idx")
+            for s, r, ag in zip(singles, refs, sel):
+                q = s.get("scans", "state", "collisions", "in_collision", "collision_idx")
+                for key in q:
+                    assert np.array_equal(o[key][ag], q[key]), (t, key)
+                assert np.array_equal(o["collisions"][ag], r.collisions) and np.array_equal(o["in_collision"][ag], r.in_collision)
+                assert rel_err(o["state"][ag], r.state) < 1e-9 and rel_err(o["scans"][ag], r.scans) < 1e-9
+    # back to one map for everybody
+    multi.set_env_maps(None)
+    with pytest.raises(Exception):
+        multi.set_env_maps(np.full(E, 7))
+    for s in singles + [multi]:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_tracks_per_env(amd):
+    """F110VecEnv(extra_maps=..., env_map=...): envs on berlin / skirk see those tracks' scans"""
+    from _util import MAPS
+    import os
+    E = 6
+    env = amd.F110VecEnv(E, map=os.path.join(MAPS, "berlin"), map_ext=".png", num_agents=1, scan_noise_std=0.0,
+                         extra_maps=[(os.path.join(MAPS, "skirk.yaml"), ".png")], env_map=[0, 1, 0, 1, 0, 1])
+    poses = np.tile(np.array([[[0.0, 0.0, 1.0]]]), (E, 1, 1))
+    obs, _, _, _ = env.reset(poses)
+    singles = {}
+    for name in ("berlin", "skirk"):
+        s = amd.ScanSimulator2D(1080, 4.7)
+        s.set_map(os.path.join(MAPS, name + ".yaml"), ".png")
+        singles[name] = s
+    # reset() advances one zero-action step from rest: the pose is unchanged
+    for e in range(E):
+        ref = singles["berlin" if e % 2 == 0 else "skirk"].scan(np.array([0.0, 0.0, 1.0]), None)
+        assert np.array_equal(obs["scans"][e, 0], ref), e
+    assert not np.array_equal(obs["scans"][0, 0], obs["scans"][1, 0])
