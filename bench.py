@@ -383,7 +383,7 @@ def main():
             ach = scan_bytes / (res["scan_ms_avg"] * 1e-3) / 1e9
             line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": ach / HBM_PEAK_GBS, "traffic": load_pmc_traffic(args, args.agents),
-                                "kernel": "k_scan_rays", "kernel_ms_avg": res["scan_ms_avg"],
+                                "kernel": "k_scan_rays_agent" if (args.layout == 3 and args.beams < 1498 and (-args.beams) % 64 * 100 <= 3 * args.beams) else "k_scan_rays", "kernel_ms_avg": res["scan_ms_avg"],
                                 "integrate_collide_ms_avg": res["dyn_ms_avg"], "finalize_ms_avg": res["fin_ms_avg"],
                                 "launches_timed": res["n_prof"],
                                 "alg_bytes_per_launch": scan_bytes, "lookups_per_ray": lbar,

@@ -35,7 +35,7 @@ def main():
     for name in ("bench_default.log", "box.txt"):
         if os.path.isfile(os.path.join(SRC, name)):
             shutil.copyfile(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (tag, name.replace(".log", ".json") if name.endswith(".log") else name)))
-    scan = merged.get("k_scan_rays", {}).get("mean_per_dispatch", {})
+    scan = (merged.get("k_scan_rays_agent") or merged.get("k_scan_rays") or {}).get("mean_per_dispatch", {})
     if "FETCH_SIZE" in scan and "WRITE_SIZE" in scan:
         rec_path = os.path.join(DST, "pmc_scan.json")
         rec = json.load(open(rec_path)) if os.path.isfile(rec_path) else {}
