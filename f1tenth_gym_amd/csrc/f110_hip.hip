@@ -1103,7 +1103,16 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     if (prof) HIPCHK(h, hipEventRecord(e2, h->stream));
     if (multi) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_collided, 0));
     if (multi)
-        hipLaunchKernelGGL(k_finalize, dim3((N + kFinalizeAgents - 1) / kFinalizeAgents), dim3(64 * kFinalizeAgents), 0, h->stream, h->dev, h->k.num_beams);
+    {
+        static const int forced = std::getenv("F110_FINALIZE_LANES") ? std::atoi(std::getenv("F110_FINALIZE_LANES")) : 0;
+        const int lanes = forced ? forced : (N >= 32768 ? 16 : 64);
+        if (lanes == 16)
+            hipLaunchKernelGGL(k_finalize<16>, dim3((N + 15) / 16), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
+        else if (lanes == 32)
+            hipLaunchKernelGGL(k_finalize<32>, dim3((N + 7) / 8), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
+        else
+            hipLaunchKernelGGL(k_finalize<64>, dim3((N + 3) / 4), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
+    }
     else
         hipLaunchKernelGGL(k_finalize_solo, grid1d(N, 256), dim3(256), 0, h->stream, h->dev);
     if (prof) HIPCHK(h, hipEventRecord(e3, h->stream));

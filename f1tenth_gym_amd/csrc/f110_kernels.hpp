@@ -514,18 +514,20 @@ __device__ __forceinline__ void reseat_agent(const AgentArrays &a, int i, bool c
 }
 
 // ---- K3: finalize ---------------------------------------------------------------------------
-// One wave per agent, kFinalizeAgents agents per workgroup (the kernel is a swarm of short waves:
-// with one-wave workgroups it was bound by the workgroup dispatch rate, not by its work).
+// kFinalizeLanes lanes per agent.  A typical opponent window is ~36 beams and what one agent costs
+// is a chain of memory round trips and float64 latencies, not throughput: with many agents, 16
+// lanes each (four agents per wave) means a quarter of the waves for the same chains; with few
+// agents the whole wave per agent (one pass over the window) is the shorter chain.
 // RaceCar.check_ttc's side effects (:246-252), Simulator's collision OR (:588-589), then
 // RaceCar.ray_cast_agents (:206-227): opponents from the :574 snapshot, ego pose = live state
 // (heading already zeroed on a wall hit), box = the ego's own params.
-constexpr int kFinalizeAgents = 4;
-
-__global__ void __launch_bounds__(64 * kFinalizeAgents) k_finalize(AgentArrays a, int32_t B)
+template <int kFinalizeLanes>
+__global__ void __launch_bounds__(256) k_finalize(AgentArrays a, int32_t B)
 {
-    const int i = blockIdx.x * kFinalizeAgents + (threadIdx.x >> 6), tid = threadIdx.x & 63;
+    constexpr int kFinalizeAgents = 256 / kFinalizeLanes;   // per 256-thread workgroup
+    const int i = blockIdx.x * kFinalizeAgents + (int)(threadIdx.x / kFinalizeLanes), tid = threadIdx.x & (kFinalizeLanes - 1);
     const int N = a.n_agents_total, A = a.agents_per_env;
-    if (i >= N) return;  // whole wave
+    if (i >= N) return;
     // everything the wave may need is requested up front (one round trip), not behind the flag
     const int wall = a.in_collision[i];
     const double ex = a.state[i], ey = a.state[(size_t)N + i];
@@ -552,7 +554,7 @@ __global__ void __launch_bounds__(64 * kFinalizeAgents) k_finalize(AgentArrays a
         for (int c = 0; c < 8; ++c) v[c] = ov[c];
         const int lo = wall ? w4.z : w4.x, hi = wall ? w4.w : w4.y;
         if (hi < lo) continue;  // nothing of this opponent can be hit
-        for (int b = lo + tid; b <= hi; b += 64) {
+        for (int b = lo + tid; b <= hi; b += kFinalizeLanes) {
             const double bt = eth + a.scan_angles[b];
             const double r0 = sc[b];
             double v3x, v3y;
