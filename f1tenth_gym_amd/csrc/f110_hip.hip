@@ -1044,7 +1044,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     if (multi) {
         HIPCHK(h, hipEventRecord(h->ev_integrated, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_integrated, 0));
-        hipLaunchKernelGGL(k_collide, grid1d(N, 256), dim3(256), 0, h->side_stream, h->dev, h->k.num_beams);
+        hipLaunchKernelGGL(k_collide, grid1d(N, 64), dim3(64), 0, h->side_stream, h->dev, h->k.num_beams);
         HIPCHK(h, hipEventRecord(h->ev_collided, h->side_stream));
     }
     if (prof) HIPCHK(h, hipEventRecord(e1, h->stream));
