@@ -39,9 +39,31 @@ def counters(d, out, kernel_filter=None):
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 
 
+def gaps(d, out):
+    """idle time between consecutive kernels of the step chain (integrate -> scan -> finalize -> integrate)
+    from a --kernel-trace CSV: where the step's time goes besides the kernels themselves"""
+    files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    rows = []
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
+    rows.sort()
+    chain = [r for r in rows if r[2].startswith(("k_integrate", "k_scan_rays", "k_finalize", "k_expand", "k_reset_collided"))]
+    acc = defaultdict(list)
+    for a, b in zip(chain[:-1], chain[1:]):
+        acc["%s -> %s" % (a[2][:18], b[2][:18])].append(b[0] - a[1])
+    lines = ["%-44s %8s %10s %10s" % ("gap", "count", "mean(us)", "median(us)")]
+    for k, v in sorted(acc.items()):
+        v = sorted(v)
+        lines.append("%-44s %8d %10.2f %10.2f" % (k, len(v), sum(v) / len(v) / 1e3, v[len(v) // 2] / 1e3))
+    open(out, "w").write("\n".join(lines) + "\n")
+
+
 if __name__ == "__main__":
     mode, d, out = sys.argv[1:4]
     if mode == "stats":
         kernel_stats(d, out)
+    elif mode == "gaps":
+        gaps(d, out)
     else:
         counters(d, out, sys.argv[4] if len(sys.argv) > 4 else None)
