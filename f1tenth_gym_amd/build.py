@@ -33,7 +33,8 @@ def build(force=False, verbose=False):
     """Build libf110_hip.so if missing or older than its sources.  Returns the path."""
     if not force and not is_stale():
         return LIB
-    cmd = [find_hipcc()] + HIPCC_FLAGS + [SRC, "-o", LIB + ".tmp"]
+    extra = os.environ.get("F110_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
+    cmd = [find_hipcc()] + HIPCC_FLAGS + extra + [SRC, "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
