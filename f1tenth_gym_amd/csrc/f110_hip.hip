@@ -1114,8 +1114,10 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     if (multi)
     {
         static const int forced = std::getenv("F110_FINALIZE_LANES") ? std::atoi(std::getenv("F110_FINALIZE_LANES")) : 0;
-        const int lanes = forced ? forced : (N >= 32768 ? 16 : 64);
-        if (lanes == 16)
+        const int lanes = forced ? forced : (N >= 131072 ? 8 : (N >= 32768 ? 16 : 64));
+        if (lanes == 8)
+            hipLaunchKernelGGL(k_finalize<8>, dim3((N + 31) / 32), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
+        else if (lanes == 16)
             hipLaunchKernelGGL(k_finalize<16>, dim3((N + 15) / 16), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
         else if (lanes == 32)
             hipLaunchKernelGGL(k_finalize<32>, dim3((N + 7) / 8), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
