@@ -293,6 +293,7 @@ __device__ __forceinline__ LaneHdr load_lane_hdr(const RayHdr *hdr, uint32_t p)
 struct RayJob;
 __device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_t p, int b, uint32_t ray, double r,
                                             int row, double vel);
+__device__ __forceinline__ void finish_beam_with(const RayJob &j, uint32_t p, int b, uint32_t ray, double r, double vel);
 
 // One ray from its (shared) first sample d0 on.  path: 0 fixed-point march, 1 fixed-point march
 // given up and re-marched exactly, 2 exact arithmetic throughout.
@@ -449,6 +450,8 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
             km.pad_row_bytes = uniform_i32((int)m0->pad_row_bytes);
             km.pad_max_samples = uniform_i32(m0->pad_max_samples);
         }
+        // the beam's noise sample is requested before the march so that its latency hides under it
+        const double nz = row >= 0 ? j.noise[(size_t)row * B + b] : 0.0;
         const double2 cs = k.cs[beam_dir_index(k, start, b)];
         int hr = -1, hc = -1, nl;
         double r = 0.;
@@ -460,18 +463,24 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
             exact = !march_padded<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl);
         }
         if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
-        finish_beam(j, B, p, b, p * B + (uint32_t)b, r, row, vel);
+        finish_beam_with(j, p, b, p * B + (uint32_t)b, row >= 0 ? r + nz : r, vel);
     }
+}
+
+// iTTC + store for one beam whose noise sample has been added already
+__device__ __forceinline__ void finish_beam_with(const RayJob &j, uint32_t p, int b, uint32_t ray, double r, double vel)
+{
+    if (vel != 0.0 && !(r > j.ttc_side_max + j.ttc_k * fabs(vel)) &&
+        ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh))
+        j.wall_flag[p] = 1;
+    j.ranges[ray] = r;
 }
 
 __device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_t p, int b, uint32_t ray, double r,
                                             int row, double vel)
 {
     if (row >= 0) r += j.noise[(size_t)row * B + b];
-    if (vel != 0.0 && !(r > j.ttc_side_max + j.ttc_k * fabs(vel)) &&
-        ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh))
-        j.wall_flag[p] = 1;
-    j.ranges[ray] = r;
+    finish_beam_with(j, p, b, ray, r, vel);
 }
 
 // ---- K2b: beam expansion of the dedupe pass ---------------------------------------------------

@@ -68,7 +68,7 @@ int main()
         hipMemset(d_tbl, 1, bytes);
         printf("table %u KiB: cycles per wave-level load (lane stride bytes -> distinct 128 B lines)\n", bytes >> 10);
         printf("%10s %8s %8s %8s %8s\n", "stride", "lines", "u8", "u32", "u64");
-        for (uint32_t ls : {0u, 1u, 8u, 16u, 32u, 64u, 128u, 136u, 520u}) {
+        for (uint32_t ls : {0u, 1u, 2u, 4u, 8u, 16u, 32u, 64u, 128u, 136u, 520u}) {
             const uint32_t span = ls * 63u;
             const uint32_t lines = ls >= 128 ? 64 : span / 128 + 1;
             const double c1 = run<uint8_t>(d_tbl, bytes, ls, d_out, cus, mhz);
