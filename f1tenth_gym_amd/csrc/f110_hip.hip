@@ -1114,7 +1114,11 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     if (multi)
     {
         static const int forced = std::getenv("F110_FINALIZE_LANES") ? std::atoi(std::getenv("F110_FINALIZE_LANES")) : 0;
-        const int lanes = forced ? forced : (N >= 131072 ? 8 : (N >= 32768 ? 16 : 64));
+        // few lanes per agent pay off when opponent windows are short (~36 beams); cars that have
+        // crashed into each other see windows of up to all beams, so the narrow forms are used only
+        // when finished envs are re-seated inside the step (f110_set_auto_reseat)
+        const bool narrow = h->dev.reseat_poses != nullptr;
+        const int lanes = forced ? forced : (narrow && N >= 131072 ? 8 : (narrow && N >= 32768 ? 16 : 64));
         if (lanes == 8)
             hipLaunchKernelGGL(k_finalize<8>, dim3((N + 31) / 32), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
         else if (lanes == 16)
