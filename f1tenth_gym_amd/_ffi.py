@@ -81,6 +81,7 @@ PROTOTYPES = {
     "f110_add_map_image": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _i32p]),
     "f110_add_map_dt": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i32p]),
     "f110_set_env_maps": (C.c_int, [C.c_void_p, _i32p]),
+    "f110_set_params_batch": (C.c_int, [C.c_void_p, _dp]),
     "f110_reset_collided_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "f110_set_auto_reseat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "f110_episode_init": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -227,6 +227,19 @@ class BatchSim(object):
         pv = _ffi.params_vector(params)
         check(_ffi.lib().f110_set_params(self._h, int(agent_idx), dptr(pv)), self._h, IndexError)
 
+    def set_params_batch(self, params):
+        """one vehicle parameter set per agent: a list of N dicts or an [N][18] array in PARAM_KEYS
+        order; None returns to the per-slot sets of set_params"""
+        if params is None:
+            check(_ffi.lib().f110_set_params_batch(self._h, None), self._h)
+            return
+        if isinstance(params, (list, tuple)) and len(params) and isinstance(params[0], dict):
+            params = np.stack([_ffi.params_vector(p) for p in params])
+        pv = as_f64(params)
+        if pv.shape != (self.N, len(_ffi.PARAM_KEYS)):
+            raise ValueError("per-agent parameters must be [num_envs*num_agents][%d]" % len(_ffi.PARAM_KEYS))
+        check(_ffi.lib().f110_set_params_batch(self._h, dptr(pv)), self._h)
+
     def set_noise_table(self, noise):
         if noise is None:
             check(_ffi.lib().f110_set_noise_table(self._h, None, 0, self.B), self._h)

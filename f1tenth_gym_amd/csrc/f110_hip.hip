@@ -41,6 +41,7 @@ struct f110_sim {
     uint32_t dir_magic = 0, dir_shift = 0;
     double *d_lut = nullptr;
     int scan_block = 64;
+    double *d_params_all = nullptr;   // [N][18] when f110_set_params_batch is active
     double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
     // a different track per env: slot 0 is the map of f110_set_map_*, further slots come from
     // f110_add_map_*; f110_set_env_maps assigns them and builds the device tables
@@ -427,7 +428,7 @@ void f110_destroy(f110_sim *h)
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
-                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_dt_pad, h->d_codes, h->d_dir_ranges, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k};
+                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_dt_pad, h->d_codes, h->d_dir_ranges, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k, h->d_params_all};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ms : h->extra_maps) {
@@ -761,9 +762,28 @@ int f110_set_beam_tables(f110_sim *h, const double *sa, const double *co, const 
     return F110_OK;
 }
 
+int f110_set_params_batch(f110_sim *h, const double *h_params)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (!h_params) {   // back to one parameter set per agent slot
+        h->dev.params = h->d_params;
+        h->dev.params_per_agent = 0;
+        return F110_OK;
+    }
+    const size_t n = (size_t)h->N * NPARAMS;
+    if (!h->d_params_all) TRY(dmalloc(h, &h->d_params_all, n));
+    HIPCHK(h, hipMemcpyAsync(h->d_params_all, h_params, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->dev.params = h->d_params_all;
+    h->dev.params_per_agent = 1;
+    return F110_OK;
+}
+
 int f110_set_params(f110_sim *h, int32_t agent_idx, const double *p)
 {
     if (!h || !p) return fail(h, F110_ERR_INVALID, "null argument");
+    if (h->dev.params_per_agent) return fail(h, F110_ERR_STATE, "per-agent parameters are active (f110_set_params_batch); clear them first");
     const int A = h->cfg.num_agents;
     if (agent_idx >= A) return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
     for (int a = 0; a < A; ++a)

@@ -65,7 +65,8 @@ struct AgentArrays {
     int32_t *opp_window;     // [N][A][4] beam range each opponent can occupy: {lo, hi} for the live
                              //           heading and {lo0, hi0} for heading 0 (after a wall hit)
     double *opp_verts;       // [N][A][8] the opponent's box drawn with the ego's length/width
-    const double *params;    // [A][18]
+    const double *params;    // [A][18] per agent slot, or [N][18] per agent (params_per_agent)
+    int32_t params_per_agent, pad_params;
     const double *noise;     // [noise_rows][B] or nullptr
     const double *scan_angles, *beam_cos, *side_dist;  // [B]
     int32_t noise_rows, integrator;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, c
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = a.n_agents_total;
     if (i >= N) return;
-    const VehicleParams vp = load_params(a.params + (size_t)(i % a.agents_per_env) * NPARAMS);
+    const VehicleParams vp = load_params(a.params + (size_t)(a.params_per_agent ? i : i % a.agents_per_env) * NPARAMS);
     double st[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) st[c] = a.state[(size_t)c * N + i];
@@ -167,8 +168,9 @@ __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
     // bodies whose centres are further apart than a box diagonal (+1 mm) cannot overlap
     const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
     // RaceCar.ray_cast_agents draws the opponents with the EGO's length/width (:223)
-    const double blen = a.params[(size_t)me * NPARAMS + P_LENGTH];
-    const double bwid = a.params[(size_t)me * NPARAMS + P_WIDTH];
+    const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
+    const double blen = a.params[prow + P_LENGTH];
+    const double bwid = a.params[prow + P_WIDTH];
     const double disc_r = 0.5 * sqrt(blen * blen + bwid * bwid);
     bool hit = false;
     int partner = -1;

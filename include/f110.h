@@ -125,6 +125,11 @@ int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map);
 
 /* Simulator.update_params base_classes.py:514-534 (agent_idx<0: all slots) */
 int f110_set_params(f110_sim *h, int32_t agent_idx, const double *h_params18);
+/* Extension (domain randomisation over vehicle dynamics): one parameter set per AGENT, h_params
+ * [N][18] in the order of f110_config.params; NULL returns to the per-slot sets of f110_set_params
+ * (which is refused while this is active).  As in the reference, the collision boxes keep the
+ * constructor's length/width (base_classes.py:549) and the iTTC tables those of the first car. */
+int f110_set_params_batch(f110_sim *h, const double *h_params);
 /* scan noise, laser_models.py:450-452 with base_classes.py:204: row k is added to every
  * agent's scan on its k-th step after reset (rows wrap modulo n_rows).  n_rows=0: no noise. */
 int f110_set_noise_table(f110_sim *h, const double *h_noise, int32_t n_rows, int32_t num_beams);

@@ -908,3 +908,52 @@ def test_step_on_rotated_non_pow2_map_vs_oracle(amd, orc, layout):
             assert np.array_equal(o["collision_idx"], ref.collision_idx)
             assert rel_err(o["state"], ref.state) < 1e-9 and rel_err(o["scans"], ref.scans) < 1e-9
     sim.close()
+
+
+@pytest.mark.gpu
+def test_per_agent_vehicle_params(amd, orc):
+    """f110_set_params_batch (a parameter set per agent, for domain randomisation): every env evolves
+    like a single-env simulator holding that env's sets in its agent slots, and like the oracle"""
+    E, A, T = 5, 2, 80
+    img, res, origin = load_map_image("example_map")
+    dt, _, _ = oracle_map_dt("example_map")
+    rng = np.random.default_rng(12)
+    sets = []
+    for i in range(E * A):
+        p = dict(amd.DEFAULT_PARAMS)
+        p.update({'mu': rng.uniform(0.6, 1.2), 'm': rng.uniform(3.0, 4.2), 'lf': rng.uniform(0.147, 0.17), 'C_Sf': rng.uniform(4.0, 5.5),
+                  'a_max': rng.uniform(7.0, 10.0), 'v_max': rng.uniform(12.0, 22.0), 'length': rng.uniform(0.5, 0.62), 'width': rng.uniform(0.27, 0.34)})
+        sets.append(p)
+    poses = bench_start_poses(E, A) + np.stack([rng.uniform(-0.3, 0.3, E * A), rng.uniform(-0.3, 0.3, E * A), rng.uniform(-0.3, 0.3, E * A)], axis=1)
+    noise = np.random.default_rng(6).normal(0., 0.01, size=(T + 2, 1080))
+    batch = amd.BatchSim(num_envs=E, num_agents=A)
+    batch.set_map_image(img, res, origin); batch.set_noise_table(noise)
+    batch.set_params_batch(sets)
+    with pytest.raises(Exception):
+        batch.set_params(sets[0], 0)
+    batch.reset(poses)
+    singles, refs = [], []
+    for e in range(E):
+        s = amd.BatchSim(num_envs=1, num_agents=A); s.set_map_image(img, res, origin); s.set_noise_table(noise)
+        r = orc.SimOracle(1, A); r.set_map_dt(dt, res, origin); r.set_noise(noise)
+        for a in range(A):
+            s.set_params(sets[e * A + a], a); r.set_params(sets[e * A + a], a)
+        s.reset(poses[e * A:(e + 1) * A]); r.reset(poses[e * A:(e + 1) * A])
+        singles.append(s); refs.append(r)
+    for t in range(T):
+        act = np.stack([rng.uniform(-0.4, 0.4, E * A), rng.uniform(0.5, 9.0, E * A)], axis=1)
+        batch.step(act)
+        for e in range(E):
+            singles[e].step(act[e * A:(e + 1) * A]); refs[e].step(act[e * A:(e + 1) * A])
+        if t % 8 == 7 or t == T - 1:
+            o = batch.get("scans", "state", "collisions", "in_collision", "collision_idx")
+            for e in range(E):
+                q = singles[e].get("scans", "state", "collisions", "in_collision", "collision_idx")
+                for key in q:
+                    assert np.array_equal(o[key][e * A:(e + 1) * A], q[key]), (t, e, key)
+                assert np.array_equal(o["collisions"][e * A:(e + 1) * A], refs[e].collisions)
+                assert rel_err(o["state"][e * A:(e + 1) * A], refs[e].state) < 1e-9
+                assert rel_err(o["scans"][e * A:(e + 1) * A], refs[e].scans) < 1e-9
+    batch.set_params_batch(None)
+    for s in singles + [batch]:
+        s.close()
