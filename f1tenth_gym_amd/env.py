@@ -215,6 +215,11 @@ class F110VecEnv(object):
             self.sim.batch.episode_init(self.ego_idx)
             self._d_actions = self.sim.batch.device_array((self.num_envs * self.num_agents, 2))
 
+    def update_params_batch(self, params):
+        """a vehicle parameter set per agent of every env ([E*A] dicts or [E*A][18] array; None: back
+        to the per-slot sets of update_params)"""
+        self.sim.batch.set_params_batch(params)
+
     def set_env_maps(self, env_map):
         """env_map [num_envs]: which registered track each env runs on (None: all on slot 0)"""
         self.sim.batch.set_env_maps(env_map)
