@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 from f1tenth_gym_amd import F110Env, Integrator, PurePursuitPlanner  # noqa: E402
 
 
-def load_conf(path=os.path.join(HERE, "config_example_map.yaml")):
+def load_conf(path=os.path.join(HERE, "run_example_map.yaml")):
     with open(path) as f:
         conf = Namespace(**yaml.safe_load(f))
     for key in ("map_path", "wpt_path"):     # paths in the config are relative to the config file

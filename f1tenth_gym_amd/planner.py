@@ -1,7 +1,7 @@
 """The reference's example policy (examples/waypoint_follow.py:145-217) on the device.
 
 `PurePursuitPlanner(conf, wb)` takes the same `conf` namespace the example builds from
-config_example_map.yaml (wpt_path, wpt_delim, wpt_rowskip, wpt_xind, wpt_yind, wpt_vind) and
+the example's yaml (wpt_path, wpt_delim, wpt_rowskip, wpt_xind, wpt_yind, wpt_vind) and
 `.plan(pose_x, pose_y, pose_theta, lookahead_distance, vgain)` returns the same `(speed, steer)`
 pair.  `.plan_batch` plans for many poses in one launch and `.plan_device` plans for every agent of
 a `BatchSim` straight from its device-resident state into a device action buffer, so a closed loop
