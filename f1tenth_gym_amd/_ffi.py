@@ -26,13 +26,14 @@ _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
 _u8p = C.POINTER(C.c_uint8)
 _u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
 
 
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("num_envs", C.c_int32), ("num_agents", C.c_int32),
                 ("num_beams", C.c_int32), ("theta_dis", C.c_int32), ("integrator", C.c_int32),
                 ("device_id", C.c_int32), ("map_layout", C.c_int32), ("scan_block", C.c_int32),
-                ("scan_tasks_per_wave", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32), ("fov", C.c_double), ("eps", C.c_double),
+                ("scan_tasks_per_wave", C.c_int32), ("step_groups", C.c_int32), ("reserved1", C.c_int32), ("fov", C.c_double), ("eps", C.c_double),
                 ("max_range", C.c_double), ("time_step", C.c_double), ("lidar_dist", C.c_double),
                 ("ttc_thresh", C.c_double), ("params", C.c_double * NPARAMS)]
 
@@ -76,6 +77,11 @@ PROTOTYPES = {
     "f110_set_beam_tables": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int32]),
     "f110_set_params": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "f110_set_noise_table": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32]),
+    "f110_set_noise_rng": (C.c_int, [C.c_void_p, _u64p, C.c_int32, C.c_double, C.c_int32]),
+    "f110_pcg64_seed": (C.c_int, [C.c_uint64, _u64p]),
+    "f110_noise_prepare": (C.c_int, [C.c_void_p, C.c_int32]),
+    "f110_noise_rows_batch": (C.c_int, [C.c_void_p, _u64p, C.c_double, C.c_int32, C.c_int32, _dp, _u64p]),
+    "f110_scan_lookup_count": (C.c_int, [C.c_void_p, C.c_int32, _i64p]),
     "f110_reset": (C.c_int, [C.c_void_p, _dp, _u8p]),
     "f110_reset_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "f110_add_map_image": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _i32p]),

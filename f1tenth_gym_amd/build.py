@@ -10,6 +10,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG_DIR, "csrc", "f110_hip.hip")
 DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "f110_math.hpp"), os.path.join(PKG_DIR, "csrc", "f110_kernels.hpp"),
+        os.path.join(PKG_DIR, "csrc", "f110_rng.hpp"), os.path.join(PKG_DIR, "csrc", "f110_ziggurat_tables.hpp"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "f110.h")]
 LIB = os.path.join(PKG_DIR, "libf110_hip.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]

@@ -110,7 +110,7 @@ class BatchSim(object):
     def __init__(self, params=None, num_envs=1, num_agents=2, num_beams=1080, fov=4.7, eps=0.0001,
                  theta_dis=2000, max_range=30.0, time_step=0.01, integrator=_ffi.INTEGRATOR_RK4,
                  lidar_dist=0.0, ttc_thresh=0.005, device_id=0, map_layout=_ffi.MAP_DEFAULT,
-                 scan_block=0, scan_tasks_per_wave=0):
+                 scan_block=0, scan_tasks_per_wave=0, step_groups=0):
         self._h = None
         L = _ffi.lib()
         self.params = dict(DEFAULT_PARAMS if params is None else params)
@@ -124,6 +124,7 @@ class BatchSim(object):
         cfg.theta_dis, cfg.integrator, cfg.device_id = self.theta_dis, int(integrator), self.device_id
         cfg.map_layout, cfg.scan_block = int(map_layout), int(scan_block)
         cfg.scan_tasks_per_wave = int(scan_tasks_per_wave)
+        cfg.step_groups = int(step_groups)
         cfg.fov, cfg.eps, cfg.max_range = float(fov), float(eps), float(max_range)
         cfg.time_step, cfg.lidar_dist, cfg.ttc_thresh = float(time_step), float(lidar_dist), float(ttc_thresh)
         pv = _ffi.params_vector(self.params)
@@ -250,6 +251,62 @@ class BatchSim(object):
             raise ValueError("noise table must be [rows][num_beams]")
         check(_ffi.lib().f110_set_noise_table(self._h, dptr(noise), noise.shape[0], self.B), self._h)
         self.noise_rows = noise.shape[0]
+
+    # ---- scan noise generated on the device: np.random.default_rng(seed).normal(0, std, B) per scan
+    @staticmethod
+    def pcg64_state(seed):
+        """(state.hi, state.lo, inc.hi, inc.lo) of np.random.PCG64(seed), computed by the library's
+        restatement of SeedSequence + pcg64_set_seed (seed: int in [0, 2^64))"""
+        out = (C.c_uint64 * 4)()
+        check(_ffi.lib().f110_pcg64_seed(C.c_uint64(int(seed)), out), None)
+        return np.array(list(out), dtype=np.uint64)
+
+    @staticmethod
+    def _state_words(seed):
+        """any seed NumPy accepts (None, int of any size, sequence, SeedSequence) -> the 4 state words"""
+        if isinstance(seed, (int, np.integer)) and 0 <= int(seed) < 2 ** 64:
+            return BatchSim.pcg64_state(seed)
+        st = np.random.PCG64(seed).state['state']
+        m = (1 << 64) - 1
+        return np.array([st['state'] >> 64, st['state'] & m, st['inc'] >> 64, st['inc'] & m], dtype=np.uint64)
+
+    def set_noise_rng(self, seed, std_dev=0.01, per_agent_seeds=None, cache_rows=0):
+        """the reference's scan noise (laser_models.py:450-452, base_classes.py:204) drawn on the
+        device, bit-identical to NumPy's stream.  seed: every agent's stream (as in the reference);
+        per_agent_seeds [N]: a stream per agent instead (extension).  seed=None with no
+        per_agent_seeds switches the noise off."""
+        L = _ffi.lib()
+        if per_agent_seeds is not None:
+            seeds = list(per_agent_seeds)
+            if len(seeds) != self.N:
+                raise ValueError("per_agent_seeds must have num_envs*num_agents=%d entries" % self.N)
+            words = np.ascontiguousarray(np.stack([self._state_words(s) for s in seeds]), dtype=np.uint64)
+            check(L.f110_set_noise_rng(self._h, words.ctypes.data_as(_ffi._u64p), 1, float(std_dev), 0), self._h)
+        elif seed is None:
+            check(L.f110_set_noise_rng(self._h, None, 0, 0.0, 0), self._h)
+        else:
+            words = np.ascontiguousarray(self._state_words(seed), dtype=np.uint64)
+            check(L.f110_set_noise_rng(self._h, words.ctypes.data_as(_ffi._u64p), 0, float(std_dev), int(cache_rows)), self._h)
+        self.noise_rows = 0
+
+    def noise_prepare(self, rows):
+        check(_ffi.lib().f110_noise_prepare(self._h, int(rows)), self._h)
+
+    def noise_rows_batch(self, seed, rows, num_beams=None, std_dev=0.01):
+        """unit entry point: `rows` consecutive rng.normal(0, std_dev, num_beams) draws of
+        default_rng(seed) -> (array [rows][num_beams], generator state after them as a Python int)"""
+        B = self.B if num_beams is None else int(num_beams)
+        words = np.ascontiguousarray(self._state_words(seed), dtype=np.uint64)
+        out = np.empty((int(rows), B))
+        st = (C.c_uint64 * 2)()
+        check(_ffi.lib().f110_noise_rows_batch(self._h, words.ctypes.data_as(_ffi._u64p), float(std_dev), int(rows), B, dptr(out), st), self._h)
+        return out, (int(st[0]) << 64) | int(st[1])
+
+    def scan_lookup_count(self, enable=None, read=True):
+        """measurement aid: table lookups of every ray the step's scan kernels marched since the last read"""
+        v = C.c_int64(0)
+        check(_ffi.lib().f110_scan_lookup_count(self._h, -1 if enable is None else int(bool(enable)), C.byref(v) if read else None), self._h)
+        return int(v.value)
 
     # ------------------------------------------------------------------ reset / step
     def reset(self, poses, env_mask=None):

@@ -61,6 +61,24 @@ struct f110_sim {
     double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_dt_pad = nullptr, *d_actions = nullptr, *d_poses = nullptr;
     double2 *d_cs = nullptr;
     uint8_t *d_mask = nullptr;
+    // env groups: the step of G > 1 independent env blocks runs on G streams of its own (no event
+    // between the kernels of a group, no dependency between groups; see f110_step_device)
+    int groups = 1;
+    std::vector<hipStream_t> gstreams;
+    std::vector<hipEvent_t> gevents;
+    hipEvent_t ev_main = nullptr;
+    bool groups_busy = false;   // group streams hold work the main stream has not been joined with
+    bool main_dirty = true;     // the main stream holds work the group streams have not waited for
+    // device RNG for the scan noise (f110_set_noise_rng)
+    NoiseGen noise_gen{};
+    uint64_t *d_zig_k = nullptr;
+    double *d_zig_w = nullptr, *d_zig_f = nullptr;
+    U128 *d_jump = nullptr;          // [2][65]
+    U128 *d_rng_state = nullptr, *d_rng_seed = nullptr, *d_rng_rowstate = nullptr;
+    int noise_rows_ready = 0;        // rows of the row cache generated so far
+    long long noise_ub = 0;          // upper bound of any agent's step_count (steps since the last full reset)
+    unsigned long long *d_lookups = nullptr;  // f110_scan_lookup_count
+    bool lookups_on = false;
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
     int comm_ranks = 0;
     EpisodeArrays ep{};
@@ -106,6 +124,30 @@ static int dmalloc(f110_sim *h, T **p, size_t count)
     do {                       \
         int rc_ = (expr);      \
         if (rc_ != F110_OK) return rc_; \
+    } while (0)
+
+// The group streams' outstanding work becomes a dependency of the main stream (stream-ordered, no
+// host wait).  Every entry point except the step itself starts with it, so the env groups are an
+// internal detail: anything enqueued or read through the handle sees completed steps.
+static int join_groups(f110_sim *h)
+{
+    if (!h->groups_busy) return F110_OK;
+    for (size_t g = 0; g < h->gstreams.size(); ++g) {
+        HIPCHK(h, hipEventRecord(h->gevents[g], h->gstreams[g]));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->gevents[g], 0));
+    }
+    h->groups_busy = false;
+    return F110_OK;
+}
+
+// first statement (after the null check) of every entry point that takes a handle: calls may come
+// from any thread, so the handle's device is made current; group streams are joined; whatever the
+// call enqueues on the main stream must be waited for by the next step's groups.
+#define ENTER(h)                                          \
+    do {                                                  \
+        HIPCHK(h, hipSetDevice((h)->cfg.device_id));      \
+        TRY(join_groups(h));                              \
+        (h)->main_dirty = true;                           \
     } while (0)
 
 // RAII scratch for the unit entry points
@@ -311,9 +353,30 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     CKH(hipEventCreateWithFlags(&h->ev_collided, hipEventDisableTiming));
     CKH(hipEventCreate(&h->ev_begin));
     CKH(hipEventCreate(&h->ev_end));
+    CKH(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    {
+        // env groups: 0 = automatic.  Small batches are bound by dependent chains
+        // (longest ray, RK4, window set-up) and kernel boundaries, which independent env blocks
+        // on their own streams overlap; big batches fill the chip with one block.
+        int G = cfg->step_groups;
+        if (const char *e = std::getenv("F110_STEP_GROUPS")) G = std::atoi(e);
+        if (G <= 0) G = (N >= 1024 && N < 32768) ? 2 : 1;
+        G = std::min(std::min(G, 16), cfg->num_envs);
+        h->groups = G;
+        for (int g = 0; g < G && G > 1; ++g) {
+            hipStream_t gs = nullptr;
+            hipEvent_t ge = nullptr;
+            CKH(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+            h->gstreams.push_back(gs);
+            CKH(hipEventCreateWithFlags(&ge, hipEventDisableTiming));
+            h->gevents.push_back(ge);
+        }
+    }
     AgentArrays &d = h->dev;
     d.n_agents_total = N;
     d.agents_per_env = cfg->num_agents;
+    d.agent_begin = 0;
+    d.agent_count = N;
     CK(dmalloc(h, &d.state, (size_t)7 * N));
     CK(dmalloc(h, &d.steer_buf, (size_t)2 * N));
     CK(dmalloc(h, &d.buf_cnt, (size_t)N));
@@ -336,6 +399,24 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     CK(dmalloc(h, &h->d_actions, (size_t)2 * N));
     CK(dmalloc(h, &h->d_poses, (size_t)3 * N));
     CK(dmalloc(h, &h->d_mask, (size_t)cfg->num_envs));
+    {
+        // constants of the device noise generator (f110_rng.hpp): NumPy's ziggurat tables and the
+        // PCG64 jump constants, 8 KB in all
+        PcgJump jt;
+        pcg_jump_table(jt);
+        CK(dmalloc(h, &h->d_zig_k, 256));
+        CK(dmalloc(h, &h->d_zig_w, 256));
+        CK(dmalloc(h, &h->d_zig_f, 256));
+        CK(dmalloc(h, &h->d_jump, 2 * 65));
+        CK(dmalloc(h, &h->d_lookups, 1));
+        CKH(hipMemcpy(h->d_zig_k, kZigK, sizeof kZigK, hipMemcpyHostToDevice));
+        CKH(hipMemcpy(h->d_zig_w, kZigW, sizeof kZigW, hipMemcpyHostToDevice));
+        CKH(hipMemcpy(h->d_zig_f, kZigF, sizeof kZigF, hipMemcpyHostToDevice));
+        CKH(hipMemcpy(h->d_jump, jt.a, sizeof jt.a, hipMemcpyHostToDevice));
+        CKH(hipMemcpy(h->d_jump + 65, jt.g, sizeof jt.g, hipMemcpyHostToDevice));
+        CKH(hipMemset(h->d_lookups, 0, sizeof(unsigned long long)));
+        h->noise_gen = NoiseGen{h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_jump + 65, 0.0};
+    }
     CKH(hipMemsetAsync(d.state, 0, sizeof(double) * 7 * N, h->stream));
     CKH(hipMemsetAsync(d.steer_buf, 0, sizeof(double) * 2 * N, h->stream));
     CKH(hipMemsetAsync(d.buf_cnt, 0, sizeof(int32_t) * N, h->stream));
@@ -422,8 +503,18 @@ int f110_create(const f110_config *cfg, f110_sim **out)
 void f110_destroy(f110_sim *h)
 {
     if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    for (hipStream_t gs : h->gstreams) (void)hipStreamSynchronize(gs);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    for (hipStream_t gs : h->gstreams) (void)hipStreamDestroy(gs);
+    for (hipEvent_t ge : h->gevents) (void)hipEventDestroy(ge);
+    if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    {
+        void *rp[] = {h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
+        for (void *p : rp)
+            if (p) (void)hipFree(p);
+    }
     (void)f110_comm_destroy(h);
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
@@ -457,6 +548,7 @@ void f110_destroy(f110_sim *h)
 int f110_sync(f110_sim *h)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return F110_OK;
 }
@@ -550,6 +642,7 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
 int f110_set_map_image(f110_sim *h, const uint8_t *h_img, int32_t H, int32_t W, double res, double ox, double oy, double oyaw)
 {
     if (!h || !h_img) return fail(h, F110_ERR_INVALID, "f110_set_map_image: null argument");
+    ENTER(h);
     if (H < 1 || W < 1 || H > 16384 || W > 16384 || !(res > 0)) return fail(h, F110_ERR_INVALID, "f110_set_map_image: bad shape %dx%d or resolution", H, W);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const size_t n = (size_t)H * W;
@@ -573,6 +666,7 @@ int f110_set_map_image(f110_sim *h, const uint8_t *h_img, int32_t H, int32_t W, 
 int f110_set_map_dt(f110_sim *h, const double *h_dt, int32_t H, int32_t W, double res, double ox, double oy, double oc, double os)
 {
     if (!h || !h_dt) return fail(h, F110_ERR_INVALID, "f110_set_map_dt: null argument");
+    ENTER(h);
     if (H < 1 || W < 1 || !(res > 0)) return fail(h, F110_ERR_INVALID, "f110_set_map_dt: bad shape or resolution");
     if ((unsigned long long)(H + 3) * (unsigned long long)(W + 3) * 8ull >= 0xFFFFFFFFull) return fail(h, F110_ERR_INVALID, "distance table must stay below 4 GiB");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
@@ -638,6 +732,7 @@ static int add_map_slot(f110_sim *h, double *d_dt_row, int H, int W, double res,
 int f110_add_map_image(f110_sim *h, const uint8_t *h_img, int32_t H, int32_t W, double res, double ox, double oy, double oyaw, int32_t *slot)
 {
     if (!h || !h_img) return fail(h, F110_ERR_INVALID, "f110_add_map_image: null argument");
+    ENTER(h);
     if (H < 1 || W < 1 || H > 16384 || W > 16384 || !(res > 0)) return fail(h, F110_ERR_INVALID, "f110_add_map_image: bad shape %dx%d or resolution", H, W);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     double *d_dt_row = nullptr;
@@ -648,6 +743,7 @@ int f110_add_map_image(f110_sim *h, const uint8_t *h_img, int32_t H, int32_t W, 
 int f110_add_map_dt(f110_sim *h, const double *h_dt, int32_t H, int32_t W, double res, double ox, double oy, double oc, double os, int32_t *slot)
 {
     if (!h || !h_dt) return fail(h, F110_ERR_INVALID, "f110_add_map_dt: null argument");
+    ENTER(h);
     if (H < 1 || W < 1 || !(res > 0)) return fail(h, F110_ERR_INVALID, "f110_add_map_dt: bad shape or resolution");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     double *d_dt_row = nullptr;
@@ -659,6 +755,7 @@ int f110_add_map_dt(f110_sim *h, const double *h_dt, int32_t H, int32_t W, doubl
 int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h_env_map) {   // back to one map for everybody
         h->multi_map = false;
@@ -707,6 +804,7 @@ int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map)
 int f110_get_map_dt(f110_sim *h, double *out)
 {
     if (!h || !out) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
     HIPCHK(h, hipMemcpyAsync(out, h->d_dt_row, (size_t)h->k.height * h->k.width * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -716,6 +814,7 @@ int f110_get_map_dt(f110_sim *h, double *out)
 int f110_map_shape(f110_sim *h, int32_t *H, int32_t *W)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
     if (H) *H = h->k.height;
     if (W) *W = h->k.width;
@@ -725,6 +824,7 @@ int f110_map_shape(f110_sim *h, int32_t *H, int32_t *W)
 int f110_set_trig_tables(f110_sim *h, const double *s, const double *c, int32_t n)
 {
     if (!h || !s || !c) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (n != h->cfg.theta_dis) return fail(h, F110_ERR_INVALID, "trig tables must have theta_dis=%d entries (got %d)", h->cfg.theta_dis, n);
     Scratch sc(h);
     double *ds = nullptr, *dc = nullptr;
@@ -739,6 +839,7 @@ int f110_set_trig_tables(f110_sim *h, const double *s, const double *c, int32_t 
 int f110_set_beam_tables(f110_sim *h, const double *sa, const double *co, const double *sd, int32_t B)
 {
     if (!h || !sa || !co || !sd) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (B != h->cfg.num_beams) return fail(h, F110_ERR_INVALID, "beam tables must have num_beams=%d entries (got %d)", h->cfg.num_beams, B);
     HIPCHK(h, hipMemcpyAsync(h->d_scan_angles, sa, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_beam_cos, co, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
@@ -765,6 +866,7 @@ int f110_set_beam_tables(f110_sim *h, const double *sa, const double *co, const 
 int f110_set_params_batch(f110_sim *h, const double *h_params)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h_params) {   // back to one parameter set per agent slot
         h->dev.params = h->d_params;
@@ -783,6 +885,7 @@ int f110_set_params_batch(f110_sim *h, const double *h_params)
 int f110_set_params(f110_sim *h, int32_t agent_idx, const double *p)
 {
     if (!h || !p) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (h->dev.params_per_agent) return fail(h, F110_ERR_STATE, "per-agent parameters are active (f110_set_params_batch); clear them first");
     const int A = h->cfg.num_agents;
     if (agent_idx >= A) return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
@@ -793,13 +896,29 @@ int f110_set_params(f110_sim *h, int32_t agent_idx, const double *p)
     return F110_OK;
 }
 
+static int noise_cache_extend(f110_sim *h, int upto);
+
+static void noise_release(f110_sim *h)
+{
+    if (h->d_noise) { (void)hipFree(h->d_noise); h->d_noise = nullptr; }
+    if (h->d_rng_state) { (void)hipFree(h->d_rng_state); h->d_rng_state = nullptr; }
+    if (h->d_rng_seed) { (void)hipFree(h->d_rng_seed); h->d_rng_seed = nullptr; }
+    if (h->d_rng_rowstate) { (void)hipFree(h->d_rng_rowstate); h->d_rng_rowstate = nullptr; }
+    h->dev.noise = nullptr;
+    h->dev.noise_rows = 0;
+    h->dev.noise_rng = 0;
+    h->dev.rng_state = nullptr;
+    h->dev.rng_seed = nullptr;
+    h->dev.rng_rowstate = nullptr;
+    h->noise_rows_ready = 0;
+}
+
 int f110_set_noise_table(f110_sim *h, const double *noise, int32_t rows, int32_t B)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (h->d_noise) { (void)hipFree(h->d_noise); h->d_noise = nullptr; }
-    h->dev.noise = nullptr;
-    h->dev.noise_rows = 0;
+    noise_release(h);
     if (!noise || rows <= 0) return F110_OK;
     if (B != h->cfg.num_beams) return fail(h, F110_ERR_INVALID, "noise table must have num_beams=%d columns (got %d)", h->cfg.num_beams, B);
     TRY(dmalloc(h, &h->d_noise, (size_t)rows * B));
@@ -810,10 +929,106 @@ int f110_set_noise_table(f110_sim *h, const double *noise, int32_t rows, int32_t
     return F110_OK;
 }
 
+int f110_pcg64_seed(uint64_t seed, uint64_t *out_state_inc)
+{
+    if (!out_state_inc) return fail(nullptr, F110_ERR_INVALID, "null argument");
+    pcg64_seed_from_u64(seed, out_state_inc);
+    return F110_OK;
+}
+
+int f110_set_noise_rng(f110_sim *h, const uint64_t *state_inc, int32_t per_agent, double std_dev, int32_t cache_rows)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    noise_release(h);
+    if (!state_inc) return F110_OK;
+    if (!(std_dev >= 0.0)) return fail(h, F110_ERR_INVALID, "noise std_dev must be >= 0");
+    const int B = h->cfg.num_beams;
+    const size_t N = (size_t)h->N;
+    h->noise_gen.scale = std_dev;
+    TRY(dmalloc(h, &h->d_rng_state, N));
+    HIPCHK(h, hipMemset(h->d_rng_state, 0, sizeof(U128) * N));
+    h->dev.rng_state = h->d_rng_state;
+    if (per_agent) {
+        // h_state_inc [N][4]: two U128 {hi, lo} per agent — the layout of rng_seed
+        TRY(dmalloc(h, &h->d_rng_seed, 2 * N));
+        HIPCHK(h, hipMemcpy(h->d_rng_seed, state_inc, sizeof(U128) * 2 * N, hipMemcpyHostToDevice));
+        h->dev.rng_seed = h->d_rng_seed;
+        h->dev.noise_rng = 2;
+        return F110_OK;
+    }
+    int rows = cache_rows > 0 ? cache_rows : 4096;
+    if ((size_t)rows * B * sizeof(double) > (size_t)1 << 31) rows = (int)(((size_t)1 << 31) / ((size_t)B * sizeof(double)));
+    TRY(dmalloc(h, &h->d_noise, (size_t)rows * B));
+    TRY(dmalloc(h, &h->d_rng_rowstate, (size_t)rows + 1));
+    const U128 st0 = {state_inc[0], state_inc[1]};
+    HIPCHK(h, hipMemcpy(h->d_rng_rowstate, &st0, sizeof st0, hipMemcpyHostToDevice));
+    h->dev.rng_inc = U128{state_inc[2], state_inc[3]};
+    h->dev.rng_rowstate = h->d_rng_rowstate;
+    h->dev.noise = h->d_noise;
+    h->dev.noise_rows = rows;
+    h->dev.noise_rng = 1;
+    h->noise_rows_ready = 0;
+    return noise_cache_extend(h, std::min(rows, 256));
+}
+
+int f110_noise_prepare(f110_sim *h, int32_t rows)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
+    if (h->dev.noise_rng != 1) return F110_OK;
+    return noise_cache_extend(h, rows);
+}
+
+int f110_noise_rows_batch(f110_sim *h, const uint64_t *state_inc, double std_dev, int32_t rows, int32_t num_beams, double *h_out,
+                          uint64_t *h_state_out)
+{
+    if (!h || !state_inc || !h_out || rows < 1 || num_beams < 1) return fail(h, F110_ERR_INVALID, "f110_noise_rows_batch: bad argument");
+    ENTER(h);
+    Scratch s(h);
+    U128 *d_rs = nullptr;
+    double *d_out = nullptr;
+    TRY(s.up<U128>(nullptr, (size_t)rows + 1, &d_rs));
+    TRY(s.up<double>(nullptr, (size_t)rows * num_beams, &d_out));
+    const U128 st0 = {state_inc[0], state_inc[1]}, inc = {state_inc[2], state_inc[3]};
+    HIPCHK(h, hipMemcpyAsync(d_rs, &st0, sizeof st0, hipMemcpyHostToDevice, h->stream));
+    NoiseGen g = h->noise_gen;
+    g.scale = std_dev;
+    hipLaunchKernelGGL(k_noise_cache, dim3(1), dim3(64), 0, h->stream, g, inc, d_rs, d_out, 0, rows, num_beams);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(h_out, d_out, (size_t)rows * num_beams));
+    U128 last{};
+    HIPCHK(h, hipMemcpyAsync(&last, d_rs + rows, sizeof last, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h_state_out) {
+        h_state_out[0] = last.hi;
+        h_state_out[1] = last.lo;
+    }
+    return F110_OK;
+}
+
+int f110_scan_lookup_count(f110_sim *h, int32_t enable, int64_t *out_total)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
+    if (out_total) {
+        unsigned long long v = 0;
+        HIPCHK(h, hipMemcpyAsync(&v, h->d_lookups, sizeof v, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_lookups, 0, sizeof v, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        *out_total = (int64_t)v;
+    }
+    if (enable >= 0) h->lookups_on = enable != 0;
+    return F110_OK;
+}
+
 // ---- reset / step ------------------------------------------------------------------------
 int f110_reset_device(f110_sim *h, const double *d_poses, const uint8_t *d_env_mask)
 {
     if (!h || !d_poses) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
+    if (!d_env_mask) h->noise_ub = 0;   // every agent's step_count is 0 again
     hipLaunchKernelGGL(k_reset, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, d_poses, d_env_mask);
     HIPCHK(h, hipGetLastError());
     return F110_OK;
@@ -822,6 +1037,7 @@ int f110_reset_device(f110_sim *h, const double *d_poses, const uint8_t *d_env_m
 int f110_set_auto_reseat(f110_sim *h, const double *d_start_poses, int32_t ego_idx, int32_t *d_count)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     if (d_start_poses && (ego_idx < 0 || ego_idx >= h->cfg.num_agents))
         return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
     h->dev.reseat_poses = d_start_poses;
@@ -833,6 +1049,7 @@ int f110_set_auto_reseat(f110_sim *h, const double *d_start_poses, int32_t ego_i
 int f110_reset_collided_device(f110_sim *h, const double *d_start_poses, int32_t ego_idx, int32_t *d_count)
 {
     if (!h || !d_start_poses) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (ego_idx < 0 || ego_idx >= h->cfg.num_agents) return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
     hipLaunchKernelGGL(k_reset_collided, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, d_start_poses, ego_idx, d_count);
     HIPCHK(h, hipGetLastError());
@@ -894,6 +1111,7 @@ int f110_comm_unique_id(void *out_id128)
 int f110_comm_init(f110_sim *h, int32_t n_ranks, int32_t rank, const void *id128)
 {
     if (!h || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(h, F110_ERR_INVALID, "f110_comm_init: bad argument");
+    ENTER(h);
     RcclApi *r = rccl_api();
     if (!r) return fail(h, F110_ERR_STATE, "RCCL (librccl.so) could not be loaded");
     if (h->comm) return fail(h, F110_ERR_STATE, "communicator already initialised");
@@ -912,6 +1130,7 @@ int f110_comm_init(f110_sim *h, int32_t n_ranks, int32_t rank, const void *id128
 int f110_comm_all_gather_scans(f110_sim *h, void *d_recv)
 {
     if (!h || !d_recv) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (!h->comm) return fail(h, F110_ERR_STATE, "f110_comm_init has not been called");
     RcclApi *r = rccl_api();
     const size_t count = (size_t)h->N * h->cfg.num_beams;
@@ -923,6 +1142,7 @@ int f110_comm_all_gather_scans(f110_sim *h, void *d_recv)
 int f110_comm_destroy(f110_sim *h)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     if (h->comm) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         RcclApi *r = rccl_api();
@@ -937,6 +1157,7 @@ int f110_comm_destroy(f110_sim *h)
 int f110_episode_init(f110_sim *h, int32_t ego_idx)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     if (ego_idx < 0 || ego_idx >= h->cfg.num_agents) return fail(h, F110_ERR_INVALID, "Index given is out of bounds for list of agents.");
     const size_t N = (size_t)h->N, E = (size_t)h->cfg.num_envs;
     EpisodeArrays &ep = h->ep;
@@ -971,11 +1192,13 @@ int f110_episode_init(f110_sim *h, int32_t ego_idx)
 int f110_episode_reset(f110_sim *h, const double *poses, const double *rot, const uint8_t *env_mask)
 {
     if (!h || !poses || !rot) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
     HIPCHK(h, hipMemcpyAsync(h->d_poses, poses, sizeof(double) * 3 * h->N, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_rot_stage, rot, sizeof(double) * 4 * h->cfg.num_envs, hipMemcpyHostToDevice, h->stream));
     if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->cfg.num_envs, hipMemcpyHostToDevice, h->stream));
     const uint8_t *dm = env_mask ? h->d_mask : nullptr;
+    if (!dm) h->noise_ub = 0;
     hipLaunchKernelGGL(k_episode_reset, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, h->ep, h->d_poses, h->d_rot_stage, dm);
     hipLaunchKernelGGL(k_reset, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, h->d_poses, dm);
     HIPCHK(h, hipGetLastError());
@@ -988,6 +1211,7 @@ int f110_episode_step_device(f110_sim *h, const double *d_actions)
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
     TRY(f110_step_device(h, d_actions));
+    ENTER(h);   // _check_done reads every group's poses and flags
     hipLaunchKernelGGL(k_episode, grid1d(h->cfg.num_envs, 256), dim3(256), 0, h->stream, h->dev, h->ep, h->cfg.num_envs);
     HIPCHK(h, hipGetLastError());
     return F110_OK;
@@ -996,6 +1220,7 @@ int f110_episode_step_device(f110_sim *h, const double *d_actions)
 int f110_episode_reset_done_device(f110_sim *h, int32_t *d_count)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
     hipLaunchKernelGGL(k_episode_reset_done, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, h->ep, d_count);
     hipLaunchKernelGGL(k_episode_clear_done, grid1d(h->cfg.num_envs, 256), dim3(256), 0, h->stream, h->ep, h->cfg.num_envs);
@@ -1006,6 +1231,7 @@ int f110_episode_reset_done_device(f110_sim *h, int32_t *d_count)
 int f110_episode_get(f110_sim *h, const f110_episode_host *o)
 {
     if (!h || !o) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
     const size_t N = (size_t)h->N, E = (size_t)h->cfg.num_envs;
     const EpisodeArrays &ep = h->ep;
@@ -1023,6 +1249,7 @@ int f110_episode_get(f110_sim *h, const f110_episode_host *o)
 int f110_episode_device_views(f110_sim *h, f110_episode_views *v)
 {
     if (!h || !v) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
     v->done = h->ep.done;
     v->checkpoint_done = h->ep.checkpoint;
@@ -1036,6 +1263,7 @@ int f110_episode_device_views(f110_sim *h, f110_episode_views *v)
 int f110_reset(f110_sim *h, const double *poses, const uint8_t *env_mask)
 {
     if (!h || !poses) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     HIPCHK(h, hipMemcpyAsync(h->d_poses, poses, sizeof(double) * 3 * h->N, hipMemcpyHostToDevice, h->stream));
     if (env_mask) HIPCHK(h, hipMemcpyAsync(h->d_mask, env_mask, (size_t)h->cfg.num_envs, hipMemcpyHostToDevice, h->stream));
     TRY(f110_reset_device(h, h->d_poses, env_mask ? h->d_mask : nullptr));
@@ -1053,33 +1281,58 @@ static hipEvent_t prof_event(f110_sim *h)
     return h->prof_events[h->prof_used++];
 }
 
-int f110_step_device(f110_sim *h, const double *d_actions)
+// rows [noise_rows_ready, upto) of the shared stream into the row cache (stream-ordered on the main stream)
+static int noise_cache_extend(f110_sim *h, int upto)
 {
-    if (!h || !d_actions) return fail(h, F110_ERR_INVALID, "null argument");
-    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
-    const int N = h->N;
-    const bool prof = h->profiling && h->prof_used + 4 <= 4 * 65536;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    if (prof) {
-        e0 = prof_event(h); e1 = prof_event(h); e2 = prof_event(h); e3 = prof_event(h);
-        if (!e0 || !e1 || !e2 || !e3) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
-        HIPCHK(h, hipEventRecord(e0, h->stream));
-    }
-    h->dev.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;
-    hipLaunchKernelGGL(k_integrate, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->k, d_actions);
+    const int cap = h->dev.noise_rows;
+    if (upto > cap) upto = cap;
+    if (upto <= h->noise_rows_ready) return F110_OK;
+    hipLaunchKernelGGL(k_noise_cache, dim3(1), dim3(64), 0, h->stream, h->noise_gen, h->dev.rng_inc, h->d_rng_rowstate, h->d_noise, h->noise_rows_ready, upto,
+                       h->cfg.num_beams);
+    HIPCHK(h, hipGetLastError());
+    h->noise_rows_ready = upto;
+    h->main_dirty = true;
+    return F110_OK;
+}
+
+// One step of the agents [begin, begin + count) (an env-aligned block) on stream `st`.
+//   collide_mode 0: k_collide on the side stream, forked / joined with events (hides under the scan)
+//                1: pair tests fused into k_integrate (2 or 4 agents per env)
+//                2: k_collide in line on `st`
+// ev[0..3] (or nullptr): profiling events before integrate / before scan / after scan / after finalize.
+static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const double *d_actions, int collide_mode, hipEvent_t *ev)
+{
+    const int N = h->N, A = h->cfg.num_agents, B = h->k.num_beams;
+    AgentArrays dev = h->dev;
+    dev.agent_begin = begin;
+    dev.agent_count = count;
+    const bool multi = A > 1;
+    if (dev.noise_rng && (dev.noise_rng == 2 || h->noise_ub >= (long long)dev.noise_rows))
+        hipLaunchKernelGGL(k_noise_rows, dim3((count + 3) / 4), dim3(256), 0, st, dev, h->noise_gen, B);
+    if (ev) HIPCHK(h, hipEventRecord(ev[0], st));
+    if (multi && collide_mode == 1 && A == 2)
+        hipLaunchKernelGGL(k_integrate<2>, grid1d(count, 64), dim3(64), 0, st, dev, h->k, d_actions);
+    else if (multi && collide_mode == 1 && A == 4)
+        hipLaunchKernelGGL(k_integrate<4>, grid1d(count, 64), dim3(64), 0, st, dev, h->k, d_actions);
+    else
+        hipLaunchKernelGGL(k_integrate<0>, grid1d(count, 256), dim3(256), 0, st, dev, h->k, d_actions);
+    const bool fused = multi && collide_mode == 1 && (A == 2 || A == 4);
     // k_collide only feeds k_finalize, k_scan_rays only needs k_integrate: run the two side by
     // side (second stream, event fork/join) so the pair test + window set-up hides under the scan
-    const bool multi = h->cfg.num_agents > 1;
-    if (multi) {
-        HIPCHK(h, hipEventRecord(h->ev_integrated, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_integrated, 0));
-        hipLaunchKernelGGL(k_collide, grid1d(N, 64), dim3(64), 0, h->side_stream, h->dev, h->k.num_beams);
-        HIPCHK(h, hipEventRecord(h->ev_collided, h->side_stream));
+    if (multi && !fused) {
+        if (collide_mode == 0) {
+            HIPCHK(h, hipEventRecord(h->ev_integrated, st));
+            HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_integrated, 0));
+            hipLaunchKernelGGL(k_collide, grid1d(count, 64), dim3(64), 0, h->side_stream, dev, B);
+            HIPCHK(h, hipEventRecord(h->ev_collided, h->side_stream));
+        } else {
+            hipLaunchKernelGGL(k_collide, grid1d(count, 64), dim3(64), 0, st, dev, B);
+        }
     }
-    if (prof) HIPCHK(h, hipEventRecord(e1, h->stream));
+    if (ev) HIPCHK(h, hipEventRecord(ev[1], st));
     {
         RayJob j{};
-        j.n_rays = (uint32_t)N * (uint32_t)h->k.num_beams;
+        j.n_rays = (uint32_t)N * (uint32_t)B;
         j.n_poses = N;
         j.pose_x = h->dev.scan_pose;
         j.pose_y = h->dev.scan_pose + N;
@@ -1095,6 +1348,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         j.ttc_thresh = h->dev.ttc_thresh;
         j.div_magic = h->step_magic;
         j.div_shift = h->step_shift;
+        j.lookups_total = h->lookups_on ? h->d_lookups : nullptr;
         j.k_cold = cold_consts(h);
         if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
         scan_rays_fn fn = pick_rays<true>(h->k, h->cfg.map_layout);
@@ -1107,32 +1361,42 @@ int f110_step_device(f110_sim *h, const double *d_actions)
             jd.div_magic = h->dir_magic;
             jd.div_shift = h->dir_shift;
             const dim3 gd = rays_grid(jd, h->scan_block, h->scan_tasks_per_wave);
-            hipLaunchKernelGGL(fn, gd, dim3(h->scan_block), 0, h->stream, jd, h->k);
+            hipLaunchKernelGGL(fn, gd, dim3(h->scan_block), 0, st, jd, h->k);
             j.dir_stride = h->dir_stride;  // pass 2: every beam picks its direction's range
             j.dir_ranges = h->d_dir_ranges;
-            hipLaunchKernelGGL(k_expand_beams, grid1d(j.n_rays, 256), dim3(256), 0, h->stream, j, h->k);
+            j.lookups_total = nullptr;
+            hipLaunchKernelGGL(k_expand_beams, grid1d(j.n_rays, 256), dim3(256), 0, st, j, h->k);
         } else if (h->multi_map || agent_aligned(h)) {
             // whole 64-ray tasks per agent, so every wave belongs to one agent (and one map)
-            const uint32_t tpa = ((uint32_t)h->k.num_beams + 63u) / 64u;
+            const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
             (void)rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
-            j.n_tasks = (uint32_t)N * tpa;
+            j.n_tasks = (uint32_t)count * tpa;
+            j.first_pose = (uint32_t)begin;
             const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave, wpb = (uint32_t)h->scan_block / 64u;
             const dim3 grid((waves + wpb - 1) / wpb), block(h->scan_block);
+            const bool cnt = j.lookups_total != nullptr;
+#define AGENT_SCAN(PM, ID)                                                                                                         \
+    do {                                                                                                                           \
+        if (cnt)                                                                                                                   \
+            hipLaunchKernelGGL((k_scan_rays_agent<PM, ID, true>), grid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa); \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((k_scan_rays_agent<PM, ID, false>), grid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa); \
+    } while (0)
             if (h->multi_map)
-                hipLaunchKernelGGL((k_scan_rays_agent<true, false>), grid, block, 0, h->stream, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                AGENT_SCAN(true, false);
             else if (h->k.ident_rot)
-                hipLaunchKernelGGL((k_scan_rays_agent<false, true>), grid, block, 0, h->stream, j, h->k, nullptr, nullptr, tpa);
+                AGENT_SCAN(false, true);
             else
-                hipLaunchKernelGGL((k_scan_rays_agent<false, false>), grid, block, 0, h->stream, j, h->k, nullptr, nullptr, tpa);
+                AGENT_SCAN(false, false);
+#undef AGENT_SCAN
         } else {
             const dim3 grid = rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
-            hipLaunchKernelGGL(fn, grid, dim3(h->scan_block), 0, h->stream, j, h->k);
+            hipLaunchKernelGGL(fn, grid, dim3(h->scan_block), 0, st, j, h->k);
         }
     }
-    if (prof) HIPCHK(h, hipEventRecord(e2, h->stream));
-    if (multi) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_collided, 0));
-    if (multi)
-    {
+    if (ev) HIPCHK(h, hipEventRecord(ev[2], st));
+    if (multi && !fused && collide_mode == 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_collided, 0));
+    if (multi) {
         static const int forced = std::getenv("F110_FINALIZE_LANES") ? std::atoi(std::getenv("F110_FINALIZE_LANES")) : 0;
         // few lanes per agent pay off when opponent windows are short (~36 beams); cars that have
         // crashed into each other see windows of up to all beams, so the narrow forms are used only
@@ -1140,17 +1404,72 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         const bool narrow = h->dev.reseat_poses != nullptr;
         const int lanes = forced ? forced : (narrow && N >= 131072 ? 8 : (narrow && N >= 32768 ? 16 : 64));
         if (lanes == 8)
-            hipLaunchKernelGGL(k_finalize<8>, dim3((N + 31) / 32), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
+            hipLaunchKernelGGL(k_finalize<8>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
         else if (lanes == 16)
-            hipLaunchKernelGGL(k_finalize<16>, dim3((N + 15) / 16), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
+            hipLaunchKernelGGL(k_finalize<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
         else if (lanes == 32)
-            hipLaunchKernelGGL(k_finalize<32>, dim3((N + 7) / 8), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
+            hipLaunchKernelGGL(k_finalize<32>, dim3((count + 7) / 8), dim3(256), 0, st, dev, B);
         else
-            hipLaunchKernelGGL(k_finalize<64>, dim3((N + 3) / 4), dim3(256), 0, h->stream, h->dev, h->k.num_beams);
+            hipLaunchKernelGGL(k_finalize<64>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
+    } else {
+        hipLaunchKernelGGL(k_finalize_solo, grid1d(count, 256), dim3(256), 0, st, dev);
     }
-    else
-        hipLaunchKernelGGL(k_finalize_solo, grid1d(N, 256), dim3(256), 0, h->stream, h->dev);
-    if (prof) HIPCHK(h, hipEventRecord(e3, h->stream));
+    if (ev) HIPCHK(h, hipEventRecord(ev[3], st));
+    return F110_OK;
+}
+
+// how the env axis is cut into `groups` blocks: whole envs, whole 64-agent waves where possible
+static int group_envs(const f110_sim *h)
+{
+    const int E = h->cfg.num_envs, G = h->groups;
+    int per = (E + G - 1) / G;
+    if (per >= 64) per = (per + 63) / 64 * 64;
+    return per;
+}
+
+int f110_step_device(f110_sim *h, const double *d_actions)
+{
+    if (!h || !d_actions) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int N = h->N, A = h->cfg.num_agents;
+    h->dev.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;
+    // shared noise stream: the row cache must reach the longest live episode (or its capacity)
+    if (h->dev.noise_rng == 1 && h->noise_ub >= h->noise_rows_ready && h->noise_rows_ready < h->dev.noise_rows) {
+        TRY(join_groups(h));
+        const long long want = std::max<long long>(2LL * h->noise_rows_ready, h->noise_ub + 1);
+        TRY(noise_cache_extend(h, (int)std::min<long long>(want, h->dev.noise_rows)));
+    }
+    const bool prof = h->profiling && h->prof_used + 4 <= 4 * 65536;
+    static const char *cm_env = std::getenv("F110_COLLIDE_MODE");
+    // the env groups need the agent-aligned scan (a launch per agent range); per-kernel profiling
+    // brackets the kernels of ONE stream, so a profiled step runs as one block on the main stream
+    const bool grouped = h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0;
+    if (!grouped) {
+        TRY(join_groups(h));
+        h->main_dirty = true;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (prof) {
+            for (int i = 0; i < 4; ++i)
+                if (!(ev[i] = prof_event(h))) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
+        }
+        TRY(step_range(h, h->stream, 0, N, d_actions, cm_env ? std::atoi(cm_env) : 0, prof ? ev : nullptr));
+    } else {
+        if (h->main_dirty) {
+            HIPCHK(h, hipEventRecord(h->ev_main, h->stream));
+            for (hipStream_t gs : h->gstreams) HIPCHK(h, hipStreamWaitEvent(gs, h->ev_main, 0));
+            h->main_dirty = false;
+        }
+        const int per = group_envs(h), E = h->cfg.num_envs;
+        const int mode = cm_env ? std::atoi(cm_env) : ((A == 2 || A == 4) ? 1 : 2);
+        for (int g = 0; g < h->groups; ++g) {
+            const int e0 = g * per, e1 = std::min(E, e0 + per);
+            if (e0 >= e1) break;
+            TRY(step_range(h, h->gstreams[g], e0 * A, (e1 - e0) * A, d_actions, mode == 0 ? 2 : mode, nullptr));
+        }
+        h->groups_busy = true;
+    }
+    h->noise_ub += 1;
     HIPCHK(h, hipGetLastError());
     return F110_OK;
 }
@@ -1159,6 +1478,7 @@ int f110_step(f110_sim *h, const double *actions)
 {
     if (!h || !actions) return fail(h, F110_ERR_INVALID, "null argument");
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    ENTER(h);   // the previous step (possibly still running on the group streams) reads d_actions
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, sizeof(double) * 2 * h->N, hipMemcpyHostToDevice, h->stream));
     TRY(f110_step_device(h, h->d_actions));
     HIPCHK(h, hipStreamSynchronize(h->stream));  // pageable host buffer: consumed on return
@@ -1175,6 +1495,7 @@ static int copy_col(f110_sim *h, double *dst, const double *src, size_t n)
 int f110_get_obs(f110_sim *h, const f110_obs_host *o)
 {
     if (!h || !o) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     const size_t N = (size_t)h->N;
     const AgentArrays &d = h->dev;
     TRY(copy_col(h, o->scans, d.scans, N * h->cfg.num_beams));
@@ -1209,6 +1530,7 @@ int f110_get_obs(f110_sim *h, const f110_obs_host *o)
 int f110_set_state(f110_sim *h, const double *state7, const double *steer_buf, const int32_t *buf_count)
 {
     if (!h || !state7) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     const size_t N = (size_t)h->N;
     std::vector<double> soa(7 * N);
     for (size_t i = 0; i < N; ++i)
@@ -1231,6 +1553,7 @@ int f110_set_state(f110_sim *h, const double *state7, const double *steer_buf, c
 int f110_get_device_views(f110_sim *h, f110_device_views *v)
 {
     if (!h || !v) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     v->scans = h->dev.scans;
     v->state = h->dev.state;
     v->agent_poses = h->dev.snap_pose;
@@ -1245,6 +1568,7 @@ int f110_get_device_views(f110_sim *h, f110_device_views *v)
 int f110_device_alloc(f110_sim *h, size_t bytes, void **out)
 {
     if (!h || !out) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipMalloc(out, bytes ? bytes : 8));
     return F110_OK;
@@ -1253,6 +1577,7 @@ int f110_device_alloc(f110_sim *h, size_t bytes, void **out)
 int f110_device_free(f110_sim *h, void *p)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     if (p) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipFree(p));
@@ -1263,6 +1588,7 @@ int f110_device_free(f110_sim *h, void *p)
 int f110_memcpy_h2d(f110_sim *h, void *dst, const void *src, size_t bytes)
 {
     if (!h || !dst || !src) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return F110_OK;
@@ -1271,6 +1597,7 @@ int f110_memcpy_h2d(f110_sim *h, void *dst, const void *src, size_t bytes)
 int f110_memcpy_d2h(f110_sim *h, void *dst, const void *src, size_t bytes)
 {
     if (!h || !dst || !src) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     HIPCHK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return F110_OK;
@@ -1280,6 +1607,7 @@ int f110_memcpy_d2h(f110_sim *h, void *dst, const void *src, size_t bytes)
 int f110_timer_begin(f110_sim *h)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     HIPCHK(h, hipEventRecord(h->ev_begin, h->stream));
     return F110_OK;
 }
@@ -1287,6 +1615,7 @@ int f110_timer_begin(f110_sim *h)
 int f110_timer_end_ms(f110_sim *h, double *ms)
 {
     if (!h || !ms) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     HIPCHK(h, hipEventRecord(h->ev_end, h->stream));
     HIPCHK(h, hipEventSynchronize(h->ev_end));
     float f = 0.f;
@@ -1298,6 +1627,7 @@ int f110_timer_end_ms(f110_sim *h, double *ms)
 int f110_profile_kernels(f110_sim *h, int32_t enable)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->profiling = enable != 0;
     h->prof_used = 0;
@@ -1307,6 +1637,7 @@ int f110_profile_kernels(f110_sim *h, int32_t enable)
 int f110_profile_read(f110_sim *h, int32_t *n_launches, double *scan_ms, double *dyn_ms, double *fin_ms)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     double s = 0, dsum = 0, fsum = 0;
     int n = 0;
@@ -1331,6 +1662,7 @@ int f110_profile_read(f110_sim *h, int32_t *n_launches, double *scan_ms, double 
 int f110_scan_batch(f110_sim *h, const double *poses, int32_t m, double *ranges, int32_t *hit_rc, int64_t *lookups)
 {
     if (!h || !poses || !ranges || m < 0) return fail(h, F110_ERR_INVALID, "f110_scan_batch: bad argument");
+    ENTER(h);
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
     if (m == 0) return F110_OK;
     const size_t B = (size_t)h->cfg.num_beams;
@@ -1390,7 +1722,7 @@ int f110_pure_pursuit_batch(f110_sim *h, const double *h_waypoints, int32_t M, c
     TRY(check_planner_args(h, h_waypoints, M, lookahead));
     if (!h_poses || !h_actions || m < 0) return fail(h, F110_ERR_INVALID, "pure pursuit: bad argument");
     if (m == 0) return F110_OK;
-    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    ENTER(h);
     Scratch s(h);
     double *dw = nullptr, *dp = nullptr, *da = nullptr;
     TRY(s.up(h_waypoints, (size_t)3 * M, &dw));
@@ -1409,6 +1741,7 @@ int f110_pure_pursuit_device(f110_sim *h, const double *d_waypoints, int32_t M, 
 {
     TRY(check_planner_args(h, d_waypoints, M, lookahead));
     if (!d_actions) return fail(h, F110_ERR_INVALID, "pure pursuit: null actions buffer");
+    ENTER(h);
     const int N = h->N;
     const double *st = h->dev.state;
     hipLaunchKernelGGL(k_pure_pursuit, grid1d((size_t)N * kPlanLanes, 256), dim3(256), 0, h->stream, d_waypoints, M, st, st + N, st + 4 * (size_t)N, 1, N, lookahead,
@@ -1420,6 +1753,7 @@ int f110_pure_pursuit_device(f110_sim *h, const double *d_waypoints, int32_t M, 
 int f110_scan_path_stats(f110_sim *h, int32_t enable, int64_t *out3)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h->d_path_stats) {
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_path_stats), 3 * sizeof(unsigned long long)));
@@ -1437,6 +1771,7 @@ int f110_scan_path_stats(f110_sim *h, int32_t enable, int64_t *out3)
 int f110_beam_dir_index_batch(f110_sim *h, const double *thetas, int32_t m, int32_t *idx)
 {
     if (!h || !thetas || !idx || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (m == 0) return F110_OK;
     Scratch s(h);
     double *dt = nullptr;
@@ -1453,6 +1788,7 @@ int f110_beam_dir_index_batch(f110_sim *h, const double *thetas, int32_t m, int3
 int f110_dynamics_batch(f110_sim *h, const double *x, const double *u, const double *params, int32_t m, double *f_st, double *f_ks)
 {
     if (!h || !x || !u || !params || !f_st || !f_ks || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (m == 0) return F110_OK;
     Scratch s(h);
     double *dx, *du, *dp, *dfs, *dfk;
@@ -1472,6 +1808,7 @@ int f110_dynamics_batch(f110_sim *h, const double *x, const double *u, const dou
 int f110_pid_batch(f110_sim *h, const double *in, const double *params, int32_t m, double *out)
 {
     if (!h || !in || !params || !out || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (m == 0) return F110_OK;
     Scratch s(h);
     double *di, *dp, *dout;
@@ -1490,6 +1827,7 @@ int f110_update_pose_batch(f110_sim *h, const double *s0, const double *b0, cons
                            double *b1, int32_t *c1, double *spose)
 {
     if (!h || !s0 || !b0 || !c0 || !act || !params || !s1 || !b1 || !c1 || !spose || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (integ != F110_INTEGRATOR_RK4 && integ != F110_INTEGRATOR_EULER) return fail(h, F110_ERR_INVALID, "Invalid Integrator Specified. Please choose RK4 or Euler");
     if (m == 0) return F110_OK;
     Scratch s(h);
@@ -1517,6 +1855,7 @@ int f110_update_pose_batch(f110_sim *h, const double *s0, const double *b0, cons
 int f110_get_vertices_batch(f110_sim *h, const double *poses, double length, double width, int32_t m, double *verts)
 {
     if (!h || !poses || !verts || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (m == 0) return F110_OK;
     Scratch s(h);
     double *dp, *dv;
@@ -1532,6 +1871,7 @@ int f110_get_vertices_batch(f110_sim *h, const double *poses, double length, dou
 int f110_gjk_batch(f110_sim *h, const double *va, const double *vb, int32_t m, int32_t *flags)
 {
     if (!h || !va || !vb || !flags || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (m == 0) return F110_OK;
     Scratch s(h);
     double *da, *db;
@@ -1549,6 +1889,7 @@ int f110_gjk_batch(f110_sim *h, const double *va, const double *vb, int32_t m, i
 int f110_collision_multiple_batch(f110_sim *h, const double *verts, int32_t groups, int32_t n, double *col, double *idx)
 {
     if (!h || !verts || !col || !idx || groups < 0 || n < 1) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (groups == 0) return F110_OK;
     const size_t t = (size_t)groups * n;
     Scratch s(h);
@@ -1567,6 +1908,7 @@ int f110_collision_multiple_batch(f110_sim *h, const double *verts, int32_t grou
 int f110_ttc_batch(f110_sim *h, const double *scans, const double *vels, int32_t m, double thresh, int32_t *flags)
 {
     if (!h || !scans || !vels || !flags || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (m == 0) return F110_OK;
     const size_t B = (size_t)h->cfg.num_beams;
     Scratch s(h);
@@ -1585,6 +1927,7 @@ int f110_ttc_batch(f110_sim *h, const double *scans, const double *vels, int32_t
 int f110_raycast_batch(f110_sim *h, const double *ego, const double *verts, int32_t m, double *scans, int32_t *minmax)
 {
     if (!h || !ego || !verts || !scans || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (m == 0) return F110_OK;
     const size_t B = (size_t)h->cfg.num_beams;
     Scratch s(h);
@@ -1605,6 +1948,7 @@ int f110_raycast_batch(f110_sim *h, const double *ego, const double *verts, int3
 int f110_get_range_batch(f110_sim *h, const double *in, int32_t m, double *out)
 {
     if (!h || !in || !out || m < 0) return fail(h, F110_ERR_INVALID, "bad argument");
+    ENTER(h);
     if (m == 0) return F110_OK;
     Scratch s(h);
     double *di, *dout;
@@ -1620,6 +1964,7 @@ int f110_get_range_batch(f110_sim *h, const double *in, int32_t m, double *out)
 int f110_edt_sq(f110_sim *h, const uint8_t *img, int32_t H, int32_t W, uint32_t *d2)
 {
     if (!h || !img || !d2) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
     if (H < 1 || W < 1 || H > 16384 || W > 16384) return fail(h, F110_ERR_INVALID, "f110_edt_sq: bad shape %dx%d", H, W);
     const size_t n = (size_t)H * W;
     Scratch s(h);

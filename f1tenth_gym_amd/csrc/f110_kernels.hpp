@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "f110_math.hpp"
+#include "f110_rng.hpp"
 
 using namespace f110;
 
@@ -30,7 +31,8 @@ struct RayHdr {
     double start;       // wrapped theta_index of beam 0 (laser_models.py:166-172)
     double vel;         // post-integration longitudinal velocity (iTTC)
     double d0;          // first table sample, shared by every beam of the scan (:129)
-    int32_t noise_row;  // row of the noise table for this step, -1 = no noise
+    int32_t noise_row;  // row of the noise table / row cache for this step; -1 = no noise; -2 = this step's
+                        // noise row was generated into the agent's own scans[] row (k_noise_rows)
     int32_t map_slot;   // which registered map this agent's env runs on (0 unless f110_set_env_maps)
     int32_t pad_hdr;
     int32_t i0;         // table index of beam 0
@@ -42,6 +44,7 @@ static_assert(sizeof(RayHdr) == 64, "RayHdr is read as 16-byte scalar loads");
 struct AgentArrays {
     int32_t n_agents_total;  // N
     int32_t agents_per_env;  // A
+    int32_t agent_begin, agent_count;  // the agents this launch covers (an env-aligned group; all: 0, N)
     double *state;           // [7][N]
     double *steer_buf;       // [2][N]
     int32_t *buf_cnt;        // [N]
@@ -67,7 +70,15 @@ struct AgentArrays {
     double *opp_verts;       // [N][A][8] the opponent's box drawn with the ego's length/width
     const double *params;    // [A][18] per agent slot, or [N][18] per agent (params_per_agent)
     int32_t params_per_agent, pad_params;
-    const double *noise;     // [noise_rows][B] or nullptr
+    const double *noise;     // [noise_rows][B] or nullptr: the uploaded table, or the device-generated row cache
+    // device RNG (f110_set_noise_rng): 0 off / table, 1 one stream shared by every agent (the reference),
+    // 2 a stream per agent.  Rows below noise_rows come from the cache in shared mode; later rows and
+    // per-agent streams are generated into scans[] by k_noise_rows from the agent's carried state.
+    int32_t noise_rng, pad_rng;
+    U128 *rng_state;              // [N] state after the agent's last generated row
+    const U128 *rng_seed;         // per-agent mode: [N][2] = {state at reset, inc}
+    const U128 *rng_rowstate;     // shared mode: [noise_rows + 1] state at the start of every cached row
+    U128 rng_inc;                 // shared mode: the stream's increment
     const double *scan_angles, *beam_cos, *side_dist;  // [B]
     int32_t noise_rows, integrator;
     double time_step, lidar_dist, ttc_thresh, angle_inc;
@@ -82,12 +93,76 @@ __device__ __forceinline__ VehicleParams load_params(const double *p)
     return vp;
 }
 
-// ---- K1: integrate every agent one time step ------------------------------------------
-__global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, const double *__restrict__ actions)
+// ---- K1b body: pairwise body collisions inside each env + opponent beam windows ---------------
+// collision_multiple visits pairs (i<j) ascending and overwrites collision_idx, so an agent's
+// final index is the largest colliding partner; flags are symmetric.  Each lane evaluates the
+// GJK of its pairs in the reference's (lower, higher) argument order.
+// AF = 0: any number of agents per env, partner poses through pose_of(j) from memory;
+// AF = 2 / 4: exactly that many, loop unrolled so pose_of(j) can index registers.
+template <int AF, typename PoseOf>
+__device__ __forceinline__ void collide_agent(const AgentArrays &a, int32_t B, int i, double mx, double my, double mth, PoseOf pose_of)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int A = AF ? AF : a.agents_per_env;
+    const int env = i / A, me = i - env * A;
+    double mine[8];
+    box_vertices(mx, my, mth, a.box_length, a.box_width, mine);
+    // bodies whose centres are further apart than a box diagonal (+1 mm) cannot overlap
+    const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+    // RaceCar.ray_cast_agents draws the opponents with the EGO's length/width (:223)
+    const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
+    const double blen = a.params[prow + P_LENGTH];
+    const double bwid = a.params[prow + P_WIDTH];
+    const double disc_r = 0.5 * sqrt(blen * blen + bwid * bwid);
+    bool hit = false;
+    int partner = -1;
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+        if (j == me) continue;
+        double ox, oy, oth;
+        pose_of(j, ox, oy, oth);
+        const double dx = ox - mx, dy = oy - my;
+        double other[8];
+        if (dx * dx + dy * dy <= reach * reach) {
+            box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
+            const bool c = (me < j) ? gjk_overlap(mine, other) : gjk_overlap(other, mine);
+            if (c) {
+                hit = true;
+                partner = j;  // j ascending -> ends at the largest colliding index
+            }
+        }
+        // beam window this opponent can occupy in my scan: once for my post-integration heading
+        // (no wall hit) and once for heading 0 (RaceCar.check_ttc zeroes it on a wall hit, and the
+        // ray-cast reads the live state, base_classes.py:225,246-249); k_finalize picks one.
+        int ref_lo, ref_hi, lo, hi;
+        box_vertices(ox, oy, oth, blen, bwid, other);
+        int32_t *win = a.opp_window + ((size_t)i * A + j) * 4;
+        opponent_beam_window(mx, my, mth, other, ox, oy, disc_r, a.scan_angles, B, a.angle_inc, ref_lo, ref_hi, lo, hi);
+        win[0] = lo;
+        win[1] = hi;
+        opponent_beam_window(mx, my, 0.0, other, ox, oy, disc_r, a.scan_angles, B, a.angle_inc, ref_lo, ref_hi, lo, hi);
+        win[2] = lo;
+        win[3] = hi;
+        double *ov = a.opp_verts + ((size_t)i * A + j) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ov[c] = other[c];
+    }
+    a.collisions[i] = hit ? 1.0 : 0.0;
+    a.collision_idx[i] = (double)partner;
+}
+
+// ---- K1: integrate every agent one time step ------------------------------------------
+// AF = 0: integration only (k_collide follows on a side stream, hidden under the scan).
+// AF = 2 / 4 (agents per env): the pair tests run in the same lane right after the integration,
+// the partners' post-integration poses (the :574 snapshot) arriving by lane shuffle — the agents
+// of an env are neighbouring lanes of one wave.  Used when the step runs as several env groups on
+// their own streams: one launch and no event fork/join per group, and the longer dependent chain
+// hides under the other groups' scans.
+template <int AF>
+__global__ void __launch_bounds__(AF ? 64 : 256) k_integrate(AgentArrays a, ScanConst k, const double *__restrict__ actions)
+{
+    const int i = a.agent_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int N = a.n_agents_total;
-    if (i >= N) return;
+    if (i >= a.agent_begin + a.agent_count) return;
     const VehicleParams vp = load_params(a.params + (size_t)(a.params_per_agent ? i : i % a.agents_per_env) * NPARAMS);
     double st[7];
 #pragma unroll
@@ -128,7 +203,12 @@ __global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, c
         int r0, c0;
         hd.d0 = sample_distance<LAYOUT_ROWMAJOR, false, false>(*km, nullptr, sp[0], sp[1], r0, c0);
         int row = -1;
-        if (a.noise_rows > 0) {
+        if (a.noise_rng) {
+            // k-th scan after reset adds the k-th B-sample draw of the stream (base_classes.py:204,
+            // laser_models.py:450-452): from the row cache, or generated by k_noise_rows (-2)
+            row = a.step_count[i];
+            if (a.noise_rng == 2 || row >= a.noise_rows) row = -2;
+        } else if (a.noise_rows > 0) {
             row = a.step_count[i];
             if (row >= a.noise_rows) row %= a.noise_rows;
         }
@@ -150,62 +230,39 @@ __global__ void __launch_bounds__(256) k_integrate(AgentArrays a, ScanConst k, c
         a.ray_hdr[i] = hd;
     }
     a.in_collision[i] = 0;  // raised by k_scan_rays when any beam's iTTC is under the threshold
+    if constexpr (AF != 0) {
+        // groups are env-aligned and AF divides 64: the AF lanes of an env are all here, in one wave.
+        // Every lane takes part in every shuffle (a lane masked off would read as zero).
+        const int lane = (int)(threadIdx.x & 63u), me = i % AF;
+        double px[AF], py[AF], pth[AF];
+#pragma unroll
+        for (int jj = 0; jj < AF; ++jj) {
+            px[jj] = __shfl(st[0], lane - me + jj);
+            py[jj] = __shfl(st[1], lane - me + jj);
+            pth[jj] = __shfl(st[4], lane - me + jj);
+        }
+        collide_agent<AF>(a, k.num_beams, i, st[0], st[1], st[4], [&](int jj, double &ox, double &oy, double &oth) {
+            ox = px[jj];
+            oy = py[jj];
+            oth = pth[jj];
+        });
+    }
 }
 
-// ---- K1b: pairwise body collisions inside each env ------------------------------------
-// collision_multiple visits pairs (i<j) ascending and overwrites collision_idx, so an agent's
-// final index is the largest colliding partner; flags are symmetric.  Each lane evaluates the
-// GJK of its pairs in the reference's (lower, higher) argument order.
+// ---- K1b: pairwise body collisions inside each env (separate launch, side stream) ------------
 __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = a.agent_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int N = a.n_agents_total, A = a.agents_per_env;
-    if (i >= N) return;
-    const int env = i / A, me = i - env * A;
-    double mine[8];
-    const double mx = a.snap_pose[i], my = a.snap_pose[(size_t)N + i], mth = a.snap_pose[2 * (size_t)N + i];
-    box_vertices(mx, my, mth, a.box_length, a.box_width, mine);
-    // bodies whose centres are further apart than a box diagonal (+1 mm) cannot overlap
-    const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
-    // RaceCar.ray_cast_agents draws the opponents with the EGO's length/width (:223)
-    const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
-    const double blen = a.params[prow + P_LENGTH];
-    const double bwid = a.params[prow + P_WIDTH];
-    const double disc_r = 0.5 * sqrt(blen * blen + bwid * bwid);
-    bool hit = false;
-    int partner = -1;
-    for (int j = 0; j < A; ++j) {
-        if (j == me) continue;
-        const int o = env * A + j;
-        const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
-        const double dx = ox - mx, dy = oy - my;
-        double other[8];
-        if (dx * dx + dy * dy <= reach * reach) {
-            box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
-            const bool c = (me < j) ? gjk_overlap(mine, other) : gjk_overlap(other, mine);
-            if (c) {
-                hit = true;
-                partner = j;  // j ascending -> ends at the largest colliding index
-            }
-        }
-        // beam window this opponent can occupy in my scan: once for my post-integration heading
-        // (no wall hit) and once for heading 0 (RaceCar.check_ttc zeroes it on a wall hit, and the
-        // ray-cast reads the live state, base_classes.py:225,246-249); k_finalize picks one.
-        int ref_lo, ref_hi, lo, hi;
-        box_vertices(ox, oy, oth, blen, bwid, other);
-        int32_t *win = a.opp_window + ((size_t)i * A + j) * 4;
-        opponent_beam_window(mx, my, mth, other, ox, oy, disc_r, a.scan_angles, B, a.angle_inc, ref_lo, ref_hi, lo, hi);
-        win[0] = lo;
-        win[1] = hi;
-        opponent_beam_window(mx, my, 0.0, other, ox, oy, disc_r, a.scan_angles, B, a.angle_inc, ref_lo, ref_hi, lo, hi);
-        win[2] = lo;
-        win[3] = hi;
-        double *ov = a.opp_verts + ((size_t)i * A + j) * 8;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) ov[c] = other[c];
-    }
-    a.collisions[i] = hit ? 1.0 : 0.0;
-    a.collision_idx[i] = (double)partner;
+    if (i >= a.agent_begin + a.agent_count) return;
+    const int env = i / A;
+    collide_agent<0>(a, B, i, a.snap_pose[i], a.snap_pose[(size_t)N + i], a.snap_pose[2 * (size_t)N + i],
+                     [&](int jj, double &ox, double &oy, double &oth) {
+                         const int o = env * A + jj;
+                         ox = a.snap_pose[o];
+                         oy = a.snap_pose[(size_t)N + o];
+                         oth = a.snap_pose[2 * (size_t)N + o];
+                     });
 }
 
 // ---- K2: ray march -------------------------------------------------------------------------
@@ -222,6 +279,8 @@ struct RayJob {
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
     int32_t dir_mode, dir_stride;   // dedupe pass: rays are (agent, distinct direction), dir_stride per agent
     const double *dir_ranges;       // k_expand_beams: [n_poses][dir_stride] raw ranges of the dedupe pass
+    uint32_t first_pose, pad_first; // k_scan_rays_agent: the launch covers agents first_pose .. (env group)
+    unsigned long long *lookups_total;  // COUNT variants: table lookups of every marched ray, summed (or nullptr)
     const double *pose_x, *pose_y, *dir_start;  // [n_poses] (unit path)
     double *ranges;           // [n_poses][B]
     // STEP only
@@ -297,6 +356,13 @@ __device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_
                                             int row, double vel);
 __device__ __forceinline__ void finish_beam_with(const RayJob &j, uint32_t p, int b, uint32_t ray, double r, double vel);
 
+// all 64 lanes (reconverged after the task loop): sum the per-lane lookup counts, one atomic per wave
+__device__ __forceinline__ void wave_add_lookups(unsigned long long *total, uint32_t mine)
+{
+    for (int off = 32; off; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(total, (unsigned long long)mine);
+}
+
 // One ray from its (shared) first sample d0 on.  path: 0 fixed-point march, 1 fixed-point march
 // given up and re-marched exactly, 2 exact arithmetic throughout.
 template <int LAYOUT, bool POW2, bool IDENT, bool WANT_CELL>
@@ -343,6 +409,7 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
         blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // bijective for any nb
     }
     const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
+    uint32_t nl_acc = 0;   // STEP: table lookups of this lane's rays (summed per wave when counting is on)
     for (uint32_t t = 0; t < tpw; ++t) {
         const uint32_t task = wave * tpw + t;
         if (task >= j.n_tasks) break;  // wave-uniform
@@ -365,11 +432,13 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
                     const double2 cs = k.cs[didx];
                     j.ranges[ray] = trace_from_first<LAYOUT, POW2, IDENT, false>(k, j.k_cold, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl,
                                                                                  path);
+                    nl_acc += (uint32_t)nl;
                 }
                 continue;
             }
             const double2 cs = k.cs[beam_dir_index(k, hd.start, b)];
             r = trace_from_first<LAYOUT, POW2, IDENT, false>(k, j.k_cold, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl, path);
+            nl_acc += (uint32_t)nl;
             finish_beam(j, B, p, b, ray, r, hd.row, hd.vel);
             continue;
         } else {
@@ -392,6 +461,7 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
         }
         j.ranges[ray] = r;
     }
+    if (STEP && j.lookups_total) wave_add_lookups(j.lookups_total, nl_acc);
 }
 
 // ---- K2a: the step's ray march, agent-aligned ----------------------------------------------------
@@ -411,7 +481,7 @@ struct MapFast {
 };
 static_assert(sizeof(MapFast) == 64, "MapFast is read as one 64-byte scalar load");
 
-template <bool PER_ENV_MAP, bool IDENT>
+template <bool PER_ENV_MAP, bool IDENT, bool COUNT>
 __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
                                                           const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
@@ -424,11 +494,13 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // XCD-contiguous, as k_scan_rays
     }
     const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
+    uint32_t nl_acc = 0;
     for (uint32_t t = 0; t < tpw; ++t) {
         const uint32_t task = __builtin_amdgcn_readfirstlane(wave * tpw + t);
         if (task >= j.n_tasks) break;
-        const uint32_t p = task / tasks_per_agent;                  // scalar
-        const int b = (int)((task - p * tasks_per_agent) * 64u + lane);
+        const uint32_t pl = task / tasks_per_agent;                 // scalar
+        const uint32_t p = j.first_pose + pl;
+        const int b = (int)((task - pl * tasks_per_agent) * 64u + lane);
         if (b >= (int)B) continue;
         typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
         typedef const __attribute__((address_space(4))) MapFast *cmap_t;
@@ -452,8 +524,10 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
             km.pad_row_bytes = uniform_i32((int)m0->pad_row_bytes);
             km.pad_max_samples = uniform_i32(m0->pad_max_samples);
         }
-        // the beam's noise sample is requested before the march so that its latency hides under it
-        const double nz = row >= 0 ? j.noise[(size_t)row * B + b] : 0.0;
+        // the beam's noise sample is requested before the march so that its latency hides under it:
+        // row of the table / row cache, or (row -2) the row k_noise_rows left in this agent's scans[]
+        const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;   // scalar
+        const double nz = row != -1 ? nrow[b] : 0.0;
         const double2 cs = k.cs[beam_dir_index(k, start, b)];
         int hr = -1, hc = -1, nl;
         double r = 0.;
@@ -465,8 +539,10 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
             exact = !march_padded<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl);
         }
         if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
-        finish_beam_with(j, p, b, p * B + (uint32_t)b, row >= 0 ? r + nz : r, vel);
+        if (COUNT) nl_acc += (uint32_t)nl;   // measurement variant only (bench.py's L-bar)
+        finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
     }
+    if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
 }
 
 // iTTC + store for one beam whose noise sample has been added already
@@ -481,7 +557,10 @@ __device__ __forceinline__ void finish_beam_with(const RayJob &j, uint32_t p, in
 __device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_t p, int b, uint32_t ray, double r,
                                             int row, double vel)
 {
-    if (row >= 0) r += j.noise[(size_t)row * B + b];
+    if (row >= 0)
+        r += j.noise[(size_t)row * B + b];
+    else if (row == -2)
+        r += j.ranges[ray];   // this step's noise row, left in the agent's scans[] by k_noise_rows
     finish_beam_with(j, p, b, ray, r, vel);
 }
 
@@ -503,6 +582,91 @@ __global__ void __launch_bounds__(256) k_expand_beams(RayJob j, ScanConst k)
     if (s < 0) s += k.theta_dis;
     const double r = j.dir_ranges[(size_t)p * j.dir_stride + s];
     finish_beam(j, B, p, b, ray, r, hd.row, hd.vel);
+}
+
+// ---- scan noise generated on the device --------------------------------------------
+// rng.normal(0., std, num_beams) of laser_models.py:450-452 — NumPy's PCG64 + ziggurat, restated in
+// f110_rng.hpp.  One wave produces one row of B samples: lane l evaluates the attempt that would
+// start at draw l of the current 64-draw chunk (its generator state comes from the jump constants:
+// A^(l+1) * s + G_(l+1) * inc), the few attempts that consume more than one draw decide which
+// positions really start an attempt (zig_chain_starts), and the accepted values are packed in order.
+struct NoiseGen {
+    const uint64_t *zk;   // ziggurat tables (device copies)
+    const double *zw, *zf;
+    const U128 *ja, *jg;  // PcgJump (device copy): [65] each
+    double scale;         // std_dev of the noise (loc = 0.)
+};
+
+// `state` (wave-uniform): stream position at the start of the row in, at its end out
+__device__ __forceinline__ void noise_row_wave(const NoiseGen &g, U128 &state, const U128 inc, double *__restrict__ out, int B)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const ZigTables zt = {g.zk, g.zw, g.zf};
+    const U128 aj = g.ja[lane + 1];
+    const U128 gi = mul128(g.jg[lane + 1], inc);
+    const uint64_t below = (1ull << lane) - 1ull;
+    int produced = 0, skip = 0;
+    U128 s = state;
+    for (;;) {
+        const U128 st = add128(mul128(aj, s), gi);
+        const ZigAttempt z = zig_attempt(pcg_output(st), st, inc, zt);
+        const uint64_t multi = __ballot(z.len > 1);
+        int skip_out;
+        const uint64_t starts = zig_chain_starts(multi, skip, [&](int p) { return __builtin_amdgcn_readlane(z.len, p); }, skip_out);
+        const uint64_t em = starts & __ballot(z.emit);
+        const int idx = produced + popc_u64(em & below);
+        if (((em >> lane) & 1ull) && idx < B) out[idx] = 0.0 + g.scale * z.val;  // loc + scale * z (random_normal)
+        const int cnt = popc_u64(em);
+        if (produced + cnt >= B) {
+            const int e = nth_set_bit(em, B - produced - 1);
+            state = pcg_advance(s, inc, g.ja, g.jg, e + __builtin_amdgcn_readlane(z.len, e));
+            return;
+        }
+        produced += cnt;
+        skip = skip_out;
+        s = pcg_advance(s, inc, g.ja, g.jg, 64);
+    }
+}
+
+__device__ __forceinline__ U128 uniform_u128(U128 v)
+{
+    U128 o;
+    o.hi = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v.hi >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v.hi);
+    o.lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v.lo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v.lo);
+    return o;
+}
+
+// rows [row0, row1) of the shared stream into the row cache, one after the other (a row's start
+// depends on how many draws the previous rows consumed); rowstate[r] = stream position at row r.
+__global__ void __launch_bounds__(64) k_noise_cache(NoiseGen g, U128 inc, U128 *__restrict__ rowstate, double *__restrict__ cache, int row0,
+                                                    int row1, int B)
+{
+    U128 state = uniform_u128(rowstate[row0]);
+    for (int r = row0; r < row1; ++r) {
+        noise_row_wave(g, state, inc, cache + (size_t)r * B, B);
+        if ((threadIdx.x & 63u) == 0u) rowstate[r + 1] = state;
+    }
+}
+
+// this step's noise row of every agent the row cache cannot serve (per-agent streams; episodes
+// longer than the cache), generated into the agent's scans[] row where the scan kernel picks it up
+// (RayHdr::noise_row == -2).  One wave per agent; agents served by the cache leave at once.
+__global__ void __launch_bounds__(256) k_noise_rows(AgentArrays a, NoiseGen g, int B)
+{
+    const int i = a.agent_begin + (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (i >= a.agent_begin + a.agent_count) return;
+    const int k = __builtin_amdgcn_readfirstlane(a.step_count[i]);
+    U128 state, inc;
+    if (a.noise_rng == 2) {
+        inc = uniform_u128(a.rng_seed[2 * (size_t)i + 1]);
+        state = uniform_u128(k == 0 ? a.rng_seed[2 * (size_t)i] : a.rng_state[i]);
+    } else {
+        if (k < a.noise_rows) return;
+        inc = a.rng_inc;
+        state = uniform_u128(k == a.noise_rows ? a.rng_rowstate[a.noise_rows] : a.rng_state[i]);
+    }
+    noise_row_wave(g, state, inc, a.scans + (size_t)i * B, B);
+    if ((threadIdx.x & 63u) == 0u) a.rng_state[i] = state;
 }
 
 // In-place re-seat of one agent of a finished env (f110_reset_collided_device / auto re-seat): what
@@ -536,9 +700,9 @@ template <int kFinalizeLanes>
 __global__ void __launch_bounds__(256) k_finalize(AgentArrays a, int32_t B)
 {
     constexpr int kFinalizeAgents = 256 / kFinalizeLanes;   // per 256-thread workgroup
-    const int i = blockIdx.x * kFinalizeAgents + (int)(threadIdx.x / kFinalizeLanes), tid = threadIdx.x & (kFinalizeLanes - 1);
+    const int i = a.agent_begin + (int)(blockIdx.x * kFinalizeAgents + threadIdx.x / kFinalizeLanes), tid = threadIdx.x & (kFinalizeLanes - 1);
     const int N = a.n_agents_total, A = a.agents_per_env;
-    if (i >= N) return;
+    if (i >= a.agent_begin + a.agent_count) return;
     // everything the wave may need is requested up front (one round trip), not behind the flag
     const int wall = a.in_collision[i];
     const double ex = a.state[i], ey = a.state[(size_t)N + i];
@@ -587,9 +751,9 @@ __global__ void __launch_bounds__(256) k_finalize(AgentArrays a, int32_t B)
 // single-agent envs: no opponents, one lane per agent is enough
 __global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = a.agent_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int N = a.n_agents_total;
-    if (i >= N) return;
+    if (i >= a.agent_begin + a.agent_count) return;
     const int wall = a.in_collision[i];
     if (wall) {
         a.state[3 * (size_t)N + i] = 0.;

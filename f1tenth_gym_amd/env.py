@@ -166,9 +166,15 @@ class F110VecEnv(object):
     """E independent F110 environments stepped by one device launch sequence.
 
     reset(poses[E][A][3], env_mask=None) / step(actions[E][A][2]) -> (obs, reward, done[E], info)
-    with array observations (leading env axis).  `auto_reset=True` re-seats finished envs at
-    their start poses inside step() (mask reset in place) — like the reference's
-    reset() that costs them one zero-action step, taken on the next call.
+    with array observations (leading env axis).
+
+    Resets.  reset(poses) of every env is the reference's reset(): re-seat + one zero-action step,
+    whose observation is returned (f110_env.py:337-338).  A PARTIAL reset — reset(poses, env_mask)
+    or `auto_reset=True`, which re-seats finished envs at their start poses inside step() (mask
+    reset in place) — only re-seats: nobody is stepped, the envs that are in the middle
+    of an episode are not disturbed, and a re-seated env's first observation arrives with the next
+    step().  reset(poses, env_mask) therefore returns the previous step's tuple with `done`
+    cleared for the re-seated envs.
 
     device_logic=True runs the lap / done bookkeeping (F110Env._check_done) and the auto-reset on
     the GPU (f110_episode_*): per step only `done`, the lap arrays and the requested observation
@@ -201,8 +207,10 @@ class F110VecEnv(object):
                              num_beams=kwargs.get('num_beams', 1080), fov=kwargs.get('fov', 4.7),
                              scan_noise_std=kwargs.get('scan_noise_std', 0.01),
                              device_id=kwargs.get('device_id', 0),
-                             map_layout=kwargs.get('map_layout', _ffi.MAP_DEFAULT))
+                             map_layout=kwargs.get('map_layout', _ffi.MAP_DEFAULT), batched=True,
+                             noise_mode=kwargs.get('noise_mode', 'device'), step_groups=kwargs.get('step_groups', 0))
         self.sim.set_map(self.map_path, self.map_ext)
+        self._last = None
         self.map_slots = [(self.map_path, self.map_ext)]
         for path, ext in kwargs.get('extra_maps', ()):
             self.sim.batch.add_map(path, ext)
@@ -242,6 +250,12 @@ class F110VecEnv(object):
         else:
             self.sim.reset(poses, env_mask)
             self._lap.reset(poses, env_mask)
+        if env_mask is not None and not np.all(env_mask) and self._last is not None:
+            # partial reset: re-seat only (class docstring); envs in mid-episode are not stepped
+            obs, reward, done, info = self._last
+            done = np.where(np.asarray(env_mask, dtype=bool), False, done)
+            self._last = (obs, reward, done, info)
+            return self._last
         return self.step(np.zeros((self.num_envs, self.num_agents, 2)))
 
     def _step_device(self, actions):
@@ -267,7 +281,8 @@ class F110VecEnv(object):
                 'toggle_list': ep["toggles"].reshape(E, A), 'near_starts': ep["near_starts"].reshape(E, A).astype(bool)}
         if self.auto_reset:
             b.episode_reset_done_device()
-        return obs, self.timestep, done, info
+        self._last = (obs, self.timestep, done, info)
+        return self._last
 
     def step(self, actions):
         if self.device_logic:
@@ -281,4 +296,5 @@ class F110VecEnv(object):
         if self.auto_reset and done.any():
             self.sim.reset(self._start_poses, done)
             self._lap.reset(self._start_poses, done)
-        return obs, self.timestep, done, info
+        self._last = (obs, self.timestep, done, info)
+        return self._last

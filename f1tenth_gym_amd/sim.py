@@ -29,22 +29,30 @@ def _integrator_code(integrator):
 
 
 class ScanNoise(object):
-    """The reference draws rng.normal(0, std, B) per agent per step from a generator that every
-    agent re-seeds with the SAME seed at reset (base_classes.py:204), so the noise is one shared
-    (steps-since-reset, beam) table.  It is produced here with NumPy's PCG64 + ziggurat — the
-    golden stream — and uploaded to HBM; the scan kernel adds row `step_count`."""
+    """The A/B form of the scan noise (noise_mode='table'): the reference draws rng.normal(0, std, B)
+    per agent per step from a generator that every agent re-seeds with the SAME seed at reset
+    (base_classes.py:204), so the noise is one shared (steps-since-reset, beam) table.  It is
+    produced here with NumPy's PCG64 + ziggurat and uploaded; the scan kernel adds row
+    `step_count`.  The default (noise_mode='device') draws the same stream on the GPU instead
+    (BatchSim.set_noise_rng) with flat memory; this table is bounded by `max_rows` episode steps."""
 
-    def __init__(self, seed, num_beams, std_dev=0.01, chunk=256):
+    def __init__(self, seed, num_beams, std_dev=0.01, chunk=256, max_rows=16384):
         self.seed, self.B, self.std, self.chunk = seed, int(num_beams), float(std_dev), int(chunk)
+        self.max_rows = int(max_rows)
         self.rng = np.random.default_rng(seed=seed)
         self.rows = np.empty((0, self.B))
 
     def ensure(self, bsim, needed_rows):
         if self.rows.shape[0] >= needed_rows and bsim.noise_rows == self.rows.shape[0]:
             return
+        if needed_rows > self.max_rows:
+            if self.rows.shape[0] >= self.max_rows and bsim.noise_rows == self.rows.shape[0]:
+                return   # the longest episode any agent can be in is unknown to the host: see step()
+            needed_rows = self.max_rows
         target = max(self.chunk, self.rows.shape[0])
         while target < needed_rows:
             target *= 2
+        target = min(target, max(self.max_rows, self.chunk))
         if target > self.rows.shape[0]:
             # successive normal(size=B) calls == one normal(size=(k,B)) call (row-major fill)
             extra = self.rng.normal(0., self.std, size=(target - self.rows.shape[0], self.B))
@@ -74,7 +82,7 @@ class AgentView(object):
 class Simulator(object):
     def __init__(self, params, num_agents, seed, time_step=0.01, ego_idx=0, integrator=Integrator.RK4,
                  lidar_dist=0.0, num_envs=1, num_beams=1080, fov=4.7, scan_noise_std=0.01, device_id=0,
-                 map_layout=_ffi.MAP_DEFAULT, scan_block=0):
+                 map_layout=_ffi.MAP_DEFAULT, scan_block=0, batched=None, noise_mode='device', step_groups=0):
         self.num_agents = num_agents
         self.num_envs = num_envs
         self.seed = seed
@@ -84,15 +92,28 @@ class Simulator(object):
         self._agent_params = [params for _ in range(num_agents)]
         self._b = BatchSim(params, num_envs=num_envs, num_agents=num_agents, num_beams=num_beams, fov=fov,
                            time_step=time_step, integrator=_integrator_code(integrator), lidar_dist=lidar_dist,
-                           device_id=device_id, map_layout=map_layout, scan_block=scan_block)
+                           device_id=device_id, map_layout=map_layout, scan_block=scan_block, step_groups=step_groups)
         N = num_envs * num_agents
-        self.agent_poses = np.empty((num_agents, 3)) if num_envs == 1 else np.empty((num_envs, num_agents, 3))
-        self.collisions = np.zeros((num_agents,)) if num_envs == 1 else np.zeros((num_envs, num_agents))
+        # batched=False: the reference's single-env layout (lists of per-agent values); True: a
+        # leading env axis on everything, also for num_envs == 1 (F110VecEnv)
+        self._batched = bool(num_envs != 1) if batched is None else bool(batched)
+        if not self._batched and num_envs != 1:
+            raise ValueError("the single-env layout needs num_envs == 1")
+        self.agent_poses = np.empty((num_envs, num_agents, 3)) if self._batched else np.empty((num_agents, 3))
+        self.collisions = np.zeros((num_envs, num_agents)) if self._batched else np.zeros((num_agents,))
         self.collision_idx = -1 * np.ones_like(self.collisions)
         self._state = np.zeros((N, 7))
         self._in_collision = np.zeros((N,), dtype=np.int32)
         self.agents = [AgentView(self, 0, i) for i in range(num_agents)]
-        self._noise = ScanNoise(seed, num_beams, scan_noise_std) if scan_noise_std and scan_noise_std > 0 else None
+        # laser_models.py:450-452: noise of std_dev 0.01 from default_rng(seed), re-seeded at reset
+        self._noise = None
+        if noise_mode not in ('device', 'table'):
+            raise ValueError("noise_mode must be 'device' or 'table'")
+        if scan_noise_std and scan_noise_std > 0:
+            if noise_mode == 'device':
+                self._b.set_noise_rng(seed, scan_noise_std)
+            else:
+                self._noise = ScanNoise(seed, num_beams, scan_noise_std)
         self._steps_since_full_reset = 0
 
     @property
@@ -119,7 +140,7 @@ class Simulator(object):
     def reset(self, poses, env_mask=None):
         poses = np.asarray(poses, dtype=np.float64)
         E, A = self.num_envs, self.num_agents
-        if E == 1:
+        if not self._batched:
             if poses.shape[0] != A:
                 raise ValueError('Number of poses for reset does not match number of agents.')
             flat = poses.reshape(A, 3)
@@ -144,7 +165,7 @@ class Simulator(object):
         self._state = o["state"]
         self._in_collision = o["in_collision"]
         st = o["state"]
-        if E == 1:
+        if not self._batched:
             self.agent_poses = o["agent_poses"]
             self.collisions = o["collisions"]
             self.collision_idx = o["collision_idx"]

@@ -74,7 +74,8 @@ typedef struct f110_config {
     int32_t map_layout;    /* F110_MAP_* */
     int32_t scan_block;    /* threads per scan workgroup (0 = default) */
     int32_t scan_tasks_per_wave; /* consecutive 64-ray tasks each wave walks (0 = default) */
-    int32_t reserved0, reserved1;
+    int32_t step_groups;   /* independent env blocks stepped on streams of their own (0 = automatic) */
+    int32_t reserved1;
     double fov, eps, max_range;
     double time_step, lidar_dist, ttc_thresh;
     double params[F110_NPARAMS]; /* initial vehicle params for every agent slot */
@@ -133,6 +134,24 @@ int f110_set_params_batch(f110_sim *h, const double *h_params);
 /* scan noise, laser_models.py:450-452 with base_classes.py:204: row k is added to every
  * agent's scan on its k-th step after reset (rows wrap modulo n_rows).  n_rows=0: no noise. */
 int f110_set_noise_table(f110_sim *h, const double *h_noise, int32_t n_rows, int32_t num_beams);
+/* The same noise generated ON THE DEVICE: np.random.default_rng(seed).normal(0.,
+ * std_dev, num_beams) per scan, laser_models.py:450-452 — NumPy's PCG64 stream through NumPy's
+ * ziggurat, bit for bit — re-started for an agent whenever it is reset (base_classes.py:204).
+ * Nothing is uploaded and memory stays flat however long the run is.
+ *   h_state_inc, per_agent = 0: [4] = {state.hi, state.lo, inc.hi, inc.lo} of np.random.PCG64(seed)
+ *       (f110_pcg64_seed computes them): one stream shared by every agent, as in the reference.  The
+ *       first cache_rows rows (0: 4096) are generated once into a device row cache, extended on
+ *       demand as episodes get longer; an agent whose episode outlives the cache continues from the
+ *       stream position it carries.
+ *   per_agent = 1: [N][4], a stream per agent (extension), always generated from the carried state.
+ *   NULL: noise off.  Replaces any table of f110_set_noise_table, and vice versa. */
+int f110_set_noise_rng(f110_sim *h, const uint64_t *h_state_inc, int32_t per_agent, double std_dev,
+                       int32_t cache_rows);
+/* np.random.PCG64(seed): SeedSequence(seed).generate_state(4, uint64) + pcg64_set_seed, host only;
+ * seed < 2^64.  out4 = {state.hi, state.lo, inc.hi, inc.lo}. */
+int f110_pcg64_seed(uint64_t seed, uint64_t *out4);
+/* generate the shared stream's rows [0, rows) into the row cache now (instead of on demand) */
+int f110_noise_prepare(f110_sim *h, int32_t rows);
 
 /* Simulator.reset base_classes.py:614-630 / RaceCar.reset :183-204.
  * h_poses [N][3]; h_env_mask [num_envs] or NULL (all). */
@@ -292,6 +311,15 @@ int f110_get_range_batch(f110_sim *h, const double *h_in, int32_t m, double *h_o
 /* exact squared EDT of a binary image (nonzero = free), laser_models.py:40-53 */
 int f110_edt_sq(f110_sim *h, const uint8_t *h_img, int32_t height, int32_t width,
                 uint32_t *h_d2);
+/* rng.normal(0., std_dev, num_beams) drawn `rows` times in a row from the PCG64 state h_state_inc4
+ * (numpy/random/src/distributions/distributions.c random_standard_normal; laser_models.py:450-452):
+ * h_out [rows][num_beams]; h_state_out2 (or NULL) = {state.hi, state.lo} after the last draw */
+int f110_noise_rows_batch(f110_sim *h, const uint64_t *h_state_inc4, double std_dev, int32_t rows,
+                          int32_t num_beams, double *h_out, uint64_t *h_state_out2);
+/* Measurement aid (bench.py's L-bar): with enable = 1 the step's scan kernels sum the table lookups
+ * of every ray they march (the reference's dependent gathers, laser_models.py:129-143).  out_total
+ * (or NULL) receives and clears the sum; enable = -1 leaves the switch as it is.  Off by default. */
+int f110_scan_lookup_count(f110_sim *h, int32_t enable, int64_t *out_total);
 /* table index int(theta_index) of every beam for M headings (get_scan :167-184) */
 int f110_beam_dir_index_batch(f110_sim *h, const double *h_thetas, int32_t m, int32_t *h_idx);
 

@@ -8,7 +8,10 @@
 #include <algorithm>
 #include <vector>
 
+#include <string.h>
+
 #include "../../f1tenth_gym_amd/csrc/f110_math.hpp"
+#include "../../f1tenth_gym_amd/csrc/f110_rng.hpp"
 
 using namespace f110;
 
@@ -236,6 +239,60 @@ void hh_raycast(const double *ego, const double *v, const double *scan_angles, i
         const double r = box_range(ego[0], ego[1], cos(bt + kPi / 2.), sin(bt + kPi / 2.), v, r0);
         if (r < r0) scan[b] = r;
     }
+}
+
+// ---- scan-noise stream (f110_rng.hpp): the chunked generation the device wave performs, lane by
+// lane on the host — same per-draw code (zig_attempt), same chain resolution (zig_chain_starts),
+// same jump constants.  rows x B samples = 0.0 + scale * z, consecutive in the stream.
+void hh_pcg64_seed(uint64_t seed, uint64_t *out4) { pcg64_seed_from_u64(seed, out4); }
+
+double hh_log1p(double x) { return log1p_glibc(x); }
+
+void hh_noise_rows(const uint64_t *state_inc, double scale, int rows, int B, double *out, uint64_t *state_out)
+{
+    static PcgJump jt;
+    static bool have = false;
+    if (!have) {
+        pcg_jump_table(jt);
+        have = true;
+    }
+    const ZigTables zt = {kZigK, kZigW, kZigF};
+    U128 state = {state_inc[0], state_inc[1]};
+    const U128 inc = {state_inc[2], state_inc[3]};
+    for (int row = 0; row < rows; ++row) {
+        double *dst = out + (size_t)row * B;
+        int produced = 0, skip = 0;
+        U128 s = state;
+        for (;;) {
+            ZigAttempt z[64];
+            uint64_t multi = 0, emit = 0;
+            for (int lane = 0; lane < 64; ++lane) {
+                const U128 st = add128(mul128(jt.a[lane + 1], s), mul128(jt.g[lane + 1], inc));
+                z[lane] = zig_attempt(pcg_output(st), st, inc, zt);
+                if (z[lane].len > 1) multi |= 1ull << lane;
+                if (z[lane].emit) emit |= 1ull << lane;
+            }
+            int skip_out;
+            const uint64_t starts = zig_chain_starts(multi, skip, [&](int p) { return z[p].len; }, skip_out);
+            const uint64_t em = starts & emit;
+            for (int lane = 0; lane < 64; ++lane) {
+                if (!((em >> lane) & 1ull)) continue;
+                const int idx = produced + popc_u64(em & ((1ull << lane) - 1ull));
+                if (idx < B) dst[idx] = 0.0 + scale * z[lane].val;
+            }
+            const int cnt = popc_u64(em);
+            if (produced + cnt >= B) {
+                const int e = nth_set_bit(em, B - produced - 1);
+                state = pcg_advance(s, inc, jt.a, jt.g, e + z[e].len);
+                break;
+            }
+            produced += cnt;
+            skip = skip_out;
+            s = pcg_advance(s, inc, jt.a, jt.g, 64);
+        }
+    }
+    state_out[0] = state.hi;
+    state_out[1] = state.lo;
 }
 
 }  // extern "C"

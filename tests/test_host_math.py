@@ -28,8 +28,9 @@ pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.is
 @pytest.fixture(scope="module")
 def hh():
     src = os.path.join(HDIR, "harness.hip")
-    hdr = os.path.join(os.path.dirname(HERE), "f1tenth_gym_amd", "csrc", "f110_math.hpp")
-    if not os.path.isfile(HLIB) or os.path.getmtime(HLIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    csrc = os.path.join(os.path.dirname(HERE), "f1tenth_gym_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in ("f110_math.hpp", "f110_rng.hpp", "f110_ziggurat_tables.hpp")]
+    if not os.path.isfile(HLIB) or os.path.getmtime(HLIB) < max(os.path.getmtime(f) for f in deps):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC",
                                "-shared", src, "-o", HLIB], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
