@@ -1,31 +1,46 @@
 #!/usr/bin/env python3
 """bench.py — agent-steps/s of the MI355X env.step() hot path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 300 --warmup 30
+    python bench.py                                   # 1 GPU, default K/W, all legs (a few minutes)
+    python bench.py --gpus N --steps K --warmup W      # spawns N ranks itself, one per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W     # or is launched as N ranks
 
 One "step" = one Simulator.step() of every agent on the GPU (pid + RK4 single-track dynamics,
 1080-beam scan incl. noise, GJK, iTTC, opponent ray-cast, observations left in HBM), dt = 0.01 s.
 Workload (BASELINE configs[2]): 65536 agents per GPU = 32768 envs x 2 agents on
 example_map; env e starts on raceline waypoint (e*7919) mod 783, the opponent 10 waypoints (2 m)
 behind; steer ~ U(-0.2, 0.2) / speed ~ U(2, 6) re-drawn every 20 steps; envs whose ego collides
-are reset in place on the device.  Inputs (action sets, start poses, noise table) are resident in
-HBM before the timed region; nothing is copied to the host inside it.
+are reset in place on the device.  Inputs (action sets, start poses) are resident in HBM before
+the timed region; the scan noise is drawn on the device (NumPy's seed-12345 stream, bit for bit);
+nothing is copied to the host inside the timed region.
 
 Multi-GPU: the path shards by environment (no interaction between envs), one process per GPU,
 no data-path collective -> "scaling": "weak" (each rank steps its own 65536 agents).  The
-rendezvous (barrier + max-over-ranks of the elapsed time) uses torch.distributed (gloo control
-plane); the simulator itself never touches torch.
+control plane (barrier + max-over-ranks of the elapsed time) is a few lines of stdlib sockets
+(class Rendezvous): no torch anywhere.  Launched without a rank environment and with --gpus N > 1
+the script spawns the N ranks itself and fails loudly when fewer than N devices are visible.
 
-The JSON line also carries
-  roofline      ALGORITHMIC bytes of the dominant kernel (k_scan_rays) / its HIP-event duration
-  cpu_baseline  the CPU oracle (oracle/, a C port of the reference) timed on this box's host cores
+The JSON line carries, besides the contract's fields:
+  roofline      SURVEY §8d: whole-step ALGORITHMIC bytes (216 + 8B + 8B*L-bar per agent-step) x
+                agent-steps/s over 8 TB/s as `frac`; the scan kernel's own figure (HIP events, a
+                separate replay of the same steps) as `kernel_frac`; L-bar counted ON THE DEVICE
+                over exactly the timed steps (a third replay with the counting kernel variant);
+                the compulsory-stream fraction, the PMC-measured HBM fraction, and the binding
+                gather-issue floor (profiles/r02_issue_floor.json)
+  steady_state  the same workload over >= 1000 timed steps after >= 100 warm-up steps
+  cpu_baseline  the CPU oracle (oracle/, a C port of the reference) on this box's host cores, plus
+                `cpu_1t`: the reference's own shape (1 env x 2 agents, one thread; BASELINE configs[0])
+  config.secondary / config.config5 / config.fixed_pose_variant: the other BASELINE configs
 """
 import argparse
 import json
 import os
+import socket
+import struct
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -33,9 +48,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+NOISE_SEED = 12345      # F110Env's default seed (f110_env.py:107)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -48,9 +64,12 @@ def parse_args():
     ap.add_argument("--scan-block", type=int, default=int(os.environ.get("F110_SCAN_BLOCK", "0")))
     ap.add_argument("--scan-tasks", type=int, default=int(os.environ.get("F110_SCAN_TASKS", "0")),
                     help="consecutive 64-ray tasks per wave (0 = default)")
+    ap.add_argument("--groups", type=int, default=0, help="env groups stepped on streams of their own (0 = the library's default)")
     ap.add_argument("--gather", action="store_true",
                     help="RCCL all-gather of every rank's scans after each step (BASELINE config 4; off by default)")
-    ap.add_argument("--no-noise", action="store_true")
+    ap.add_argument("--noise", choices=["rng", "table", "off"], default="rng",
+                    help="rng: drawn on the device (default); table: NumPy's rows uploaded (A/B); off")
+    ap.add_argument("--no-noise", action="store_true", help="same as --noise off")
     ap.add_argument("--policy", choices=["random", "pure_pursuit", "parked"], default="random",
                     help="random: pre-drawn device-resident action sets (the default workload); pure_pursuit: the reference's "
                          "example planner (examples/waypoint_follow.py) evaluated on the device every step, closed loop; "
@@ -58,16 +77,25 @@ def parse_args():
     ap.add_argument("--no-reset", action="store_true")
     ap.add_argument("--separate-reset", action="store_true", help="re-seat finished envs with a separate launch per step instead of inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--map-tiles", type=int, default=1, help="tile example_map k x k (BASELINE config 5 uses 2: a 3200x3200 table)")
     ap.add_argument("--fixed-pose-steps", type=int, default=100, help="also time this many steps with all cars parked (0 = skip)")
     ap.add_argument("--secondary", type=int, default=4096, help="also time this many agents (configs[1]); 0 = skip")
+    ap.add_argument("--steady-steps", type=int, default=1000, help="steady-state leg: timed steps (SURVEY 8d: >= 1000); 0 = skip")
+    ap.add_argument("--steady-warmup", type=int, default=100)
+    ap.add_argument("--no-config5", action="store_true", help="skip the 65536 x 4096-beam / 3200x3200-table leg")
+    ap.add_argument("--only-headline", action="store_true", help="the timed region only (profiling / PMC runs): no replays, no other legs")
     ap.add_argument("--no-profile-events", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # tests: no GPU, a sleep stands in for the step
+    return ap.parse_args(argv)
 
 
+# ---------------------------------------------------------------------------------------------
+# control plane: barrier / max / sum / broadcast over a Unix socket, rank 0 is the hub
 class Rendezvous(object):
-    """barrier + max-reduce across the ranks torchrun started (gloo; no GPU tensors)."""
+    """The ranks of ONE node (torchrun's or our own): RANK / LOCAL_RANK / WORLD_SIZE from the
+    environment, the meeting point derived from F110_BENCH_RDV or MASTER_PORT.  Every collective
+    is: each rank sends its value to rank 0, rank 0 replies with the reduction."""
 
     def __init__(self):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,47 +103,113 @@ class Rendezvous(object):
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if "F110_BENCH_DEVICE" in os.environ:   # testing aid: several ranks on one GPU
             self.local_rank = int(os.environ["F110_BENCH_DEVICE"])
-        self.dist = None
+        self.peers, self.sock = [], None
         if self.world > 1:
-            import torch  # imported BEFORE libf110_hip.so so both share one libamdhip64
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world)
-            self.dist, self.torch = dist, torch
+            name = os.environ.get("F110_BENCH_RDV") or ("f110-bench-%s-%s" % (os.environ.get("MASTER_PORT", "0"),
+                                                                            os.environ.get("TORCHELASTIC_RUN_ID", "none")))
+            addr = "\0" + name    # abstract namespace: nothing to clean up, nothing on disk
+            if self.rank == 0:
+                srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                srv.bind(addr)
+                srv.listen(self.world)
+                srv.settimeout(300)
+                got = {}
+                while len(got) < self.world - 1:
+                    c, _ = srv.accept()
+                    c.settimeout(600)
+                    r = struct.unpack("<i", self._recv(c, 4))[0]
+                    got[r] = c
+                self.peers = [got[r] for r in sorted(got)]
+                srv.close()
+            else:
+                deadline = time.time() + 300
+                while True:
+                    try:
+                        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                        s.connect(addr)
+                        break
+                    except (ConnectionRefusedError, FileNotFoundError):
+                        s.close()
+                        if time.time() > deadline:
+                            raise RuntimeError("bench rendezvous: rank 0 never appeared at %r" % name)
+                        time.sleep(0.05)
+                s.settimeout(600)
+                s.sendall(struct.pack("<i", self.rank))
+                self.sock = s
+
+    @staticmethod
+    def _recv(c, n):
+        buf = b""
+        while len(buf) < n:
+            part = c.recv(n - len(buf))
+            if not part:
+                raise RuntimeError("bench rendezvous: peer went away")
+            buf += part
+        return buf
+
+    def _reduce(self, payload, combine):
+        """payload: bytes of fixed length; combine(list_of_payloads) -> bytes; everybody gets the result"""
+        if self.world == 1:
+            return combine([payload])
+        if self.rank == 0:
+            vals = [payload] + [self._recv(c, len(payload)) for c in self.peers]
+            out = combine(vals)
+            for c in self.peers:
+                c.sendall(out)
+            return out
+        self.sock.sendall(payload)
+        return self._recv(self.sock, len(payload))
 
     def barrier(self):
-        if self.dist:
-            self.dist.barrier()
+        self._reduce(b"\0", lambda v: b"\0")
 
     def max(self, x):
-        if not self.dist:
-            return x
-        t = self.torch.tensor([x], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t[0])
+        return struct.unpack("<d", self._reduce(struct.pack("<d", x), lambda v: struct.pack("<d", max(struct.unpack("<d", b)[0] for b in v))))[0]
 
     def sum(self, x):
-        if not self.dist:
-            return x
-        t = self.torch.tensor([x], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t[0])
+        return struct.unpack("<d", self._reduce(struct.pack("<d", x), lambda v: struct.pack("<d", sum(struct.unpack("<d", b)[0] for b in v))))[0]
 
     def broadcast_bytes(self, payload, n):
         """rank 0's `payload` (n bytes) to every rank"""
-        if not self.dist:
-            return payload
-        t = self.torch.zeros(n, dtype=self.torch.uint8)
-        if self.rank == 0:
-            t = self.torch.tensor(list(payload), dtype=self.torch.uint8)
-        self.dist.broadcast(t, src=0)
-        return bytes(t.tolist())
+        mine = bytes(payload) if self.rank == 0 else b"\0" * n
+        return self._reduce(mine, lambda v: v[0])
 
     def close(self):
-        if self.dist:
-            self.dist.destroy_process_group()
+        for c in self.peers:
+            c.close()
+        if self.sock:
+            self.sock.close()
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` outside any launcher: start the N ranks (one process per GPU of this
+    node), stream rank 0's stdout through, fail if any rank fails.  Returns the exit code."""
+    n = args.gpus
+    if not args.stub:
+        from f1tenth_gym_amd import _ffi
+        import __graft_entry__
+        __graft_entry__.build()
+        have = _ffi.device_count()
+        if have < n:
+            print("bench.py: --gpus %d but only %d HIP device(s) visible — refusing to run a smaller job under that label" % (n, have),
+                  file=sys.stderr)
+            return 2
+    rdv = "f110-bench-self-%d-%d" % (os.getpid(), int(time.time() * 1e3) % 100000)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), F110_BENCH_RDV=rdv)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
 def shard_envs(total_envs_per_rank, rank):
     """global env ids owned by `rank` (contiguous blocks)"""
     import numpy as np
@@ -142,103 +236,181 @@ def action_sets(n_sets, n_agents, seed):
     return [np.stack([rng.uniform(-0.2, 0.2, n_agents), rng.uniform(2.0, 6.0, n_agents)], axis=1) for _ in range(n_sets)]
 
 
-def run_gpu(args, rdv, n_agents, steps, warmup, profile_events=True):
-    """returns dict(elapsed_s, scan_ms_avg, dyn_ms_avg, n_reset, sim-less copies of a parity slice)"""
-    import numpy as np
-    from _util import load_map_image
-    from f1tenth_gym_amd import BatchSim
-    A = args.agents_per_env
-    E = n_agents // A
-    env_ids = shard_envs(E, rdv.rank)
-    img, res, origin = load_map_image("example_map")
-    if args.map_tiles > 1:
-        # BASELINE config 5 (SURVEY 8d): example_map tiled k x k, resolution unchanged; the image is
-        # stored top row first and the origin is the bottom-left corner, so tile (0,0) of the world
-        # (where the raceline starts live) is the bottom-left copy and the origin does not move
-        img = np.tile(img, (args.map_tiles, args.map_tiles))
-    sim = BatchSim(num_envs=E, num_agents=A, num_beams=args.beams, device_id=rdv.local_rank,
-                   map_layout=args.layout, scan_block=args.scan_block, scan_tasks_per_wave=args.scan_tasks)
-    sim.set_map_image(img, res, origin)
-    total = warmup + steps
-    if not args.no_noise:
-        sim.set_noise_table(np.random.default_rng(12345).normal(0., 0.01, size=(total + 2, args.beams)))
-    poses = start_poses_for(env_ids, A)
-    d_start = sim.device_array((E * A, 3)); d_start.upload(poses)
-    sets = action_sets((total + 19) // 20, E * A, seed=1000 + rdv.rank)
-    d_sets = []
-    for s in sets:
-        d = sim.device_array((E * A, 2)); d.upload(s); d_sets.append(d)
-    d_count = sim.device_array((1,), dtype=np.int32); d_count.upload(np.zeros(1, dtype=np.int32))
-    d_all = None
-    if args.gather:
-        uid = BatchSim.comm_unique_id() if rdv.rank == 0 else b"\0" * 128
-        sim.comm_init(rdv.world, rdv.rank, rdv.broadcast_bytes(uid, 128))
-        d_all = sim.device_array((rdv.world, E * A, args.beams))
-    sim.reset_device(d_start)
-    sim.sync()
-    # finished envs (ego collided) are re-seated in place every step: folded into the step's last
-    # kernel (f110_set_auto_reseat), or as the separate f110_reset_collided_device launch
-    fused_reset = not args.no_reset and not args.separate_reset
-    if fused_reset:
-        sim.set_auto_reseat(d_start, 0, d_count)
+class Workload(object):
+    """One rank's simulator + device-resident inputs.  run() always starts from the same reset, so
+    passes over the same (warmup, steps) replay the same states: the timed pass is clean, the
+    per-kernel events and the lookup count come from replays of the identical steps."""
 
-    planner, d_plan = None, None
-    if args.policy == "pure_pursuit":
-        from f1tenth_gym_amd import PurePursuitPlanner
-        from _util import raceline
-        w = raceline()
-        planner = PurePursuitPlanner(np.ascontiguousarray(np.stack([w[:, 1], w[:, 2], w[:, 5]], axis=1)), 0.17145 + 0.15875, sim=sim)
-        d_plan = sim.device_array((E * A, 2))
+    def __init__(self, args, rdv, n_agents, max_total_steps, beams=None, map_tiles=None, policy=None, no_reset=None):
+        import numpy as np
+        from _util import load_map_image
+        from f1tenth_gym_amd import BatchSim
+        self.args, self.rdv, self.np = args, rdv, np
+        self.beams = args.beams if beams is None else beams
+        self.tiles = args.map_tiles if map_tiles is None else map_tiles
+        self.policy = args.policy if policy is None else policy
+        self.no_reset = args.no_reset if no_reset is None else no_reset
+        A = args.agents_per_env
+        self.A, self.E, self.N = A, n_agents // A, n_agents
+        env_ids = shard_envs(self.E, rdv.rank)
+        img, res, origin = load_map_image("example_map")
+        if self.tiles > 1:
+            # BASELINE config 5 (SURVEY 8d): example_map tiled k x k, resolution unchanged; the image is
+            # stored top row first and the origin is the bottom-left corner, so tile (0,0) of the world
+            # (where the raceline starts live) is the bottom-left copy and the origin does not move
+            img = np.tile(img, (self.tiles, self.tiles))
+        self.sim = sim = BatchSim(num_envs=self.E, num_agents=A, num_beams=self.beams, device_id=rdv.local_rank,
+                                  map_layout=args.layout, scan_block=args.scan_block, scan_tasks_per_wave=args.scan_tasks,
+                                  step_groups=args.groups)
+        sim.set_map_image(img, res, origin)
+        self.max_total = max_total_steps
+        noise = "off" if args.no_noise else args.noise
+        if noise == "rng":
+            sim.set_noise_rng(NOISE_SEED, 0.01)
+            sim.noise_prepare(max_total_steps + 2)   # row cache filled before any timed region
+        elif noise == "table":
+            sim.set_noise_table(np.random.default_rng(NOISE_SEED).normal(0., 0.01, size=(max_total_steps + 2, self.beams)))
+        self.noise = noise
+        self.poses = start_poses_for(env_ids, A)
+        self.d_start = sim.device_array((self.N, 3)); self.d_start.upload(self.poses)
+        self.d_sets = []
+        for s in action_sets((max_total_steps + 19) // 20, self.N, seed=1000 + rdv.rank):
+            d = sim.device_array((self.N, 2)); d.upload(s); self.d_sets.append(d)
+        self.d_count = sim.device_array((1,), dtype=np.int32)
+        self.d_all = None
+        if args.gather:
+            from f1tenth_gym_amd import BatchSim as _B
+            uid = _B.comm_unique_id() if rdv.rank == 0 else b"\0" * 128
+            sim.comm_init(rdv.world, rdv.rank, rdv.broadcast_bytes(uid, 128))
+            self.d_all = sim.device_array((rdv.world, self.N, self.beams))
+        self.planner = self.d_plan = self.d_zero = None
+        if self.policy == "pure_pursuit":
+            from f1tenth_gym_amd import PurePursuitPlanner
+            from _util import raceline
+            w = raceline()
+            self.planner = PurePursuitPlanner(np.ascontiguousarray(np.stack([w[:, 1], w[:, 2], w[:, 5]], axis=1)), 0.17145 + 0.15875, sim=sim)
+            self.d_plan = sim.device_array((self.N, 2))
+        if self.policy == "parked":
+            self.d_zero = sim.device_array((self.N, 2)); self.d_zero.upload(np.zeros((self.N, 2)))
+        # finished envs (ego collided) are re-seated in place every step: folded into the step's last
+        # kernel (f110_set_auto_reseat), or as the separate f110_reset_collided_device launch
+        self.fused_reset = not self.no_reset and not args.separate_reset
 
-    d_zero = None
-    if args.policy == "parked":
-        d_zero = sim.device_array((E * A, 2)); d_zero.upload(np.zeros((E * A, 2)))
-
-    def one(t):
-        if d_zero is not None:
-            sim.step_device(d_zero)
-        elif planner is not None:
-            planner.plan_device(sim, d_plan, 0.82461887897713965, 1.375 * 0.8)   # the example's look-ahead; 80 % of its speed gain
-            sim.step_device(d_plan)
+    def one(self, t):
+        sim = self.sim
+        if self.d_zero is not None:
+            sim.step_device(self.d_zero)
+        elif self.planner is not None:
+            self.planner.plan_device(sim, self.d_plan, 0.82461887897713965, 1.375 * 0.8)   # the example's look-ahead; 80 % of its speed gain
+            sim.step_device(self.d_plan)
         else:
-            sim.step_device(d_sets[t // 20])
-        if d_all is not None:
-            sim.comm_all_gather_scans(d_all)
-        if not args.no_reset and not fused_reset:
-            sim.reset_collided_device(d_start, 0, d_count)
+            sim.step_device(self.d_sets[t // 20])
+        if self.d_all is not None:
+            sim.comm_all_gather_scans(self.d_all)
+        if not self.no_reset and not self.fused_reset:
+            sim.reset_collided_device(self.d_start, 0, self.d_count)
 
-    for t in range(warmup):
-        one(t)
-    sim.sync()
-    d_count.upload(np.zeros(1, dtype=np.int32))
-    if profile_events:
-        sim.profile_kernels(True)
-    rdv.barrier()
-    sim.sync()
-    t0 = time.perf_counter()
-    sim.timer_begin()
-    for t in range(warmup, total):
-        one(t)
-    gpu_ms = sim.timer_end_ms()       # records + waits for the end event on the stream
-    sim.sync()
-    rdv.barrier()
-    elapsed = time.perf_counter() - t0
-    out = {"elapsed_s": elapsed, "gpu_ms": gpu_ms, "n_reset": int(d_count.download()[0]), "E": E, "A": A}
-    if profile_events:
-        n, scan_ms, dyn_ms, fin_ms = sim.profile_read()
-        out.update({"scan_ms_avg": scan_ms / max(n, 1), "dyn_ms_avg": dyn_ms / max(n, 1),
-                    "fin_ms_avg": fin_ms / max(n, 1), "n_prof": n})
-        sim.profile_kernels(False)
-    out["final"] = sim.get("collisions", "in_collision", "step_count")
-    if d_all is not None:   # the gathered block of this rank must equal its own scans
-        mine = sim.get("scans")["scans"]
-        got = d_all.download()[rdv.rank]
-        out["gather_ok"] = bool((mine == got).all())
-        d_all.free()
-    for d in d_sets + [d_start, d_count] + [x for x in (d_plan, d_zero) if x is not None]:
-        d.free()
-    sim.close()
-    return out
+    def run(self, steps, warmup, mode="timed"):
+        """mode: timed (clean), profile (per-kernel HIP events), count (table lookups, counting kernels)"""
+        np, sim, rdv = self.np, self.sim, self.rdv
+        assert warmup + steps <= self.max_total
+        sim.set_auto_reseat(None)
+        sim.reset_device(self.d_start)
+        if self.fused_reset:
+            sim.set_auto_reseat(self.d_start, 0, self.d_count)
+        for t in range(warmup):
+            self.one(t)
+        sim.sync()
+        self.d_count.upload(np.zeros(1, dtype=np.int32))
+        if mode == "profile":
+            sim.profile_kernels(True)
+        if mode == "count":
+            sim.scan_lookup_count(enable=True, read=True)
+        rdv.barrier()
+        sim.sync()
+        t0 = time.perf_counter()
+        sim.timer_begin()
+        for t in range(warmup, warmup + steps):
+            self.one(t)
+        gpu_ms = sim.timer_end_ms()       # records + waits for the end event on the stream
+        sim.sync()
+        rdv.barrier()
+        elapsed = time.perf_counter() - t0
+        out = {"elapsed_s": elapsed, "gpu_ms": gpu_ms, "n_reset": int(self.d_count.download()[0]), "steps": steps, "warmup": warmup}
+        if mode == "profile":
+            n, scan_ms, dyn_ms, fin_ms = sim.profile_read()
+            out.update({"scan_ms_avg": scan_ms / max(n, 1), "dyn_ms_avg": dyn_ms / max(n, 1), "fin_ms_avg": fin_ms / max(n, 1), "n_prof": n})
+            sim.profile_kernels(False)
+        if mode == "count":
+            out["lookups"] = sim.scan_lookup_count(enable=False)
+        if self.d_all is not None and mode == "timed":   # the gathered block of this rank must equal its own scans
+            mine = sim.get("scans")["scans"]
+            out["gather_ok"] = bool((mine == self.d_all.download()[rdv.rank]).all())
+        return out
+
+    def close(self):
+        for d in self.d_sets + [self.d_start, self.d_count] + [x for x in (self.d_plan, self.d_zero, self.d_all) if x is not None]:
+            d.free()
+        self.sim.close()
+
+
+def scan_kernel_name(args, beams):
+    aligned = args.layout == 3 and beams < 1498 and (-beams) % 64 * 100 <= 3 * beams
+    return "k_scan_rays_agent" if aligned else ("k_scan_rays (direction dedupe) + k_expand_beams" if beams >= 1498 else "k_scan_rays")
+
+
+def load_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(p) as f:
+            return json.load(f)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def roofline_record(args, n_agents, beams, timed, prof, cnt, tiles=1):
+    """SURVEY §8d.  timed / prof / cnt: the three passes over the same steps."""
+    B = float(beams)
+    steps = timed["steps"]
+    agent_steps_per_s = n_agents * steps / timed["elapsed_s"]
+    dedupe = beams >= 1498
+    # lookups per ray the kernels performed over exactly the timed steps.  With more beams than
+    # table directions the step marches each distinct direction once: the lookups are counted (and
+    # the gathers priced) per distinct direction, so frac stays <= 1
+    lbar = cnt["lookups"] / float(n_agents * B * cnt["steps"])
+    b_stream = 216.0 + 8.0 * B
+    b_alg = b_stream + 8.0 * B * lbar
+    step_gbs = agent_steps_per_s * b_alg / 1e9
+    rec = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
+           "definition": "SURVEY 8d: agent-steps/s x B_alg / 8 TB/s over the timed steps; B_alg = 216 + 8*B + 8*B*L-bar bytes per agent-step",
+           "lookups_per_ray": lbar,
+           "lookups_counted": "on the device over the same %d steps after the same %d warm-up steps (replay with the counting kernels)%s"
+                              % (cnt["steps"], cnt["warmup"], "; per distinct table direction (dedupe pass)" if dedupe else ""),
+           "alg_bytes_per_agent_step": b_alg, "b_stream_bytes_per_agent_step": b_stream,
+           "b_stream_frac": agent_steps_per_s * b_stream / 1e9 / HBM_PEAK_GBS}
+    key = "agents=%d,beams=%d,layout=%d" % (n_agents, beams, args.layout) + (",tiles=%d" % tiles if tiles > 1 else "")
+    pmc = (load_json("pmc_scan.json") or {}).get(key)
+    rec["traffic"] = pmc.get("hbm_bytes_per_launch") if pmc else None
+    if prof and "scan_ms_avg" in prof:
+        scan_bytes = n_agents * (8.0 * B + 8.0 * B * lbar)   # range write + L-bar gathers of 8 B per ray
+        k_ms = prof["scan_ms_avg"]
+        k_gbs = scan_bytes / (k_ms * 1e-3) / 1e9
+        rec.update({"kernel": scan_kernel_name(args, beams), "kernel_ms_avg": k_ms, "kernel_alg_bytes_per_launch": scan_bytes,
+                    "kernel_achieved": k_gbs, "kernel_frac": k_gbs / HBM_PEAK_GBS,
+                    "kernel_timing": "HIP events around every launch in a replay of the same steps (%d launches)" % prof["n_prof"],
+                    "integrate_collide_ms_avg": prof["dyn_ms_avg"], "finalize_ms_avg": prof["fin_ms_avg"]})
+        if pmc:
+            rec["hbm_measured_frac"] = pmc["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            rec["hbm_measured_note"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this kernel (profiles/pmc_scan.json, %s) / this run's kernel time" % pmc.get("round", "?")
+        fl = load_json("r02_issue_floor.json")
+        if fl and key in fl.get("vmem_instr_per_launch", {}):
+            vm = fl["vmem_instr_per_launch"][key]
+            floor_ms = vm * fl["gather_cycles_per_wave_instr"] / fl["cus"] / (fl["clock_mhz"] * 1e3)
+            rec["issue_floor"] = {"what": "the binding unit: wave-level vector-memory instructions x the cheapest a 64-lane gather can issue "
+                                          "on a gfx950 CU (tools/debug/ta_bench.hip, profiles/r02_ta_bench.txt)",
+                                  "vmem_wave_instr_per_launch": vm, "cycles_per_instr": fl["gather_cycles_per_wave_instr"],
+                                  "floor_ms": floor_ms, "kernel_ms": k_ms, "frac": floor_ms / k_ms}
+    return rec
 
 
 def parity_gate(args, rdv):
@@ -250,14 +422,19 @@ def parity_gate(args, rdv):
     A, E, T = args.agents_per_env, 64, 200
     img, res, origin = load_map_image("example_map")
     dt, _, _ = oracle_map_dt("example_map")
-    noise = None if args.no_noise else np.random.default_rng(12345).normal(0., 0.01, size=(T + 2, args.beams))
+    no_noise = args.no_noise or args.noise == "off"
+    noise = None if no_noise else np.random.default_rng(NOISE_SEED).normal(0., 0.01, size=(T + 2, args.beams))
     sim = BatchSim(num_envs=E, num_agents=A, num_beams=args.beams, device_id=rdv.local_rank, map_layout=args.layout,
-                   scan_block=args.scan_block, scan_tasks_per_wave=args.scan_tasks)
+                   scan_block=args.scan_block, scan_tasks_per_wave=args.scan_tasks, step_groups=args.groups)
     sim.set_map_image(img, res, origin)
     ref = orc.SimOracle(E, A, num_beams=args.beams)
     ref.set_map_dt(dt, res, origin)
     if noise is not None:
-        sim.set_noise_table(noise); ref.set_noise(noise)
+        ref.set_noise(noise)          # the oracle adds NumPy's rows ...
+        if args.noise == "table":
+            sim.set_noise_table(noise)
+        else:
+            sim.set_noise_rng(NOISE_SEED, 0.01)   # ... the device draws them itself
     poses = start_poses_for(shard_envs(E, 0), A)
     sim.reset(poses); ref.reset(poses)
     sets = action_sets((T + 19) // 20, E * A, seed=1000)
@@ -279,71 +456,96 @@ def parity_gate(args, rdv):
 
 
 def cpu_baseline(args, seconds):
-    """time the CPU oracle (C port of the reference, OpenMP over envs) on a bounded sample of the
-    same workload; also yields L-bar = mean table lookups per ray on these inputs."""
+    """the CPU oracle (C port of the reference) on a bounded sample of the same workload:
+    (i) OpenMP over envs on all host cores (the "best CPU" comparator), (ii) cpu_1t: the reference's
+    own shape — 1 env x 2 agents, one thread (BASELINE configs[0], SURVEY 8d "Config 1")."""
     import numpy as np
     from _util import oracle_map_dt
     from oracle import orc
     A = args.agents_per_env
+    dt, res, origin = oracle_map_dt("example_map")
+    no_noise = args.no_noise or args.noise == "off"
+
+    def leg(E, threads, budget):
+        ref = orc.SimOracle(E, A, num_beams=args.beams)
+        ref.set_map_dt(dt, res, origin)
+        T_est = 400
+        if not no_noise:
+            ref.set_noise(np.random.default_rng(NOISE_SEED).normal(0., 0.01, size=(T_est + 2, args.beams)))
+        poses = start_poses_for(shard_envs(E, 0), A)
+        ref.reset(poses)
+        sets = action_sets((T_est + 19) // 20, E * A, seed=1000)
+        t0 = time.perf_counter(); ref.step(sets[0], threads); one = time.perf_counter() - t0   # calibrate
+        steps = int(max(3, min(T_est - 1, budget / max(one, 1e-6))))
+        look0 = ref.lookups
+        t0 = time.perf_counter()
+        for t in range(1, 1 + steps):
+            ref.step(sets[t // 20], threads)
+            if not args.no_reset:
+                mask = (ref.collisions.reshape(E, A)[:, 0] != 0).astype(np.uint8)
+                if mask.any():
+                    ref.reset(poses, mask)
+        el = time.perf_counter() - t0
+        return E * A * steps / el, steps, el, (ref.lookups - look0) / float(steps * E * A * args.beams)
+
     threads = max(1, min(os.cpu_count() or 1, 64))
     E = max(64, 32 * threads)
-    dt, res, origin = oracle_map_dt("example_map")
-    ref = orc.SimOracle(E, A, num_beams=args.beams)
-    ref.set_map_dt(dt, res, origin)
-    T_est = 400
-    if not args.no_noise:
-        ref.set_noise(np.random.default_rng(12345).normal(0., 0.01, size=(T_est + 2, args.beams)))
-    poses = start_poses_for(shard_envs(E, 0), A)
-    ref.reset(poses)
-    sets = action_sets((T_est + 19) // 20, E * A, seed=1000)
-    # calibrate, then run ~`seconds`
-    t0 = time.perf_counter(); ref.step(sets[0], threads); one = time.perf_counter() - t0
-    steps = int(max(3, min(T_est - 1, seconds / max(one, 1e-6))))
-    look0 = ref.lookups
-    t0 = time.perf_counter()
-    for t in range(1, 1 + steps):
-        ref.step(sets[t // 20], threads)
-        if not args.no_reset:
-            mask = (ref.collisions.reshape(E, A)[:, 0] != 0).astype(np.uint8)
-            if mask.any():
-                ref.reset(poses, mask)
-    el = time.perf_counter() - t0
-    lbar = (ref.lookups - look0) / float(steps * E * A * args.beams)
-    return {"value": E * A * steps / el, "unit": "agent-steps/s", "cores": threads, "kind": "port",
+    v, steps, el, lbar = leg(E, threads, seconds)
+    v1, steps1, el1, _ = leg(1, 1, min(seconds, 5.0))
+    return {"value": v, "unit": "agent-steps/s", "cores": threads, "kind": "port",
             "sample": "%d envs x %d agents x %d steps of the bench workload (oracle/f110_oracle.c, gcc -O2 "
-                      "-ffp-contract=off, OpenMP over envs), %.1f s" % (E, A, steps, el)}, lbar
+                      "-ffp-contract=off, OpenMP over envs), %.1f s" % (E, A, steps, el),
+            "lookups_per_ray_on_sample": lbar,
+            "cpu_1t": {"value": v1, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+                       "sample": "BASELINE configs[0] shape: 1 env x %d agents, %d steps, one thread, %.1f s (the reference runs this "
+                                 "shape in numba on one core; numba cannot be installed here, so the C restatement stands in)" % (A, steps1, el1)}}
 
 
-def load_pmc_traffic(args, n_agents):
-    """HBM bytes per scan-kernel launch from a committed rocprofv3 --pmc pass of this same
-    configuration (profiles/pmc_scan.json), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_scan.json")
-    if not os.path.isfile(p):
-        return None
-    try:
-        rec = json.load(open(p))
-        key = "agents=%d,beams=%d,layout=%d" % (n_agents, args.beams, args.layout)
-        return rec.get(key, {}).get("hbm_bytes_per_launch")
-    except Exception:  # noqa: BLE001
-        return None
-
-
-def main():
-    args = parse_args()
-    rdv = Rendezvous()
-    if rdv.world != args.gpus and rdv.rank == 0 and rdv.world > 1:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, rdv.world), file=sys.stderr)
-    import __graft_entry__
-    if rdv.local_rank == 0:
-        __graft_entry__.build()
+def stub_run(args, rdv, steps):
+    """tests (no GPU): every rank 'steps' by sleeping; rank r pretends to be slower by r ms"""
     rdv.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.001 * steps + 0.001 * rdv.rank)
+    rdv.barrier()
+    return {"elapsed_s": time.perf_counter() - t0, "n_reset": rdv.rank + 1, "steps": steps, "warmup": args.warmup}
 
-    res = run_gpu(args, rdv, args.agents, args.steps, args.warmup, profile_events=not args.no_profile_events)
-    elapsed = rdv.max(res["elapsed_s"])
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.no_noise:
+        args.noise = "off"
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args, argv)
+    rdv = Rendezvous()
+    if rdv.world != args.gpus:
+        if rdv.rank == 0:
+            print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, rdv.world), file=sys.stderr)
+        return 2
     n_gpus = rdv.world
+    if not args.stub:
+        import __graft_entry__
+        if rdv.local_rank == 0:
+            __graft_entry__.build()
+        rdv.barrier()
+        from f1tenth_gym_amd import _ffi
+        if _ffi.device_count() <= rdv.local_rank:
+            raise SystemExit("bench.py: rank %d needs HIP device %d, %d visible" % (rdv.rank, rdv.local_rank, _ffi.device_count()))
+
+    extras = n_gpus == 1 and not args.only_headline and not args.stub
+    total_needed = args.warmup + args.steps
+    if extras and args.steady_steps > 0:
+        total_needed = max(total_needed, args.steady_warmup + args.steady_steps)
+    wl = None
+    if args.stub:
+        timed = stub_run(args, rdv, args.steps)
+    else:
+        wl = Workload(args, rdv, args.agents, total_needed)
+        timed = wl.run(args.steps, args.warmup, "timed")
+    elapsed = rdv.max(timed["elapsed_s"])
     total_agents = args.agents * n_gpus
     value = total_agents * args.steps / elapsed
-    n_reset = rdv.sum(res["n_reset"])
+    n_reset = rdv.sum(timed["n_reset"])
 
     line = {
         "metric": "agent-steps/s (1080-beam scan + ST dynamics)", "value": value, "unit": "agent-steps/s",
@@ -354,64 +556,81 @@ def main():
                                 % (args.agents, args.agents // args.agents_per_env, args.agents_per_env,
                                    " 1600x1600" if args.map_tiles == 1 else " tiled %dx%d = %dx%d cells" % (args.map_tiles, args.map_tiles, 1600 * args.map_tiles, 1600 * args.map_tiles),
                                    args.beams,
-                                   "off" if args.no_noise else "on", "off" if args.no_reset else "on"))
+                                   {"rng": "on (drawn on the device: NumPy's seed-12345 PCG64/ziggurat stream)", "table": "on (NumPy rows uploaded)", "off": "off"}[args.noise],
+                                   "off" if args.no_reset else "on"))
                                + (" (BASELINE configs[2])" if args.agents == 65536 and args.beams == 1080 else ""),
                    "policy": {"random": "pre-drawn random actions, device resident",
                               "pure_pursuit": "reference pure-pursuit planner evaluated on the device every step (closed loop, planner time included)",
                               "parked": "zero actions: every car stays on its start pose"}[args.policy],
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
                    "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64"}[args.layout],
-                   "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks,
+                   "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks, "step_groups": args.groups,
                    "parallelism": "env-sharded x%d, %s" % (n_gpus, "RCCL all-gather of scans after every step" if args.gather
                                                            else "no data-path collective"),
                    "env_resets_in_timed_region": int(n_reset)},
     }
     if args.gather:
-        line["config"]["gather_ok"] = res.get("gather_ok")
-    if rdv.rank == 0:
-        lbar = None
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            cb, lbar = cpu_baseline(args, args.cpu_seconds)
-            line["cpu_baseline"] = cb
+        line["config"]["gather_ok"] = timed.get("gather_ok")
+
+    if wl is not None and rdv.rank == 0 and not args.only_headline:
+        # the same steps twice more on rank 0: per-kernel HIP events, then the counting kernels
+        solo = Rendezvous.__new__(Rendezvous)
+        solo.world, solo.rank, solo.local_rank, solo.peers, solo.sock = 1, 0, rdv.local_rank, [], None
+        wl.rdv = solo
+        prof = None if args.no_profile_events else wl.run(args.steps, args.warmup, "profile")
+        cnt = wl.run(args.steps, args.warmup, "count")
+        line["roofline"] = roofline_record(args, args.agents, args.beams, dict(timed, elapsed_s=elapsed), prof, cnt, args.map_tiles)
+        if extras and args.steady_steps > 0:
+            st = wl.run(args.steady_steps, args.steady_warmup, "timed")
+            sp = wl.run(args.steady_steps, args.steady_warmup, "profile")
+            sc = wl.run(args.steady_steps, args.steady_warmup, "count")
+            line["steady_state"] = {"value": args.agents * args.steady_steps / st["elapsed_s"], "unit": "agent-steps/s",
+                                    "steps": args.steady_steps, "warmup": args.steady_warmup,
+                                    "ms_per_step": 1e3 * st["elapsed_s"] / args.steady_steps, "env_resets_in_timed_region": st["n_reset"],
+                                    "roofline": roofline_record(args, args.agents, args.beams, st, sp, sc, args.map_tiles)}
+        wl.rdv = rdv
+    if wl is not None:
+        wl.close()
+
+    if extras and rdv.rank == 0:
+        def other(n_agents, steps, warmup, **kw):
+            w2 = Workload(args, rdv, n_agents, steps + warmup, **kw)
+            t = w2.run(steps, warmup, "timed")
+            p = w2.run(steps, warmup, "profile")
+            c = w2.run(steps, warmup, "count")
+            w2.close()
+            return t, p, c
+        if args.secondary and args.secondary != args.agents:
+            k2 = max(args.steps, 300)
+            t, p, c = other(args.secondary, k2, max(args.warmup, 30))
+            line["config"]["secondary"] = {"workload": "%d agents (BASELINE configs[1])" % args.secondary,
+                                           "value": args.secondary * k2 / t["elapsed_s"], "ms_per_step": 1e3 * t["elapsed_s"] / k2,
+                                           "steps": k2, "env_resets_in_timed_region": t["n_reset"],
+                                           "roofline": roofline_record(args, args.secondary, args.beams, t, p, c)}
+        if not args.no_config5 and args.beams == 1080 and args.map_tiles == 1 and args.agents == 65536:
+            k5 = 100
+            t, p, c = other(65536, k5, 20, beams=4096, map_tiles=2)
+            line["config"]["config5"] = {"workload": "65536 agents, 4096 beams, example_map tiled 2x2 = 3200x3200 cells (BASELINE configs[4])",
+                                         "value": 65536 * k5 / t["elapsed_s"], "ms_per_step": 1e3 * t["elapsed_s"] / k5, "steps": k5,
+                                         "env_resets_in_timed_region": t["n_reset"],
+                                         "roofline": roofline_record(args, 65536, 4096, t, p, c, tiles=2)}
+        if args.fixed_pose_steps > 0 and args.policy == "random":
+            w3 = Workload(args, rdv, args.agents, args.fixed_pose_steps + 10, policy="parked", no_reset=True)
+            r3 = w3.run(args.fixed_pose_steps, 10, "timed")
+            w3.close()
+            line["config"]["fixed_pose_variant"] = {"workload": "same agents parked on their start poses (speed 0, no resets)",
+                                                    "value": args.agents * args.fixed_pose_steps / r3["elapsed_s"],
+                                                    "ms_per_step": 1e3 * r3["elapsed_s"] / args.fixed_pose_steps}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             line["parity_gate"] = parity_gate(args, rdv)
-        if "scan_ms_avg" in res:
-            if lbar is None:
-                lbar = 6.65   # SURVEY §6 probe value; replaced by the measured one whenever the CPU leg runs
-            B = args.beams
-            scan_bytes = args.agents * (8.0 * B + 8.0 * B * lbar)   # range write + L-bar gathers of 8 B per ray
-            step_bytes = args.agents * ((216.0 + 8.0 * B) + 8.0 * B * lbar)  # SURVEY §8d B_alg
-            ach = scan_bytes / (res["scan_ms_avg"] * 1e-3) / 1e9
-            line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": ach / HBM_PEAK_GBS, "traffic": load_pmc_traffic(args, args.agents),
-                                "kernel": "k_scan_rays_agent" if (args.layout == 3 and args.beams < 1498 and (-args.beams) % 64 * 100 <= 3 * args.beams) else "k_scan_rays", "kernel_ms_avg": res["scan_ms_avg"],
-                                "integrate_collide_ms_avg": res["dyn_ms_avg"], "finalize_ms_avg": res["fin_ms_avg"],
-                                "launches_timed": res["n_prof"],
-                                "alg_bytes_per_launch": scan_bytes, "lookups_per_ray": lbar,
-                                **({"note": "more beams than table directions (theta_dis = 2000): beams that share a direction are "
-                                            "marched once and expanded, so the algorithmic bytes (counted per beam, as the "
-                                            "reference works) can exceed what the kernel had to fetch and frac can pass 1"}
-                                   if B >= 1498 else {}),
-                                "step_alg_bytes": step_bytes,
-                                "step_achieved_GBs": step_bytes * args.steps / elapsed / 1e9}
-    if n_gpus == 1 and args.secondary and args.secondary != args.agents and rdv.rank == 0:
-        r2 = run_gpu(args, rdv, args.secondary, max(args.steps, 200), args.warmup, profile_events=False)
-        line["config"]["secondary"] = {"workload": "%d agents (BASELINE configs[1])" % args.secondary,
-                                       "value": args.secondary * max(args.steps, 200) / r2["elapsed_s"],
-                                       "ms_per_step": 1e3 * r2["elapsed_s"] / max(args.steps, 200)}
-    if n_gpus == 1 and args.fixed_pose_steps > 0 and args.policy == "random" and rdv.rank == 0:
-        import copy
-        a3 = copy.copy(args)
-        a3.policy, a3.no_reset = "parked", True
-        r3 = run_gpu(a3, rdv, args.agents, args.fixed_pose_steps, 10, profile_events=False)
-        line["config"]["fixed_pose_variant"] = {"workload": "same agents parked on their start poses (speed 0, no resets)",
-                                                "value": args.agents * args.fixed_pose_steps / r3["elapsed_s"],
-                                                "ms_per_step": 1e3 * r3["elapsed_s"] / args.fixed_pose_steps}
     if rdv.rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()
     rdv.barrier()
     rdv.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

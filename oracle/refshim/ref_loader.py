@@ -70,8 +70,10 @@ def load_reference(with_env=False):
         pkg.__path__ = []
         envs = types.ModuleType("f110_gym.envs")
         envs.__path__ = []
-        sys.modules.setdefault("f110_gym", pkg)
-        sys.modules.setdefault("f110_gym.envs", envs)
+        # the repo ships an `f110_gym` alias package of its own (the drop-in): the reference's
+        # modules must not be mixed with it, so the names are (re)bound to empty packages here
+        sys.modules["f110_gym"] = pkg
+        sys.modules["f110_gym.envs"] = envs
         ns = types.SimpleNamespace()
         ns.dynamic_models = _load("dynamic_models", "dynamic_models.py")
         ns.laser_models = _load("laser_models", "laser_models.py")

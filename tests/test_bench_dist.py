@@ -1,5 +1,7 @@
-"""CPU-only, world_size 2 over gloo: bench.py's rendezvous (barrier, max / sum over ranks) and the
-env sharding used for N > 1 GPUs (contiguous env blocks, disjoint start poses, per-rank seeds)."""
+"""CPU-only, world_size 2: bench.py's rendezvous (barrier, max / sum / broadcast over ranks — stdlib
+sockets, no torch), the env sharding used for N > 1 GPUs (contiguous env blocks, disjoint start
+poses, per-rank seeds), bench.main() itself at world size 2 with a stubbed step — launched as ranks
+(the driver's torchrun form) and self-launched (`python bench.py --gpus 2`)."""
 import json
 import os
 import socket
@@ -19,7 +21,9 @@ rdv.barrier()
 ids = bench.shard_envs(5, rdv.rank)
 poses = bench.start_poses_for(ids, 2)
 acts = bench.action_sets(2, 10, seed=1000 + rdv.rank)
+blob = rdv.broadcast_bytes(bytes(range(128)) if rdv.rank == 0 else b"", 128)
 out = {"rank": rdv.rank, "world": rdv.world, "max": rdv.max(1.0 + rdv.rank), "sum": rdv.sum(10.0 * (rdv.rank + 1)),
+       "blob_ok": blob == bytes(range(128)),
        "ids": ids.tolist(), "pose0": poses[0].tolist(), "act0": acts[0][0].tolist()}
 rdv.barrier()
 print("RESULT " + json.dumps(out)); sys.stdout.flush()
@@ -48,6 +52,7 @@ def test_two_rank_rendezvous_and_sharding():
     assert [o["world"] for o in outs] == [2, 2]
     assert outs[0]["max"] == outs[1]["max"] == 2.0          # max over ranks (the timing rule)
     assert outs[0]["sum"] == outs[1]["sum"] == 30.0
+    assert outs[0]["blob_ok"] and outs[1]["blob_ok"]       # the RCCL unique id travels this way
     assert outs[0]["ids"] == [0, 1, 2, 3, 4] and outs[1]["ids"] == [5, 6, 7, 8, 9]   # contiguous, disjoint
     assert outs[0]["pose0"] != outs[1]["pose0"] and outs[0]["act0"] != outs[1]["act0"]
 
@@ -67,3 +72,51 @@ def test_single_process_rendezvous_is_a_noop():
     p = bench.start_poses_for(ids, 2)
     from _util import bench_start_poses
     assert np.array_equal(p, bench_start_poses(16, 2)[24:32])
+
+
+def _bench_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bench_main_as_two_launched_ranks_with_stub_step():
+    """what the driver does for N > 1: N processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT in
+    the environment; rank 0 prints the one JSON line, value = all ranks' agent-steps over the MAX time"""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "3",
+                                       "--agents", "1000", "--stub"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    line = _bench_line(outs[0][0])
+    assert outs[1][0].strip() == ""                         # only rank 0 prints
+    assert line["n_gpus"] == 2 and line["steps"] == 40 and line["warmup"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["agents_total"] == 2000 and line["config"]["env_resets_in_timed_region"] == 3   # sum over ranks (1 + 2)
+    assert abs(line["value"] - 2000 * 40 / (line["ms_per_step"] * 40e-3)) < 1e-6 * line["value"]
+    assert line["ms_per_step"] * 40e-3 >= 0.041              # the slower rank's time (stub: 40 ms + 1 ms x rank)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it spawns the two ranks itself"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "F110_BENCH_RDV")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "2", "--agents", "512",
+                          "--stub"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1000:]
+    line = _bench_line(out.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["agents_total"] == 1024
+
+
+def test_bench_refuses_a_mismatched_world():
+    """--gpus 4 inside a 2-rank launch must not print a line labelled with either number"""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "5", "--stub"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode != 0 for p in procs)
+    assert not any(o[0].strip() for o in outs)

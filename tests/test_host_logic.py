@@ -91,3 +91,33 @@ def test_named_maps_ship_with_the_package():
     n, path = _resolve_map_path({})
     assert n == 'vegas' and os.path.isfile(path)
     assert _resolve_map_path({'map': '/x/custom'})[1] == '/x/custom.yaml'
+
+
+def test_f110_gym_alias_package_registers_and_exports(monkeypatch):
+    """import-level drop-in: `import f110_gym` registers 'f110-v0' with gym (a stub stands in for gym,
+    absent from the image), and the reference's import paths resolve to the MI355X classes"""
+    import sys
+    import types
+    calls = []
+    gym = types.ModuleType("gym")
+    gym.Env = object
+    gym.envs = types.ModuleType("gym.envs")
+    gym.envs.registration = types.ModuleType("gym.envs.registration")
+    gym.envs.registration.register = lambda **kw: calls.append(kw)
+    for name, mod in (("gym", gym), ("gym.envs", gym.envs), ("gym.envs.registration", gym.envs.registration)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    for name in [m for m in sys.modules if m == "f110_gym" or m.startswith("f110_gym.")]:
+        monkeypatch.delitem(sys.modules, name)
+    import f110_gym
+    assert calls == [{"id": "f110-v0", "entry_point": "f110_gym.envs:F110Env"}]     # gym/f110_gym/__init__.py:1-5
+    from f110_gym.envs import F110Env, Simulator, ScanSimulator2D, Integrator, pid, collision_multiple, ray_cast  # noqa: F401
+    from f110_gym.envs.base_classes import Integrator as I2
+    from f110_gym.envs.f110_env import F110Env as E2
+    import f1tenth_gym_amd
+    assert E2 is f1tenth_gym_amd.F110Env and I2 is f1tenth_gym_amd.Integrator and I2.RK4.value == 1
+    import importlib
+    mod, cls = f110_gym.ENTRY_POINT.split(":")
+    assert getattr(importlib.import_module(mod), cls) is f1tenth_gym_amd.F110Env      # what gym.make resolves
+    import pytest
+    with pytest.raises(ValueError):
+        f110_gym.make("other-v0")

@@ -33,6 +33,93 @@ __global__ void __launch_bounds__(256) k_gather(const char *__restrict__ tbl, ui
     if (acc == 0x1234567u) out[0] = acc;  // never true; keeps the loads alive
 }
 
+// (c) partially active waves: the same u64 gather with only the lanes of `active` executing it
+__global__ void __launch_bounds__(256) k_gather_masked(const char *__restrict__ tbl, uint32_t mask, uint32_t window, uint64_t active,
+                                                       int iters, uint64_t *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint32_t h = (lane + 1u) * 2654435761u ^ (wave * 40503u);
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    uint32_t off = ((h & (window - 1u)) + wave * 4096u) & mask;
+    uint64_t acc = 0;
+    if ((active >> lane) & 1ull) {
+        for (int i = 0; i < iters; ++i) {
+            const uint64_t v = *reinterpret_cast<const uint64_t *>(tbl + (off & ~7u));
+            acc += v;
+            off = (off + 8192u + 136u) & mask;
+        }
+    }
+    if (acc == 0x1234567u) out[0] = acc;
+}
+
+// (d) the LDS alternative (north_star's "grid in LDS"): one byte code gathered from a window staged in
+// LDS, then the dependent 8-byte value from a 256-entry LUT in LDS — per sample two LDS reads instead
+// of one global gather.  Cycles per wave-level (code, value) pair at 8 waves/SIMD... as many waves as
+// the LDS footprint admits.
+template <int WIN_BYTES>
+__global__ void __launch_bounds__(256) k_lds_pair(int iters, uint32_t spread, uint64_t *out)
+{
+    __shared__ uint8_t win[WIN_BYTES];
+    __shared__ double lut[256];
+    for (int t = threadIdx.x; t < WIN_BYTES; t += blockDim.x) win[t] = (uint8_t)((t * 37u + (t >> 7)) & 0xffu);
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) lut[t] = 1.0 + t;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t h = (lane + 1u) * 2654435761u ^ (wave * 40503u + blockIdx.x * 977u);
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    uint32_t off = (h & (spread - 1u)) % WIN_BYTES;
+    double acc = 0.;
+    for (int i = 0; i < iters; ++i) {
+        const uint32_t code = win[off];
+        const double v = lut[code];
+        acc += v;
+        off = (off + 4099u + (uint32_t)v) % WIN_BYTES;   // next address depends on the value, as the march does
+    }
+    if (acc == 0.123) out[0] = (uint64_t)acc;
+}
+
+template <int WIN_BYTES>
+static double run_lds(uint32_t spread, uint64_t *d_out, int cus, double mhz, int *waves_per_cu)
+{
+    const int iters = 4096, threads = 256;
+    int per_cu = (160 * 1024) / (WIN_BYTES + 2048);
+    if (per_cu > 8) per_cu = 8;
+    const int blocks = cus * per_cu;
+    *waves_per_cu = per_cu * 4;
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    hipLaunchKernelGGL(k_lds_pair<WIN_BYTES>, dim3(blocks), dim3(threads), 0, 0, 64, spread, d_out);
+    hipEventRecord(a, 0);
+    hipLaunchKernelGGL(k_lds_pair<WIN_BYTES>, dim3(blocks), dim3(threads), 0, 0, iters, spread, d_out);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms * 1e-3 * mhz * 1e6 / ((double)per_cu * 4.0 * iters);
+}
+
+static double run_masked(const char *d_tbl, uint32_t bytes, uint32_t window, uint64_t active, uint64_t *d_out, int cus, double mhz)
+{
+    const int iters = 4096, blocks = cus * 8, threads = 256;
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    hipLaunchKernelGGL(k_gather_masked, dim3(blocks), dim3(threads), 0, 0, d_tbl, bytes - 1, window, active, 64, d_out);
+    hipEventRecord(a, 0);
+    hipLaunchKernelGGL(k_gather_masked, dim3(blocks), dim3(threads), 0, 0, d_tbl, bytes - 1, window, active, iters, d_out);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    return ms * 1e-3 * mhz * 1e6 / (32.0 * iters);
+}
+
 template <typename T>
 static double run(const char *d_tbl, uint32_t bytes, uint32_t lane_stride, uint64_t *d_out, int cus, double mhz)
 {
@@ -84,7 +171,26 @@ int main()
             const double c8 = run<uint64_t>(d_tbl, bytes, ls, d_out, cus, mhz);
             printf("%10u %8.1f %8.1f %8.1f\n", w, c1, c4, c8);
         }
+        if (bytes == (1u << 20)) {
+            printf("partially active waves, u64 gather, random inside a 2048-byte window: cycles per wave-level load\n");
+            struct { const char *name; uint64_t m; } masks[] = {
+                {"all 64 lanes", ~0ull}, {"lanes 0-47", (1ull << 48) - 1}, {"lanes 0-31", (1ull << 32) - 1}, {"lanes 0-15", 0xffffull},
+                {"lanes 0-3", 0xfull}, {"every other quad (32)", 0x0f0f0f0f0f0f0f0full}, {"1 lane per quad (16)", 0x1111111111111111ull},
+                {"every other lane (32)", 0x5555555555555555ull}, {"scattered 37 lanes", 0x9b5e3d27a4c6f1b3ull}};
+            for (auto &mk : masks) printf("%28s %8.1f\n", mk.name, run_masked(d_tbl, bytes, 2048u, mk.m, d_out, cus, mhz));
+        }
         hipFree(d_tbl);
+    }
+    printf("LDS window: cycles per wave-level (1-byte code from the window, dependent 8-byte LUT value) pair\n");
+    printf("%10s %10s %10s %10s\n", "window", "spread", "waves/CU", "cycles");
+    for (uint32_t spread : {256u, 4096u, 1u << 20}) {
+        int w;
+        double c = run_lds<16384>(spread, d_out, cus, mhz, &w);
+        printf("%10d %10u %10d %10.1f\n", 16384, spread, w, c);
+        c = run_lds<36864>(spread, d_out, cus, mhz, &w);
+        printf("%10d %10u %10d %10.1f\n", 36864, spread, w, c);
+        c = run_lds<65536>(spread, d_out, cus, mhz, &w);
+        printf("%10d %10u %10d %10.1f\n", 65536, spread, w, c);
     }
     return 0;
 }

@@ -1,0 +1,62 @@
+#!/bin/bash
+# Round-2 GPU sessions (one gpurun call each; GPU minutes are scarce, so every phase is bounded):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_r2.sh test ab'
+#   gpurun --timeout 1500 -- 'bash tools/gpu_r2.sh bench prof pmc'
+cd "${GRAFT_REPO_ROOT:-.}"
+R="$PWD"; export TMPDIR=/tmp
+OUT=$R/gpurun_out; mkdir -p $OUT
+{ rocminfo | grep -E "Marketing Name|gfx9|Compute Unit" | head -8; nproc; lscpu | grep "Model name" | head -1; } > $OUT/box.txt 2>&1
+python -c "import __graft_entry__ as g; print(g.build())" > $OUT/build.log 2>&1
+H="--only-headline --steps 300 --warmup 30"
+line() { grep -h '^{' "$1" 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); r = d.get('roofline', {})
+    print('%-28s %8.2f M/s  %.4f ms/step  resets %d' % ('$2', d['value']/1e6, d['ms_per_step'], d['config']['env_resets_in_timed_region']))
+"; }
+for MODE in "$@"; do
+case $MODE in
+test)
+  timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 -x --durations=12 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
+  tail -25 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log
+  ;;
+ta)
+  timeout 300 tools/debug/ta_bench > $OUT/ta_bench.txt 2>&1; tail -24 $OUT/ta_bench.txt
+  ;;
+ab)
+  # env groups x batch size, collide placement (one JSON line each, headline leg only)
+  for n in 4096 16384 65536; do for g in 1 2 4; do
+    timeout 200 python bench.py $H --agents $n --groups $g > $OUT/ab_n${n}_g${g}.log 2>&1; line $OUT/ab_n${n}_g${g}.log "agents $n groups $g"
+  done; done
+  timeout 200 python bench.py $H --agents 4096 --groups 8 > $OUT/ab_n4096_g8.log 2>&1; line $OUT/ab_n4096_g8.log "agents 4096 groups 8"
+  F110_COLLIDE_MODE=2 timeout 200 python bench.py $H --agents 65536 --groups 1 > $OUT/ab_n65536_inline.log 2>&1; line $OUT/ab_n65536_inline.log "65536 g1 collide inline"
+  F110_COLLIDE_MODE=1 timeout 200 python bench.py $H --agents 65536 --groups 1 > $OUT/ab_n65536_fused.log 2>&1; line $OUT/ab_n65536_fused.log "65536 g1 collide fused"
+  F110_COLLIDE_MODE=1 timeout 200 python bench.py $H --agents 4096 --groups 1 > $OUT/ab_n4096_fused.log 2>&1; line $OUT/ab_n4096_fused.log "4096 g1 collide fused"
+  timeout 200 python bench.py $H --agents 65536 --noise table > $OUT/ab_n65536_table.log 2>&1; line $OUT/ab_n65536_table.log "65536 noise table"
+  ;;
+bench)
+  timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo "bench exit $?" >> $OUT/bench_default.log
+  tail -c 6000 $OUT/bench_default.log
+  ;;
+prof)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats -o stats -- python $R/bench.py $H > $OUT/prof_stats.log 2>&1
+  python $R/tools/summarize_prof.py stats $OUT/prof_stats $OUT/kernel_stats.txt; rm -rf $OUT/prof_stats
+  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats4k -o stats -- python $R/bench.py $H --agents 4096 > $OUT/prof_stats4k.log 2>&1
+  python $R/tools/summarize_prof.py stats $OUT/prof_stats4k $OUT/kernel_stats_4096.txt; rm -rf $OUT/prof_stats4k
+  cd "$R"; cat $OUT/kernel_stats.txt | head -30
+  ;;
+pmc)
+  cd /tmp
+  i=0
+  for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_TA_BUSY GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays|k_finalize|k_integrate|k_collide" -T -f csv -d $OUT/pmc_$i -o p -- python $R/bench.py --only-headline --steps 12 --warmup 2 > $OUT/pmc_$i.log 2>&1
+    python $R/tools/summarize_prof.py pmc $OUT/pmc_$i $OUT/pmc_pass$i.json
+    rm -rf $OUT/pmc_$i
+  done
+  cd "$R"
+  ;;
+esac
+done
