@@ -466,10 +466,9 @@ def cpu_baseline(args, seconds):
     dt, res, origin = oracle_map_dt("example_map")
     no_noise = args.no_noise or args.noise == "off"
 
-    def leg(E, threads, budget):
+    def leg(E, threads, budget, T_est=400):
         ref = orc.SimOracle(E, A, num_beams=args.beams)
         ref.set_map_dt(dt, res, origin)
-        T_est = 400
         if not no_noise:
             ref.set_noise(np.random.default_rng(NOISE_SEED).normal(0., 0.01, size=(T_est + 2, args.beams)))
         poses = start_poses_for(shard_envs(E, 0), A)
@@ -491,7 +490,7 @@ def cpu_baseline(args, seconds):
     threads = max(1, min(os.cpu_count() or 1, 64))
     E = max(64, 32 * threads)
     v, steps, el, lbar = leg(E, threads, seconds)
-    v1, steps1, el1, _ = leg(1, 1, min(seconds, 5.0))
+    v1, steps1, el1, _ = leg(1, 1, min(seconds, 5.0), T_est=20000)
     return {"value": v, "unit": "agent-steps/s", "cores": threads, "kind": "port",
             "sample": "%d envs x %d agents x %d steps of the bench workload (oracle/f110_oracle.c, gcc -O2 "
                       "-ffp-contract=off, OpenMP over envs), %.1f s" % (E, A, steps, el),

@@ -11,7 +11,7 @@ from oracle import orc
 import f1tenth_gym_amd as amd
 
 
-def run(seed, verbose=True):
+def run(seed, verbose=True, tol=1e-9, stop_when_diverged=False):
     rng = np.random.default_rng(seed)
     mapname = rng.choice(["example_map", "berlin", "skirk"])
     A = int(rng.choice([1, 2, 2, 3, 4])); E = int(rng.integers(1, 40))
@@ -48,13 +48,19 @@ def run(seed, verbose=True):
             s.reset(poses, mask); ref.reset(poses, mask)
         o = s.get("scans", "state", "collisions", "collision_idx", "in_collision", "step_count")
         big = np.abs(ref.state).max() > 1e6
+        if big and stop_when_diverged:
+            # the random actions blew a car's yaw rate / slip past 1e6: from here on 1-ulp libm differences
+            # are amplified without bound (and hidden again by the next wall hit's zeroing) — every step
+            # up to this one has been compared
+            tag += " (stopped at step %d: dynamics diverged)" % t
+            break
         bad_flags = int(np.sum(o["collisions"] != ref.collisions) + np.sum(o["in_collision"] != ref.in_collision) + np.sum(o["collision_idx"] != ref.collision_idx))
         es = np.max(np.abs(o["state"] - ref.state) / np.maximum(1.0, np.abs(ref.state)))
         with np.errstate(invalid="ignore"):
             dsc = np.abs(o["scans"] - ref.scans) / np.maximum(1.0, np.abs(ref.scans))
         dsc = np.where(np.isnan(dsc), np.where(np.isnan(o["scans"]) == np.isnan(ref.scans), 0.0, np.inf), dsc)
         er = dsc.max()
-        if bad_flags or es > 1e-9 or er > 1e-9 or not np.array_equal(o["step_count"], ref.step_count):
+        if bad_flags or es > tol or er > tol or not np.array_equal(o["step_count"], ref.step_count):
             print("MISMATCH", tag, "step", t, "flags", bad_flags, "state", es, "scan", er, "diverged" if big else "")
             if verbose:
                 i, b = np.unravel_index(np.argmax(dsc), dsc.shape)
