@@ -60,11 +60,12 @@ def parse_args(argv=None):
     ap.add_argument("--agents-per-env", type=int, default=2)
     ap.add_argument("--beams", type=int, default=1080)
     ap.add_argument("--layout", type=int, default=int(os.environ.get("F110_MAP_LAYOUT", "3")),
-                    help="0 row-major f64, 1 tiled 4x4 f64, 2 byte codes + LDS LUT, 3 row-major f64 with an out-of-bounds border + fixed-point addressing")
+                    help="0 row-major f64, 1 tiled 4x4 f64, 2 byte codes + LDS LUT, 3 row-major f64 with an out-of-bounds border + fixed-point addressing, 4 = 3 + the 128x128 cells around each lidar staged in LDS")
     ap.add_argument("--scan-block", type=int, default=int(os.environ.get("F110_SCAN_BLOCK", "0")))
     ap.add_argument("--scan-tasks", type=int, default=int(os.environ.get("F110_SCAN_TASKS", "0")),
                     help="consecutive 64-ray tasks per wave (0 = default)")
     ap.add_argument("--groups", type=int, default=0, help="env groups stepped on streams of their own (0 = the library's default)")
+    ap.add_argument("--graph", type=int, default=-1, help="1: submit each step as one captured HIP graph; 0: separate launches; -1: the library's default")
     ap.add_argument("--gather", action="store_true",
                     help="RCCL all-gather of every rank's scans after each step (BASELINE config 4; off by default)")
     ap.add_argument("--noise", choices=["rng", "table", "off"], default="rng",
@@ -261,7 +262,7 @@ class Workload(object):
             img = np.tile(img, (self.tiles, self.tiles))
         self.sim = sim = BatchSim(num_envs=self.E, num_agents=A, num_beams=self.beams, device_id=rdv.local_rank,
                                   map_layout=args.layout, scan_block=args.scan_block, scan_tasks_per_wave=args.scan_tasks,
-                                  step_groups=args.groups)
+                                  step_groups=args.groups, **({} if args.graph < 0 else {"step_graph": args.graph}))
         sim.set_map_image(img, res, origin)
         self.max_total = max_total_steps
         noise = "off" if args.no_noise else args.noise
@@ -355,6 +356,8 @@ class Workload(object):
 
 
 def scan_kernel_name(args, beams):
+    if args.layout == 4 and beams < 1498 and (-beams) % 64 * 100 <= 3 * beams:
+        return "k_scan_rays_window"
     aligned = args.layout == 3 and beams < 1498 and (-beams) % 64 * 100 <= 3 * beams
     return "k_scan_rays_agent" if aligned else ("k_scan_rays (direction dedupe) + k_expand_beams" if beams >= 1498 else "k_scan_rays")
 
@@ -562,8 +565,8 @@ def main(argv=None):
                               "pure_pursuit": "reference pure-pursuit planner evaluated on the device every step (closed loop, planner time included)",
                               "parked": "zero actions: every car stays on its start pose"}[args.policy],
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
-                   "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64"}[args.layout],
-                   "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks, "step_groups": args.groups,
+                   "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64", 4: "padded_rowmajor_f64 + lds_window_codes"}[args.layout],
+                   "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks, "step_groups": args.groups, "step_graph": args.graph,
                    "parallelism": "env-sharded x%d, %s" % (n_gpus, "RCCL all-gather of scans after every step" if args.gather
                                                            else "no data-path collective"),
                    "env_resets_in_timed_region": int(n_reset)},

@@ -17,7 +17,7 @@ PARAM_KEYS = ['mu', 'C_Sf', 'C_Sr', 'lf', 'lr', 'h', 'm', 'I', 's_min', 's_max',
               'sv_max', 'v_switch', 'a_max', 'v_min', 'v_max', 'width', 'length']
 
 OK, ERR_INVALID, ERR_NO_MAP, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5
-MAP_ROWMAJOR_F64, MAP_TILED_F64, MAP_CODE8, MAP_PADDED_F64 = 0, 1, 2, 3
+MAP_ROWMAJOR_F64, MAP_TILED_F64, MAP_CODE8, MAP_PADDED_F64, MAP_WINDOW_LDS = 0, 1, 2, 3, 4
 MAP_DEFAULT = MAP_PADDED_F64   # fastest; falls back to row-major for maps too large for it
 INTEGRATOR_RK4, INTEGRATOR_EULER = 1, 2
 
@@ -33,7 +33,7 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("num_envs", C.c_int32), ("num_agents", C.c_int32),
                 ("num_beams", C.c_int32), ("theta_dis", C.c_int32), ("integrator", C.c_int32),
                 ("device_id", C.c_int32), ("map_layout", C.c_int32), ("scan_block", C.c_int32),
-                ("scan_tasks_per_wave", C.c_int32), ("step_groups", C.c_int32), ("reserved1", C.c_int32), ("fov", C.c_double), ("eps", C.c_double),
+                ("scan_tasks_per_wave", C.c_int32), ("step_groups", C.c_int32), ("step_graph", C.c_int32), ("fov", C.c_double), ("eps", C.c_double),
                 ("max_range", C.c_double), ("time_step", C.c_double), ("lidar_dist", C.c_double),
                 ("ttc_thresh", C.c_double), ("params", C.c_double * NPARAMS)]
 

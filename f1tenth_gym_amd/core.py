@@ -110,7 +110,7 @@ class BatchSim(object):
     def __init__(self, params=None, num_envs=1, num_agents=2, num_beams=1080, fov=4.7, eps=0.0001,
                  theta_dis=2000, max_range=30.0, time_step=0.01, integrator=_ffi.INTEGRATOR_RK4,
                  lidar_dist=0.0, ttc_thresh=0.005, device_id=0, map_layout=_ffi.MAP_DEFAULT,
-                 scan_block=0, scan_tasks_per_wave=0, step_groups=0):
+                 scan_block=0, scan_tasks_per_wave=0, step_groups=0, step_graph=0):
         self._h = None
         L = _ffi.lib()
         self.params = dict(DEFAULT_PARAMS if params is None else params)
@@ -125,6 +125,7 @@ class BatchSim(object):
         cfg.map_layout, cfg.scan_block = int(map_layout), int(scan_block)
         cfg.scan_tasks_per_wave = int(scan_tasks_per_wave)
         cfg.step_groups = int(step_groups)
+        cfg.step_graph = int(step_graph)
         cfg.fov, cfg.eps, cfg.max_range = float(fov), float(eps), float(max_range)
         cfg.time_step, cfg.lidar_dist, cfg.ttc_thresh = float(time_step), float(lidar_dist), float(ttc_thresh)
         pv = _ffi.params_vector(self.params)
@@ -302,11 +303,12 @@ class BatchSim(object):
         check(_ffi.lib().f110_noise_rows_batch(self._h, words.ctypes.data_as(_ffi._u64p), float(std_dev), int(rows), B, dptr(out), st), self._h)
         return out, (int(st[0]) << 64) | int(st[1])
 
-    def scan_lookup_count(self, enable=None, read=True):
-        """measurement aid: table lookups of every ray the step's scan kernels marched since the last read"""
-        v = C.c_int64(0)
-        check(_ffi.lib().f110_scan_lookup_count(self._h, -1 if enable is None else int(bool(enable)), C.byref(v) if read else None), self._h)
-        return int(v.value)
+    def scan_lookup_count(self, enable=None, read=True, detail=False):
+        """measurement aid: table lookups of every ray the step's scan kernels marched since the last read
+        (detail=True: also how many of them the LDS window of map_layout 4 served)"""
+        v = (C.c_int64 * 2)()
+        check(_ffi.lib().f110_scan_lookup_count(self._h, -1 if enable is None else int(bool(enable)), v if read else None), self._h)
+        return (int(v[0]), int(v[1])) if detail else int(v[0])
 
     # ------------------------------------------------------------------ reset / step
     def reset(self, poses, env_mask=None):

@@ -40,6 +40,9 @@ struct f110_sim {
     int dir_stride = 0;              // > 0: dedupe enabled
     uint32_t dir_magic = 0, dir_shift = 0;
     double *d_lut = nullptr;
+    uint8_t *d_wcodes = nullptr;     // WINDOW_LDS: 1-byte codes of the padded table, row-major
+    double *d_wlut = nullptr;
+    uint32_t wcode_pitch = 0;
     int scan_block = 64;
     double *d_params_all = nullptr;   // [N][18] when f110_set_params_batch is active
     double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
@@ -79,6 +82,16 @@ struct f110_sim {
     long long noise_ub = 0;          // upper bound of any agent's step_count (steps since the last full reset)
     unsigned long long *d_lookups = nullptr;  // f110_scan_lookup_count
     bool lookups_on = false;
+    // the single-block step captured as a HIP graph (f110_config.step_graph): one submission per step
+    struct StepGraph {
+        AgentArrays dev;
+        ScanConst k;
+        const double *actions;
+        int flags;
+        hipGraphExec_t exec;
+    };
+    std::vector<StepGraph> graphs;
+    bool use_graph = false;
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
     int comm_ranks = 0;
     EpisodeArrays ep{};
@@ -175,6 +188,8 @@ struct Scratch {
     }
 };
 
+static inline bool padded_family(int layout) { return layout == F110_MAP_PADDED_F64 || layout == F110_MAP_WINDOW_LDS; }
+
 static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 typedef void (*scan_rays_fn)(RayJob, ScanConst);
@@ -235,7 +250,7 @@ static const ScanConst *cold_consts(f110_sim *h)
 static bool agent_aligned(const f110_sim *h)
 {
     static const bool force_flat = std::getenv("F110_SCAN_FLAT") != nullptr;
-    if (force_flat || h->cfg.map_layout != F110_MAP_PADDED_F64 || !h->k.pad || h->dir_stride > 0) return false;
+    if (force_flat || !padded_family(h->cfg.map_layout) || !h->k.pad || h->dir_stride > 0) return false;
     const int B = h->k.num_beams, lanes = (B + 63) / 64 * 64;
     return (lanes - B) * 100 <= 3 * B;
 }
@@ -246,7 +261,7 @@ static scan_rays_fn pick_rays(const ScanConst &k, int layout)
 #define SEL(L) (k.res_pow2 ? (k.ident_rot ? k_scan_rays<L, true, true, STEP> : k_scan_rays<L, true, false, STEP>) \
                            : (k.ident_rot ? k_scan_rays<L, false, true, STEP> : k_scan_rays<L, false, false, STEP>))
     if (layout == F110_MAP_CODE8) return SEL(LAYOUT_CODE8);
-    if (layout == F110_MAP_PADDED_F64 && k.pad) return SEL(LAYOUT_PADDED);
+    if (padded_family(layout) && k.pad) return SEL(LAYOUT_PADDED);
     return layout == F110_MAP_TILED_F64 ? SEL(LAYOUT_TILED) : SEL(LAYOUT_ROWMAJOR);
 #undef SEL
 }
@@ -310,7 +325,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     if (cfg->integrator != F110_INTEGRATOR_RK4 && cfg->integrator != F110_INTEGRATOR_EULER)
         return fail(nullptr, F110_ERR_INVALID, "Invalid Integrator Specified. Please choose RK4 or Euler");
     if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_TILED_F64 && cfg->map_layout != F110_MAP_CODE8 &&
-        cfg->map_layout != F110_MAP_PADDED_F64)
+        cfg->map_layout != F110_MAP_PADDED_F64 && cfg->map_layout != F110_MAP_WINDOW_LDS)
         return fail(nullptr, F110_ERR_INVALID, "unknown map_layout %d", cfg->map_layout);
     if ((long long)cfg->num_envs * cfg->num_agents * (long long)cfg->num_beams > 0xFFFFFF00LL) return fail(nullptr, F110_ERR_INVALID, "num_envs*num_agents*num_beams must stay below 2^32");
     int ndev = 0;
@@ -364,6 +379,8 @@ int f110_create(const f110_config *cfg, f110_sim **out)
                              // the group streams share a hardware queue — opt-in
         G = std::min(std::min(G, 16), cfg->num_envs);
         h->groups = G;
+        h->use_graph = cfg->step_graph != 0;
+        if (const char *e = std::getenv("F110_STEP_GRAPH")) h->use_graph = std::atoi(e) != 0;
         for (int g = 0; g < G && G > 1; ++g) {
             hipStream_t gs = nullptr;
             hipEvent_t ge = nullptr;
@@ -409,13 +426,13 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         CK(dmalloc(h, &h->d_zig_w, 256));
         CK(dmalloc(h, &h->d_zig_f, 256));
         CK(dmalloc(h, &h->d_jump, 2 * 65));
-        CK(dmalloc(h, &h->d_lookups, 1));
+        CK(dmalloc(h, &h->d_lookups, 2));
         CKH(hipMemcpy(h->d_zig_k, kZigK, sizeof kZigK, hipMemcpyHostToDevice));
         CKH(hipMemcpy(h->d_zig_w, kZigW, sizeof kZigW, hipMemcpyHostToDevice));
         CKH(hipMemcpy(h->d_zig_f, kZigF, sizeof kZigF, hipMemcpyHostToDevice));
         CKH(hipMemcpy(h->d_jump, jt.a, sizeof jt.a, hipMemcpyHostToDevice));
         CKH(hipMemcpy(h->d_jump + 65, jt.g, sizeof jt.g, hipMemcpyHostToDevice));
-        CKH(hipMemset(h->d_lookups, 0, sizeof(unsigned long long)));
+        CKH(hipMemset(h->d_lookups, 0, 2 * sizeof(unsigned long long)));
         h->noise_gen = NoiseGen{h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_jump + 65, 0.0};
     }
     CKH(hipMemsetAsync(d.state, 0, sizeof(double) * 7 * N, h->stream));
@@ -508,11 +525,12 @@ void f110_destroy(f110_sim *h)
     for (hipStream_t gs : h->gstreams) (void)hipStreamSynchronize(gs);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (hipStream_t gs : h->gstreams) (void)hipStreamDestroy(gs);
     for (hipEvent_t ge : h->gevents) (void)hipEventDestroy(ge);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     {
-        void *rp[] = {h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
+        void *rp[] = {h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
         for (void *p : rp)
             if (p) (void)hipFree(p);
     }
@@ -601,7 +619,7 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
     }
     k.pad = nullptr;
     if (h->d_dt_pad) { (void)hipFree(h->d_dt_pad); h->d_dt_pad = nullptr; }
-    if (h->cfg.map_layout == F110_MAP_PADDED_F64 && setup_padded(k)) {
+    if (padded_family(h->cfg.map_layout) && setup_padded(k)) {
         // the table again with a border of out-of-bounds cells wide enough for any ray of a lidar
         // that is on (or within kPadSlack cells of) the map; maps too large for 16-bit cell
         // coordinates keep k.pad == nullptr and run the plain row-major kernel
@@ -634,6 +652,28 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
         k.codes = h->d_codes;
         k.lut = h->d_lut;
         k.code_tile_row_bytes = ctw * 128;
+    }
+    if (h->d_wcodes) { (void)hipFree(h->d_wcodes); h->d_wcodes = nullptr; }
+    if (h->cfg.map_layout == F110_MAP_WINDOW_LDS && k.pad && k.pad_border >= kWin / 2 + kPadSlack + 18) {
+        // the k_scan_rays_window form: 1-byte codes over the padded table + the exact value LUT (the 255
+        // smallest distinct table values, one-time host sort of the downloaded table)
+        std::vector<double> vals((size_t)H * W);
+        HIPCHK(h, hipMemcpyAsync(vals.data(), h->d_dt_row, vals.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        vals.erase(std::remove_if(vals.begin(), vals.end(), [](double v) { return v != v; }), vals.end());
+        std::sort(vals.begin(), vals.end());
+        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+        std::vector<double> lut(256, INFINITY);
+        const int n_lut = (int)std::min<size_t>(vals.size(), (size_t)kLutEntries);
+        for (int i = 0; i < n_lut; ++i) lut[i] = vals[i];
+        if (!h->d_wlut) TRY(dmalloc(h, &h->d_wlut, (size_t)256));
+        HIPCHK(h, hipMemcpyAsync(h->d_wlut, lut.data(), 256 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        h->wcode_pitch = (uint32_t)(k.pad_width + 15) / 16u * 16u;
+        const size_t total = (size_t)k.pad_height * h->wcode_pitch;
+        TRY(dmalloc(h, &h->d_wcodes, total));
+        hipLaunchKernelGGL(k_build_codes_padded, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_pad, k.pad_height, k.pad_width, (int)h->wcode_pitch,
+                           h->d_wlut, n_lut, h->d_wcodes);
+        HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->has_map = true;
@@ -765,7 +805,7 @@ int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map)
         return F110_OK;
     }
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
-    if (h->cfg.map_layout != F110_MAP_PADDED_F64 || !h->k.pad)
+    if (!padded_family(h->cfg.map_layout) || !h->k.pad)
         return fail(h, F110_ERR_STATE, "f110_set_env_maps needs map_layout = F110_MAP_PADDED_F64 and a slot-0 map that fits it");
     if (h->dir_stride > 0) return fail(h, F110_ERR_STATE, "f110_set_env_maps is not available with more beams than table directions");
     const int E = h->cfg.num_envs, M = 1 + (int)h->extra_maps.size();
@@ -1014,11 +1054,12 @@ int f110_scan_lookup_count(f110_sim *h, int32_t enable, int64_t *out_total)
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     ENTER(h);
     if (out_total) {
-        unsigned long long v = 0;
-        HIPCHK(h, hipMemcpyAsync(&v, h->d_lookups, sizeof v, hipMemcpyDeviceToHost, h->stream));
+        unsigned long long v[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(v, h->d_lookups, sizeof v, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_lookups, 0, sizeof v, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        *out_total = (int64_t)v;
+        out_total[0] = (int64_t)v[0];
+        out_total[1] = (int64_t)v[1];
     }
     if (enable >= 0) h->lookups_on = enable != 0;
     return F110_OK;
@@ -1376,6 +1417,21 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave, wpb = (uint32_t)h->scan_block / 64u;
             const dim3 grid((waves + wpb - 1) / wpb), block(h->scan_block);
             const bool cnt = j.lookups_total != nullptr;
+            static const bool no_window = std::getenv("F110_NO_WINDOW") != nullptr;
+            if (h->cfg.map_layout == F110_MAP_WINDOW_LDS && h->d_wcodes && !h->multi_map && !no_window) {
+                // one workgroup per agent, its neighbourhood of the table staged in LDS
+                j.win_codes = h->d_wcodes;
+                j.win_lut = h->d_wlut;
+                j.win_pitch = h->wcode_pitch;
+                const dim3 wgrid((unsigned)count), wblock(256);
+                if (h->k.ident_rot) {
+                    if (cnt) hipLaunchKernelGGL((k_scan_rays_window<true, true>), wgrid, wblock, 0, st, j, h->k, tpa);
+                    else hipLaunchKernelGGL((k_scan_rays_window<true, false>), wgrid, wblock, 0, st, j, h->k, tpa);
+                } else {
+                    if (cnt) hipLaunchKernelGGL((k_scan_rays_window<false, true>), wgrid, wblock, 0, st, j, h->k, tpa);
+                    else hipLaunchKernelGGL((k_scan_rays_window<false, false>), wgrid, wblock, 0, st, j, h->k, tpa);
+                }
+            } else {
 #define AGENT_SCAN(PM, ID)                                                                                                         \
     do {                                                                                                                           \
         if (cnt)                                                                                                                   \
@@ -1390,6 +1446,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             else
                 AGENT_SCAN(false, false);
 #undef AGENT_SCAN
+            }
         } else {
             const dim3 grid = rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
             hipLaunchKernelGGL(fn, grid, dim3(h->scan_block), 0, st, j, h->k);
@@ -1454,7 +1511,48 @@ int f110_step_device(f110_sim *h, const double *d_actions)
             for (int i = 0; i < 4; ++i)
                 if (!(ev[i] = prof_event(h))) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
         }
-        TRY(step_range(h, h->stream, 0, N, d_actions, cm_env ? std::atoi(cm_env) : 0, prof ? ev : nullptr));
+        const int cmode = cm_env ? std::atoi(cm_env) : 0;
+        if (h->use_graph && !prof) {
+            // the four launches and the fork/join of the side stream as ONE graph submission.  A graph is
+            // valid for one set of launch arguments: every value a launch depends on is part of the key
+            // (the agent arrays incl. re-seat / noise pointers, the scan constants, the action buffer, which
+            // optional kernels run); a handful of graphs cover a training loop (one per action buffer).
+            if (!cold_consts(h)) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
+            const int flags = (h->lookups_on ? 1 : 0) | (h->path_stats_on ? 2 : 0) | (cmode << 2) |
+                              ((h->dev.noise_rng && (h->dev.noise_rng == 2 || h->noise_ub >= (long long)h->dev.noise_rows)) ? 16 : 0);
+            hipGraphExec_t exec = nullptr;
+            for (auto &g : h->graphs)
+                if (g.actions == d_actions && g.flags == flags && std::memcmp(&g.dev, &h->dev, sizeof(AgentArrays)) == 0 &&
+                    std::memcmp(&g.k, &h->k, sizeof(ScanConst)) == 0) {
+                    exec = g.exec;
+                    break;
+                }
+            if (!exec) {
+                if (h->graphs.size() >= 64) {
+                    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+                    h->graphs.clear();
+                }
+                hipGraph_t graph = nullptr;
+                HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+                const int rc = step_range(h, h->stream, 0, N, d_actions, cmode, nullptr);
+                const hipError_t ec = hipStreamEndCapture(h->stream, &graph);
+                if (rc != F110_OK) return rc;
+                if (ec != hipSuccess || !graph) return fail(h, F110_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+                const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ei != hipSuccess) return fail(h, F110_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+                f110_sim::StepGraph g;
+                g.dev = h->dev;
+                g.k = h->k;
+                g.actions = d_actions;
+                g.flags = flags;
+                g.exec = exec;
+                h->graphs.push_back(g);
+            }
+            HIPCHK(h, hipGraphLaunch(exec, h->stream));
+        } else {
+            TRY(step_range(h, h->stream, 0, N, d_actions, cmode, prof ? ev : nullptr));
+        }
     } else {
         if (h->main_dirty) {
             HIPCHK(h, hipEventRecord(h->ev_main, h->stream));

@@ -281,6 +281,11 @@ struct RayJob {
     const double *dir_ranges;       // k_expand_beams: [n_poses][dir_stride] raw ranges of the dedupe pass
     uint32_t first_pose, pad_first; // k_scan_rays_agent: the launch covers agents first_pose .. (env group)
     unsigned long long *lookups_total;  // COUNT variants: table lookups of every marched ray, summed (or nullptr)
+    // k_scan_rays_window: 1-byte codes of the padded table (row-major, `win_pitch` bytes per row, a multiple
+    // of 16) and the 256-entry exact value LUT (entry 255 unused: code 255 = "read the float64 table")
+    const uint8_t *win_codes;
+    const double *win_lut;
+    uint32_t win_pitch, pad_win;
     const double *pose_x, *pose_y, *dir_start;  // [n_poses] (unit path)
     double *ranges;           // [n_poses][B]
     // STEP only
@@ -543,6 +548,109 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
     }
     if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
+}
+
+// ---- K2w: the step's ray march with the agent's neighbourhood staged in LDS ------------------------
+// north_star's "occupancy grid in LDS".  One workgroup = one agent: the kWin x kWin cells around the
+// lidar (1-byte codes of the padded table, 16 KB) and the exact 256-entry value LUT (2 KB) are staged
+// with coalesced 16-byte loads; a sample that lands inside the window costs two LDS reads (code,
+// value) and no vector-memory instruction; a sample outside it, or on a cell whose value is not one
+// of the 255 LUT values (code 255), reads the float64 table exactly as k_scan_rays_agent does.
+// Same march arithmetic (march_padded), hence the same bits.  The window origin is folded into the
+// fixed-point constant, so the word pair is window-relative: both cells inside <=> (wx | wy) < kWin<<16.
+constexpr int kWin = 128;   // cells per side (power of two: one OR + one compare decides "inside")
+
+template <bool IDENT, bool COUNT>
+__global__ void __launch_bounds__(256) k_scan_rays_window(RayJob j, ScanConst k, uint32_t tasks_per_agent)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWin * kWin];
+    __shared__ double lut[256];
+    const uint32_t B = (uint32_t)k.num_beams;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t blk = blockIdx.x;
+    {
+        const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
+        blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // XCD-contiguous, as k_scan_rays
+    }
+    const uint32_t p = j.first_pose + blk;
+    typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
+    const chdr_t h0 = (chdr_t)(j.hdr) + p;
+    const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
+    const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
+    const int row = uniform_i32(h0->noise_row), fast = uniform_i32(h0->fast);
+    double ux0 = 0., uy0 = 0.;
+    int x0 = 0, y0 = 0;
+    if (fast) {   // workgroup-uniform
+        padded_position<IDENT>(k, x, y, ux0, uy0);
+        x0 = (((int)ux0) - kWin / 2) & ~15;   // 16-byte aligned rows
+        y0 = ((int)uy0) - kWin / 2;
+        const uint8_t *src = j.win_codes + (size_t)y0 * j.win_pitch + x0;
+#pragma unroll
+        for (int i = 0; i < kWin * kWin / 16 / 256; ++i) {
+            const uint32_t r = (threadIdx.x >> 3) + 32u * i, c16 = (threadIdx.x & 7u) << 4;
+            *reinterpret_cast<uint4 *>(win + r * kWin + c16) = *reinterpret_cast<const uint4 *>(src + (size_t)r * j.win_pitch + c16);
+        }
+        lut[threadIdx.x] = j.win_lut[threadIdx.x];
+    }
+    __syncthreads();
+    const double fixx = kFixBig - (double)x0, fixy = kFixBig - (double)y0;   // exact: integers below 2^16
+    const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;   // scalar
+    const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)(k.pad);
+    uint32_t nl_acc = 0, lds_acc = 0;
+    for (uint32_t task = wv; task < tasks_per_agent; task += 4u) {
+        const int b = (int)(task * 64u + lane);
+        if (b >= (int)B) continue;
+        const double nz = row != -1 ? nrow[b] : 0.0;
+        const double2 cs = k.cs[beam_dir_index(k, start, b)];
+        int hr = -1, hc = -1, nl = 1;
+        double r = 0.;
+        bool exact = fast == 0;
+        if (fast) {
+            double ux = ux0, uy = uy0, cux, cuy;
+            padded_rate<IDENT>(k, cs.x, cs.y, cux, cuy);
+            double d = d0, total = d0;
+            bool redo = false;
+            while ((d > k.eps) & (total <= k.max_range) & !redo) {
+                ux = fma(d, cux, ux);
+                uy = fma(d, cuy, uy);
+                const uint32_t wx = low_word(ux + fixx);   // window-relative 16.16 words
+                const uint32_t wy = low_word(uy + fixy);
+                uint32_t code = 255u;
+                bool have_off = false;
+                uint32_t off = 0u;
+                if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {
+                    // march_padded's guard band: floor in full precision, give up inside kPadGuard
+                    redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
+                    off = mul24((uint32_t)(int)floor(uy), (uint32_t)k.pad_row_bytes) + ((uint32_t)(int)floor(ux) << 3);
+                    have_off = true;
+                } else if ((wx | wy) < ((uint32_t)kWin << kFixFracBits)) {
+                    code = win[((wy >> kFixFracBits) << 7) | (wx >> kFixFracBits)];
+                }
+                // the LUT read is unconditional (entry 255 is a dummy) and the table read goes through an
+                // explicit global pointer: left as two arms of one `if`, the compiler merges them into a
+                // single FLAT load of a selected pointer — which travels the texture path for every lane
+                d = lut[code];
+                if (COUNT) lds_acc += code != 255u ? 1u : 0u;
+                if (code == 255u) {
+                    if (!have_off)
+                        off = mul24((uint32_t)(((int32_t)wy >> kFixFracBits) + y0), (uint32_t)k.pad_row_bytes) +
+                              ((uint32_t)(((int32_t)wx >> kFixFracBits) + x0) << 3);
+                    d = *reinterpret_cast<const __attribute__((address_space(1))) double *>(base + off);
+                }
+                total += d;
+                ++nl;
+            }
+            r = (total > k.max_range) ? k.max_range : total;
+            exact = redo | (nl > k.pad_max_samples);
+        }
+        if (exact) r = march_exact_cold<IDENT>(j.k_cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
+        if (COUNT) nl_acc += (uint32_t)nl;
+        finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
+    }
+    if (COUNT) {
+        wave_add_lookups(j.lookups_total, nl_acc);
+        wave_add_lookups(j.lookups_total + 1, lds_acc);   // [1]: samples served by the LDS window
+    }
 }
 
 // iTTC + store for one beam whose noise sample has been added already
@@ -1199,6 +1307,30 @@ __global__ void k_build_codes(const double *__restrict__ rowmajor, int H, int W,
     uint8_t code = 255;
     if (r < H && c < W) {
         const double v = rowmajor[(size_t)r * W + c];
+        int lo = 0, hi = n_lut - 1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const double m = lut[mid];
+            if (m == v) {
+                code = (uint8_t)mid;
+                break;
+            }
+            if (m < v) lo = mid + 1; else hi = mid - 1;
+        }
+    }
+    codes[t] = code;
+}
+
+// window layout: the same codes over the PADDED table, row-major, `pitch` bytes per row
+__global__ void k_build_codes_padded(const double *__restrict__ pad, int Hp, int Wp, int pitch, const double *__restrict__ lut, int n_lut,
+                                     uint8_t *__restrict__ codes)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)Hp * pitch) return;
+    const int r = (int)(t / pitch), c = (int)(t % pitch);
+    uint8_t code = 255;
+    if (c < Wp) {
+        const double v = pad[(size_t)r * Wp + c];
         int lo = 0, hi = n_lut - 1;
         while (lo <= hi) {
             const int mid = (lo + hi) >> 1;

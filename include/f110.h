@@ -54,10 +54,14 @@ enum {
     F110_MAP_TILED_F64 = 1,    /* 4x4-cell tiles, one 128-byte line per tile */
     F110_MAP_CODE8 = 2,        /* 1-byte code per cell (16x8-cell tiles) + 255-entry exact float64
                                   value LUT staged in LDS; code 255 escapes to the row-major table */
-    F110_MAP_PADDED_F64 = 3    /* dt[r][c] inside a border of out-of-bounds cells (max_range wide), so
+    F110_MAP_PADDED_F64 = 3,   /* dt[r][c] inside a border of out-of-bounds cells (max_range wide), so
                                   the march loop needs no range test, with fixed-point cell addressing
                                   and an exact re-march for samples in the guard band (the fastest
                                   layout; maps too large for it run as F110_MAP_ROWMAJOR_F64) */
+    F110_MAP_WINDOW_LDS = 4  /* F110_MAP_PADDED_F64 plus, for the step, the 128x128 cells around each
+                                  lidar staged in LDS as 1-byte codes with the exact value LUT (one
+                                  workgroup per agent); samples outside the window, and everything
+                                  else, behave as F110_MAP_PADDED_F64 */
 };
 
 /* Simulator(params, num_agents, seed, time_step, ego_idx, integrator, lidar_dist)
@@ -75,7 +79,7 @@ typedef struct f110_config {
     int32_t scan_block;    /* threads per scan workgroup (0 = default) */
     int32_t scan_tasks_per_wave; /* consecutive 64-ray tasks each wave walks (0 = default) */
     int32_t step_groups;   /* independent env blocks stepped on streams of their own (0 = automatic) */
-    int32_t reserved1;
+    int32_t step_graph;    /* 1: submit the step as one captured HIP graph (0 = separate launches) */
     double fov, eps, max_range;
     double time_step, lidar_dist, ttc_thresh;
     double params[F110_NPARAMS]; /* initial vehicle params for every agent slot */
@@ -317,9 +321,10 @@ int f110_edt_sq(f110_sim *h, const uint8_t *h_img, int32_t height, int32_t width
 int f110_noise_rows_batch(f110_sim *h, const uint64_t *h_state_inc4, double std_dev, int32_t rows,
                           int32_t num_beams, double *h_out, uint64_t *h_state_out2);
 /* Measurement aid (bench.py's L-bar): with enable = 1 the step's scan kernels sum the table lookups
- * of every ray they march (the reference's dependent gathers, laser_models.py:129-143).  out_total
- * (or NULL) receives and clears the sum; enable = -1 leaves the switch as it is.  Off by default. */
-int f110_scan_lookup_count(f110_sim *h, int32_t enable, int64_t *out_total);
+ * of every ray they march (the reference's dependent gathers, laser_models.py:129-143).  out2 (or
+ * NULL) receives and clears {the sum, how many of them the LDS window of F110_MAP_WINDOW_LDS served};
+ * enable = -1 leaves the switch as it is.  Off by default. */
+int f110_scan_lookup_count(f110_sim *h, int32_t enable, int64_t *out2);
 /* table index int(theta_index) of every beam for M headings (get_scan :167-184) */
 int f110_beam_dir_index_batch(f110_sim *h, const double *h_thetas, int32_t m, int32_t *h_idx);
 

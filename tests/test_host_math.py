@@ -319,3 +319,4 @@ def test_pure_pursuit_planner(hh):
             if li >= -1:
                 assert goal.value == (li if li >= 0 else M + li)
             assert np.max(np.abs(act - g["actions"][k])) < 1e-14
+

@@ -35,6 +35,16 @@ ab)
   F110_COLLIDE_MODE=1 timeout 200 python bench.py $H --agents 4096 --groups 1 > $OUT/ab_n4096_fused.log 2>&1; line $OUT/ab_n4096_fused.log "4096 g1 collide fused"
   timeout 200 python bench.py $H --agents 65536 --noise table > $OUT/ab_n65536_table.log 2>&1; line $OUT/ab_n65536_table.log "65536 noise table"
   ;;
+graph)
+  for n in 4096 16384 65536; do for g in 0 1; do
+    timeout 200 python bench.py $H --agents $n --graph $g > $OUT/graph_n${n}_g${g}.log 2>&1; line $OUT/graph_n${n}_g${g}.log "agents $n graph $g"
+  done; done
+  ;;
+win)
+  for n in 4096 16384 65536; do for l in 3 4; do
+    timeout 200 python bench.py $H --agents $n --layout $l > $OUT/win_n${n}_l${l}.log 2>&1; line $OUT/win_n${n}_l${l}.log "agents $n layout $l"
+  done; done
+  ;;
 bench)
   timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo "bench exit $?" >> $OUT/bench_default.log
   tail -c 6000 $OUT/bench_default.log
