@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--graph", type=int, default=-1, help="1: submit each step as one captured HIP graph; 0: separate launches; -1: the library's default")
     ap.add_argument("--gather", action="store_true",
                     help="RCCL all-gather of every rank's scans after each step (BASELINE config 4; off by default)")
+    ap.add_argument("--gather-overlap", action="store_true",
+                    help="with --gather: double-buffered scans, the gather of step t runs beside step t+1 (f110_comm_set_overlap)")
     ap.add_argument("--noise", choices=["rng", "table", "off"], default="rng",
                     help="rng: drawn on the device (default); table: NumPy's rows uploaded (A/B); off")
     ap.add_argument("--no-noise", action="store_true", help="same as --noise off")
@@ -284,6 +286,10 @@ class Workload(object):
             uid = _B.comm_unique_id() if rdv.rank == 0 else b"\0" * 128
             sim.comm_init(rdv.world, rdv.rank, rdv.broadcast_bytes(uid, 128))
             self.d_all = sim.device_array((rdv.world, self.N, self.beams))
+            self.d_alls = [self.d_all]
+            if args.gather_overlap:
+                sim.comm_set_overlap(True)
+                self.d_alls.append(sim.device_array((rdv.world, self.N, self.beams)))
         self.planner = self.d_plan = self.d_zero = None
         if self.policy == "pure_pursuit":
             from f1tenth_gym_amd import PurePursuitPlanner
@@ -307,7 +313,7 @@ class Workload(object):
         else:
             sim.step_device(self.d_sets[t // 20])
         if self.d_all is not None:
-            sim.comm_all_gather_scans(self.d_all)
+            sim.comm_all_gather_scans(self.d_alls[t % len(self.d_alls)])
         if not self.no_reset and not self.fused_reset:
             sim.reset_collided_device(self.d_start, 0, self.d_count)
 
@@ -346,11 +352,11 @@ class Workload(object):
             out["lookups"] = sim.scan_lookup_count(enable=False)
         if self.d_all is not None and mode == "timed":   # the gathered block of this rank must equal its own scans
             mine = sim.get("scans")["scans"]
-            out["gather_ok"] = bool((mine == self.d_all.download()[rdv.rank]).all())
+            out["gather_ok"] = bool((mine == self.d_alls[(warmup + steps - 1) % len(self.d_alls)].download()[rdv.rank]).all())
         return out
 
     def close(self):
-        for d in self.d_sets + [self.d_start, self.d_count] + [x for x in (self.d_plan, self.d_zero, self.d_all) if x is not None]:
+        for d in self.d_sets + [self.d_start, self.d_count] + [x for x in (self.d_plan, self.d_zero) if x is not None] + (self.d_alls if self.d_all is not None else []):
             d.free()
         self.sim.close()
 
@@ -567,7 +573,7 @@ def main(argv=None):
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
                    "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64", 4: "padded_rowmajor_f64 + lds_window_codes"}[args.layout],
                    "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks, "step_groups": args.groups, "step_graph": args.graph,
-                   "parallelism": "env-sharded x%d, %s" % (n_gpus, "RCCL all-gather of scans after every step" if args.gather
+                   "parallelism": "env-sharded x%d, %s" % (n_gpus, ("RCCL all-gather of scans after every step" + (" (overlapped with the next step, double-buffered)" if args.gather_overlap else "")) if args.gather
                                                            else "no data-path collective"),
                    "env_resets_in_timed_region": int(n_reset)},
     }

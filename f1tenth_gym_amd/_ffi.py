@@ -108,6 +108,7 @@ PROTOTYPES = {
     "f110_comm_unique_id": (C.c_int, [C.c_void_p]),
     "f110_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "f110_comm_all_gather_scans": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "f110_comm_set_overlap": (C.c_int, [C.c_void_p, C.c_int32]),
     "f110_comm_destroy": (C.c_int, [C.c_void_p]),
     "f110_timer_begin": (C.c_int, [C.c_void_p]),
     "f110_timer_end_ms": (C.c_int, [C.c_void_p, _dp]),

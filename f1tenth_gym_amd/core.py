@@ -364,6 +364,10 @@ class BatchSim(object):
         check(_ffi.lib().f110_comm_init(self._h, int(n_ranks), int(rank), buf), self._h)
         self.comm_ranks = int(n_ranks)
 
+    def comm_set_overlap(self, enable=True):
+        """double-buffer the scans so that comm_all_gather_scans overlaps the following step"""
+        check(_ffi.lib().f110_comm_set_overlap(self._h, 1 if enable else 0), self._h)
+
     def comm_all_gather_scans(self, d_recv):
         ptr = d_recv.ptr if isinstance(d_recv, DeviceArray) else int(d_recv)
         check(_ffi.lib().f110_comm_all_gather_scans(self._h, ptr), self._h)

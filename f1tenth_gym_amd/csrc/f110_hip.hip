@@ -94,6 +94,14 @@ struct f110_sim {
     bool use_graph = false;
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
     int comm_ranks = 0;
+    // overlapped gather (f110_comm_set_overlap): scans are double-buffered, the all-gather of step t
+    // runs on comm_stream while step t+1 fills the other buffer
+    bool comm_overlap = false, comm_swap_next = false, comm_inflight = false;
+    double *scan_bufs[2] = {nullptr, nullptr};
+    int scans_cur = 0;
+    bool gather_pending[2] = {false, false};
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_step_done = nullptr, ev_gather_done[2] = {nullptr, nullptr};
     EpisodeArrays ep{};
     bool has_episode = false;
     double *d_rot_stage = nullptr;
@@ -144,6 +152,11 @@ static int dmalloc(f110_sim *h, T **p, size_t count)
 // internal detail: anything enqueued or read through the handle sees completed steps.
 static int join_groups(f110_sim *h)
 {
+    if (h->comm_inflight) {   // an overlapped gather: whatever follows on the main stream sees its result
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather_done[0], 0));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather_done[1], 0));
+        h->comm_inflight = false;
+    }
     if (!h->groups_busy) return F110_OK;
     for (size_t g = 0; g < h->gstreams.size(); ++g) {
         HIPCHK(h, hipEventRecord(h->gevents[g], h->gstreams[g]));
@@ -525,6 +538,15 @@ void f110_destroy(f110_sim *h)
     for (hipStream_t gs : h->gstreams) (void)hipStreamSynchronize(gs);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    (void)f110_comm_destroy(h);
+    h->comm_inflight = false;
+    if (h->comm_stream) { (void)hipStreamSynchronize(h->comm_stream); (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
+    for (hipEvent_t e : {h->ev_step_done, h->ev_gather_done[0], h->ev_gather_done[1]})
+        if (e) (void)hipEventDestroy(e);
+    if (h->comm_overlap || h->scan_bufs[1]) {
+        if (h->scan_bufs[0]) h->dev.scans = h->scan_bufs[0];   // the list below frees dev.scans
+        if (h->scan_bufs[1]) (void)hipFree(h->scan_bufs[1]);
+    }
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (hipStream_t gs : h->gstreams) (void)hipStreamDestroy(gs);
     for (hipEvent_t ge : h->gevents) (void)hipEventDestroy(ge);
@@ -534,7 +556,6 @@ void f110_destroy(f110_sim *h)
         for (void *p : rp)
             if (p) (void)hipFree(p);
     }
-    (void)f110_comm_destroy(h);
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
@@ -1169,15 +1190,68 @@ int f110_comm_init(f110_sim *h, int32_t n_ranks, int32_t rank, const void *id128
     return F110_OK;
 }
 
+int f110_comm_set_overlap(f110_sim *h, int32_t enable)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (enable && !h->comm_overlap) {
+        const size_t count = (size_t)h->N * h->cfg.num_beams;
+        if (!h->scan_bufs[1]) {
+            TRY(dmalloc(h, &h->scan_bufs[1], count));
+            HIPCHK(h, hipMemset(h->scan_bufs[1], 0, sizeof(double) * count));
+            HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_step_done, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather_done[0], hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather_done[1], hipEventDisableTiming));
+        }
+        h->scan_bufs[0] = h->dev.scans;
+        h->scans_cur = 0;
+        h->gather_pending[0] = h->gather_pending[1] = false;
+        h->comm_swap_next = false;
+        h->comm_overlap = true;
+    } else if (!enable && h->comm_overlap) {
+        if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
+        if (h->scans_cur != 0) {   // back on the buffer the handle owns by name
+            HIPCHK(h, hipMemcpy(h->scan_bufs[0], h->scan_bufs[1], sizeof(double) * (size_t)h->N * h->cfg.num_beams, hipMemcpyDeviceToDevice));
+            h->scans_cur = 0;
+        }
+        h->dev.scans = h->scan_bufs[0];
+        h->comm_overlap = false;
+    }
+    return F110_OK;
+}
+
 int f110_comm_all_gather_scans(f110_sim *h, void *d_recv)
 {
     if (!h || !d_recv) return fail(h, F110_ERR_INVALID, "null argument");
-    ENTER(h);
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h->comm) return fail(h, F110_ERR_STATE, "f110_comm_init has not been called");
     RcclApi *r = rccl_api();
     const size_t count = (size_t)h->N * h->cfg.num_beams;
-    const ncclResult_t rc = r->AllGather(h->dev.scans, d_recv, count, ncclFloat64, h->comm, h->stream);
+    if (!h->comm_overlap) {
+        ENTER(h);
+        const ncclResult_t rc = r->AllGather(h->dev.scans, d_recv, count, ncclFloat64, h->comm, h->stream);
+        if (rc != ncclSuccess) return fail(h, F110_ERR_HIP, "ncclAllGather failed: %s", r->GetErrorString(rc));
+        return F110_OK;
+    }
+    // overlapped: the gather waits for the step that produced this buffer and runs beside the next one,
+    // which writes the other buffer; the step after that waits for this gather before reusing the buffer
+    {
+        const bool inflight = h->comm_inflight;   // join the groups, not earlier gathers (they stay asynchronous)
+        h->comm_inflight = false;
+        const int rj = join_groups(h);
+        h->comm_inflight = inflight;
+        if (rj != F110_OK) return rj;
+    }
+    HIPCHK(h, hipEventRecord(h->ev_step_done, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step_done, 0));
+    const ncclResult_t rc = r->AllGather(h->scan_bufs[h->scans_cur], d_recv, count, ncclFloat64, h->comm, h->comm_stream);
     if (rc != ncclSuccess) return fail(h, F110_ERR_HIP, "ncclAllGather failed: %s", r->GetErrorString(rc));
+    HIPCHK(h, hipEventRecord(h->ev_gather_done[h->scans_cur], h->comm_stream));
+    h->gather_pending[h->scans_cur] = true;
+    h->comm_swap_next = true;
+    h->comm_inflight = true;
     return F110_OK;
 }
 
@@ -1186,6 +1260,7 @@ int f110_comm_destroy(f110_sim *h)
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     ENTER(h);
     if (h->comm) {
+        if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         RcclApi *r = rccl_api();
         if (r) (void)r->CommDestroy(h->comm);
@@ -1492,6 +1567,23 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int N = h->N, A = h->cfg.num_agents;
     h->dev.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;
+    if (h->comm_overlap && h->comm_swap_next) {
+        // the previous step's scans are being gathered: this step fills the other buffer, once the
+        // gather that last read THAT buffer (two steps ago) is done
+        h->scans_cur ^= 1;
+        h->dev.scans = h->scan_bufs[h->scans_cur];
+        if (h->gather_pending[h->scans_cur]) {
+            const bool inflight = h->comm_inflight;
+            h->comm_inflight = false;
+            const int rj = join_groups(h);
+            h->comm_inflight = inflight;
+            if (rj != F110_OK) return rj;
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_gather_done[h->scans_cur], 0));
+            h->gather_pending[h->scans_cur] = false;
+            h->main_dirty = true;
+        }
+        h->comm_swap_next = false;
+    }
     // shared noise stream: the row cache must reach the longest live episode (or its capacity)
     if (h->dev.noise_rng == 1 && h->noise_ub >= h->noise_rows_ready && h->noise_rows_ready < h->dev.noise_rows) {
         TRY(join_groups(h));

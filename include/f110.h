@@ -249,6 +249,15 @@ int f110_memcpy_d2h(f110_sim *h, void *h_dst, const void *d_src, size_t bytes);
 int f110_comm_unique_id(void *out_id128);
 int f110_comm_init(f110_sim *h, int32_t n_ranks, int32_t rank, const void *id128);
 int f110_comm_all_gather_scans(f110_sim *h, void *d_recv);
+/* enable = 1: the gather OVERLAPS the following step.  The scans are double-buffered (a second
+ * [N][B] buffer): f110_comm_all_gather_scans then runs on a stream of its own behind the step that
+ * produced the current buffer, the next f110_step* fills the other buffer, and the step after that
+ * waits for the gather before reusing the first.  While enabled, f110_device_views.scans alternates
+ * between the two buffers (fetch it after each step); d_recv must not be reused by the caller before
+ * the data has been consumed (alternate two receive buffers).  Any other call on the handle
+ * (f110_sync, f110_get_obs, f110_memcpy_d2h, ...) first makes the main stream wait for outstanding
+ * gathers. */
+int f110_comm_set_overlap(f110_sim *h, int32_t enable);
 int f110_comm_destroy(f110_sim *h);
 
 /* HIP-event timing on the handle's stream (bench.py roofline leg).

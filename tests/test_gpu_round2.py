@@ -355,6 +355,37 @@ def test_comm_all_gather_world_size_one(amd):
     s.close()
 
 
+def test_comm_overlapped_gather_double_buffered(amd):
+    """f110_comm_set_overlap: the gather of step t runs on its own stream beside step t+1, which
+    fills the second scans buffer.  World size 1: every gathered block must equal the scans of the
+    step it was issued after, also when the next step has already overwritten... the other buffer."""
+    E, A, T = 64, 2, 9
+    s = _pair(amd, E, A); ref = _pair(amd, E, A)
+    poses = bench_start_poses(E, A)
+    for x in (s, ref):
+        x.set_noise_rng(12345, 0.01); x.reset(poses)
+    s.comm_init(1, 0, amd.BatchSim.comm_unique_id())
+    s.comm_set_overlap(True)
+    recv = [s.device_array((1, E * A, 1080)) for _ in range(2)]
+    rng = np.random.default_rng(0)
+    want = []
+    for t in range(T):
+        act = _actions(rng, E * A)
+        s.step(act); ref.step(act)
+        s.comm_all_gather_scans(recv[t % 2])
+        want.append(ref.get("scans")["scans"])
+        if t >= 1:   # consume the PREVIOUS gather while this step's gather is in flight
+            assert np.array_equal(recv[(t - 1) % 2].download()[0], want[t - 1]), t
+        assert np.array_equal(s.get("scans")["scans"], want[t]), t   # observations unaffected by the buffering
+    assert np.array_equal(recv[(T - 1) % 2].download()[0], want[T - 1])
+    s.comm_set_overlap(False)
+    s.step(act); ref.step(act)
+    assert np.array_equal(s.get("scans")["scans"], ref.get("scans")["scans"])
+    for d in recv:
+        d.free()
+    s.close(); ref.close()
+
+
 # ---------------------------------------------------------------------------- fuzzers, bounded seeds
 def _load(path, name):
     spec = importlib.util.spec_from_file_location(name, path)
