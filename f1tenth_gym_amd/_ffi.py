@@ -95,6 +95,10 @@ PROTOTYPES = {
     "f110_episode_step_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_episode_reset_done_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_episode_get": (C.c_int, [C.c_void_p, C.POINTER(EpisodeHost)]),
+    "f110_episode_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "f110_episode_packed_bytes": (C.c_size_t, [C.c_void_p]),
+    "f110_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "f110_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_episode_device_views": (C.c_int, [C.c_void_p, C.POINTER(EpisodeViews)]),
     "f110_step": (C.c_int, [C.c_void_p, _dp]),
     "f110_step_device": (C.c_int, [C.c_void_p, C.c_void_p]),

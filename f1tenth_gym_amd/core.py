@@ -146,6 +146,9 @@ class BatchSim(object):
     # ------------------------------------------------------------------ lifetime
     def close(self):
         if self._h:
+            for p in getattr(self, "_pinned", []):
+                _ffi.lib().f110_host_free(self._h, p)
+            self._pinned = []
             _ffi.lib().f110_destroy(self._h)
             self._h = None
 
@@ -399,6 +402,33 @@ class BatchSim(object):
     def episode_reset_done_device(self, d_count=None):
         c = None if d_count is None else (d_count.ptr if isinstance(d_count, DeviceArray) else int(d_count))
         check(_ffi.lib().f110_episode_reset_done_device(self._h, c), self._h)
+
+    def pinned_empty(self, shape, dtype=np.float64):
+        """a NumPy array over page-locked host memory (full-rate DMA); freed with the handle"""
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(_ffi.lib().f110_host_alloc(self._h, nbytes, C.byref(p)), self._h)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def episode_step_host(self, actions_pinned, packed_pinned, auto_reset=False):
+        """actions up, step, _check_done, the packed scalar observation down (one copy), optional re-seat;
+        returns views into packed_pinned (overwritten by the next call)"""
+        check(_ffi.lib().f110_episode_step_host(self._h, actions_pinned.ctypes.data, 1 if auto_reset else 0, packed_pinned.ctypes.data), self._h)
+        N, E = self.N, self.E
+        cols = packed_pinned[:(9 * N + E) * 8].view(np.float64)
+        fl = packed_pinned[(9 * N + E) * 8:]
+        names = ("poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions", "lap_times", "lap_counts", "toggles")
+        out = {k: cols[i * N:(i + 1) * N] for i, k in enumerate(names)}
+        out["current_time"] = cols[9 * N:9 * N + E]
+        out["near_starts"], out["checkpoint_done"], out["done"] = fl[:N], fl[N:2 * N], fl[2 * N:2 * N + E]
+        return out
+
+    def packed_bytes(self):
+        return int(_ffi.lib().f110_episode_packed_bytes(self._h))
 
     def episode_get(self):
         N, E = self.N, self.E

@@ -105,6 +105,7 @@ struct f110_sim {
     EpisodeArrays ep{};
     bool has_episode = false;
     double *d_rot_stage = nullptr;
+    void *d_packed = nullptr;   // f110_episode_step_host's packed block
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool profiling = false;
@@ -571,7 +572,7 @@ void f110_destroy(f110_sim *h)
     if (h->d_env_map) (void)hipFree(h->d_env_map);
     {
         void *eptrs[] = {h->ep.start_poses, h->ep.rot, h->ep.current_time, h->ep.near_start, h->ep.toggle,
-                         h->ep.lap_count, h->ep.lap_time, h->ep.done, h->ep.checkpoint, h->d_rot_stage};
+                         h->ep.lap_count, h->ep.lap_time, h->ep.done, h->ep.checkpoint, h->d_rot_stage, h->d_packed};
         for (void *p : eptrs)
             if (p) (void)hipFree(p);
     }
@@ -1342,6 +1343,57 @@ int f110_episode_reset_done_device(f110_sim *h, int32_t *d_count)
     hipLaunchKernelGGL(k_episode_reset_done, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, h->ep, d_count);
     hipLaunchKernelGGL(k_episode_clear_done, grid1d(h->cfg.num_envs, 256), dim3(256), 0, h->stream, h->ep, h->cfg.num_envs);
     HIPCHK(h, hipGetLastError());
+    return F110_OK;
+}
+
+size_t f110_episode_packed_bytes(const f110_sim *h)
+{
+    if (!h) return 0;
+    const size_t N = (size_t)h->N, E = (size_t)h->cfg.num_envs;
+    return (9 * N + E) * sizeof(double) + 2 * N + E;
+}
+
+int f110_host_alloc(f110_sim *h, size_t bytes, void **out)
+{
+    if (!h || !out) return fail(h, F110_ERR_INVALID, "null argument");
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipHostMalloc(out, bytes > 0 ? bytes : 8, hipHostMallocDefault));
+    return F110_OK;
+}
+
+int f110_host_free(f110_sim *h, void *p)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    if (p) {
+        ENTER(h);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipHostFree(p));
+    }
+    return F110_OK;
+}
+
+int f110_episode_step_host(f110_sim *h, const double *h_actions, int32_t auto_reset, void *h_packed)
+{
+    if (!h || !h_actions || !h_packed) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
+    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    ENTER(h);
+    const size_t N = (size_t)h->N, E = (size_t)h->cfg.num_envs, bytes = f110_episode_packed_bytes(h);
+    if (!h->d_packed) HIPCHK(h, hipMalloc(&h->d_packed, bytes));
+    HIPCHK(h, hipMemcpyAsync(h->d_actions, h_actions, sizeof(double) * 2 * N, hipMemcpyHostToDevice, h->stream));
+    TRY(f110_step_device(h, h->d_actions));
+    ENTER(h);
+    hipLaunchKernelGGL(k_episode, grid1d(E, 256), dim3(256), 0, h->stream, h->dev, h->ep, (int)E);
+    double *cols = reinterpret_cast<double *>(h->d_packed);
+    uint8_t *flags = reinterpret_cast<uint8_t *>(cols + 9 * N + E);
+    hipLaunchKernelGGL(k_pack_episode, grid1d(N > E ? N : E, 256), dim3(256), 0, h->stream, h->dev, h->ep, (int)E, cols, flags);
+    HIPCHK(h, hipMemcpyAsync(h_packed, h->d_packed, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (auto_reset) {   // the packed block holds the terminal observation; the re-seat follows it
+        hipLaunchKernelGGL(k_episode_reset_done, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->ep, (int32_t *)nullptr);
+        hipLaunchKernelGGL(k_episode_clear_done, grid1d(E, 256), dim3(256), 0, h->stream, h->ep, (int)E);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return F110_OK;
 }
 

@@ -992,6 +992,32 @@ __global__ void __launch_bounds__(256) k_episode(AgentArrays a, EpisodeArrays ep
     ep.done[e] = (a.collisions[e * A + ep.ego_idx] != 0.0 || all4) ? 1 : 0;  // :244
 }
 
+// every per-agent / per-env scalar a host-side RL loop reads per step, packed into one block so that
+// it crosses PCIe in one copy (f110_episode_step_host): 9 double columns [N], current_time [E], then
+// the byte flags near_starts [N], checkpoint_done [N], done [E]
+__global__ void __launch_bounds__(256) k_pack_episode(AgentArrays a, EpisodeArrays ep, int num_envs, double *__restrict__ cols, uint8_t *__restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = a.n_agents_total;
+    if (i < N) {
+        cols[i] = a.state[i];
+        cols[(size_t)N + i] = a.state[(size_t)N + i];
+        cols[2 * (size_t)N + i] = a.state[4 * (size_t)N + i];
+        cols[3 * (size_t)N + i] = a.state[3 * (size_t)N + i];
+        cols[4 * (size_t)N + i] = a.state[5 * (size_t)N + i];
+        cols[5 * (size_t)N + i] = a.collisions[i];
+        cols[6 * (size_t)N + i] = ep.lap_time[i];
+        cols[7 * (size_t)N + i] = ep.lap_count[i];
+        cols[8 * (size_t)N + i] = ep.toggle[i];
+        flags[i] = ep.near_start[i];
+        flags[(size_t)N + i] = ep.checkpoint[i];
+    }
+    if (i < num_envs) {
+        cols[9 * (size_t)N + i] = ep.current_time[i];
+        flags[2 * (size_t)N + i] = ep.done[i];
+    }
+}
+
 // re-seat every env whose done flag is set (F110Env.reset :319-334 without its zero-action step)
 __global__ void __launch_bounds__(256) k_episode_reset_done(AgentArrays a, EpisodeArrays ep, int32_t *__restrict__ n_reset)
 {

@@ -177,9 +177,12 @@ class F110VecEnv(object):
     cleared for the re-seated envs.
 
     device_logic=True runs the lap / done bookkeeping (F110Env._check_done) and the auto-reset on
-    the GPU (f110_episode_*): per step only `done`, the lap arrays and the requested observation
-    fields cross PCIe.  obs_fields selects what is read back ('scans' is 8.6 KB per agent);
-    everything stays available in HBM through `device_views()`.
+    the GPU (f110_episode_*): one call per step (f110_episode_step_host) uploads the actions from a
+    pinned buffer and brings `done`, the lap arrays and the scalar observation fields back in ONE
+    device-to-host copy into pinned memory.  The arrays step() returns in that mode are VIEWS of
+    that pinned block, overwritten by the next step(): copy what you keep, or pass copy_obs=True.
+    obs_fields selects the fields put into `obs` ('scans', 8.6 KB per agent, is a separate
+    read-back); everything stays available in HBM through `device_views()`.
 
     Domain randomisation over tracks: `extra_maps=[(yaml_path, ext), ...]` registers further maps
     (slots 1, 2, ...; `map` is slot 0) and `env_map=[slot per env]` assigns them; `set_env_maps()`
@@ -188,7 +191,7 @@ class F110VecEnv(object):
 
     _ALL = ("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions")
 
-    def __init__(self, num_envs, auto_reset=False, device_logic=False, obs_fields=None, **kwargs):
+    def __init__(self, num_envs, auto_reset=False, device_logic=False, obs_fields=None, copy_obs=False, **kwargs):
         self.num_envs = int(num_envs)
         self.seed = kwargs.get('seed', 12345)
         self.map_name, self.map_path = _resolve_map_path(kwargs)
@@ -219,9 +222,13 @@ class F110VecEnv(object):
             self.set_env_maps(kwargs['env_map'])
         self._start_poses = None
         self._d_actions = None
+        self.copy_obs = bool(copy_obs)
         if self.device_logic:
-            self.sim.batch.episode_init(self.ego_idx)
-            self._d_actions = self.sim.batch.device_array((self.num_envs * self.num_agents, 2))
+            b = self.sim.batch
+            b.episode_init(self.ego_idx)
+            self._d_actions = b.device_array((self.num_envs * self.num_agents, 2))
+            self._h_actions = b.pinned_empty((self.num_envs * self.num_agents, 2))
+            self._h_packed = b.pinned_empty((b.packed_bytes(),), np.uint8)
 
     def update_params_batch(self, params):
         """a vehicle parameter set per agent of every env ([E*A] dicts or [E*A][18] array; None: back
@@ -263,24 +270,22 @@ class F110VecEnv(object):
         b = self.sim.batch
         if self.sim._noise is not None:
             self.sim._noise.ensure(b, self.sim._steps_since_full_reset + 1)
-        self._d_actions.upload(np.asarray(actions, dtype=np.float64).reshape(E * A, 2))
-        b.episode_step_device(self._d_actions)
+        self._h_actions[...] = np.asarray(actions, dtype=np.float64).reshape(E * A, 2)
+        p = b.episode_step_host(self._h_actions, self._h_packed, auto_reset=self.auto_reset)
         self.sim._steps_since_full_reset += 1
-        names = {"poses_x": "poses_x", "poses_y": "poses_y", "poses_theta": "poses_theta",
-                 "linear_vels_x": "linear_vels_x", "ang_vels_z": "ang_vels_z", "collisions": "collisions",
-                 "scans": "scans"}
-        o = b.get(*[names[f] for f in self.obs_fields]) if self.obs_fields else {}
+        if self.copy_obs:
+            p = {k: v.copy() for k, v in p.items()}
         obs = {'ego_idx': self.ego_idx}
         for f in self.obs_fields:
-            obs[f] = o[f].reshape(E, A, -1) if f == "scans" else o[f].reshape(E, A)
-        ep = b.episode_get()
-        obs['lap_times'] = ep["lap_times"].reshape(E, A)
-        obs['lap_counts'] = ep["lap_counts"].reshape(E, A)
-        done = ep["done"].astype(bool)
-        info = {'checkpoint_done': ep["checkpoint_done"].reshape(E, A).astype(bool),
-                'toggle_list': ep["toggles"].reshape(E, A), 'near_starts': ep["near_starts"].reshape(E, A).astype(bool)}
-        if self.auto_reset:
-            b.episode_reset_done_device()
+            if f == "scans":
+                obs[f] = b.get("scans")["scans"].reshape(E, A, -1)
+            else:
+                obs[f] = p[f].reshape(E, A)
+        obs['lap_times'] = p["lap_times"].reshape(E, A)
+        obs['lap_counts'] = p["lap_counts"].reshape(E, A)
+        done = p["done"].astype(bool)
+        info = {'checkpoint_done': p["checkpoint_done"].reshape(E, A).astype(bool),
+                'toggle_list': p["toggles"].reshape(E, A), 'near_starts': p["near_starts"].reshape(E, A).astype(bool)}
         self._last = (obs, self.timestep, done, info)
         return self._last
 

@@ -194,6 +194,19 @@ int f110_episode_reset(f110_sim *h, const double *h_poses, const double *h_rot,
 int f110_episode_step_device(f110_sim *h, const double *d_actions); /* f110_step_device + _check_done */
 int f110_episode_reset_done_device(f110_sim *h, int32_t *d_count);  /* re-seat envs whose done flag is set */
 int f110_episode_get(f110_sim *h, const f110_episode_host *out);
+/* One host round trip per step for host-side RL loops (F110VecEnv): h_actions [N][2] up, the step,
+ * _check_done, every per-agent / per-env scalar of the observation down in ONE copy, then (auto_reset)
+ * the in-place re-seat of the envs whose done flag is set.  h_packed (f110_episode_packed_bytes(h)
+ * bytes; pinned memory from f110_host_alloc for a full-rate copy) receives
+ *   double [9][N]  poses_x, poses_y, poses_theta, linear_vels_x, ang_vels_z, collisions,
+ *                  lap_times, lap_counts, toggles
+ *   double [E]     current_time
+ *   uint8  [N] near_starts, [N] checkpoint_done, [E] done
+ * — the observation of the step just taken (before any re-seat).  Scans stay in HBM. */
+int f110_episode_step_host(f110_sim *h, const double *h_actions, int32_t auto_reset, void *h_packed);
+size_t f110_episode_packed_bytes(const f110_sim *h);
+int f110_host_alloc(f110_sim *h, size_t bytes, void **h_out);   /* page-locked host memory */
+int f110_host_free(f110_sim *h, void *h_ptr);
 int f110_episode_device_views(f110_sim *h, f110_episode_views *out);
 
 /* Simulator.step base_classes.py:553-612.  actions [N][2] = (steer, speed).
