@@ -40,6 +40,14 @@ graph)
     timeout 200 python bench.py $H --agents $n --graph $g > $OUT/graph_n${n}_g${g}.log 2>&1; line $OUT/graph_n${n}_g${g}.log "agents $n graph $g"
   done; done
   ;;
+gaps)
+  cd /tmp
+  for n in 4096 65536; do
+    timeout 300 rocprofv3 --kernel-trace -T -f csv -d $OUT/trace_$n -o t -- python $R/bench.py --only-headline --steps 100 --warmup 10 --agents $n > $OUT/trace_$n.log 2>&1
+    python $R/tools/summarize_prof.py gaps $OUT/trace_$n $OUT/gaps_$n.txt; rm -rf $OUT/trace_$n; echo "agents $n"; cat $OUT/gaps_$n.txt
+  done
+  cd "$R"
+  ;;
 win)
   for n in 4096 16384 65536; do for l in 3 4; do
     timeout 200 python bench.py $H --agents $n --layout $l > $OUT/win_n${n}_l${l}.log 2>&1; line $OUT/win_n${n}_l${l}.log "agents $n layout $l"
