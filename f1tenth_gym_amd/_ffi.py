@@ -105,6 +105,7 @@ PROTOTYPES = {
     "f110_get_obs": (C.c_int, [C.c_void_p, C.POINTER(ObsHost)]),
     "f110_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _i32p]),
     "f110_get_device_views": (C.c_int, [C.c_void_p, C.POINTER(DeviceViews)]),
+    "f110_device_mem_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "f110_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "f110_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -454,6 +454,12 @@ class BatchSim(object):
                 "toggles": DeviceArray(self, (N,), np.float64, v.toggles),
                 "current_time": DeviceArray(self, (E,), np.float64, v.current_time)}
 
+    def device_mem_info(self):
+        """(free, total) bytes of the handle's GPU"""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        check(_ffi.lib().f110_device_mem_info(self._h, C.byref(f), C.byref(t)), self._h)
+        return int(f.value), int(t.value)
+
     def device_array(self, shape, dtype=np.float64):
         return DeviceArray(self, shape, dtype)
 

@@ -1808,6 +1808,15 @@ int f110_get_device_views(f110_sim *h, f110_device_views *v)
     return F110_OK;
 }
 
+int f110_device_mem_info(f110_sim *h, size_t *free_bytes, size_t *total_bytes)
+{
+    if (!h || !free_bytes || !total_bytes) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemGetInfo(free_bytes, total_bytes));
+    return F110_OK;
+}
+
 int f110_device_alloc(f110_sim *h, size_t bytes, void **out)
 {
     if (!h || !out) return fail(h, F110_ERR_INVALID, "null argument");

@@ -247,6 +247,8 @@ typedef struct f110_device_views {
     void *stream;         /* hipStream_t */
 } f110_device_views;
 int f110_get_device_views(f110_sim *h, f110_device_views *out);
+/* free / total bytes of the handle's GPU (hipMemGetInfo) — lets a long run show that memory stays flat */
+int f110_device_mem_info(f110_sim *h, size_t *free_bytes, size_t *total_bytes);
 int f110_device_alloc(f110_sim *h, size_t bytes, void **d_out);
 int f110_device_free(f110_sim *h, void *d_ptr);
 int f110_memcpy_h2d(f110_sim *h, void *d_dst, const void *h_src, size_t bytes);

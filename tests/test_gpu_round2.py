@@ -543,3 +543,26 @@ def test_graph_step_equals_separate_launches(amd, A):
             mask = (rng.random(E) < 0.3).astype(np.uint8)
             a.reset(poses, mask); b.reset(poses, mask)
     a.close(); b.close()
+
+
+def test_memory_flat_in_long_auto_reset_loop(amd):
+    """(f)-3's reason to exist: a training-style loop must not grow memory with the step count (the
+    round-1 host noise table grew 8.6 KB per step of the longest episode).  4000 steps, row cache of 32
+    rows so that live episodes run far past it; device free memory identical at 1000 and 4000 steps."""
+    from _util import MAPS
+    E = 8
+    env = amd.F110VecEnv(E, auto_reset=True, device_logic=True, obs_fields=("collisions",), map=os.path.join(MAPS, "example_map"), map_ext=".png", num_agents=2)
+    b = env.sim.batch
+    b.set_noise_rng(12345, 0.01, cache_rows=32)
+    env.reset(bench_start_poses(E, 2).reshape(E, 2, 3))
+    act = np.tile(np.array([[0.0, 1.0]]), (E, 2, 1))
+    free_at = {}
+    longest = 0
+    for t in range(4000):
+        env.step(act)
+        if t in (999, 3999):
+            free_at[t] = b.device_mem_info()[0]
+            longest = max(longest, int(b.get("step_count")["step_count"].max()))
+    assert longest > 32, "no episode outlived the row cache"
+    assert free_at[999] == free_at[3999], free_at
+    b.close()
