@@ -365,7 +365,9 @@ def scan_kernel_name(args, beams):
     if args.layout == 4 and beams < 1498 and (-beams) % 64 * 100 <= 3 * beams:
         return "k_scan_rays_window"
     aligned = args.layout == 3 and beams < 1498 and (-beams) % 64 * 100 <= 3 * beams
-    return "k_scan_rays_agent" if aligned else ("k_scan_rays (direction dedupe) + k_expand_beams" if beams >= 1498 else "k_scan_rays")
+    if beams >= 1498:
+        return "k_scan_dirs_agent" if args.layout in (3, 4) else "k_scan_rays (direction dedupe) + k_expand_beams"
+    return "k_scan_rays_agent" if aligned else "k_scan_rays"
 
 
 def load_json(name):

@@ -1521,7 +1521,25 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         j.k_cold = cold_consts(h);
         if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
         scan_rays_fn fn = pick_rays<true>(h->k, h->cfg.map_layout);
-        if (h->dir_stride > 0) {
+        static const bool two_pass_dedupe = std::getenv("F110_DEDUPE_TWO_PASS") != nullptr;   // A/B
+        if (h->dir_stride > 0 && padded_family(h->cfg.map_layout) && h->k.pad && !h->multi_map && !two_pass_dedupe) {
+            // more beams than table directions, PADDED table: march each distinct direction once and write
+            // the beams that share it from the same wave (k_scan_dirs_agent)
+            const uint32_t tpa = (uint32_t)h->dir_stride / 64u;
+            (void)rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
+            j.n_tasks = (uint32_t)count * tpa;
+            j.first_pose = (uint32_t)begin;
+            const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave, wpb = (uint32_t)h->scan_block / 64u;
+            const dim3 grid((waves + wpb - 1) / wpb), block(h->scan_block);
+            const bool cnt = j.lookups_total != nullptr;
+            if (h->k.ident_rot) {
+                if (cnt) hipLaunchKernelGGL((k_scan_dirs_agent<true, true>), grid, block, 0, st, j, h->k, tpa);
+                else hipLaunchKernelGGL((k_scan_dirs_agent<true, false>), grid, block, 0, st, j, h->k, tpa);
+            } else {
+                if (cnt) hipLaunchKernelGGL((k_scan_dirs_agent<false, true>), grid, block, 0, st, j, h->k, tpa);
+                else hipLaunchKernelGGL((k_scan_dirs_agent<false, false>), grid, block, 0, st, j, h->k, tpa);
+            }
+        } else if (h->dir_stride > 0) {
             RayJob jd = j;  // pass 1: one ray per (agent, distinct direction)
             jd.n_rays = (uint32_t)N * (uint32_t)h->dir_stride;
             jd.ranges = h->d_dir_ranges;

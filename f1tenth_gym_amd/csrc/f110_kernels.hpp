@@ -672,6 +672,85 @@ __device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_
     finish_beam_with(j, p, b, ray, r, vel);
 }
 
+// ---- K2d: more beams than table directions, one pass -----------------------------------------------
+// BASELINE config 5 (4096 beams, theta_dis = 2000 -> 1497 distinct directions per scan).  Agent-aligned
+// like k_scan_rays_agent, but a task is 64 consecutive DISTINCT directions of one agent: each lane
+// marches one direction once, then the wave writes the ~175 consecutive beams that use those 64
+// directions in coalesced passes of 64 — beam b takes its range from lane rel(b) - s0 by shuffle and
+// gets its own noise sample and iTTC test.  Replaces the (march to a [N][dir_stride] buffer,
+// k_expand_beams) pair: one launch less and no 1.6 GB round trip of intermediate ranges per step.
+// Bit-identical to marching every beam (beams that share a table index from one origin are one ray).
+template <bool IDENT, bool COUNT>
+__global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, uint32_t tasks_per_agent)
+{
+    const uint32_t B = (uint32_t)k.num_beams;
+    const uint32_t tpw = j.tasks_per_wave;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t blk = blockIdx.x;
+    {
+        const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
+        blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // XCD-contiguous, as k_scan_rays
+    }
+    const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
+    uint32_t nl_acc = 0;
+    for (uint32_t t = 0; t < tpw; ++t) {
+        const uint32_t task = __builtin_amdgcn_readfirstlane(wave * tpw + t);
+        if (task >= j.n_tasks) break;
+        const uint32_t pl = task / tasks_per_agent;
+        const uint32_t p = j.first_pose + pl;
+        const int s0 = (int)((task - pl * tasks_per_agent) * 64u);
+        typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
+        const chdr_t h0 = (chdr_t)(j.hdr) + p;
+        const int n_dirs = uniform_i32(h0->n_dirs);
+        if (s0 >= n_dirs) continue;   // wave-uniform: the padding tasks of dir_stride
+        const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
+        const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
+        const int row = uniform_i32(h0->noise_row), fast = uniform_i32(h0->fast), i0 = uniform_i32(h0->i0);
+        double r_dir = 0.;
+        if (s0 + (int)lane < n_dirs) {
+            int didx = i0 + s0 + (int)lane;
+            if (didx >= k.theta_dis) didx -= k.theta_dis;
+            const double2 cs = k.cs[didx];
+            int hr = -1, hc = -1, nl;
+            bool exact = fast == 0;
+            if (fast) {
+                double ux, uy, cux, cuy;
+                padded_position<IDENT>(k, x, y, ux, uy);
+                padded_rate<IDENT>(k, cs.x, cs.y, cux, cuy);
+                exact = !march_padded<false>(k, ux, uy, cux, cuy, d0, r_dir, hr, hc, nl);
+            }
+            if (exact) r_dir = march_exact_cold<IDENT>(j.k_cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
+            if (COUNT) nl_acc += (uint32_t)nl;
+        }
+        // first beam whose table index is direction s0 (relative indices never decrease with the beam):
+        // closed-form estimate, then the exact index function decides
+        auto rel_of = [&](int b) {
+            int rr = beam_dir_index(k, start, b) - i0;
+            return rr < 0 ? rr + k.theta_dis : rr;
+        };
+        int b0 = 0;
+        if (s0 > 0) {
+            b0 = (int)ceil(((double)s0 - (start - floor(start))) / k.theta_inc) - 2;
+            b0 = b0 < 0 ? 0 : (b0 >= (int)B ? (int)B - 1 : b0);
+            b0 = __builtin_amdgcn_readfirstlane(b0);
+            while (b0 > 0 && rel_of(b0 - 1) >= s0) --b0;
+            while (b0 < (int)B && rel_of(b0) < s0) ++b0;
+        }
+        for (int b = b0 + (int)lane;; b += 64) {   // every lane takes part in every shuffle
+            bool in = b < (int)B;
+            int src = 0;
+            if (in) {
+                src = rel_of(b) - s0;
+                in = src < 64;
+            }
+            const double r = __shfl(r_dir, in ? src : 0);
+            if (in) finish_beam(j, B, p, b, p * B + (uint32_t)b, r, row, vel);
+            if (__ballot(!in) != 0ull) break;   // the indices are monotone: nothing further belongs to this task
+        }
+    }
+    if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
+}
+
 // ---- K2b: beam expansion of the dedupe pass ---------------------------------------------------
 // More beams than table directions (BASELINE config 5: 4096 beams, theta_dis = 2000 -> 1497
 // distinct directions per scan): beams that share a table index from the same origin are the same
