@@ -566,3 +566,30 @@ def test_memory_flat_in_long_auto_reset_loop(amd):
     assert longest > 32, "no episode outlived the row cache"
     assert free_at[999] == free_at[3999], free_at
     b.close()
+
+
+def test_vec_env_single_env_host_path(amd):
+    """F110VecEnv(num_envs=1, num_agents=2) on the HOST logic path keeps the batched layout (leading env
+    axis) — round 1 inferred the layout from num_envs == 1 and raised on reset — and equals env 0 of a
+    2-env run; a partial reset re-seats without stepping anybody"""
+    from _util import MAPS
+    kw = dict(map=os.path.join(MAPS, "example_map"), map_ext='.png', num_agents=2, seed=12345)
+    one = amd.F110VecEnv(1, **kw)
+    two = amd.F110VecEnv(2, **kw)
+    p = bench_start_poses(2, 2).reshape(2, 2, 3)
+    o1, _, d1, _ = one.reset(p[:1]); o2, _, d2, _ = two.reset(p)
+    assert o1['scans'].shape == (1, 2, 1080) and d1.shape == (1,)
+    rng = np.random.default_rng(1)
+    for t in range(15):
+        act = np.stack([rng.uniform(-0.2, 0.2, (2, 2)), rng.uniform(1, 5, (2, 2))], axis=2)
+        o1, _, d1, i1 = one.step(act[:1]); o2, _, d2, i2 = two.step(act)
+        for k in ("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "collisions", "lap_times"):
+            assert np.array_equal(o1[k][0], o2[k][0]), (k, t)
+    # partial reset: env 1 re-seated, env 0 untouched, nobody stepped
+    before = two.sim.batch.get("state", "step_count")
+    o, _, d, _ = two.reset(p, env_mask=np.array([0, 1], dtype=np.uint8))
+    after = two.sim.batch.get("state", "step_count")
+    assert np.array_equal(before["state"][:2], after["state"][:2]) and np.array_equal(before["step_count"][:2], after["step_count"][:2])
+    assert np.array_equal(after["step_count"][2:], [0, 0]) and np.allclose(after["state"][2:, 0], p[1, :, 0])
+    assert not d[1]
+    one.sim.batch.close(); two.sim.batch.close()
