@@ -1021,7 +1021,7 @@ int f110_set_noise_rng(f110_sim *h, const uint64_t *state_inc, int32_t per_agent
         h->dev.noise_rng = 2;
         return F110_OK;
     }
-    int rows = cache_rows > 0 ? cache_rows : 4096;
+    int rows = cache_rows > 0 ? cache_rows : 16384;   // 164 s of simulated time; rows are generated on demand
     if ((size_t)rows * B * sizeof(double) > (size_t)1 << 31) rows = (int)(((size_t)1 << 31) / ((size_t)B * sizeof(double)));
     TRY(dmalloc(h, &h->d_noise, (size_t)rows * B));
     TRY(dmalloc(h, &h->d_rng_rowstate, (size_t)rows + 1));
@@ -1476,8 +1476,10 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     dev.agent_begin = begin;
     dev.agent_count = count;
     const bool multi = A > 1;
-    if (dev.noise_rng && (dev.noise_rng == 2 || h->noise_ub >= (long long)dev.noise_rows))
-        hipLaunchKernelGGL(k_noise_rows, dim3((count + 3) / 4), dim3(256), 0, st, dev, h->noise_gen, B);
+    if (dev.noise_rng && (dev.noise_rng == 2 || h->noise_ub >= (long long)dev.noise_rows)) {
+        const int apb = dev.noise_rng == 2 ? 16 : 64;   // per-agent streams: every agent needs a row, keep the waves many
+        hipLaunchKernelGGL(k_noise_rows, dim3((count + apb - 1) / apb), dim3(256), 0, st, dev, h->noise_gen, B, apb);
+    }
     if (ev) HIPCHK(h, hipEventRecord(ev[0], st));
     if (multi && collide_mode == 1 && A == 2)
         hipLaunchKernelGGL(k_integrate<2>, grid1d(count, 64), dim3(64), 0, st, dev, h->k, d_actions);

@@ -836,24 +836,39 @@ __global__ void __launch_bounds__(64) k_noise_cache(NoiseGen g, U128 inc, U128 *
 }
 
 // this step's noise row of every agent the row cache cannot serve (per-agent streams; episodes
-// longer than the cache), generated into the agent's scans[] row where the scan kernel picks it up
-// (RayHdr::noise_row == -2).  One wave per agent; agents served by the cache leave at once.
-__global__ void __launch_bounds__(256) k_noise_rows(AgentArrays a, NoiseGen g, int B)
+// longer than the cache), generated into the agent's own scans[] row where the scan kernel picks it up
+// (RayHdr::noise_row == -2).  A 256-thread workgroup first checks `agents_per_block` agents one lane each
+// and lists the ones that need a row; its four waves then generate the listed rows, a wave per row.  In
+// the shared-stream mode the list is almost always empty, and a launch of N / 256 workgroups that look
+// and leave costs a couple of microseconds — the host cannot know the longest live episode without a
+// round trip (re-seats happen on the device), so the launch is unconditional once the steps since the
+// last full reset exceed the cache.
+__global__ void __launch_bounds__(256) k_noise_rows(AgentArrays a, NoiseGen g, int B, int agents_per_block)
 {
-    const int i = a.agent_begin + (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (i >= a.agent_begin + a.agent_count) return;
-    const int k = __builtin_amdgcn_readfirstlane(a.step_count[i]);
-    U128 state, inc;
-    if (a.noise_rng == 2) {
-        inc = uniform_u128(a.rng_seed[2 * (size_t)i + 1]);
-        state = uniform_u128(k == 0 ? a.rng_seed[2 * (size_t)i] : a.rng_state[i]);
-    } else {
-        if (k < a.noise_rows) return;
-        inc = a.rng_inc;
-        state = uniform_u128(k == a.noise_rows ? a.rng_rowstate[a.noise_rows] : a.rng_state[i]);
+    __shared__ int list[256];
+    __shared__ int n_listed;
+    if (threadIdx.x == 0) n_listed = 0;
+    __syncthreads();
+    const int end = a.agent_begin + a.agent_count;
+    const int i = a.agent_begin + (int)blockIdx.x * agents_per_block + (int)threadIdx.x;
+    if ((int)threadIdx.x < agents_per_block && i < end && (a.noise_rng == 2 || a.step_count[i] >= a.noise_rows))
+        list[atomicAdd(&n_listed, 1)] = i;
+    __syncthreads();
+    const int n = n_listed;
+    for (int q = (int)(threadIdx.x >> 6); q < n; q += 4) {
+        const int ag = __builtin_amdgcn_readfirstlane(list[q]);
+        const int k = __builtin_amdgcn_readfirstlane(a.step_count[ag]);
+        U128 state, inc;
+        if (a.noise_rng == 2) {
+            inc = uniform_u128(a.rng_seed[2 * (size_t)ag + 1]);
+            state = uniform_u128(k == 0 ? a.rng_seed[2 * (size_t)ag] : a.rng_state[ag]);
+        } else {
+            inc = a.rng_inc;
+            state = uniform_u128(k == a.noise_rows ? a.rng_rowstate[a.noise_rows] : a.rng_state[ag]);
+        }
+        noise_row_wave(g, state, inc, a.scans + (size_t)ag * B, B);
+        if ((threadIdx.x & 63u) == 0u) a.rng_state[ag] = state;
     }
-    noise_row_wave(g, state, inc, a.scans + (size_t)i * B, B);
-    if ((threadIdx.x & 63u) == 0u) a.rng_state[i] = state;
 }
 
 // In-place re-seat of one agent of a finished env (f110_reset_collided_device / auto re-seat): what

@@ -144,7 +144,7 @@ int f110_set_noise_table(f110_sim *h, const double *h_noise, int32_t n_rows, int
  * Nothing is uploaded and memory stays flat however long the run is.
  *   h_state_inc, per_agent = 0: [4] = {state.hi, state.lo, inc.hi, inc.lo} of np.random.PCG64(seed)
  *       (f110_pcg64_seed computes them): one stream shared by every agent, as in the reference.  The
- *       first cache_rows rows (0: 4096) are generated once into a device row cache, extended on
+ *       first cache_rows rows (0: 16384) are generated once into a device row cache, extended on
  *       demand as episodes get longer; an agent whose episode outlives the cache continues from the
  *       stream position it carries.
  *   per_agent = 1: [N][4], a stream per agent (extension), always generated from the carried state.
