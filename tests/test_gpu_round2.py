@@ -593,3 +593,26 @@ def test_vec_env_single_env_host_path(amd):
     assert np.array_equal(after["step_count"][2:], [0, 0]) and np.allclose(after["state"][2:, 0], p[1, :, 0])
     assert not d[1]
     one.sim.batch.close(); two.sim.batch.close()
+
+
+def test_bench_two_launched_ranks_on_one_gpu():
+    """the driver's N > 1 form — N processes with RANK / LOCAL_RANK / WORLD_SIZE set — with real GPU steps:
+    two ranks share device 0 (F110_BENCH_DEVICE, a testing aid), each steps its own env shard, rank 0
+    prints one line for the whole job"""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   F110_BENCH_DEVICE="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
+                                       "--agents", "4096", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not outs[1][0].strip()
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["agents_total"] == 8192 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8192 * 30 / (d["ms_per_step"] * 30e-3)) < 1e-6 * d["value"]
+    assert "roofline" in d and 0.0 < d["roofline"]["frac"] < 1.0 and d["roofline"]["lookups_per_ray"] > 5.0
