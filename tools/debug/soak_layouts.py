@@ -1,4 +1,4 @@
-"""long-run identity check: PADDED layout vs the plain row-major kernel, same inputs, many steps
+"""long-run identity check: PADDED layout + device-drawn noise vs the plain row-major kernel + uploaded NumPy noise rows, same inputs, many steps
     gpurun -- 'python tools/debug/soak_layouts.py 32768 2000'"""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
@@ -13,7 +13,10 @@ sims = []
 for layout in (3, 0):
     s = amd.BatchSim(num_envs=E, num_agents=A, map_layout=layout)
     s.set_map_image(img, res, origin)
-    s.set_noise_table(np.random.default_rng(1).normal(0, 0.01, size=(512, 1080)))
+    if layout == 3:
+        s.set_noise_rng(12345, 0.01, cache_rows=256)     # the device generator, with episodes that outlive its row cache ...
+    else:
+        s.set_noise_table(np.random.default_rng(12345).normal(0, 0.01, size=(4096, 1080)))   # ... against NumPy's rows, uploaded
     d_start = s.device_array((E * A, 3)); d_start.upload(poses)
     d_cnt = s.device_array((1,), dtype=np.int32); d_cnt.upload(np.zeros(1, dtype=np.int32))
     s.reset_device(d_start)
