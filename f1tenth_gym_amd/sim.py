@@ -34,7 +34,9 @@ class ScanNoise(object):
     (base_classes.py:204), so the noise is one shared (steps-since-reset, beam) table.  It is
     produced here with NumPy's PCG64 + ziggurat and uploaded; the scan kernel adds row
     `step_count`.  The default (noise_mode='device') draws the same stream on the GPU instead
-    (BatchSim.set_noise_rng) with flat memory; this table is bounded by `max_rows` episode steps."""
+    (BatchSim.set_noise_rng) with flat memory.  This table stops growing at `max_rows` rows (141 MB at 1080
+    beams); an episode longer than that re-uses the rows from the start (the kernel indexes them modulo the
+    table length), i.e. its noise repeats — use the device mode for such runs."""
 
     def __init__(self, seed, num_beams, std_dev=0.01, chunk=256, max_rows=16384):
         self.seed, self.B, self.std, self.chunk = seed, int(num_beams), float(std_dev), int(chunk)
