@@ -92,6 +92,7 @@ struct f110_sim {
     };
     std::vector<StepGraph> graphs;
     bool use_graph = false;
+    int collide_mode = 0;        // where the pair tests run: 0 side stream, 1 fused into k_integrate, 2 in line, 3 inside k_finalize (A = 2)
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
     int comm_ranks = 0;
     // overlapped gather (f110_comm_set_overlap): scans are double-buffered, the all-gather of step t
@@ -394,6 +395,8 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         G = std::min(std::min(G, 16), cfg->num_envs);
         h->groups = G;
         h->use_graph = cfg->step_graph != 0;
+        h->collide_mode = cfg->num_agents == 2 ? 3 : 0;
+        if (const char *e = std::getenv("F110_COLLIDE_MODE")) h->collide_mode = std::atoi(e);
         if (const char *e = std::getenv("F110_STEP_GRAPH")) h->use_graph = std::atoi(e) != 0;
         for (int g = 0; g < G && G > 1; ++g) {
             hipStream_t gs = nullptr;
@@ -1487,7 +1490,8 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         hipLaunchKernelGGL(k_integrate<4>, grid1d(count, 64), dim3(64), 0, st, dev, h->k, d_actions);
     else
         hipLaunchKernelGGL(k_integrate<0>, grid1d(count, 256), dim3(256), 0, st, dev, h->k, d_actions);
-    const bool fused = multi && collide_mode == 1 && (A == 2 || A == 4);
+    const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0;
+    const bool fused = (multi && collide_mode == 1 && (A == 2 || A == 4)) || pair_in_finalize;   // no k_collide launch
     // k_collide only feeds k_finalize, k_scan_rays only needs k_integrate: run the two side by
     // side (second stream, event fork/join) so the pair test + window set-up hides under the scan
     if (multi && !fused) {
@@ -1607,8 +1611,14 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         // crashed into each other see windows of up to all beams, so the narrow forms are used only
         // when finished envs are re-seated inside the step (f110_set_auto_reseat)
         const bool narrow = h->dev.reseat_poses != nullptr;
-        const int lanes = forced ? forced : (narrow && N >= 131072 ? 8 : (narrow && N >= 32768 ? 16 : 64));
-        if (lanes == 8)
+        // (with the pair test inside the kernel a group also carries that prologue: 16 lanes from 8192 agents up)
+        const int lanes = forced ? forced : (narrow && N >= 131072 ? 8 : (narrow && N >= (pair_in_finalize ? 8192 : 32768) ? 16 : 64));
+        if (pair_in_finalize) {
+            if (lanes == 8) hipLaunchKernelGGL(k_finalize_pair<8>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
+            else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
+            else if (lanes == 32) hipLaunchKernelGGL(k_finalize_pair<32>, dim3((count + 7) / 8), dim3(256), 0, st, dev, B);
+            else hipLaunchKernelGGL(k_finalize_pair<64>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
+        } else if (lanes == 8)
             hipLaunchKernelGGL(k_finalize<8>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
         else if (lanes == 16)
             hipLaunchKernelGGL(k_finalize<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
@@ -1663,7 +1673,6 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         TRY(noise_cache_extend(h, (int)std::min<long long>(want, h->dev.noise_rows)));
     }
     const bool prof = h->profiling && h->prof_used + 4 <= 4 * 65536;
-    static const char *cm_env = std::getenv("F110_COLLIDE_MODE");
     // the env groups need the agent-aligned scan (a launch per agent range); per-kernel profiling
     // brackets the kernels of ONE stream, so a profiled step runs as one block on the main stream
     const bool grouped = h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0;
@@ -1675,7 +1684,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
             for (int i = 0; i < 4; ++i)
                 if (!(ev[i] = prof_event(h))) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
         }
-        const int cmode = cm_env ? std::atoi(cm_env) : 0;
+        const int cmode = h->collide_mode;
         if (h->use_graph && !prof) {
             // the four launches and the fork/join of the side stream as ONE graph submission.  A graph is
             // valid for one set of launch arguments: every value a launch depends on is part of the key
@@ -1724,7 +1733,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
             h->main_dirty = false;
         }
         const int per = group_envs(h), E = h->cfg.num_envs;
-        const int mode = cm_env ? std::atoi(cm_env) : ((A == 2 || A == 4) ? 1 : 2);
+        const int mode = h->collide_mode == 3 && A == 2 ? 3 : ((A == 2 || A == 4) ? 1 : 2);
         for (int g = 0; g < h->groups; ++g) {
             const int e0 = g * per, e1 = std::min(E, e0 + per);
             if (e0 >= e1) break;

@@ -950,6 +950,87 @@ __global__ void __launch_bounds__(256) k_finalize(AgentArrays a, int32_t B)
     }
 }
 
+// ---- K3p: finalize for two-agent envs, pair test and opponent window computed in place ------------------
+// What k_collide prepares for k_finalize — the GJK flag of the env's one pair and the beam window the
+// opponent can occupy — costs a second stream and an event fork/join per step (14 us).  With
+// two agents per env the work is small enough to sit at the top of k_finalize, spread over the lanes an
+// agent has there: lanes 0-3 take one box corner each (vertex_beam_index), lane 4 the disc cull, lane 5
+// the pair test; group shuffles combine them.  Only the window for the heading that is actually live
+// (zeroed or not) is needed here, where k_collide had to prepare both.  Same functions on the same
+// inputs as k_collide + k_finalize: bit-identical.
+template <int kFinalizeLanes>
+__global__ void __launch_bounds__(256) k_finalize_pair(AgentArrays a, int32_t B)
+{
+    constexpr int kFinalizeAgents = 256 / kFinalizeLanes;
+    const int i = a.agent_begin + (int)(blockIdx.x * kFinalizeAgents + threadIdx.x / kFinalizeLanes), tid = threadIdx.x & (kFinalizeLanes - 1);
+    const int N = a.n_agents_total;
+    if (i >= a.agent_begin + a.agent_count) return;   // whole groups leave together
+    const int me = i & 1, o = i ^ 1;                   // env-aligned ranges: the pair is (2e, 2e + 1)
+    const int wall = a.in_collision[i];
+    const double ex = a.state[i], ey = a.state[(size_t)N + i];
+    const double th_live = a.state[4 * (size_t)N + i];   // == the :574 snapshot heading: nothing has zeroed it yet
+    const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
+    const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
+    const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
+    const double eth = wall ? 0.0 : th_live;
+    double v[8];   // the opponent drawn with MY length / width (RaceCar.ray_cast_agents :223)
+    box_vertices(ox, oy, oth, blen, bwid, v);
+    int idx = 0, cl = 0, ch = B - 1, hit = 0;
+    if (tid < 4) {
+        const double vx = tid == 0 ? v[0] : (tid == 1 ? v[2] : (tid == 2 ? v[4] : v[6]));
+        const double vy = tid == 0 ? v[1] : (tid == 1 ? v[3] : (tid == 2 ? v[5] : v[7]));
+        idx = vertex_beam_index(ex, ey, eth, vx, vy, a.scan_angles, B, a.angle_inc);
+    } else if (tid == 4) {
+        disc_beam_range(ex, ey, eth, ox, oy, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
+    } else if (tid == 5) {
+        // collision_multiple on the env's one pair, boxes with the Simulator's length / width (:549)
+        const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+        const double dx = ox - ex, dy = oy - ey;
+        if (dx * dx + dy * dy <= reach * reach) {
+            double mine[8], other[8];
+            box_vertices(ex, ey, th_live, a.box_length, a.box_width, mine);
+            box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
+            hit = (me == 0 ? gjk_overlap(mine, other) : gjk_overlap(other, mine)) ? 1 : 0;
+        }
+    }
+    const int i0 = __shfl(idx, 0, kFinalizeLanes), i1 = __shfl(idx, 1, kFinalizeLanes), i2 = __shfl(idx, 2, kFinalizeLanes),
+              i3 = __shfl(idx, 3, kFinalizeLanes);
+    cl = __shfl(cl, 4, kFinalizeLanes);
+    ch = __shfl(ch, 4, kFinalizeLanes);
+    hit = __shfl(hit, 5, kFinalizeLanes);
+    int ref_lo = i0 < i1 ? i0 : i1, t2 = i2 < i3 ? i2 : i3;
+    ref_lo = ref_lo < t2 ? ref_lo : t2;
+    int ref_hi = i0 > i1 ? i0 : i1;
+    t2 = i2 > i3 ? i2 : i3;
+    ref_hi = ref_hi > t2 ? ref_hi : t2;
+    const int lo = ref_lo > cl ? ref_lo : cl, hi = ref_hi < ch ? ref_hi : ch;
+    if (tid == 0) {
+        if (wall) {
+            a.state[3 * (size_t)N + i] = 0.;
+            a.state[4 * (size_t)N + i] = 0.;
+            a.state[5 * (size_t)N + i] = 0.;
+            a.state[6 * (size_t)N + i] = 0.;
+        }
+        a.collisions[i] = (hit || wall) ? 1.0 : 0.0;
+        a.collision_idx[i] = hit ? (double)(1 - me) : -1.0;
+        a.step_count[i] += 1;
+    }
+    double *sc = a.scans + (size_t)i * B;
+    for (int b = lo + tid; b <= hi; b += kFinalizeLanes) {
+        const double bt = eth + a.scan_angles[b];
+        const double r0 = sc[b];
+        double v3x, v3y;
+        sincos(bt + kPi / 2., &v3y, &v3x);
+        const double r = box_range(ex, ey, v3x, v3y, v, r0);
+        if (r < r0) sc[b] = r;
+    }
+    if (a.reseat_poses && tid == 0) {
+        // the ego's collisions value of this step: the pair flag (the same test for both agents) OR its wall flag
+        const int ego = (i & ~1) + a.reseat_ego;
+        if (hit || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
+    }
+}
+
 // single-agent envs: no opponents, one lane per agent is enough
 __global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
 {

@@ -616,3 +616,43 @@ def test_bench_two_launched_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["agents_total"] == 8192 and d["scaling"] == "weak"
     assert abs(d["value"] - 8192 * 30 / (d["ms_per_step"] * 30e-3)) < 1e-6 * d["value"]
     assert "roofline" in d and 0.0 < d["roofline"]["frac"] < 1.0 and d["roofline"]["lookups_per_ray"] > 5.0
+
+
+# ---------------------------------------------------------------------------- pair test inside k_finalize
+@pytest.mark.parametrize("lanes", ["8", "16", "64"])
+def test_pair_test_in_finalize_is_bit_identical(amd, monkeypatch, lanes):
+    """two-agent envs: the GJK pair test and the opponent beam window computed at the top of k_finalize
+    (k_finalize_pair, the default for A = 2: no side stream, no events) against k_collide on the side
+    stream + k_finalize: every array incl. collision_idx identical, through wall hits, car-to-car
+    contacts, the fused re-seat and resets, for every lanes-per-agent form"""
+    monkeypatch.setenv("F110_FINALIZE_LANES", lanes)
+    E, A, T = 200, 2, 120
+    monkeypatch.setenv("F110_COLLIDE_MODE", "0")
+    a = _pair(amd, E, A)
+    monkeypatch.setenv("F110_COLLIDE_MODE", "3")
+    b = _pair(amd, E, A)
+    poses = bench_start_poses(E, A, gap_wp=3)     # 0.6 m apart: contacts happen
+    rng = np.random.default_rng(21)
+    for s in (a, b):
+        s.set_noise_rng(12345, 0.01); s.reset(poses)
+    st = [s.device_array((E * A, 3)) for s in (a, b)]
+    for d in st:
+        d.upload(poses)
+    n_pair = n_wall = 0
+    for t in range(T):
+        if t % 10 == 0:
+            act = np.stack([rng.uniform(-0.3, 0.3, E * A), rng.uniform(0.5, 7.0, E * A)], axis=1)
+        if t == 60:
+            for s, d in zip((a, b), st):
+                s.set_auto_reseat(d, 0, None)
+        a.step(act); b.step(act)
+        oa = a.get("scans", "state", "collisions", "collision_idx", "in_collision", "step_count")
+        ob = b.get("scans", "state", "collisions", "collision_idx", "in_collision", "step_count")
+        for kk in oa:
+            assert np.array_equal(oa[kk], ob[kk]), (kk, t)
+        n_pair += int((oa["collision_idx"] >= 0).sum()); n_wall += int(oa["in_collision"].sum())
+        if t == 90:
+            mask = (rng.random(E) < 0.3).astype(np.uint8)
+            a.reset(poses, mask); b.reset(poses, mask)
+    assert n_pair > 0 and n_wall > 0, (n_pair, n_wall)
+    a.close(); b.close()

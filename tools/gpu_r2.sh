@@ -48,6 +48,11 @@ gaps)
   done
   cd "$R"
   ;;
+pairfin)
+  for n in 1024 4096 16384 65536; do for c in 0 3; do
+    F110_COLLIDE_MODE=$c timeout 200 python bench.py $H --agents $n > $OUT/pf_n${n}_c${c}.log 2>&1; line $OUT/pf_n${n}_c${c}.log "agents $n collide-mode $c"
+  done; done
+  ;;
 win)
   for n in 4096 16384 65536; do for l in 3 4; do
     timeout 200 python bench.py $H --agents $n --layout $l > $OUT/win_n${n}_l${l}.log 2>&1; line $OUT/win_n${n}_l${l}.log "agents $n layout $l"
