@@ -1490,7 +1490,11 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         hipLaunchKernelGGL(k_integrate<4>, grid1d(count, 64), dim3(64), 0, st, dev, h->k, d_actions);
     else
         hipLaunchKernelGGL(k_integrate<0>, grid1d(count, 256), dim3(256), 0, st, dev, h->k, d_actions);
-    const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0;
+    // A = 2: the pair test and the opponent window inside k_finalize (k_finalize_pair) — unless the batch is
+    // big AND finished envs are not re-seated inside the step: then k_finalize runs a wave per agent (crashed
+    // cars pile up, windows grow to all beams) and 65 536 waves each carrying the prologue cost more than the
+    // side stream does (parked cars, 65 536 agents: 0.70 vs 0.63 ms)
+    const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0 && (h->dev.reseat_poses != nullptr || N < 8192);
     const bool fused = (multi && collide_mode == 1 && (A == 2 || A == 4)) || pair_in_finalize;   // no k_collide launch
     // k_collide only feeds k_finalize, k_scan_rays only needs k_integrate: run the two side by
     // side (second stream, event fork/join) so the pair test + window set-up hides under the scan
