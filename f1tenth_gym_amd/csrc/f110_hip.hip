@@ -1,7 +1,8 @@
 // f110_hip.hip — host side of libf110_hip.so: the handle (one MI355X, one HIP stream + a side
 // stream), device-memory ownership, kernel launches and the C ABI declared in include/f110.h.
 // The kernels live in f110_kernels.hpp, the scalar float64 building blocks in f110_math.hpp.
-// A step is k_integrate -> { k_scan_rays || k_collide (side stream) } -> k_finalize.
+// A step is k_integrate -> k_scan_rays_agent -> k_finalize_pair on one stream for two-agent envs,
+// k_integrate -> { k_scan_rays || k_collide (side stream) } -> k_finalize otherwise.
 // Compiled with -ffp-contract=off.  There is no CPU fallback in this library.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>

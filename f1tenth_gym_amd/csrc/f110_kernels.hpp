@@ -11,6 +11,8 @@
 //   (k_expand_beams: second pass when beams outnumber table directions)
 //   k_finalize    1 wave / agent   wall-hit side effects (base_classes.py:246-249), collision OR
 //                                  (:588-589), opponent ray-cast on the culled window (:206-227)
+//   (k_finalize_pair: two-agent envs — k_collide's work done at the top of k_finalize, no side stream)
+//   (k_noise_cache / k_noise_rows: the scan noise, NumPy's PCG64 + ziggurat stream, f110_rng.hpp)
 // plus reset / episode-logic kernels, the unit kernels behind the parity entry points, and the
 // map pipeline (flip + threshold + exact EDT + dt = res*sqrt(d2)).
 // Compiled with -ffp-contract=off: float64, reference operation order, no FMA contraction.
