@@ -978,21 +978,33 @@ __global__ void __launch_bounds__(256) k_finalize_pair(AgentArrays a, int32_t B)
     double v[8];   // the opponent drawn with MY length / width (RaceCar.ray_cast_agents :223)
     box_vertices(ox, oy, oth, blen, bwid, v);
     int idx = 0, cl = 0, ch = B - 1, hit = 0;
-    if (tid < 4) {
-        const double vx = tid == 0 ? v[0] : (tid == 1 ? v[2] : (tid == 2 ? v[4] : v[6]));
-        const double vy = tid == 0 ? v[1] : (tid == 1 ? v[3] : (tid == 2 ? v[5] : v[7]));
-        idx = vertex_beam_index(ex, ey, eth, vx, vy, a.scan_angles, B, a.angle_inc);
-    } else if (tid == 4) {
-        disc_beam_range(ex, ey, eth, ox, oy, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
-    } else if (tid == 5) {
-        // collision_multiple on the env's one pair, boxes with the Simulator's length / width (:549)
-        const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
-        const double dx = ox - ex, dy = oy - ey;
-        if (dx * dx + dy * dy <= reach * reach) {
-            double mine[8], other[8];
-            box_vertices(ex, ey, th_live, a.box_length, a.box_width, mine);
-            box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
-            hit = (me == 0 ? gjk_overlap(mine, other) : gjk_overlap(other, mine)) ? 1 : 0;
+    {
+        // One instruction stream for lanes 0-4: the arc tangent of the heading that both
+        // vertex_beam_index and disc_beam_range take is computed once, and the arc tangent of the
+        // direction to "my point" — a box corner (normalised, :296-300) for lanes 0-3, the box centre
+        // (as it is, disc_beam_range) for lane 4 — in one call.  The same operations on the same operands
+        // as the two functions, only not twice.
+        const double head = atan2(sin(eth), cos(eth));
+        const double px = tid == 0 ? v[0] : (tid == 1 ? v[2] : (tid == 2 ? v[4] : (tid == 3 ? v[6] : ox)));
+        const double py = tid == 0 ? v[1] : (tid == 1 ? v[3] : (tid == 2 ? v[5] : (tid == 3 ? v[7] : oy)));
+        const double dx = px - ex, dy = py - ey;
+        const double norm = sqrt(dx * dx + dy * dy);
+        const double qx = tid < 4 ? dx / norm : dx, qy = tid < 4 ? dy / norm : dy;
+        const double dir = atan2(qy, qx);
+        if (tid < 4) {
+            idx = vertex_beam_from_angles(head, dir, a.scan_angles, B, a.angle_inc);
+        } else if (tid == 4) {
+            disc_beam_range_from(norm, eth, dir, head, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
+        } else if (tid == 5) {
+            // collision_multiple on the env's one pair, boxes with the Simulator's length / width (:549)
+            const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+            const double cdx = ox - ex, cdy = oy - ey;
+            if (cdx * cdx + cdy * cdy <= reach * reach) {
+                double mine[8], other[8];
+                box_vertices(ex, ey, th_live, a.box_length, a.box_width, mine);
+                box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
+                hit = (me == 0 ? gjk_overlap(mine, other) : gjk_overlap(other, mine)) ? 1 : 0;
+            }
         }
     }
     const int i0 = __shfl(idx, 0, kFinalizeLanes), i1 = __shfl(idx, 1, kFinalizeLanes), i2 = __shfl(idx, 2, kFinalizeLanes),

@@ -610,18 +610,25 @@ F110_HD int nearest_beam(const double *scan_angles, int num_beams, double angle_
 }
 
 // one vertex's beam index of get_blocked_view_indices :282-315
+// get_blocked_view_indices :296-311 for one vertex, with its two arc tangents supplied:
+// head = atan2(sin(etheta), cos(etheta)), dir = atan2(uy, ux) of the normalised lidar -> vertex vector
+F110_HD int vertex_beam_from_angles(double head, double dir, const double *scan_angles, int num_beams, double angle_inc)
+{
+    double angle = head - dir;
+    if (angle > kPi)
+        angle = angle - 2 * kPi;
+    else if (angle < -kPi)
+        angle = angle + 2 * kPi;
+    return nearest_beam(scan_angles, num_beams, angle_inc, -angle);
+}
+
 F110_HD int vertex_beam_index(double ex, double ey, double etheta, double vx, double vy,
                               const double *scan_angles, int num_beams, double angle_inc)
 {
     const double dx = vx - ex, dy = vy - ey;
     const double norm = sqrt(dx * dx + dy * dy);
     const double ux = dx / norm, uy = dy / norm;
-    double angle = atan2(sin(etheta), cos(etheta)) - atan2(uy, ux);
-    if (angle > kPi)
-        angle = angle - 2 * kPi;
-    else if (angle < -kPi)
-        angle = angle + 2 * kPi;
-    return nearest_beam(scan_angles, num_beams, angle_inc, -angle);
+    return vertex_beam_from_angles(atan2(sin(etheta), cos(etheta)), atan2(uy, ux), scan_angles, num_beams, angle_inc);
 }
 
 // Conservative beam-index range whose rays can touch a disc (centre c, radius R) seen from the
@@ -631,11 +638,10 @@ F110_HD int vertex_beam_index(double ex, double ey, double etheta, double vx, do
 // result-preserving.  (When the opponent straddles the rear +-pi direction the reference window
 // degenerates to all B beams although none of them can hit: this cull removes that work.)
 // Beams are sa[0] + b*inc to within rounding; the range is padded by 3 beams + 1e-6 rad.
-F110_HD void disc_beam_range(double ex, double ey, double eth, double cx, double cy, double R,
-                             const double *scan_angles, int num_beams, double angle_inc, int &cl, int &ch)
+// disc_beam_range with dist = |centre - lidar|, dir = atan2(dy, dx) and head = atan2(sin(eth), cos(eth)) supplied
+F110_HD void disc_beam_range_from(double dist, double eth, double dir, double head, double R, const double *scan_angles, int num_beams,
+                                  double angle_inc, int &cl, int &ch)
 {
-    const double dx = cx - ex, dy = cy - ey;
-    const double dist = sqrt(dx * dx + dy * dy);
     // No cull when the lidar is inside / on the disc (or anything is NaN), and none when the
     // heading is astronomically large: the reference wraps yaw by a single 2*pi per step
     // (base_classes.py:400-404), so a diverged yaw rate leaves |yaw| ~ 1e15, where
@@ -646,7 +652,7 @@ F110_HD void disc_beam_range(double ex, double ey, double eth, double cx, double
         ch = num_beams - 1;
         return;
     }
-    double phi = atan2(dy, dx) - atan2(sin(eth), cos(eth));
+    double phi = dir - head;
     phi -= kTwoPi * rint(phi / kTwoPi);  // (-pi, pi]
     const double psi = asin(R / dist) + 3.0 * angle_inc + 1e-6;
     const double sa0 = scan_angles[0];
@@ -664,6 +670,19 @@ F110_HD void disc_beam_range(double ex, double ey, double eth, double cx, double
             ch = (int)hi > ch ? (int)hi : ch;
         }
     }
+}
+
+F110_HD void disc_beam_range(double ex, double ey, double eth, double cx, double cy, double R,
+                             const double *scan_angles, int num_beams, double angle_inc, int &cl, int &ch)
+{
+    const double dx = cx - ex, dy = cy - ey;
+    const double dist = sqrt(dx * dx + dy * dy);
+    if (!(dist > R * 1.000001 + 1e-9) || !(fabs(eth) < 1e6)) {   // before any trigonometry, as it always was
+        cl = 0;
+        ch = num_beams - 1;
+        return;
+    }
+    disc_beam_range_from(dist, eth, atan2(dy, dx), atan2(sin(eth), cos(eth)), R, scan_angles, num_beams, angle_inc, cl, ch);
 }
 
 // get_blocked_view_indices :282-315 (min/max of the four vertex beam indices) intersected with
