@@ -67,6 +67,7 @@ struct AgentArrays {
     const double *reseat_poses;      // [N][3] or nullptr
     int32_t *reseat_count;           // device counter or nullptr
     int32_t reseat_ego, pad_reseat;
+    uint32_t *sched_count_zero;  // longest-first scan order: this step's list counter, zeroed here (or nullptr)
     int32_t *opp_window;     // [N][A][4] beam range each opponent can occupy: {lo, hi} for the live
                              //           heading and {lo0, hi0} for heading 0 (after a wall hit)
     double *opp_verts;       // [N][A][8] the opponent's box drawn with the ego's length/width
@@ -232,6 +233,7 @@ __global__ void __launch_bounds__(AF ? 64 : 256) k_integrate(AgentArrays a, Scan
         a.ray_hdr[i] = hd;
     }
     a.in_collision[i] = 0;  // raised by k_scan_rays when any beam's iTTC is under the threshold
+    if (a.sched_count_zero && i == a.agent_begin) *a.sched_count_zero = 0u;
     if constexpr (AF != 0) {
         // groups are env-aligned and AF divides 64: the AF lanes of an env are all here, in one wave.
         // Every lane takes part in every shuffle (a lane masked off would read as zero).
@@ -273,6 +275,24 @@ __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
 // have correlated lengths.  STEP=true is the env.step() form (SoA poses written by
 // k_integrate, noise row, iTTC predicate); STEP=false is ScanSimulator2D.scan for the unit
 // entry point (also reports terminating cells and lookup counts).
+// Longest-first dispatch of the step's scan tasks, for SMALL batches.  With few agents the scan kernel
+// ends when its longest ray ends, and a 64-ray task whose longest ray takes 300 samples may
+// only be STARTED in the last of the launch's eight-odd rounds of waves.  Ray lengths barely change from
+// one step to the next and workgroups start in block order: a task whose longest ray exceeded `thr`
+// lookups in the PREVIOUS step is put on a list, and the list is served by the first blocks of this step's
+// launch.  flags_r[task] == epoch_r marks "on the list" (the normal blocks skip those tasks); this step's
+// long tasks go to list_w / flags_w for the next step (stamped epoch_w; stale stamps never match again, so
+// nothing is ever cleared).  Stale or missing entries only cost speed: every task is marched exactly once.
+struct TaskSched {
+    const uint32_t *flags_r;
+    uint32_t *flags_w;
+    const uint32_t *list_r;
+    uint32_t *list_w;
+    const uint32_t *count_r;
+    uint32_t *count_w;   // zeroed by k_integrate of the same step
+    uint32_t cap, thr;
+};
+
 struct RayJob {
     uint32_t n_rays;          // poses * B
     uint32_t n_tasks;         // ceil(n_rays / 64): one task = 64 consecutive rays
@@ -283,6 +303,9 @@ struct RayJob {
     const double *dir_ranges;       // k_expand_beams: [n_poses][dir_stride] raw ranges of the dedupe pass
     uint32_t first_pose, pad_first; // k_scan_rays_agent: the launch covers agents first_pose .. (env group)
     unsigned long long *lookups_total;  // COUNT variants: table lookups of every marched ray, summed (or nullptr)
+    // longest-first task order (k_scan_rays_agent<.., SCHED>): see TaskSched
+    const struct TaskSched *sched;
+    uint32_t epoch_r, epoch_w, long_blocks, pad_sched;
     // k_scan_rays_window: 1-byte codes of the padded table (row-major, `win_pitch` bytes per row, a multiple
     // of 16) and the 256-entry exact value LUT (entry 255 unused: code 255 = "read the float64 table")
     const uint8_t *win_codes;
@@ -488,23 +511,41 @@ struct MapFast {
 };
 static_assert(sizeof(MapFast) == 64, "MapFast is read as one 64-byte scalar load");
 
-template <bool PER_ENV_MAP, bool IDENT, bool COUNT>
+template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false>
 __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
                                                           const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
     const uint32_t B = (uint32_t)k.num_beams;
-    const uint32_t tpw = j.tasks_per_wave;
+    uint32_t tpw = j.tasks_per_wave;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t blk = blockIdx.x;
-    {
-        const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
+    typedef const __attribute__((address_space(4))) TaskSched *csched_t;
+    typedef const __attribute__((address_space(4))) uint32_t *cu32_t;
+    bool long_pass = false;
+    uint32_t long_task = 0;
+    if (SCHED) {
+        if (blk < j.long_blocks) {   // the first blocks of the launch serve last step's long tasks, one per wave
+            const csched_t sc = (csched_t)j.sched;
+            const uint32_t wl = __builtin_amdgcn_readfirstlane((blk * blockDim.x + threadIdx.x) >> 6);
+            const uint32_t cnt = *(cu32_t)sc->count_r;
+            if (wl >= (cnt < sc->cap ? cnt : sc->cap)) return;
+            long_pass = true;
+            long_task = ((cu32_t)sc->list_r)[wl];
+            tpw = 1u;
+        } else {
+            blk -= j.long_blocks;
+        }
+    }
+    if (!long_pass) {
+        const uint32_t nb = gridDim.x - (SCHED ? j.long_blocks : 0u), q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
         blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // XCD-contiguous, as k_scan_rays
     }
     const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
     uint32_t nl_acc = 0;
     for (uint32_t t = 0; t < tpw; ++t) {
-        const uint32_t task = __builtin_amdgcn_readfirstlane(wave * tpw + t);
+        const uint32_t task = __builtin_amdgcn_readfirstlane(long_pass ? long_task : wave * tpw + t);
         if (task >= j.n_tasks) break;
+        if (SCHED && !long_pass && ((cu32_t)((csched_t)j.sched)->flags_r)[task] == j.epoch_r) continue;   // served by the long pass
         const uint32_t pl = task / tasks_per_agent;                 // scalar
         const uint32_t p = j.first_pose + pl;
         const int b = (int)((task - pl * tasks_per_agent) * 64u + lane);
@@ -547,6 +588,17 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         }
         if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
         if (COUNT) nl_acc += (uint32_t)nl;   // measurement variant only (bench.py's L-bar)
+        if (SCHED) {
+            const csched_t sc = (csched_t)j.sched;
+            if (__ballot(nl > (int)sc->thr) != 0ull && lane == 0u) {
+                // lane 0 (beam task*64, always a valid beam) appends the task for the next step
+                const uint32_t pos = atomicAdd(sc->count_w, 1u);
+                if (pos < sc->cap) {
+                    sc->list_w[pos] = task;
+                    sc->flags_w[task] = j.epoch_w;
+                }
+            }
+        }
         finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
     }
     if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);

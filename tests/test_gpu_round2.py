@@ -656,3 +656,45 @@ def test_pair_test_in_finalize_is_bit_identical(amd, monkeypatch, lanes):
             a.reset(poses, mask); b.reset(poses, mask)
     assert n_pair > 0 and n_wall > 0, (n_pair, n_wall)
     a.close(); b.close()
+
+
+# ---------------------------------------------------------------------------- longest-first task order
+@pytest.mark.parametrize("thr", ["4", "96"])
+def test_longest_first_task_order_is_invisible(amd, monkeypatch, thr):
+    """small batches: tasks whose longest ray was long in the previous step are served by the first blocks
+    of the next scan launch and skipped by the normal blocks (TaskSched).  Forced on — with a low threshold,
+    so that most tasks go through the list, and with the default one — against forced off: not a bit may
+    change, through resets, re-seat arming, lookup counting (which suspends the ordering) and 70 steps"""
+    E, A, T = 300, 2, 70
+    monkeypatch.setenv("F110_TASK_ORDER", "0")
+    a = _pair(amd, E, A)
+    monkeypatch.setenv("F110_TASK_ORDER", "1")
+    monkeypatch.setenv("F110_TASK_THR", thr)
+    b = _pair(amd, E, A)
+    poses = bench_start_poses(E, A)
+    rng = np.random.default_rng(8)
+    for s in (a, b):
+        s.set_noise_rng(12345, 0.01)
+        s.reset(poses)
+    st = [s.device_array((E * A, 3)) for s in (a, b)]
+    for d in st:
+        d.upload(poses)
+    for t in range(T):
+        if t % 10 == 0:
+            act = _actions(rng, E * A)
+        if t == 30:
+            for s, d in zip((a, b), st):
+                s.set_auto_reseat(d, 0, None)
+        if t == 50:
+            for s in (a, b):
+                s.scan_lookup_count(enable=True, read=True)
+        if t == 55:
+            assert a.scan_lookup_count(enable=False) == b.scan_lookup_count(enable=False)
+        a.step(act); b.step(act)
+        oa = a.get("scans", "state", "collisions", "in_collision", "step_count"); ob = b.get("scans", "state", "collisions", "in_collision", "step_count")
+        for kk in oa:
+            assert np.array_equal(oa[kk], ob[kk]), (kk, t)
+        if t == 45:
+            mask = (rng.random(E) < 0.3).astype(np.uint8)
+            a.reset(poses, mask); b.reset(poses, mask)
+    a.close(); b.close()

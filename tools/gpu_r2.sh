@@ -53,6 +53,12 @@ pairfin)
     F110_COLLIDE_MODE=$c timeout 200 python bench.py $H --agents $n > $OUT/pf_n${n}_c${c}.log 2>&1; line $OUT/pf_n${n}_c${c}.log "agents $n collide-mode $c"
   done; done
   ;;
+order)
+  for n in 1024 2048 4096 8192; do for o in 0 1; do
+    F110_TASK_ORDER=$o timeout 200 python bench.py $H --agents $n > $OUT/order_n${n}_o${o}.log 2>&1; line $OUT/order_n${n}_o${o}.log "agents $n order $o"
+  done; done
+  for thr in 24 32 64 96; do F110_TASK_ORDER=1 F110_TASK_THR=$thr timeout 200 python bench.py $H --agents 4096 > $OUT/order_thr$thr.log 2>&1; line $OUT/order_thr$thr.log "4096 thr $thr"; done
+  ;;
 win)
   for n in 4096 16384 65536; do for l in 3 4; do
     timeout 200 python bench.py $H --agents $n --layout $l > $OUT/win_n${n}_l${l}.log 2>&1; line $OUT/win_n${n}_l${l}.log "agents $n layout $l"
