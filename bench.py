@@ -15,11 +15,21 @@ are reset in place on the device.  Inputs (action sets, start poses) are residen
 the timed region; the scan noise is drawn on the device (NumPy's seed-12345 stream, bit for bit);
 nothing is copied to the host inside the timed region.
 
+The timed window is steady state by construction: after the reset the script runs --preroll (500)
+un-timed steps of its own, then the caller's --warmup, then times exactly --steps — so a short
+`--steps 20 --warmup 5` measures the regime with episodes of every age and in-place resets, not the
+easy steps right after a reset (`steady_state.headline_over_steady` checks it against the >= 1000-step leg).
+
 Multi-GPU: the path shards by environment (no interaction between envs), one process per GPU,
 no data-path collective -> "scaling": "weak" (each rank steps its own 65536 agents).  The
 control plane (barrier + max-over-ranks of the elapsed time) is a few lines of stdlib sockets
 (class Rendezvous): no torch anywhere.  Launched without a rank environment and with --gpus N > 1
 the script spawns the N ranks itself and fails loudly when fewer than N devices are visible.
+Each rank pins itself to its GPU's NUMA node (f1tenth_gym_amd/numa.py).  With N > 1 ONE invocation
+reports three legs (`multi_gpu`): the headline without any collective, the same steps with the RCCL
+observation gather (scans + 7 scalars per agent, f110_comm_all_gather_obs) on the step's stream, and
+with the gather overlapped with the next step — each with every rank's own ms per step (min / max),
+the communicator size as RCCL reports it, and the per-GPU rate.
 
 The JSON line carries, besides the contract's fields:
   roofline      SURVEY §8d: whole-step ALGORITHMIC bytes (216 + 8B + 8B*L-bar per agent-step) x
@@ -56,6 +66,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--preroll", type=int, default=500,
+                    help="un-timed steps between the reset and the warm-up: the batch reaches its steady regime (episodes of every age, "
+                         "in-place resets, long rays) before anything is timed, whatever --warmup / --steps the caller picks")
     ap.add_argument("--agents", type=int, default=65536, help="agents per GPU (envs x 2)")
     ap.add_argument("--agents-per-env", type=int, default=2)
     ap.add_argument("--beams", type=int, default=1080)
@@ -70,6 +83,10 @@ def parse_args(argv=None):
                     help="RCCL all-gather of every rank's scans after each step (BASELINE config 4; off by default)")
     ap.add_argument("--gather-overlap", action="store_true",
                     help="with --gather: double-buffered scans, the gather of step t runs beside step t+1 (f110_comm_set_overlap)")
+    ap.add_argument("--no-gather-legs", action="store_true",
+                    help="N > 1: skip the two extra legs (observation gather in-stream, and overlapped) that follow the headline")
+    ap.add_argument("--gather-legs", action="store_true", help="run the gather legs at N = 1 too (a device copy there)")
+    ap.add_argument("--no-numa", action="store_true", help="do not pin the rank to its GPU's NUMA node")
     ap.add_argument("--noise", choices=["rng", "table", "off"], default="rng",
                     help="rng: drawn on the device (default); table: NumPy's rows uploaded (A/B); off")
     ap.add_argument("--no-noise", action="store_true", help="same as --noise off")
@@ -171,6 +188,24 @@ class Rendezvous(object):
 
     def sum(self, x):
         return struct.unpack("<d", self._reduce(struct.pack("<d", x), lambda v: struct.pack("<d", sum(struct.unpack("<d", b)[0] for b in v))))[0]
+
+    def gather_bytes(self, payload):
+        """every rank's fixed-length payload, in rank order, on every rank"""
+        n = len(payload)
+        if self.world == 1:
+            return [bytes(payload)]
+        if self.rank == 0:
+            vals = [bytes(payload)] + [self._recv(c, n) for c in self.peers]
+            out = b"".join(vals)
+            for c in self.peers:
+                c.sendall(out)
+        else:
+            self.sock.sendall(bytes(payload))
+            out = self._recv(self.sock, n * self.world)
+        return [out[i * n:(i + 1) * n] for i in range(self.world)]
+
+    def gather(self, x):
+        return [struct.unpack("<d", b)[0] for b in self.gather_bytes(struct.pack("<d", x))]
 
     def broadcast_bytes(self, payload, n):
         """rank 0's `payload` (n bytes) to every rank"""
@@ -280,16 +315,10 @@ class Workload(object):
         for s in action_sets((max_total_steps + 19) // 20, self.N, seed=1000 + rdv.rank):
             d = sim.device_array((self.N, 2)); d.upload(s); self.d_sets.append(d)
         self.d_count = sim.device_array((1,), dtype=np.int32)
-        self.d_all = None
+        self.d_all = None       # gather off
+        self.d_alls, self.d_scals, self.comm_ready = [], [], False
         if args.gather:
-            from f1tenth_gym_amd import BatchSim as _B
-            uid = _B.comm_unique_id() if rdv.rank == 0 else b"\0" * 128
-            sim.comm_init(rdv.world, rdv.rank, rdv.broadcast_bytes(uid, 128))
-            self.d_all = sim.device_array((rdv.world, self.N, self.beams))
-            self.d_alls = [self.d_all]
-            if args.gather_overlap:
-                sim.comm_set_overlap(True)
-                self.d_alls.append(sim.device_array((rdv.world, self.N, self.beams)))
+            self.set_gather(True, args.gather_overlap)
         self.planner = self.d_plan = self.d_zero = None
         if self.policy == "pure_pursuit":
             from f1tenth_gym_amd import PurePursuitPlanner
@@ -303,6 +332,29 @@ class Workload(object):
         # kernel (f110_set_auto_reseat), or as the separate f110_reset_collided_device launch
         self.fused_reset = not self.no_reset and not args.separate_reset
 
+    def set_gather(self, on, overlap=False):
+        """the RCCL observation gather after every step: off / in-stream / overlapped with the next step.
+        The communicator is created once (rank 0 makes the id, the control plane broadcasts it)."""
+        sim, rdv = self.sim, self.rdv
+        if self.d_all is not None:
+            sim.sync()
+            sim.comm_set_overlap(False)
+        self.d_all = None
+        if not on:
+            return
+        if not self.comm_ready:
+            from f1tenth_gym_amd import BatchSim as _B
+            uid = _B.comm_unique_id() if rdv.rank == 0 else b"\0" * 128
+            sim.comm_init(rdv.world, rdv.rank, rdv.broadcast_bytes(uid, 128))
+            self.comm_ready = True
+        want = 2 if overlap else 1
+        while len(self.d_alls) < want:   # receive buffers: scans [ranks][N][B] + scalars [ranks][7][N]
+            self.d_alls.append(sim.device_array((rdv.world, self.N, self.beams)))
+            self.d_scals.append(sim.device_array((rdv.world, 7, self.N)))
+        self.n_recv = want
+        self.d_all = self.d_alls[0]
+        sim.comm_set_overlap(bool(overlap))
+
     def one(self, t):
         sim = self.sim
         if self.d_zero is not None:
@@ -313,19 +365,23 @@ class Workload(object):
         else:
             sim.step_device(self.d_sets[t // 20])
         if self.d_all is not None:
-            sim.comm_all_gather_scans(self.d_alls[t % len(self.d_alls)])
+            sim.comm_all_gather_obs(self.d_alls[t % self.n_recv], self.d_scals[t % self.n_recv])
         if not self.no_reset and not self.fused_reset:
             sim.reset_collided_device(self.d_start, 0, self.d_count)
 
-    def run(self, steps, warmup, mode="timed"):
-        """mode: timed (clean), profile (per-kernel HIP events), count (table lookups, counting kernels)"""
+    def run(self, steps, warmup, mode="timed", preroll=None):
+        """mode: timed (clean), profile (per-kernel HIP events), count (table lookups, counting kernels).
+        Steps [0, preroll) and [preroll, preroll + warmup) are not timed; the pre-roll is this script's own
+        (fixed), the warm-up the caller's."""
         np, sim, rdv = self.np, self.sim, self.rdv
-        assert warmup + steps <= self.max_total
+        preroll = self.args.preroll if preroll is None else preroll
+        first = preroll + warmup
+        assert first + steps <= self.max_total
         sim.set_auto_reseat(None)
         sim.reset_device(self.d_start)
         if self.fused_reset:
             sim.set_auto_reseat(self.d_start, 0, self.d_count)
-        for t in range(warmup):
+        for t in range(first):
             self.one(t)
         sim.sync()
         self.d_count.upload(np.zeros(1, dtype=np.int32))
@@ -337,26 +393,46 @@ class Workload(object):
         sim.sync()
         t0 = time.perf_counter()
         sim.timer_begin()
-        for t in range(warmup, warmup + steps):
+        for t in range(first, first + steps):
             self.one(t)
         gpu_ms = sim.timer_end_ms()       # records + waits for the end event on the stream
         sim.sync()
+        mine = time.perf_counter() - t0   # this rank's own time (reported per rank); the job's time is max over ranks
         rdv.barrier()
         elapsed = time.perf_counter() - t0
-        out = {"elapsed_s": elapsed, "gpu_ms": gpu_ms, "n_reset": int(self.d_count.download()[0]), "steps": steps, "warmup": warmup}
+        out = {"elapsed_s": elapsed, "rank_s": mine, "gpu_ms": gpu_ms, "n_reset": int(self.d_count.download()[0]), "steps": steps,
+               "warmup": warmup, "preroll": preroll}
         if mode == "profile":
             n, scan_ms, dyn_ms, fin_ms = sim.profile_read()
             out.update({"scan_ms_avg": scan_ms / max(n, 1), "dyn_ms_avg": dyn_ms / max(n, 1), "fin_ms_avg": fin_ms / max(n, 1), "n_prof": n})
             sim.profile_kernels(False)
         if mode == "count":
             out["lookups"] = sim.scan_lookup_count(enable=False)
-        if self.d_all is not None and mode == "timed":   # the gathered block of this rank must equal its own scans
-            mine = sim.get("scans")["scans"]
-            out["gather_ok"] = bool((mine == self.d_alls[(warmup + steps - 1) % len(self.d_alls)].download()[rdv.rank]).all())
+        if self.d_all is not None and mode == "timed":
+            # (with --separate-reset the re-seat follows the gather, so the state read back here is a later one)
+            out["gather_ok"] = self.check_gather((first + steps - 1) % self.n_recv) if (self.fused_reset or self.no_reset) else None
         return out
 
+    @staticmethod
+    def digest(arr):
+        """16 bytes that pin an array of doubles bit for bit: xor and wrapping sum of its 64-bit words"""
+        import numpy as np
+        w = np.ascontiguousarray(arr).view(np.uint64).reshape(-1)
+        return struct.pack("<QQ", int(np.bitwise_xor.reduce(w)), int(np.sum(w, dtype=np.uint64)))
+
+    def check_gather(self, slot):
+        """after the last step: every rank's block in MY receive buffers must be that rank's own scans and
+        scalar observation (each rank publishes digests of what it holds over the control plane)"""
+        np, sim, rdv = self.np, self.sim, self.rdv
+        o = sim.get("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions")
+        scal = np.stack([o["poses_x"], o["poses_y"], o["poses_theta"], o["linear_vels_x"], np.zeros(self.N), o["ang_vels_z"], o["collisions"]])
+        theirs = rdv.gather_bytes(self.digest(o["scans"]) + self.digest(scal))
+        got_s, got_c = self.d_alls[slot].download(), self.d_scals[slot].download()
+        ok = all(self.digest(got_s[r]) + self.digest(got_c[r]) == theirs[r] for r in range(rdv.world))
+        return bool(ok)
+
     def close(self):
-        for d in self.d_sets + [self.d_start, self.d_count] + [x for x in (self.d_plan, self.d_zero) if x is not None] + (self.d_alls if self.d_all is not None else []):
+        for d in self.d_sets + [self.d_start, self.d_count] + [x for x in (self.d_plan, self.d_zero) if x is not None] + self.d_alls + self.d_scals:
             d.free()
         self.sim.close()
 
@@ -511,13 +587,26 @@ def cpu_baseline(args, seconds):
                                  "shape in numba on one core; numba cannot be installed here, so the C restatement stands in)" % (A, steps1, el1)}}
 
 
-def stub_run(args, rdv, steps):
-    """tests (no GPU): every rank 'steps' by sleeping; rank r pretends to be slower by r ms"""
+def stub_run(args, rdv, steps, leg="headline"):
+    """tests (no GPU): every rank 'steps' by sleeping; rank r pretends to be slower by r ms, the gather legs by 2 / 1 ms"""
     rdv.barrier()
     t0 = time.perf_counter()
-    time.sleep(0.001 * steps + 0.001 * rdv.rank)
+    time.sleep(0.001 * steps + 0.001 * rdv.rank + {"headline": 0.0, "gather": 0.002, "gather_overlap": 0.001}[leg])
+    mine = time.perf_counter() - t0
     rdv.barrier()
-    return {"elapsed_s": time.perf_counter() - t0, "n_reset": rdv.rank + 1, "steps": steps, "warmup": args.warmup}
+    return {"elapsed_s": time.perf_counter() - t0, "rank_s": mine, "n_reset": rdv.rank + 1, "steps": steps, "warmup": args.warmup,
+            "preroll": args.preroll, "gather_ok": None if leg == "headline" else True}
+
+
+def leg_record(rdv, total_agents, t):
+    """one timed leg -> the job's numbers: the time is the MAX over ranks (barrier to barrier), per-rank own times beside it"""
+    elapsed = rdv.max(t["elapsed_s"])
+    per_rank = [1e3 * x / t["steps"] for x in rdv.gather(t["rank_s"])]
+    oks = rdv.gather(-1.0 if t.get("gather_ok") is None else float(bool(t["gather_ok"])))
+    return {"value": total_agents * t["steps"] / elapsed, "ms_per_step": 1e3 * elapsed / t["steps"],
+            "per_rank_ms_per_step": per_rank, "per_rank_ms_per_step_min": min(per_rank), "per_rank_ms_per_step_max": max(per_rank),
+            "env_resets_in_timed_region": int(rdv.sum(t["n_reset"])),
+            "gather_ok": None if all(o < 0 for o in oks) else bool(all(o != 0.0 for o in oks))}
 
 
 def main(argv=None):
@@ -533,6 +622,7 @@ def main(argv=None):
             print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, rdv.world), file=sys.stderr)
         return 2
     n_gpus = rdv.world
+    numa = {"pci": None, "numa_node": -1, "cpus_bound": None, "note": "not attempted"}
     if not args.stub:
         import __graft_entry__
         if rdv.local_rank == 0:
@@ -541,21 +631,44 @@ def main(argv=None):
         from f1tenth_gym_amd import _ffi
         if _ffi.device_count() <= rdv.local_rank:
             raise SystemExit("bench.py: rank %d needs HIP device %d, %d visible" % (rdv.rank, rdv.local_rank, _ffi.device_count()))
+        if not args.no_numa:
+            from f1tenth_gym_amd import numa as _numa
+            numa = _numa.bind_to_device(rdv.local_rank)   # before the first launch: the HIP runtime's threads inherit it
 
     extras = n_gpus == 1 and not args.only_headline and not args.stub
-    total_needed = args.warmup + args.steps
+    total_needed = args.preroll + args.warmup + args.steps
     if extras and args.steady_steps > 0:
         total_needed = max(total_needed, args.steady_warmup + args.steady_steps)
+    total_agents = args.agents * n_gpus
+    # the legs of ONE invocation: the headline (no data-path collective unless --gather asks for it), then — on
+    # more than one GPU — the same steps with the RCCL observation gather in-stream and overlapped (SURVEY 8e:
+    # "report scaling both with and without it")
+    gather_legs = (n_gpus > 1 or args.gather_legs) and not args.no_gather_legs and not args.gather and not args.only_headline
     wl = None
+    legs = {}
+    rccl_ranks = None
     if args.stub:
         timed = stub_run(args, rdv, args.steps)
+        head = leg_record(rdv, total_agents, timed)
+        if gather_legs:
+            for name in ("gather", "gather_overlap"):
+                legs[name] = leg_record(rdv, total_agents, stub_run(args, rdv, args.steps, name))
     else:
         wl = Workload(args, rdv, args.agents, total_needed)
         timed = wl.run(args.steps, args.warmup, "timed")
-    elapsed = rdv.max(timed["elapsed_s"])
-    total_agents = args.agents * n_gpus
-    value = total_agents * args.steps / elapsed
-    n_reset = rdv.sum(timed["n_reset"])
+        head = leg_record(rdv, total_agents, timed)
+        if gather_legs:
+            for name, overlap in (("gather", False), ("gather_overlap", True)):
+                wl.set_gather(True, overlap)
+                legs[name] = leg_record(rdv, total_agents, wl.run(args.steps, args.warmup, "timed"))
+            rccl_ranks = wl.sim.comm_info()[0]
+            wl.set_gather(False)
+        elif args.gather:
+            rccl_ranks = wl.sim.comm_info()[0]
+    elapsed = head["ms_per_step"] * args.steps / 1e3
+    value = head["value"]
+    n_reset = head["env_resets_in_timed_region"]
+    numa_all = [json.loads(b.rstrip(b"\0").decode()) for b in rdv.gather_bytes(json.dumps(numa).encode().ljust(256, b"\0")[:256])]
 
     line = {
         "metric": "agent-steps/s (1080-beam scan + ST dynamics)", "value": value, "unit": "agent-steps/s",
@@ -575,27 +688,44 @@ def main(argv=None):
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
                    "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64", 4: "padded_rowmajor_f64 + lds_window_codes"}[args.layout],
                    "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks, "step_groups": args.groups, "step_graph": args.graph,
-                   "parallelism": "env-sharded x%d, %s" % (n_gpus, ("RCCL all-gather of scans after every step" + (" (overlapped with the next step, double-buffered)" if args.gather_overlap else "")) if args.gather
+                   "parallelism": "env-sharded x%d, %s" % (n_gpus, ("RCCL all-gather of the observation (scans + 7 scalars per agent) after every step" + (" (overlapped with the next step, double-buffered)" if args.gather_overlap else "")) if args.gather
                                                            else "no data-path collective"),
+                   "preroll_steps": args.preroll,
+                   "timed_window": "steps [%d, %d) after the reset: %d un-timed pre-roll steps (fixed by this script, so the timed steps run in the "
+                                   "steady regime with in-place resets), then the caller's %d warm-up steps" % (args.preroll + args.warmup, args.preroll + args.warmup + args.steps, args.preroll, args.warmup),
                    "env_resets_in_timed_region": int(n_reset)},
+        # one process per GPU: each rank's own time for the timed steps (the job's time above is the max, barrier to barrier)
+        "multi_gpu": {"per_rank_ms_per_step": head["per_rank_ms_per_step"], "per_rank_ms_per_step_min": head["per_rank_ms_per_step_min"],
+                      "per_rank_ms_per_step_max": head["per_rank_ms_per_step_max"], "per_gpu_value": value / n_gpus,
+                      "rccl_ranks": rccl_ranks, "numa": numa_all,
+                      "legs": "headline = no collective on the step path" + ("; gather = f110_comm_all_gather_obs after every step on the step's stream; "
+                              "gather_overlap = the same on a stream of its own beside the next step (double-buffered observation)" if legs else "")},
     }
+    for name, rec in legs.items():
+        line["multi_gpu"][name] = dict(rec, per_gpu_value=rec["value"] / n_gpus,
+                                       bytes_gathered_per_rank_per_step=8 * args.agents * (args.beams + 7) * n_gpus)
     if args.gather:
-        line["config"]["gather_ok"] = timed.get("gather_ok")
+        line["config"]["gather_ok"] = head["gather_ok"]
 
     if wl is not None and rdv.rank == 0 and not args.only_headline:
         # the same steps twice more on rank 0: per-kernel HIP events, then the counting kernels
         solo = Rendezvous.__new__(Rendezvous)
         solo.world, solo.rank, solo.local_rank, solo.peers, solo.sock = 1, 0, rdv.local_rank, [], None
         wl.rdv = solo
+        if wl.d_all is not None and n_gpus > 1:
+            wl.set_gather(False)   # rank 0 replays alone: no collective may be enqueued
         prof = None if args.no_profile_events else wl.run(args.steps, args.warmup, "profile")
         cnt = wl.run(args.steps, args.warmup, "count")
         line["roofline"] = roofline_record(args, args.agents, args.beams, dict(timed, elapsed_s=elapsed), prof, cnt, args.map_tiles)
         if extras and args.steady_steps > 0:
-            st = wl.run(args.steady_steps, args.steady_warmup, "timed")
-            sp = wl.run(args.steady_steps, args.steady_warmup, "profile")
-            sc = wl.run(args.steady_steps, args.steady_warmup, "count")
+            st = wl.run(args.steady_steps, args.steady_warmup, "timed", preroll=0)
+            sp = wl.run(args.steady_steps, args.steady_warmup, "profile", preroll=0)
+            sc = wl.run(args.steady_steps, args.steady_warmup, "count", preroll=0)
             line["steady_state"] = {"value": args.agents * args.steady_steps / st["elapsed_s"], "unit": "agent-steps/s",
                                     "steps": args.steady_steps, "warmup": args.steady_warmup,
+                                    "definition": "SURVEY 8d: >= 1000 timed steps after 100 warm-up steps from the reset (no pre-roll); the headline's "
+                                                  "pre-rolled window must agree with it",
+                                    "headline_over_steady": value / (args.agents * args.steady_steps / st["elapsed_s"]),
                                     "ms_per_step": 1e3 * st["elapsed_s"] / args.steady_steps, "env_resets_in_timed_region": st["n_reset"],
                                     "roofline": roofline_record(args, args.agents, args.beams, st, sp, sc, args.map_tiles)}
         wl.rdv = rdv
@@ -604,7 +734,7 @@ def main(argv=None):
 
     if extras and rdv.rank == 0:
         def other(n_agents, steps, warmup, **kw):
-            w2 = Workload(args, rdv, n_agents, steps + warmup, **kw)
+            w2 = Workload(args, rdv, n_agents, args.preroll + steps + warmup, **kw)
             t = w2.run(steps, warmup, "timed")
             p = w2.run(steps, warmup, "profile")
             c = w2.run(steps, warmup, "count")
@@ -626,7 +756,7 @@ def main(argv=None):
                                          "roofline": roofline_record(args, 65536, 4096, t, p, c, tiles=2)}
         if args.fixed_pose_steps > 0 and args.policy == "random":
             w3 = Workload(args, rdv, args.agents, args.fixed_pose_steps + 10, policy="parked", no_reset=True)
-            r3 = w3.run(args.fixed_pose_steps, 10, "timed")
+            r3 = w3.run(args.fixed_pose_steps, 10, "timed", preroll=0)
             w3.close()
             line["config"]["fixed_pose_variant"] = {"workload": "same agents parked on their start poses (speed 0, no resets)",
                                                     "value": args.agents * args.fixed_pose_steps / r3["elapsed_s"],

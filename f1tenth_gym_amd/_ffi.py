@@ -66,6 +66,8 @@ PROTOTYPES = {
     "f110_last_error": (C.c_char_p, [C.c_void_p]),
     "f110_abi_version": (C.c_int, []),
     "f110_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "f110_device_pci_bus_id": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
+    "f110_build_info": (C.c_char_p, []),
     "f110_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "f110_destroy": (None, [C.c_void_p]),
     "f110_sync": (C.c_int, [C.c_void_p]),
@@ -113,6 +115,8 @@ PROTOTYPES = {
     "f110_comm_unique_id": (C.c_int, [C.c_void_p]),
     "f110_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "f110_comm_all_gather_scans": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "f110_comm_all_gather_obs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "f110_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "f110_comm_set_overlap": (C.c_int, [C.c_void_p, C.c_int32]),
     "f110_comm_destroy": (C.c_int, [C.c_void_p]),
     "f110_timer_begin": (C.c_int, [C.c_void_p]),

@@ -3,6 +3,7 @@
 hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the parity contract
 (DESIGN.md): float64 in the reference's operation order, never contracted into FMAs.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -14,6 +15,18 @@ DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "f110_math.hpp"), os.path.join(PKG_DI
         os.path.join(os.path.dirname(PKG_DIR), "include", "f110.h")]
 LIB = os.path.join(PKG_DIR, "libf110_hip.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def src_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and the ABI header, in a fixed order: the
+    identity of the code a library / a profile entry / a bench line belongs to.  (A git tree hash would
+    do the same, but the GPU box receives a snapshot without .git.)"""
+    hsh = hashlib.sha256()
+    for d in sorted(DEPS, key=os.path.basename):
+        hsh.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()[:16]
 
 
 def find_hipcc():
@@ -35,7 +48,7 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     extra = os.environ.get("F110_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
-    cmd = [find_hipcc()] + HIPCC_FLAGS + extra + [SRC, "-o", LIB + ".tmp"]
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ['-DF110_SRC_HASH="%s"' % src_hash()] + extra + [SRC, "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -375,6 +375,21 @@ class BatchSim(object):
         ptr = d_recv.ptr if isinstance(d_recv, DeviceArray) else int(d_recv)
         check(_ffi.lib().f110_comm_all_gather_scans(self._h, ptr), self._h)
 
+    OBS_SCALARS = ("poses_x", "poses_y", "poses_theta", "linear_vels_x", "linear_vels_y", "ang_vels_z", "collisions")
+
+    def comm_all_gather_obs(self, d_recv_scans, d_recv_scalars):
+        """the whole observation to every rank: scans [ranks][N][B] and the scalar block
+        [ranks][7][N] in OBS_SCALARS order (one RCCL group, see f110_comm_all_gather_obs)"""
+        a = d_recv_scans.ptr if isinstance(d_recv_scans, DeviceArray) else int(d_recv_scans)
+        b = d_recv_scalars.ptr if isinstance(d_recv_scalars, DeviceArray) else int(d_recv_scalars)
+        check(_ffi.lib().f110_comm_all_gather_obs(self._h, a, b), self._h)
+
+    def comm_info(self):
+        """(n_ranks, rank) as RCCL reports them"""
+        n, r = C.c_int32(0), C.c_int32(-1)
+        check(_ffi.lib().f110_comm_info(self._h, C.byref(n), C.byref(r)), self._h)
+        return int(n.value), int(r.value)
+
     # ------------------------------------------------------------------ episode logic on the device
     def episode_init(self, ego_idx=0):
         check(_ffi.lib().f110_episode_init(self._h, int(ego_idx)), self._h, IndexError)

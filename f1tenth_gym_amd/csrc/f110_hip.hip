@@ -105,6 +105,7 @@ struct f110_sim {
     // runs on comm_stream while step t+1 fills the other buffer
     bool comm_overlap = false, comm_swap_next = false, comm_inflight = false;
     double *scan_bufs[2] = {nullptr, nullptr};
+    double *obs_scal[2] = {nullptr, nullptr};   // [7][N] scalar observation block(s) of the observation gather
     int scans_cur = 0;
     bool gather_pending[2] = {false, false};
     hipStream_t comm_stream = nullptr;
@@ -312,6 +313,19 @@ int f110_device_count(int *count)
     if (count) *count = n;
     return F110_OK;
 }
+
+int f110_device_pci_bus_id(int32_t device, char *out, int32_t len)
+{
+    if (!out || len < 16) return fail(nullptr, F110_ERR_INVALID, "f110_device_pci_bus_id: buffer of at least 16 bytes required");
+    const hipError_t e = hipDeviceGetPCIBusId(out, len, device);
+    if (e != hipSuccess) return fail(nullptr, F110_ERR_HIP, "hipDeviceGetPCIBusId(%d) failed: %s", device, hipGetErrorString(e));
+    return F110_OK;
+}
+
+#ifndef F110_SRC_HASH
+#define F110_SRC_HASH "unknown"
+#endif
+const char *f110_build_info(void) { return "csrc=" F110_SRC_HASH; }
 
 static void default_beam_tables(const f110_config &c, std::vector<double> &sa, std::vector<double> &co, std::vector<double> &sd)
 {
@@ -581,6 +595,8 @@ void f110_destroy(f110_sim *h)
         if (h->scan_bufs[0]) h->dev.scans = h->scan_bufs[0];   // the list below frees dev.scans
         if (h->scan_bufs[1]) (void)hipFree(h->scan_bufs[1]);
     }
+    for (double *p : h->obs_scal)
+        if (p) (void)hipFree(p);
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (hipStream_t gs : h->gstreams) (void)hipStreamDestroy(gs);
     for (hipEvent_t ge : h->gevents) (void)hipEventDestroy(ge);
@@ -1165,6 +1181,10 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -1185,9 +1205,14 @@ RcclApi *rccl_api()
             api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.lib, "ncclAllGather"));
             api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
             api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+            api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.lib, "ncclGroupStart"));
+            api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.lib, "ncclGroupEnd"));
+            api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
+            api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.lib, "ncclCommUserRank"));
         }
     }
-    const bool ok = api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy && api.GetErrorString;
+    const bool ok = api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy && api.GetErrorString &&
+                    api.GroupStart && api.GroupEnd && api.CommCount && api.CommUserRank;
     return ok ? &api : nullptr;
 }
 }  // namespace
@@ -1256,18 +1281,32 @@ int f110_comm_set_overlap(f110_sim *h, int32_t enable)
     return F110_OK;
 }
 
-int f110_comm_all_gather_scans(f110_sim *h, void *d_recv)
+// scans (+ the [7][N] scalar block when d_recv_scal != nullptr) of every rank to every rank.  The two
+// ncclAllGather calls are one group (ncclGroupStart / End): RCCL fuses them into one launch per rank.
+static int comm_gather(f110_sim *h, void *d_recv_scans, void *d_recv_scal)
 {
-    if (!h || !d_recv) return fail(h, F110_ERR_INVALID, "null argument");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h->comm) return fail(h, F110_ERR_STATE, "f110_comm_init has not been called");
     RcclApi *r = rccl_api();
-    const size_t count = (size_t)h->N * h->cfg.num_beams;
-    if (!h->comm_overlap) {
-        ENTER(h);
-        const ncclResult_t rc = r->AllGather(h->dev.scans, d_recv, count, ncclFloat64, h->comm, h->stream);
+    const size_t N = (size_t)h->N, count = N * h->cfg.num_beams, scount = N * kObsScalars;
+    const int cur = h->comm_overlap ? h->scans_cur : 0;
+    if (d_recv_scal && !h->obs_scal[cur]) {
+        TRY(dmalloc(h, &h->obs_scal[cur], scount));
+        HIPCHK(h, hipMemset(h->obs_scal[cur], 0, sizeof(double) * scount));
+    }
+    auto gather_on = [&](hipStream_t st, const double *scans) -> int {
+        ncclResult_t rc = r->GroupStart();
+        if (rc == ncclSuccess) rc = r->AllGather(scans, d_recv_scans, count, ncclFloat64, h->comm, st);
+        if (rc == ncclSuccess && d_recv_scal) rc = r->AllGather(h->obs_scal[cur], d_recv_scal, scount, ncclFloat64, h->comm, st);
+        const ncclResult_t re = r->GroupEnd();
+        if (rc == ncclSuccess) rc = re;
         if (rc != ncclSuccess) return fail(h, F110_ERR_HIP, "ncclAllGather failed: %s", r->GetErrorString(rc));
         return F110_OK;
+    };
+    if (!h->comm_overlap) {
+        ENTER(h);
+        if (d_recv_scal) hipLaunchKernelGGL(k_pack_obs, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->obs_scal[0]);
+        return gather_on(h->stream, h->dev.scans);
     }
     // overlapped: the gather waits for the step that produced this buffer and runs beside the next one,
     // which writes the other buffer; the step after that waits for this gather before reusing the buffer
@@ -1278,14 +1317,43 @@ int f110_comm_all_gather_scans(f110_sim *h, void *d_recv)
         h->comm_inflight = inflight;
         if (rj != F110_OK) return rj;
     }
+    // the scalar block is packed on the main stream, behind the step and before anything (a re-seat, the
+    // next step) can change the state it reads; obs_scal[cur] was last read by the gather of two steps ago,
+    // which the step that just ran has waited for
+    if (d_recv_scal) hipLaunchKernelGGL(k_pack_obs, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->obs_scal[cur]);
     HIPCHK(h, hipEventRecord(h->ev_step_done, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step_done, 0));
-    const ncclResult_t rc = r->AllGather(h->scan_bufs[h->scans_cur], d_recv, count, ncclFloat64, h->comm, h->comm_stream);
-    if (rc != ncclSuccess) return fail(h, F110_ERR_HIP, "ncclAllGather failed: %s", r->GetErrorString(rc));
-    HIPCHK(h, hipEventRecord(h->ev_gather_done[h->scans_cur], h->comm_stream));
-    h->gather_pending[h->scans_cur] = true;
+    TRY(gather_on(h->comm_stream, h->scan_bufs[cur]));
+    HIPCHK(h, hipEventRecord(h->ev_gather_done[cur], h->comm_stream));
+    h->gather_pending[cur] = true;
     h->comm_swap_next = true;
     h->comm_inflight = true;
+    return F110_OK;
+}
+
+int f110_comm_all_gather_scans(f110_sim *h, void *d_recv)
+{
+    if (!h || !d_recv) return fail(h, F110_ERR_INVALID, "null argument");
+    return comm_gather(h, d_recv, nullptr);
+}
+
+int f110_comm_all_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scalars)
+{
+    if (!h || !d_recv_scans || !d_recv_scalars) return fail(h, F110_ERR_INVALID, "null argument");
+    return comm_gather(h, d_recv_scans, d_recv_scalars);
+}
+
+int f110_comm_info(f110_sim *h, int32_t *n_ranks, int32_t *rank)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    if (!h->comm) return fail(h, F110_ERR_STATE, "f110_comm_init has not been called");
+    RcclApi *r = rccl_api();
+    int n = 0, me = -1;
+    ncclResult_t rc = r->CommCount(h->comm, &n);
+    if (rc == ncclSuccess) rc = r->CommUserRank(h->comm, &me);
+    if (rc != ncclSuccess) return fail(h, F110_ERR_HIP, "ncclCommCount / ncclCommUserRank failed: %s", r->GetErrorString(rc));
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = me;
     return F110_OK;
 }
 

@@ -1259,6 +1259,24 @@ __global__ void __launch_bounds__(256) k_pack_episode(AgentArrays a, EpisodeArra
     }
 }
 
+// The scalar part of Simulator.step's observation (base_classes.py:594-610), packed for the RCCL
+// observation gather: [7][N] = poses_x, poses_y, poses_theta, linear_vels_x, linear_vels_y (always 0.,
+// :603), ang_vels_z, collisions.  Next to the scans it is what a consumer on another GPU needs.
+constexpr int kObsScalars = 7;
+__global__ void __launch_bounds__(256) k_pack_obs(AgentArrays a, double *__restrict__ cols)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t N = (size_t)a.n_agents_total;
+    if (i >= a.n_agents_total) return;
+    cols[i] = a.state[i];
+    cols[N + i] = a.state[N + i];
+    cols[2 * N + i] = a.state[4 * N + i];
+    cols[3 * N + i] = a.state[3 * N + i];
+    cols[4 * N + i] = 0.;
+    cols[5 * N + i] = a.state[5 * N + i];
+    cols[6 * N + i] = a.collisions[i];
+}
+
 // re-seat every env whose done flag is set (F110Env.reset :319-334 without its zero-action step)
 __global__ void __launch_bounds__(256) k_episode_reset_done(AgentArrays a, EpisodeArrays ep, int32_t *__restrict__ n_reset)
 {

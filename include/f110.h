@@ -90,6 +90,12 @@ typedef struct f110_sim f110_sim;
 const char *f110_last_error(const f110_sim *h);
 int f110_abi_version(void);
 int f110_device_count(int *count);
+/* "dddd:bb:dd.f" of HIP device `device` (hipDeviceGetPCIBusId): lets the launcher pin each rank's host
+ * threads to the NUMA node its GPU hangs off (f1tenth_gym_amd/numa.py); out: >= 16 bytes */
+int f110_device_pci_bus_id(int32_t device, char *out, int32_t len);
+/* "csrc=<sha256 prefix of the kernel sources this library was built from>": profiles/ entries and
+ * bench.py's roofline record carry the same hash, so a reader can tie a number to the code */
+const char *f110_build_info(void);
 
 int f110_create(const f110_config *cfg, f110_sim **out);
 void f110_destroy(f110_sim *h);
@@ -264,6 +270,17 @@ int f110_memcpy_d2h(f110_sim *h, void *h_dst, const void *d_src, size_t bytes);
 int f110_comm_unique_id(void *out_id128);
 int f110_comm_init(f110_sim *h, int32_t n_ranks, int32_t rank, const void *id128);
 int f110_comm_all_gather_scans(f110_sim *h, void *d_recv);
+/* The whole observation of Simulator.step (base_classes.py:594-610; SURVEY 8e: "scans [N_g,B] + 7
+ * scalars/agent"): the scans as above AND the per-agent scalars, packed by a kernel behind the step as
+ * double [F110_OBS_SCALARS][N] = poses_x, poses_y, poses_theta, linear_vels_x, linear_vels_y (always
+ * 0., :603), ang_vels_z, collisions — two ncclAllGather calls inside ONE ncclGroupStart / End.
+ * d_recv_scans: n_ranks*N*B doubles; d_recv_scalars: n_ranks*F110_OBS_SCALARS*N doubles (rank-major).
+ * Honours f110_comm_set_overlap exactly like f110_comm_all_gather_scans (the scalar block is
+ * double-buffered with the scans). */
+#define F110_OBS_SCALARS 7
+int f110_comm_all_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scalars);
+/* size and rank of the communicator as RCCL itself reports them (ncclCommCount / ncclCommUserRank) */
+int f110_comm_info(f110_sim *h, int32_t *n_ranks, int32_t *rank);
 /* enable = 1: the gather OVERLAPS the following step.  The scans are double-buffered (a second
  * [N][B] buffer): f110_comm_all_gather_scans then runs on a stream of its own behind the step that
  * produced the current buffer, the next f110_step* fills the other buffer, and the step after that

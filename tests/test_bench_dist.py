@@ -97,6 +97,19 @@ def test_bench_main_as_two_launched_ranks_with_stub_step():
     assert line["config"]["agents_total"] == 2000 and line["config"]["env_resets_in_timed_region"] == 3   # sum over ranks (1 + 2)
     assert abs(line["value"] - 2000 * 40 / (line["ms_per_step"] * 40e-3)) < 1e-6 * line["value"]
     assert line["ms_per_step"] * 40e-3 >= 0.041              # the slower rank's time (stub: 40 ms + 1 ms x rank)
+    # ONE invocation carries the three legs SURVEY 8e asks for, each with every rank's own time
+    mg = line["multi_gpu"]
+    assert len(mg["per_rank_ms_per_step"]) == 2 and mg["per_rank_ms_per_step"][1] > mg["per_rank_ms_per_step"][0]
+    assert mg["per_rank_ms_per_step_min"] == min(mg["per_rank_ms_per_step"]) and mg["per_rank_ms_per_step_max"] <= line["ms_per_step"] * 1.0001
+    assert abs(mg["per_gpu_value"] - line["value"] / 2) < 1e-9 * line["value"]
+    for leg in ("gather", "gather_overlap"):
+        assert mg[leg]["gather_ok"] is True and len(mg[leg]["per_rank_ms_per_step"]) == 2
+        assert mg[leg]["value"] < line["value"]                # the stub's gather legs are slower by 2 / 1 ms
+        assert mg[leg]["bytes_gathered_per_rank_per_step"] == 8 * 1000 * (1080 + 7) * 2
+    assert mg["gather_overlap"]["value"] > mg["gather"]["value"]
+    assert mg["rccl_ranks"] is None                          # no communicator in the stub
+    assert len(mg["numa"]) == 2
+    assert line["config"]["preroll_steps"] == 500 and "pre-roll" in line["config"]["timed_window"]
 
 
 def test_bench_self_launches_its_ranks():
@@ -107,6 +120,49 @@ def test_bench_self_launches_its_ranks():
     assert out.returncode == 0, out.stderr[-1000:]
     line = _bench_line(out.stdout)
     assert line["n_gpus"] == 2 and line["config"]["agents_total"] == 1024
+
+
+def test_bench_single_rank_has_no_gather_legs_unless_asked():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "F110_BENCH_RDV")}
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "1", "--agents", "64", "--stub"]
+    out = subprocess.run(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr[-1000:]
+    mg = _bench_line(out.stdout)["multi_gpu"]
+    assert "gather" not in mg and len(mg["per_rank_ms_per_step"]) == 1
+    out = subprocess.run(base + ["--gather-legs"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    assert "gather" in _bench_line(out.stdout)["multi_gpu"]
+
+
+def test_rendezvous_gather_in_rank_order():
+    sys.path.insert(0, ROOT)
+    import bench
+    env = {k: os.environ.pop(k) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK") if k in os.environ}
+    try:
+        r = bench.Rendezvous()
+        assert r.gather(2.5) == [2.5] and r.gather_bytes(b"ab") == [b"ab"]
+        r.close()
+    finally:
+        os.environ.update(env)
+
+
+def test_numa_binding_follows_sysfs(tmp_path):
+    """f1tenth_gym_amd.numa: PCI bus id -> sysfs numa_node -> that node's cpulist (cut to the allowed set)"""
+    from f1tenth_gym_amd import numa
+    assert numa.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("64-127\n")
+    bound = []
+    rec = numa.bind_to_node_of("0000:c1:00.0", sysfs=str(tmp_path), setaffinity=bound.append, allowed=range(0, 96))
+    assert rec["numa_node"] == 1 and rec["cpus_bound"] == 32 and bound == [list(range(64, 96))]
+    (dev / "numa_node").write_text("-1\n")   # single-node boxes / VMs
+    rec = numa.bind_to_node_of("0000:c1:00.0", sysfs=str(tmp_path), setaffinity=bound.append)
+    assert rec["numa_node"] == -1 and rec["cpus_bound"] is None and len(bound) == 1
+    rec = numa.bind_to_node_of("0000:ff:00.0", sysfs=str(tmp_path), setaffinity=bound.append)   # unknown device
+    assert rec["cpus_bound"] is None and len(bound) == 1
 
 
 def test_bench_refuses_a_mismatched_world():

@@ -607,7 +607,7 @@ def test_bench_two_launched_ranks_on_one_gpu():
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    F110_BENCH_DEVICE="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5",
-                                       "--agents", "4096", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+                                       "--agents", "4096", "--no-cpu-baseline", "--no-gather-legs"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
     lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
