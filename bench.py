@@ -503,7 +503,7 @@ def roofline_record(args, n_agents, beams, timed, prof, cnt, tiles=1):
 def parity_gate(args, rdv):
     """first 64 envs x 200 steps of the bench inputs: HIP vs oracle (flags exact, floats <= 1e-5)"""
     import numpy as np
-    from _util import load_map_image, oracle_map_dt
+    from _util import load_map_image, oracle_map_dt, rel_err   # |a - b| <= tol*|b| + 1e-12: relative to the reference value itself
     from oracle import orc
     from f1tenth_gym_amd import BatchSim
     A, E, T = args.agents_per_env, 64, 200
@@ -535,10 +535,11 @@ def parity_gate(args, rdv):
         if t % 8 == 7 or t == T - 1:
             o = sim.get("scans", "state", "collisions", "in_collision")
             flag_mismatch += int(np.sum(o["collisions"] != ref.collisions) + np.sum(o["in_collision"] != ref.in_collision))
-            es = max(es, float(np.max(np.abs(o["state"] - ref.state) / np.maximum(1.0, np.abs(ref.state)))))
-            er = max(er, float(np.max(np.abs(o["scans"] - ref.scans) / np.maximum(1.0, np.abs(ref.scans)))))
+            es = max(es, rel_err(o["state"], ref.state))
+            er = max(er, rel_err(o["scans"], ref.scans))
     sim.close()
     return {"envs": E, "steps": T, "flag_mismatches": flag_mismatch, "max_rel_err_state": es, "max_rel_err_scan": er,
+            "tolerance": "|hip - oracle| <= 1e-5*|oracle| + 1e-12 per element (north_star: 1e-5 relative); flags exact",
             "ok": bool(flag_mismatch == 0 and es < 1e-5 and er < 1e-5)}
 
 

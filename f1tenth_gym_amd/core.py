@@ -6,6 +6,7 @@ The reference-compatible façades (Simulator, ScanSimulator2D, F110Env) are buil
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -55,17 +56,19 @@ def beam_tables(num_beams, fov, params):
 def load_map_files(map_path, map_ext):
     """ScanSimulator2D.set_map's file handling, laser_models.py:397-416: <stem><ext> image +
     yaml with 'resolution' and 'origin'.  Returns (uint8 image top-row-first, resolution, origin)."""
-    import yaml
-    from PIL import Image
+    from . import mapio   # stdlib zlib + NumPy: the box needs neither PIL nor PyYAML
     map_img_path = os.path.splitext(map_path)[0] + map_ext
-    img = np.array(Image.open(map_img_path))
-    if img.ndim != 2:
-        raise ValueError("map image must be single-channel grayscale, got shape %s" % (img.shape,))
+    if map_img_path.lower().endswith(".png"):
+        img = mapio.read_png_gray(map_img_path)
+    else:   # any other image format the reference would hand to PIL: PIL it is, if installed
+        from PIL import Image
+        img = np.array(Image.open(map_img_path))
+        if img.ndim != 2:
+            raise ValueError("map image must be single-channel grayscale, got shape %s" % (img.shape,))
     if img.dtype != np.uint8:
         # the reference thresholds the decoded values at 128 (laser_models.py:403-404)
         img = np.where(img.astype(np.float64) > 128., 255, 0).astype(np.uint8)
-    with open(map_path, 'r') as yaml_stream:
-        meta = yaml.safe_load(yaml_stream)
+    meta = mapio.read_map_yaml(map_path)
     return np.ascontiguousarray(img), float(meta['resolution']), [float(v) for v in meta['origin']]
 
 
@@ -84,6 +87,24 @@ class DeviceArray(object):
             check(_ffi.lib().f110_device_alloc(sim._h, self.nbytes, C.byref(p)), sim._h)
             ptr = p.value
         self.ptr = ptr
+        # an owned buffer is returned to the device when the array is collected, on `with` exit, or by
+        # free() — whichever comes first; never after its handle is gone (the handle frees nothing of ours,
+        # but f110_device_free needs it alive: BatchSim.close() runs the outstanding finalisers first)
+        self._fin = weakref.finalize(self, DeviceArray._release, sim, ptr) if self._owned else None
+        if self._fin is not None:
+            sim._device_arrays.add(self._fin)
+
+    @staticmethod
+    def _release(sim, ptr):
+        if sim._h and ptr:
+            _ffi.lib().f110_device_free(sim._h, ptr)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+        return False
 
     @property
     def __cuda_array_interface__(self):
@@ -101,8 +122,9 @@ class DeviceArray(object):
         return out
 
     def free(self):
-        if self._owned and self.ptr and self.sim._h:
-            _ffi.lib().f110_device_free(self.sim._h, self.ptr)
+        if self._fin is not None:
+            self.sim._device_arrays.discard(self._fin)
+            self._fin()          # runs at most once
         self.ptr = None
 
 
@@ -112,6 +134,7 @@ class BatchSim(object):
                  lidar_dist=0.0, ttc_thresh=0.005, device_id=0, map_layout=_ffi.MAP_DEFAULT,
                  scan_block=0, scan_tasks_per_wave=0, step_groups=0, step_graph=0):
         self._h = None
+        self._device_arrays = set()   # finalisers of the DeviceArrays this handle owns memory for
         L = _ffi.lib()
         self.params = dict(DEFAULT_PARAMS if params is None else params)
         self.E, self.A, self.B = int(num_envs), int(num_agents), int(num_beams)
@@ -146,17 +169,28 @@ class BatchSim(object):
     # ------------------------------------------------------------------ lifetime
     def close(self):
         if self._h:
-            for p in getattr(self, "_pinned", []):
-                _ffi.lib().f110_host_free(self._h, p)
-            self._pinned = []
+            for fin in list(self._device_arrays):   # device buffers still alive: give them back first
+                fin()
+            self._device_arrays.clear()
+            # pinned host blocks (pinned_empty) belong to the NumPy arrays that view them: each block is
+            # unpinned and freed when its last view is collected, which may be after this handle is gone
             _ffi.lib().f110_destroy(self._h)
             self._h = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        if getattr(self, "_h", None):
+            try:
+                self.close()
+            except _ffi.F110LibraryError as ex:   # interpreter teardown: report, do not raise from a finaliser
+                import sys
+                print("BatchSim.__del__: %s" % ex, file=sys.stderr)
 
     def sync(self):
         check(_ffi.lib().f110_sync(self._h), self._h)
@@ -274,24 +308,28 @@ class BatchSim(object):
         m = (1 << 64) - 1
         return np.array([st['state'] >> 64, st['state'] & m, st['inc'] >> 64, st['inc'] & m], dtype=np.uint64)
 
-    def set_noise_rng(self, seed, std_dev=0.01, per_agent_seeds=None, cache_rows=0):
+    def set_noise_rng(self, seed, std_dev=0.01, per_agent_seeds=None, cache_rows=0, enabled=True):
         """the reference's scan noise (laser_models.py:450-452, base_classes.py:204) drawn on the
-        device, bit-identical to NumPy's stream.  seed: every agent's stream (as in the reference);
-        per_agent_seeds [N]: a stream per agent instead (extension).  seed=None with no
-        per_agent_seeds switches the noise off."""
+        device, bit-identical to NumPy's stream.  seed: every agent's stream (as in the reference) —
+        anything np.random.default_rng accepts, None included (fresh OS entropy, exactly as
+        default_rng(None) in the reference); per_agent_seeds [N]: a stream per agent instead (extension).
+        enabled=False (or set_noise_off()) switches the noise off; a seed never does."""
         L = _ffi.lib()
-        if per_agent_seeds is not None:
+        if not enabled:
+            check(L.f110_set_noise_rng(self._h, None, 0, 0.0, 0), self._h)
+        elif per_agent_seeds is not None:
             seeds = list(per_agent_seeds)
             if len(seeds) != self.N:
                 raise ValueError("per_agent_seeds must have num_envs*num_agents=%d entries" % self.N)
             words = np.ascontiguousarray(np.stack([self._state_words(s) for s in seeds]), dtype=np.uint64)
             check(L.f110_set_noise_rng(self._h, words.ctypes.data_as(_ffi._u64p), 1, float(std_dev), 0), self._h)
-        elif seed is None:
-            check(L.f110_set_noise_rng(self._h, None, 0, 0.0, 0), self._h)
         else:
             words = np.ascontiguousarray(self._state_words(seed), dtype=np.uint64)
             check(L.f110_set_noise_rng(self._h, words.ctypes.data_as(_ffi._u64p), 0, float(std_dev), int(cache_rows)), self._h)
         self.noise_rows = 0
+
+    def set_noise_off(self):
+        self.set_noise_rng(None, enabled=False)
 
     def noise_prepare(self, rows):
         check(_ffi.lib().f110_noise_prepare(self._h, int(rows)), self._h)
@@ -419,14 +457,15 @@ class BatchSim(object):
         check(_ffi.lib().f110_episode_reset_done_device(self._h, c), self._h)
 
     def pinned_empty(self, shape, dtype=np.float64):
-        """a NumPy array over page-locked host memory (full-rate DMA); freed with the handle"""
+        """a NumPy array over page-locked host memory (full-rate DMA).  The memory lives as long as any
+        array that views it (slices, .view(), reshape ...) and is returned when the last one is collected —
+        closing the BatchSim first is fine."""
         shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         p = C.c_void_p()
         check(_ffi.lib().f110_host_alloc(self._h, nbytes, C.byref(p)), self._h)
-        self._pinned = getattr(self, "_pinned", [])
-        self._pinned.append(p.value)
-        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)   # every NumPy view keeps `buf` alive through .base
+        weakref.finalize(buf, _ffi.lib().f110_host_free, None, p.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def episode_step_host(self, actions_pinned, packed_pinned, auto_reset=False):

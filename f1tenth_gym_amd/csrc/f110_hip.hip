@@ -80,6 +80,7 @@ struct f110_sim {
     U128 *d_jump = nullptr;          // [2][65]
     U128 *d_rng_state = nullptr, *d_rng_seed = nullptr, *d_rng_rowstate = nullptr;
     int noise_rows_ready = 0;        // rows of the row cache generated so far
+    int noise_rows_alloc = 0;        // rows the row cache has memory for (grows on demand up to dev.noise_rows)
     long long noise_ub = 0;          // upper bound of any agent's step_count (steps since the last full reset)
     unsigned long long *d_lookups = nullptr;  // f110_scan_lookup_count
     bool lookups_on = false;
@@ -1023,6 +1024,7 @@ static void noise_release(f110_sim *h)
     h->dev.rng_seed = nullptr;
     h->dev.rng_rowstate = nullptr;
     h->noise_rows_ready = 0;
+    h->noise_rows_alloc = 0;
 }
 
 int f110_set_noise_table(f110_sim *h, const double *noise, int32_t rows, int32_t B)
@@ -1070,9 +1072,13 @@ int f110_set_noise_rng(f110_sim *h, const uint64_t *state_inc, int32_t per_agent
         h->dev.noise_rng = 2;
         return F110_OK;
     }
-    int rows = cache_rows > 0 ? cache_rows : 16384;   // 164 s of simulated time; rows are generated on demand
+    // capacity: 164 s of simulated time by default.  Rows are generated on demand, and the memory behind
+    // them grows on demand too (noise_cache_extend): a short-lived Simulator pays for the rows it uses
+    // (8.6 KB each at 1080 beams), not for the capacity (141 MB)
+    int rows = cache_rows > 0 ? cache_rows : 16384;
     if ((size_t)rows * B * sizeof(double) > (size_t)1 << 31) rows = (int)(((size_t)1 << 31) / ((size_t)B * sizeof(double)));
-    TRY(dmalloc(h, &h->d_noise, (size_t)rows * B));
+    h->noise_rows_alloc = std::min(rows, 512);
+    TRY(dmalloc(h, &h->d_noise, (size_t)h->noise_rows_alloc * B));
     TRY(dmalloc(h, &h->d_rng_rowstate, (size_t)rows + 1));
     const U128 st0 = {state_inc[0], state_inc[1]};
     HIPCHK(h, hipMemcpy(h->d_rng_rowstate, &st0, sizeof st0, hipMemcpyHostToDevice));
@@ -1464,12 +1470,12 @@ int f110_host_alloc(f110_sim *h, size_t bytes, void **out)
 
 int f110_host_free(f110_sim *h, void *p)
 {
-    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
-    if (p) {
+    if (!p) return F110_OK;
+    if (h) {   // the handle's stream may still be copying from / into the block
         ENTER(h);
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipHostFree(p));
     }
+    HIPCHK(h, hipHostFree(p));
     return F110_OK;
 }
 
@@ -1557,6 +1563,19 @@ static int noise_cache_extend(f110_sim *h, int upto)
     const int cap = h->dev.noise_rows;
     if (upto > cap) upto = cap;
     if (upto <= h->noise_rows_ready) return F110_OK;
+    if (upto > h->noise_rows_alloc) {
+        // grow the cache's memory (doubling, capped): the rows generated so far move to the new block
+        const size_t B = (size_t)h->cfg.num_beams;
+        const int want = std::min(cap, std::max(2 * h->noise_rows_alloc, upto));
+        double *bigger = nullptr;
+        TRY(dmalloc(h, &bigger, (size_t)want * B));
+        HIPCHK(h, hipMemcpyAsync(bigger, h->d_noise, sizeof(double) * (size_t)h->noise_rows_ready * B, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // earlier steps may still read the old block
+        (void)hipFree(h->d_noise);
+        h->d_noise = bigger;
+        h->dev.noise = bigger;
+        h->noise_rows_alloc = want;
+    }
     hipLaunchKernelGGL(k_noise_cache, dim3(1), dim3(64), 0, h->stream, h->noise_gen, h->dev.rng_inc, h->d_rng_rowstate, h->d_noise, h->noise_rows_ready, upto,
                        h->cfg.num_beams);
     HIPCHK(h, hipGetLastError());

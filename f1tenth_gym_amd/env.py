@@ -180,7 +180,8 @@ class F110VecEnv(object):
     the GPU (f110_episode_*): one call per step (f110_episode_step_host) uploads the actions from a
     pinned buffer and brings `done`, the lap arrays and the scalar observation fields back in ONE
     device-to-host copy into pinned memory.  The arrays step() returns in that mode are VIEWS of
-    that pinned block, overwritten by the next step(): copy what you keep, or pass copy_obs=True.
+    that pinned block, overwritten by the next step(): copy what you keep, or pass copy_obs=True
+    (the block itself stays valid as long as any array views it, also after close()).
     obs_fields selects the fields put into `obs` ('scans', 8.6 KB per agent, is a separate
     read-back); everything stays available in HBM through `device_views()`.
 
@@ -189,7 +190,8 @@ class F110VecEnv(object):
     re-assigns later.
     """
 
-    _ALL = ("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions")
+    # every key of the reference's observation (base_classes.py:594-610, docs/api/obv.rst:6-14)
+    _ALL = ("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "linear_vels_y", "ang_vels_z", "collisions")
 
     def __init__(self, num_envs, auto_reset=False, device_logic=False, obs_fields=None, copy_obs=False, **kwargs):
         self.num_envs = int(num_envs)
@@ -279,6 +281,8 @@ class F110VecEnv(object):
         for f in self.obs_fields:
             if f == "scans":
                 obs[f] = b.get("scans")["scans"].reshape(E, A, -1)
+            elif f == "linear_vels_y":
+                obs[f] = np.zeros((E, A))      # base_classes.py:603: always 0. in the reference
             else:
                 obs[f] = p[f].reshape(E, A)
         obs['lap_times'] = p["lap_times"].reshape(E, A)

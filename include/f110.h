@@ -212,7 +212,7 @@ int f110_episode_get(f110_sim *h, const f110_episode_host *out);
 int f110_episode_step_host(f110_sim *h, const double *h_actions, int32_t auto_reset, void *h_packed);
 size_t f110_episode_packed_bytes(const f110_sim *h);
 int f110_host_alloc(f110_sim *h, size_t bytes, void **h_out);   /* page-locked host memory */
-int f110_host_free(f110_sim *h, void *h_ptr);
+int f110_host_free(f110_sim *h, void *h_ptr);  /* h may be NULL once the handle that allocated it is destroyed */
 int f110_episode_device_views(f110_sim *h, f110_episode_views *out);
 
 /* Simulator.step base_classes.py:553-612.  actions [N][2] = (steer, speed).

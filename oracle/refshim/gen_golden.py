@@ -535,13 +535,15 @@ GROUPS = {"planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": ge
 
 def main(argv):
     os.makedirs(GOLD, exist_ok=True)
-    ns = ref_loader.load_reference()
     which = argv or list(GROUPS)
-    for g in which:
-        t = time.time()
-        print("[%s]" % g)
-        GROUPS[g](ns)
-        print("  %.1f s" % (time.time() - t))
+    # the reference's example scripts import f110_gym.envs.* by name: bind those names to the reference
+    # for the duration of the generation only (ref_loader.reference_modules)
+    with ref_loader.reference_modules() as ns:
+        for g in which:
+            t = time.time()
+            print("[%s]" % g)
+            GROUPS[g](ns)
+            print("  %.1f s" % (time.time() - t))
 
 
 if __name__ == "__main__":

@@ -72,19 +72,66 @@ def load_reference(with_env=False):
         envs.__path__ = []
         # the repo ships an `f110_gym` alias package of its own (the drop-in): the reference's
         # modules must not be mixed with it, so the names are (re)bound to empty packages here
+        # ... for the duration of the load only: afterwards `import f110_gym` resolves to whatever it did before
+        # (the drop-in alias, if it was imported, else a fresh import), and the reference's modules stay
+        # reachable through the returned namespace alone
+        saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "f110_gym" or k.startswith("f110_gym.")}
+        for k in saved:
+            del sys.modules[k]
         sys.modules["f110_gym"] = pkg
         sys.modules["f110_gym.envs"] = envs
-        ns = types.SimpleNamespace()
-        ns.dynamic_models = _load("dynamic_models", "dynamic_models.py")
-        ns.laser_models = _load("laser_models", "laser_models.py")
-        ns.collision_models = _load("collision_models", "collision_models.py")
-        ns.base_classes = _load("base_classes", "base_classes.py")
-        _loaded["core"] = ns
+        try:
+            ns = types.SimpleNamespace()
+            ns.dynamic_models = _load("dynamic_models", "dynamic_models.py")
+            ns.laser_models = _load("laser_models", "laser_models.py")
+            ns.collision_models = _load("collision_models", "collision_models.py")
+            ns.base_classes = _load("base_classes", "base_classes.py")
+            _loaded["core"] = ns
+            _loaded["ref_modules"] = {k: v for k, v in sys.modules.items() if k == "f110_gym" or k.startswith("f110_gym.")}
+        finally:
+            for k in [k for k in sys.modules if k == "f110_gym" or k.startswith("f110_gym.")]:
+                del sys.modules[k]
+            sys.modules.update({k: v for k, v in saved.items() if v is not None})
     ns = _loaded["core"]
     if with_env and not hasattr(ns, "f110_env"):
-        _install_gym_pyglet_stubs()
-        ns.f110_env = _load("f110_env", "f110_env.py")
+        # f110_env.py imports its siblings by name: put the reference's modules back for the load
+        saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "f110_gym" or k.startswith("f110_gym.")}
+        for k in saved:
+            del sys.modules[k]
+        sys.modules.update(_loaded["ref_modules"])
+        try:
+            _install_gym_pyglet_stubs()
+            ns.f110_env = _load("f110_env", "f110_env.py")
+            _loaded["ref_modules"]["f110_gym.envs.f110_env"] = ns.f110_env
+        finally:
+            for k in [k for k in sys.modules if k == "f110_gym" or k.startswith("f110_gym.")]:
+                del sys.modules[k]
+            sys.modules.update({k: v for k, v in saved.items() if v is not None})
+            if saved.get("f110_gym.envs.base_classes") is ns.base_classes and hasattr(ns, "f110_env"):
+                sys.modules["f110_gym.envs.f110_env"] = ns.f110_env   # called inside a reference_modules() block
     return ns
+
+
+class reference_modules(object):
+    """`with reference_modules():` — inside the block `import f110_gym...` resolves to the REFERENCE's
+    modules (a generator script that loads the reference's examples needs that); on exit the names are
+    bound again to what they were before (the repo's drop-in alias package, or nothing)."""
+
+    def __enter__(self):
+        load_reference()
+        self.saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "f110_gym" or k.startswith("f110_gym.")}
+        for k in self.saved:
+            del sys.modules[k]
+        sys.modules.update(_loaded["ref_modules"])
+        return _loaded["core"]
+
+    def __exit__(self, *exc):
+        for k in [k for k in sys.modules if k == "f110_gym" or k.startswith("f110_gym.")]:
+            if k not in _loaded["ref_modules"]:
+                _loaded["ref_modules"][k] = sys.modules[k]   # e.g. f110_env, loaded inside the block
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in self.saved.items() if v is not None})
+        return False
 
 
 def fresh_racecar_class(ns):

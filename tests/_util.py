@@ -51,6 +51,17 @@ def bench_start_poses(num_envs, num_agents=2, gap_wp=10):
     return poses.reshape(num_envs * num_agents, 3)
 
 
-def rel_err(a, b):
+def rel_err(a, b, atol=1e-12):
+    """north_star's tolerance as a number: the smallest tol with |a - b| <= tol*|b| + atol everywhere, so
+    `rel_err(a, b) < 1e-5` IS "within 1e-5 relative" — relative to the reference value itself, also below 1
+    (a 0.1 m range off by 1e-6 m fails a 1e-5 gate).  The absolute floor only forgives differences of the
+    size of float64 rounding around zero (atol = 1e-12; a reference of exactly 0 allows nothing more)."""
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
-    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) if a.size else 0.0
+    if not a.size:
+        return 0.0
+    a, b = np.broadcast_arrays(a, b)
+    excess = np.maximum(np.abs(a - b) - atol, 0.0)
+    mag = np.abs(b)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        e = np.where(excess > 0.0, excess / mag, 0.0)   # excess > 0 over |b| == 0 -> inf
+    return float(np.max(e))

@@ -75,6 +75,62 @@ def test_map_file_loading():
         load_map_files(os.path.join(MAPS, "nope.yaml"), ".png")
 
 
+def test_png_and_yaml_readers_need_neither_pil_nor_pyyaml(tmp_path, monkeypatch):
+    """f1tenth_gym_amd.mapio (stdlib zlib + NumPy): every shipped map decodes to exactly the array PIL
+    returns and the yaml fields PyYAML returns — and load_map_files works with both packages hidden"""
+    import glob
+    import sys
+    import yaml
+    from PIL import Image
+    from f1tenth_gym_amd import mapio
+    import f1tenth_gym_amd
+    pkg_maps = os.path.join(os.path.dirname(f1tenth_gym_amd.__file__), "maps")
+    pngs = sorted(glob.glob(os.path.join(MAPS, "*.png")) + glob.glob(os.path.join(pkg_maps, "*.png")))
+    assert len(pngs) >= 6
+    filters = set()
+    for f in pngs:
+        got = mapio.read_png_gray(f)
+        want = np.array(Image.open(f))
+        assert got.dtype == want.dtype == np.uint8 and np.array_equal(got, want), f
+    for f in sorted(glob.glob(os.path.join(MAPS, "*.yaml")) + glob.glob(os.path.join(pkg_maps, "*.yaml"))):
+        with open(f) as fh:
+            want = yaml.safe_load(fh)
+        assert mapio.read_map_yaml(f) == want, f
+    # every filter type incl. Average / Paeth, 8 and 16 bit: re-encode a map with PIL's encoder variants
+    src = np.array(Image.open(os.path.join(MAPS, "berlin.png")))[100:340, 150:401]
+    noisy = (src.astype(np.int32) + np.random.default_rng(0).integers(-20, 20, src.shape)).clip(0, 255).astype(np.uint8)
+    for k, arr in enumerate((src, noisy, noisy.astype(np.uint16) * 257)):
+        out = str(tmp_path / ("t%d.png" % k))
+        Image.fromarray(arr).save(out, optimize=bool(k % 2))
+        assert np.array_equal(mapio.read_png_gray(out), arr)
+        import struct
+        import zlib
+        raw = open(out, "rb").read()
+        pos, idat = 8, b""
+        while pos < len(raw):
+            n, = struct.unpack(">I", raw[pos:pos + 4])
+            if raw[pos + 4:pos + 8] == b"IDAT":
+                idat += raw[pos + 8:pos + 8 + n]
+            pos += 12 + n
+        stride = arr.shape[1] * arr.dtype.itemsize + 1
+        filters |= set(np.frombuffer(zlib.decompress(idat), np.uint8)[::stride].tolist())
+    assert 4 in filters   # Paeth rows were exercised here; Average rows occur in the shipped stata_basement.png
+    rgb = str(tmp_path / "rgb.png")
+    Image.fromarray(np.zeros((4, 4, 3), np.uint8)).save(rgb)
+    with pytest.raises(ValueError):
+        mapio.read_png_gray(rgb)
+    bad = tmp_path / "nested.yaml"
+    bad.write_text("a:\n  b: 1\n")
+    with pytest.raises(ValueError):
+        mapio.read_map_yaml(str(bad))
+    # with PIL and yaml unimportable, set_map's file handling still works
+    from f1tenth_gym_amd.core import load_map_files
+    monkeypatch.setitem(sys.modules, "PIL", None)
+    monkeypatch.setitem(sys.modules, "yaml", None)
+    img, res, origin = load_map_files(os.path.join(pkg_maps, "vegas.yaml"), ".png")
+    assert img.shape == (2248, 3000) and res == 0.05 and origin == [-11.60654, -27.320793, 0.0]
+
+
 def test_integrator_enum_and_validation():
     from f1tenth_gym_amd.sim import Integrator, _integrator_code
     assert Integrator.RK4.value == 1 and Integrator.Euler.value == 2

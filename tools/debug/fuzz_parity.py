@@ -55,9 +55,12 @@ def run(seed, verbose=True, tol=1e-9, stop_when_diverged=False):
             tag += " (stopped at step %d: dynamics diverged)" % t
             break
         bad_flags = int(np.sum(o["collisions"] != ref.collisions) + np.sum(o["in_collision"] != ref.in_collision) + np.sum(o["collision_idx"] != ref.collision_idx))
-        es = np.max(np.abs(o["state"] - ref.state) / np.maximum(1.0, np.abs(ref.state)))
-        with np.errstate(invalid="ignore"):
-            dsc = np.abs(o["scans"] - ref.scans) / np.maximum(1.0, np.abs(ref.scans))
+        def rel(a, b):   # |a - b| <= tol*|b| + 1e-12 per element (tests/_util.rel_err), element-wise
+            with np.errstate(invalid="ignore", divide="ignore"):
+                ex = np.maximum(np.abs(a - b) - 1e-12, 0.0)
+                return np.where(ex > 0.0, ex / np.abs(b), np.where(np.isnan(ex), np.nan, 0.0))
+        es = np.max(rel(o["state"], ref.state))
+        dsc = rel(o["scans"], ref.scans)
         dsc = np.where(np.isnan(dsc), np.where(np.isnan(o["scans"]) == np.isnan(ref.scans), 0.0, np.inf), dsc)
         er = dsc.max()
         if bad_flags or es > tol or er > tol or not np.array_equal(o["step_count"], ref.step_count):

@@ -16,8 +16,9 @@ pv = orc.params_vec(P)
 
 def rel(a, b):
     a = np.asarray(a, float); b = np.asarray(b, float)
-    with np.errstate(invalid="ignore"):
-        d = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    with np.errstate(invalid="ignore", divide="ignore"):   # |a - b| <= tol*|b| + 1e-12 (tests/_util.rel_err)
+        ex = np.maximum(np.abs(a - b) - 1e-12, 0.0)
+        d = np.where(ex > 0.0, ex / np.abs(b), 0.0)
     same_nan = np.isnan(a) & np.isnan(b)
     same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
     d = np.where(same_nan | same_inf, 0.0, d)
