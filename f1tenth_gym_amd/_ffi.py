@@ -10,7 +10,10 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libf110_hip.so")
+# F110_LIB_VARIANT=experimental (read HERE, by the Python host — the library reads no environment) selects
+# libf110_hip_exp.so: the product plus every variant that was measured and not adopted, and f110_exp_set
+VARIANT = "experimental" if os.environ.get("F110_LIB_VARIANT", "product").lower().startswith("exp") else "product"
+LIB_PATH = os.path.join(_PKG, "libf110_hip_exp.so" if VARIANT == "experimental" else "libf110_hip.so")
 ABI_VERSION = 1
 NPARAMS = 18
 PARAM_KEYS = ['mu', 'C_Sf', 'C_Sr', 'lf', 'lr', 'h', 'm', 'I', 's_min', 's_max', 'sv_min',
@@ -68,6 +71,8 @@ PROTOTYPES = {
     "f110_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "f110_device_pci_bus_id": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
     "f110_build_info": (C.c_char_p, []),
+    "f110_is_experimental": (C.c_int, []),
+    "f110_exp_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "f110_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "f110_destroy": (None, [C.c_void_p]),
     "f110_sync": (C.c_int, [C.c_void_p]),
@@ -148,6 +153,11 @@ class F110LibraryError(RuntimeError):
     """libf110_hip.so is missing/unloadable, or the HIP runtime reported an error."""
 
 
+class ExperimentalOnly(F110LibraryError):
+    """the call needs libf110_hip_exp.so (F110_LIB_VARIANT=experimental): a layout, a step form or a
+    switch that was measured and not adopted into the product library"""
+
+
 def lib():
     """Load libf110_hip.so (built in-tree by f1tenth_gym_amd.build / __graft_entry__.build)."""
     global _lib
@@ -194,6 +204,8 @@ def check(rc, handle=None, invalid_exc=ValueError):
         raise invalid_exc(msg)
     if rc == ERR_NOMEM:
         raise MemoryError(msg)
+    if rc == ERR_STATE and "experimental build only" in msg:
+        raise ExperimentalOnly(msg)
     raise F110LibraryError(msg or ("libf110_hip error %d" % rc))
 
 

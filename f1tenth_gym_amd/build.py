@@ -14,6 +14,7 @@ DEPS = [SRC, os.path.join(PKG_DIR, "csrc", "f110_math.hpp"), os.path.join(PKG_DI
         os.path.join(PKG_DIR, "csrc", "f110_rng.hpp"), os.path.join(PKG_DIR, "csrc", "f110_ziggurat_tables.hpp"),
         os.path.join(os.path.dirname(PKG_DIR), "include", "f110.h")]
 LIB = os.path.join(PKG_DIR, "libf110_hip.so")
+LIB_EXP = os.path.join(PKG_DIR, "libf110_hip_exp.so")   # -DF110_EXPERIMENTAL: the lab (A/B variants, f110_exp_set)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
@@ -36,27 +37,35 @@ def find_hipcc():
     raise RuntimeError("hipcc not found: the MI355X extension cannot be built")
 
 
-def is_stale():
-    if not os.path.isfile(LIB):
+def is_stale(lib=LIB):
+    if not os.path.isfile(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    """Build libf110_hip.so if missing or older than its sources.  Returns the path."""
-    if not force and not is_stale():
-        return LIB
+def build(force=False, verbose=False, variant="product"):
+    """Build libf110_hip.so (variant="product") or libf110_hip_exp.so ("experimental") if missing or
+    older than its sources.  Returns the path."""
+    lib = LIB_EXP if variant == "experimental" else LIB
+    if not force and not is_stale(lib):
+        return lib
     extra = os.environ.get("F110_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ['-DF110_SRC_HASH="%s"' % src_hash()] + extra + [SRC, "-o", LIB + ".tmp"]
+    if variant == "experimental":
+        extra = ["-DF110_EXPERIMENTAL"] + extra
+    cmd = [find_hipcc()] + HIPCC_FLAGS + ['-DF110_SRC_HASH="%s"' % src_hash()] + extra + [SRC, "-o", lib + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + proc.stdout)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
+
+
+def build_all(force=False, verbose=False):
+    return [build(force, verbose, "product"), build(force, verbose, "experimental")]
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build_all(force=True, verbose=True))

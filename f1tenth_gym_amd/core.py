@@ -132,7 +132,7 @@ class BatchSim(object):
     def __init__(self, params=None, num_envs=1, num_agents=2, num_beams=1080, fov=4.7, eps=0.0001,
                  theta_dis=2000, max_range=30.0, time_step=0.01, integrator=_ffi.INTEGRATOR_RK4,
                  lidar_dist=0.0, ttc_thresh=0.005, device_id=0, map_layout=_ffi.MAP_DEFAULT,
-                 scan_block=0, scan_tasks_per_wave=0, step_groups=0, step_graph=0):
+                 scan_block=0, scan_tasks_per_wave=0, step_groups=0, step_graph=0, exp=None):
         self._h = None
         self._device_arrays = set()   # finalisers of the DeviceArrays this handle owns memory for
         L = _ffi.lib()
@@ -165,6 +165,16 @@ class BatchSim(object):
                                      dptr(self.side_distances), self.B), self._h)
         self.has_map = False
         self.noise_rows = 0
+        # experimental build only (libf110_hip_exp.so, F110_LIB_VARIANT=experimental): A/B switches, from the
+        # `exp` argument and from F110_EXP="key=value,key=value" — read here, by the host; the library itself
+        # reads no environment variable.  The product library refuses every key (ExperimentalOnly).
+        switches = dict(kv.split("=", 1) for kv in os.environ.get("F110_EXP", "").split(",") if "=" in kv)
+        switches.update(exp or {})
+        for key, val in switches.items():
+            self.exp_set(key, int(val))
+
+    def exp_set(self, key, value):
+        check(_ffi.lib().f110_exp_set(self._h, str(key).encode(), int(value)), self._h)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):

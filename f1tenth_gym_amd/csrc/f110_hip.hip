@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/f110.h"
@@ -23,6 +24,31 @@
 
 
 // ============================================================================ host side
+
+// Two builds of this file: libf110_hip.so (the product: ONE step dispatch per (agents per env, beams) case,
+// the row-major and PADDED table layouts, no environment variables read anywhere) and, with
+// -DF110_EXPERIMENTAL, libf110_hip_exp.so, which adds everything that was built, measured and not adopted
+// (tiled / byte-code / LDS-window layouts, env groups, the HIP-graph step, other places
+// for the pair tests, two-pass dedupe) plus f110_exp_set, the switchboard the A/B tests and profiles use.
+#ifdef F110_EXPERIMENTAL
+constexpr bool kExperimental = true;
+#else
+constexpr bool kExperimental = false;
+#endif
+
+// f110_exp_set keys (experimental build; the product keeps the defaults)
+struct ExpSwitches {
+    int scan_flat = 0;         // 1: the flat ray kernel instead of the agent-aligned one
+    int dedupe_two_pass = 0;   // 1: march distinct directions into a buffer, then k_expand_beams
+    int no_window = 0;         // 1: F110_MAP_WINDOW_LDS handles step with the PADDED kernel
+    int finalize_lanes = 0;    // 8 / 16 / 32 / 64 lanes per agent in k_finalize*, 0 = by batch size
+    int finalize_flat = -1;    // A = 2: 1 the workgroup-flattened window loop, 0 fixed lanes per agent, -1 = default
+    int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
+    int scan_env_counter = 0;  // 1: the scan kernel also counts finished tasks per env (fusion feasibility A/B)
+};
+
+// A = 2 finalize: the workgroup-flattened window loop (k_finalize_pair_flat) or fixed lanes per agent
+constexpr bool kFinalizeFlatDefault = false;
 
 struct f110_sim {
     f110_config cfg{};
@@ -88,6 +114,8 @@ struct f110_sim {
     struct StepGraph {
         AgentArrays dev;
         ScanConst k;
+        ExpSwitches exp;
+        double noise_scale;
         const double *actions;
         int flags;
         hipGraphExec_t exec;
@@ -100,6 +128,8 @@ struct f110_sim {
     uint32_t *d_tflags[2] = {nullptr, nullptr}, *d_tlist[2] = {nullptr, nullptr}, *d_tcount = nullptr;
     TaskSched *d_tsched = nullptr;   // [2]
     uint32_t task_epoch = 2, task_cap = 0, task_thr = 96;   // epochs start above the flags' initial 0
+    ExpSwitches exp;
+    uint32_t *d_env_done = nullptr;   // [num_envs] scan_env_counter probe
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
     int comm_ranks = 0;
     // overlapped gather (f110_comm_set_overlap): scans are double-buffered, the all-gather of step t
@@ -269,11 +299,10 @@ static const ScanConst *cold_consts(f110_sim *h)
 }
 
 // The step's scan runs agent-aligned (k_scan_rays_agent) with the PADDED layout unless that would
-// leave more than 3 % of the lanes idle (few beams); F110_SCAN_FLAT=1 forces the flat kernel (A/B).
+// leave more than 3 % of the lanes idle (few beams); exp.scan_flat forces the flat kernel (A/B).
 static bool agent_aligned(const f110_sim *h)
 {
-    static const bool force_flat = std::getenv("F110_SCAN_FLAT") != nullptr;
-    if (force_flat || !padded_family(h->cfg.map_layout) || !h->k.pad || h->dir_stride > 0) return false;
+    if (h->exp.scan_flat || !padded_family(h->cfg.map_layout) || !h->k.pad || h->dir_stride > 0) return false;
     const int B = h->k.num_beams, lanes = (B + 63) / 64 * 64;
     return (lanes - B) * 100 <= 3 * B;
 }
@@ -283,9 +312,12 @@ static scan_rays_fn pick_rays(const ScanConst &k, int layout)
 {
 #define SEL(L) (k.res_pow2 ? (k.ident_rot ? k_scan_rays<L, true, true, STEP> : k_scan_rays<L, true, false, STEP>) \
                            : (k.ident_rot ? k_scan_rays<L, false, true, STEP> : k_scan_rays<L, false, false, STEP>))
+#ifdef F110_EXPERIMENTAL
     if (layout == F110_MAP_CODE8) return SEL(LAYOUT_CODE8);
+    if (layout == F110_MAP_TILED_F64) return SEL(LAYOUT_TILED);
+#endif
     if (padded_family(layout) && k.pad) return SEL(LAYOUT_PADDED);
-    return layout == F110_MAP_TILED_F64 ? SEL(LAYOUT_TILED) : SEL(LAYOUT_ROWMAJOR);
+    return SEL(LAYOUT_ROWMAJOR);
 #undef SEL
 }
 
@@ -296,6 +328,45 @@ static dim3 rays_grid(RayJob &j, int block, int tasks_per_wave)
     const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave;
     const uint32_t wpb = (uint32_t)block / 64u;
     return dim3((waves + wpb - 1) / wpb);
+}
+
+// Cached step graphs (experimental build) hold raw device pointers: whenever the handle frees or replaces a
+// buffer a launch reads (maps, window codes, noise buffers, per-env map tables, beam tables, parameter sets)
+// the cache is dropped — after the stream has drained, so no exec is destroyed while it may still run.
+static int graphs_clear(f110_sim *h)
+{
+    if (h->graphs.empty()) return F110_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+    return F110_OK;
+}
+
+// longest-first order of the step's scan tasks (TaskSched): buffers on first use, then on / off
+static int task_order_setup(f110_sim *h, bool on)
+{
+    const size_t n_tasks = (size_t)h->N * (((size_t)h->cfg.num_beams + 63) / 64);
+    if (!on || n_tasks >= 0x7fffffffu) {
+        h->task_order = false;
+        return F110_OK;
+    }
+    if (!h->d_tsched) {
+        h->task_cap = (uint32_t)std::max<size_t>(64, n_tasks / 32);
+        for (int q = 0; q < 2; ++q) {
+            TRY(dmalloc(h, &h->d_tflags[q], n_tasks));
+            TRY(dmalloc(h, &h->d_tlist[q], (size_t)h->task_cap));
+            HIPCHK(h, hipMemset(h->d_tflags[q], 0, sizeof(uint32_t) * n_tasks));
+        }
+        TRY(dmalloc(h, &h->d_tcount, 2));
+        HIPCHK(h, hipMemset(h->d_tcount, 0, 2 * sizeof(uint32_t)));
+        TRY(dmalloc(h, &h->d_tsched, 2));
+    }
+    TaskSched ts[2];
+    for (int q = 0; q < 2; ++q)   // struct q is used at steps of parity q: it reads what parity q^1 wrote
+        ts[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr};
+    HIPCHK(h, hipMemcpy(h->d_tsched, ts, sizeof ts, hipMemcpyHostToDevice));
+    h->task_order = true;
+    return F110_OK;
 }
 
 extern "C" {
@@ -327,6 +398,38 @@ int f110_device_pci_bus_id(int32_t device, char *out, int32_t len)
 #define F110_SRC_HASH "unknown"
 #endif
 const char *f110_build_info(void) { return "csrc=" F110_SRC_HASH; }
+
+int f110_is_experimental(void) { return kExperimental ? 1 : 0; }
+
+int f110_exp_set(f110_sim *h, const char *key, int32_t value)
+{
+    if (!h || !key) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!kExperimental) return fail(h, F110_ERR_STATE, "f110_exp_set(%s) is available in the experimental build only (libf110_hip_exp.so)", key);
+    ENTER(h);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    TRY(graphs_clear(h));
+    const std::string k(key);
+    if (k == "scan_flat") h->exp.scan_flat = value;
+    else if (k == "dedupe_two_pass") h->exp.dedupe_two_pass = value;
+    else if (k == "no_window") h->exp.no_window = value;
+    else if (k == "finalize_lanes") {
+        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(h, F110_ERR_INVALID, "finalize_lanes must be 0, 8, 16, 32 or 64");
+        h->exp.finalize_lanes = value;
+    } else if (k == "finalize_flat") h->exp.finalize_flat = value;
+    else if (k == "scan_occupancy") h->exp.scan_occupancy = value;
+    else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
+    else if (k == "collide_mode") {
+        if (value < 0 || value > 3) return fail(h, F110_ERR_INVALID, "collide_mode must be 0..3");
+        h->collide_mode = value;
+    } else if (k == "step_graph") h->use_graph = value != 0;
+    else if (k == "task_order") return task_order_setup(h, value != 0);
+    else if (k == "task_thr") {
+        h->task_thr = (uint32_t)value;
+        if (h->task_order) return task_order_setup(h, true);
+    } else
+        return fail(h, F110_ERR_INVALID, "f110_exp_set: unknown key '%s'", key);
+    return F110_OK;
+}
 
 static void default_beam_tables(const f110_config &c, std::vector<double> &sa, std::vector<double> &co, std::vector<double> &sd)
 {
@@ -363,6 +466,12 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_TILED_F64 && cfg->map_layout != F110_MAP_CODE8 &&
         cfg->map_layout != F110_MAP_PADDED_F64 && cfg->map_layout != F110_MAP_WINDOW_LDS)
         return fail(nullptr, F110_ERR_INVALID, "unknown map_layout %d", cfg->map_layout);
+    if (!kExperimental) {
+        if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_PADDED_F64)
+            return fail(nullptr, F110_ERR_STATE, "map_layout %d is available in the experimental build only (libf110_hip_exp.so)", cfg->map_layout);
+        if (cfg->step_groups > 1 || cfg->step_graph != 0)
+            return fail(nullptr, F110_ERR_STATE, "step_groups / step_graph are available in the experimental build only (libf110_hip_exp.so)");
+    }
     if ((long long)cfg->num_envs * cfg->num_agents * (long long)cfg->num_beams > 0xFFFFFF00LL) return fail(nullptr, F110_ERR_INVALID, "num_envs*num_agents*num_beams must stay below 2^32");
     int ndev = 0;
     {
@@ -410,15 +519,12 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         // (longest ray, RK4, window set-up) and kernel boundaries, which independent env blocks
         // on their own streams overlap; big batches fill the chip with one block.
         int G = cfg->step_groups;
-        if (const char *e = std::getenv("F110_STEP_GROUPS")) G = std::atoi(e);
         if (G <= 0) G = 1;   // measured: +4..7 % with 2 groups on a fresh process, but a loss as soon as
                              // the group streams share a hardware queue — opt-in
         G = std::min(std::min(G, 16), cfg->num_envs);
         h->groups = G;
         h->use_graph = cfg->step_graph != 0;
         h->collide_mode = cfg->num_agents == 2 ? 3 : 0;
-        if (const char *e = std::getenv("F110_COLLIDE_MODE")) h->collide_mode = std::atoi(e);
-        if (const char *e = std::getenv("F110_STEP_GRAPH")) h->use_graph = std::atoi(e) != 0;
         for (int g = 0; g < G && G > 1; ++g) {
             hipStream_t gs = nullptr;
             hipEvent_t ge = nullptr;
@@ -475,27 +581,9 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     }
     {
         // longest-first task order: for batches whose scan lasts as long as its longest ray (one task per wave)
-        const size_t n_tasks = (size_t)N * (((size_t)B + 63) / 64);
         // (measured: 4096 agents 0.110 -> 0.103 ms, 8192: 0.159 -> 0.155, 1024: 0.073 -> 0.071; 16 384: a loss)
-        bool on = n_tasks >= 4096 && n_tasks < 160000;
-        if (const char *e = std::getenv("F110_TASK_ORDER")) on = std::atoi(e) != 0;
-        if (const char *e = std::getenv("F110_TASK_THR")) h->task_thr = (uint32_t)std::atoi(e);
-        if (on && n_tasks < 0x7fffffffu) {
-            h->task_cap = (uint32_t)std::max<size_t>(64, n_tasks / 32);
-            for (int q = 0; q < 2; ++q) {
-                CK(dmalloc(h, &h->d_tflags[q], n_tasks));
-                CK(dmalloc(h, &h->d_tlist[q], (size_t)h->task_cap));
-                CKH(hipMemset(h->d_tflags[q], 0, sizeof(uint32_t) * n_tasks));
-            }
-            CK(dmalloc(h, &h->d_tcount, 2));
-            CKH(hipMemset(h->d_tcount, 0, 2 * sizeof(uint32_t)));
-            CK(dmalloc(h, &h->d_tsched, 2));
-            TaskSched ts[2];
-            for (int q = 0; q < 2; ++q)   // struct q is used at steps of parity q: it reads what parity q^1 wrote
-                ts[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr};
-            CKH(hipMemcpy(h->d_tsched, ts, sizeof ts, hipMemcpyHostToDevice));
-            h->task_order = true;
-        }
+        const size_t n_tasks = (size_t)N * (((size_t)B + 63) / 64);
+        if (n_tasks >= 4096 && n_tasks < 160000) CK(task_order_setup(h, true));
     }
     CKH(hipMemsetAsync(d.state, 0, sizeof(double) * 7 * N, h->stream));
     CKH(hipMemsetAsync(d.steer_buf, 0, sizeof(double) * 2 * N, h->stream));
@@ -551,8 +639,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         stride = std::min(stride, cfg->theta_dis);
         stride = (stride + 63) / 64 * 64;
         if (stride < B && (long long)N * stride < 0xFFFFFF00LL) {
-            h->dir_stride = stride;
-            CK(dmalloc(h, &h->d_dir_ranges, (size_t)N * stride));
+            h->dir_stride = stride;   // (the two-pass form's [N][stride] buffer is allocated when that form first runs)
             RayJob tmp{};
             tmp.n_rays = (uint32_t)N * (uint32_t)stride;
             set_div_magic(tmp, (uint32_t)stride);
@@ -603,7 +690,7 @@ void f110_destroy(f110_sim *h)
     for (hipEvent_t ge : h->gevents) (void)hipEventDestroy(ge);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     {
-        void *rp[] = {h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_tsched, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
+        void *rp[] = {h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_tsched, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
         for (void *p : rp)
             if (p) (void)hipFree(p);
     }
@@ -670,12 +757,14 @@ static void fill_map_fields(ScanConst &k, int H, int W, double res, double ox, d
 
 static int finish_map(f110_sim *h, int H, int W, double res, double ox, double oy, double oc, double os)
 {
+    TRY(graphs_clear(h));
     ScanConst &k = h->k;
     h->multi_map = false;       // slot 0 changed: f110_set_env_maps has to be called again
     h->dev.maps_full = nullptr;
     h->dev.env_map = nullptr;
     fill_map_fields(k, H, W, res, ox, oy, oc, os);
     HIPCHK(h, hipMemcpyAsync(&k.oob_value, h->d_dt_row + ((size_t)H * W - 1), sizeof(double), hipMemcpyDeviceToHost, h->stream));
+#ifdef F110_EXPERIMENTAL
     if (h->cfg.map_layout == F110_MAP_TILED_F64) {
         const int tiles_h = (H + 3) / 4;
         if (h->d_dt_tiled) { (void)hipFree(h->d_dt_tiled); h->d_dt_tiled = nullptr; }
@@ -685,7 +774,9 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
         HIPCHK(h, hipGetLastError());
         k.table = h->d_dt_tiled;
         k.table_rm = h->d_dt_row;
-    } else {
+    } else
+#endif
+    {
         k.table = h->d_dt_row;
         k.table_rm = h->d_dt_row;
     }
@@ -701,7 +792,19 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
                            h->d_dt_pad);
         HIPCHK(h, hipGetLastError());
         k.pad = h->d_dt_pad;
+        if (h->cfg.map_layout == F110_MAP_PADDED_F64) {
+            // ONE table per map: the exact paths (k_integrate's first sample, the cold re-march, the unit
+            // kernels) address dt[r][c] as table_rm + r * row_bytes + 8 c — point them at the interior of
+            // the padded copy (its row pitch) and give the row-major original back (20.5 MB on example_map,
+            // and the first sample now touches lines the march keeps hot)
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            k.table = k.table_rm = h->d_dt_pad + (size_t)k.pad_border * k.pad_width + k.pad_border;
+            k.row_bytes = k.pad_row_bytes;
+            (void)hipFree(h->d_dt_row);
+            h->d_dt_row = nullptr;
+        }
     }
+#ifdef F110_EXPERIMENTAL
     if (h->cfg.map_layout == F110_MAP_CODE8) {
         // the 255 smallest distinct table values (one-time host sort of the downloaded table)
         std::vector<double> vals((size_t)H * W);
@@ -747,6 +850,7 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
                            h->d_wlut, n_lut, h->d_wcodes);
         HIPCHK(h, hipGetLastError());
     }
+#endif
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->has_map = true;
     return F110_OK;
@@ -837,6 +941,11 @@ static int add_map_slot(f110_sim *h, double *d_dt_row, int H, int W, double res,
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     ms.k.pad = ms.d_dt_pad;
+    // one table per track (see finish_map): the exact paths read the padded copy's interior
+    ms.k.table = ms.k.table_rm = ms.d_dt_pad + (size_t)ms.k.pad_border * ms.k.pad_width + ms.k.pad_border;
+    ms.k.row_bytes = ms.k.pad_row_bytes;
+    (void)hipFree(ms.d_dt_row);
+    ms.d_dt_row = nullptr;
     h->extra_maps.push_back(ms);
     if (slot) *slot = (int32_t)h->extra_maps.size();   // slot 0 is the map of f110_set_map_*
     return F110_OK;
@@ -869,6 +978,7 @@ int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     ENTER(h);
+    TRY(graphs_clear(h));
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h_env_map) {   // back to one map for everybody
         h->multi_map = false;
@@ -879,7 +989,6 @@ int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map)
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
     if (!padded_family(h->cfg.map_layout) || !h->k.pad)
         return fail(h, F110_ERR_STATE, "f110_set_env_maps needs map_layout = F110_MAP_PADDED_F64 and a slot-0 map that fits it");
-    if (h->dir_stride > 0) return fail(h, F110_ERR_STATE, "f110_set_env_maps is not available with more beams than table directions");
     const int E = h->cfg.num_envs, M = 1 + (int)h->extra_maps.size();
     for (int e = 0; e < E; ++e)
         if (h_env_map[e] < 0 || h_env_map[e] >= M) return fail(h, F110_ERR_INVALID, "f110_set_env_maps: env %d -> slot %d, but %d maps are registered", e, h_env_map[e], M);
@@ -919,7 +1028,11 @@ int f110_get_map_dt(f110_sim *h, double *out)
     if (!h || !out) return fail(h, F110_ERR_INVALID, "null argument");
     ENTER(h);
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
-    HIPCHK(h, hipMemcpyAsync(out, h->d_dt_row, (size_t)h->k.height * h->k.width * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    const size_t row = (size_t)h->k.width * sizeof(double);
+    if (h->d_dt_row)
+        HIPCHK(h, hipMemcpyAsync(out, h->d_dt_row, (size_t)h->k.height * row, hipMemcpyDeviceToHost, h->stream));
+    else   // the table lives inside its padded copy only
+        HIPCHK(h, hipMemcpy2DAsync(out, row, h->k.table_rm, (size_t)h->k.row_bytes, row, (size_t)h->k.height, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return F110_OK;
 }
@@ -954,6 +1067,7 @@ int f110_set_beam_tables(f110_sim *h, const double *sa, const double *co, const 
     if (!h || !sa || !co || !sd) return fail(h, F110_ERR_INVALID, "null argument");
     ENTER(h);
     if (B != h->cfg.num_beams) return fail(h, F110_ERR_INVALID, "beam tables must have num_beams=%d entries (got %d)", h->cfg.num_beams, B);
+    TRY(graphs_clear(h));   // ttc_side_max / ttc_cos_max below are launch arguments
     HIPCHK(h, hipMemcpyAsync(h->d_scan_angles, sa, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_beam_cos, co, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_side, sd, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
@@ -980,6 +1094,7 @@ int f110_set_params_batch(f110_sim *h, const double *h_params)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     ENTER(h);
+    TRY(graphs_clear(h));
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h_params) {   // back to one parameter set per agent slot
         h->dev.params = h->d_params;
@@ -1013,6 +1128,7 @@ static int noise_cache_extend(f110_sim *h, int upto);
 
 static void noise_release(f110_sim *h)
 {
+    (void)graphs_clear(h);
     if (h->d_noise) { (void)hipFree(h->d_noise); h->d_noise = nullptr; }
     if (h->d_rng_state) { (void)hipFree(h->d_rng_state); h->d_rng_state = nullptr; }
     if (h->d_rng_seed) { (void)hipFree(h->d_rng_seed); h->d_rng_seed = nullptr; }
@@ -1585,10 +1701,31 @@ static int noise_cache_extend(f110_sim *h, int upto)
 }
 
 // One step of the agents [begin, begin + count) (an env-aligned block) on stream `st`.
-//   collide_mode 0: k_collide on the side stream, forked / joined with events (hides under the scan)
-//                1: pair tests fused into k_integrate (2 or 4 agents per env)
-//                2: k_collide in line on `st`
+// Product build, one dispatch per (agents per env, beams) case:
+//   A = 1                      k_integrate -> scan -> k_finalize_solo
+//   A = 2 (re-seat armed, or a small batch)
+//                              k_integrate -> scan -> k_finalize_pair[_flat]   (pair test + window inside the last kernel)
+//   otherwise                  k_integrate -> { scan || k_collide on the side stream } -> k_finalize
+// and the scan kernel by table / beam count: k_scan_rays_agent (PADDED table; longest-first order for small
+// batches), k_scan_dirs_agent (more beams than table directions), k_scan_rays (row-major table, few beams).
+// The experimental build adds collide_mode 1 (pair tests fused into k_integrate) / 2 (k_collide in line), the
+// other layouts' kernels, two-pass dedupe and the forced geometries of f110_exp_set.
 // ev[0..3] (or nullptr): profiling events before integrate / before scan / after scan / after finalize.
+enum ScanKind { SCAN_FLAT, SCAN_AGENT, SCAN_AGENT_SCHED, SCAN_DIRS, SCAN_TWO_PASS, SCAN_WINDOW };
+
+static ScanKind pick_scan(const f110_sim *h, int begin, int count)
+{
+    const bool padded = padded_family(h->cfg.map_layout) && h->k.pad;
+    if (h->dir_stride > 0) {
+        if (padded && !(kExperimental && h->exp.dedupe_two_pass)) return SCAN_DIRS;
+        return (kExperimental && !h->multi_map) ? SCAN_TWO_PASS : SCAN_FLAT;   // product: every beam is marched
+    }
+    if (!(h->multi_map || agent_aligned(h))) return SCAN_FLAT;
+    if (kExperimental && h->cfg.map_layout == F110_MAP_WINDOW_LDS && h->d_wcodes && !h->multi_map && !h->exp.no_window) return SCAN_WINDOW;
+    if (h->task_order && !h->multi_map && !h->lookups_on && begin == 0 && count == h->N && !h->use_graph && !h->exp.scan_env_counter) return SCAN_AGENT_SCHED;
+    return SCAN_AGENT;
+}
+
 static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const double *d_actions, int collide_mode, hipEvent_t *ev)
 {
     const int N = h->N, A = h->cfg.num_agents, B = h->k.num_beams;
@@ -1596,30 +1733,37 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     dev.agent_begin = begin;
     dev.agent_count = count;
     const bool multi = A > 1;
-    const bool sched_step = h->task_order && !h->multi_map && !h->lookups_on && begin == 0 && count == N && !h->use_graph &&
-                            h->dir_stride == 0 && agent_aligned(h) && !(h->cfg.map_layout == F110_MAP_WINDOW_LDS && h->d_wcodes);
-    dev.sched_count_zero = sched_step ? h->d_tcount + (h->task_epoch & 1u) : nullptr;
+    // the scan kernel of this step, decided ONCE: the launch below and what k_integrate prepares for it
+    // (the longest-first list counter) follow the same answer
+    const ScanKind scan = pick_scan(h, begin, count);
+    dev.sched_count_zero = scan == SCAN_AGENT_SCHED ? h->d_tcount + (h->task_epoch & 1u) : nullptr;
     if (dev.noise_rng && (dev.noise_rng == 2 || h->noise_ub >= (long long)dev.noise_rows)) {
         const int apb = dev.noise_rng == 2 ? 16 : 64;   // per-agent streams: every agent needs a row, keep the waves many
         hipLaunchKernelGGL(k_noise_rows, dim3((count + apb - 1) / apb), dim3(256), 0, st, dev, h->noise_gen, B, apb);
     }
     if (ev) HIPCHK(h, hipEventRecord(ev[0], st));
-    if (multi && collide_mode == 1 && A == 2)
+    bool fused_integrate = false;
+#ifdef F110_EXPERIMENTAL
+    if (multi && collide_mode == 1 && A == 2) {
         hipLaunchKernelGGL(k_integrate<2>, grid1d(count, 64), dim3(64), 0, st, dev, h->k, d_actions);
-    else if (multi && collide_mode == 1 && A == 4)
+        fused_integrate = true;
+    } else if (multi && collide_mode == 1 && A == 4) {
         hipLaunchKernelGGL(k_integrate<4>, grid1d(count, 64), dim3(64), 0, st, dev, h->k, d_actions);
-    else
-        hipLaunchKernelGGL(k_integrate<0>, grid1d(count, 256), dim3(256), 0, st, dev, h->k, d_actions);
+        fused_integrate = true;
+    }
+#endif
+    if (!fused_integrate) hipLaunchKernelGGL(k_integrate<0>, grid1d(count, 256), dim3(256), 0, st, dev, h->k, d_actions);
     // A = 2: the pair test and the opponent window inside k_finalize (k_finalize_pair) — unless the batch is
     // big AND finished envs are not re-seated inside the step: then k_finalize runs a wave per agent (crashed
     // cars pile up, windows grow to all beams) and 65 536 waves each carrying the prologue cost more than the
     // side stream does (parked cars, 65 536 agents: 0.70 vs 0.63 ms)
     const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0 && (h->dev.reseat_poses != nullptr || N < 8192);
-    const bool fused = (multi && collide_mode == 1 && (A == 2 || A == 4)) || pair_in_finalize;   // no k_collide launch
+    const bool no_collide_launch = fused_integrate || pair_in_finalize;
+    const bool side_collide = multi && !no_collide_launch && !(kExperimental && collide_mode == 2);
     // k_collide only feeds k_finalize, k_scan_rays only needs k_integrate: run the two side by
     // side (second stream, event fork/join) so the pair test + window set-up hides under the scan
-    if (multi && !fused) {
-        if (collide_mode == 0) {
+    if (multi && !no_collide_launch) {
+        if (side_collide) {
             HIPCHK(h, hipEventRecord(h->ev_integrated, st));
             HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_integrated, 0));
             hipLaunchKernelGGL(k_collide, grid1d(count, 64), dim3(64), 0, h->side_stream, dev, B);
@@ -1650,26 +1794,39 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         j.lookups_total = h->lookups_on ? h->d_lookups : nullptr;
         j.k_cold = cold_consts(h);
         if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
-        scan_rays_fn fn = pick_rays<true>(h->k, h->cfg.map_layout);
-        static const bool two_pass_dedupe = std::getenv("F110_DEDUPE_TWO_PASS") != nullptr;   // A/B
-        if (h->dir_stride > 0 && padded_family(h->cfg.map_layout) && h->k.pad && !h->multi_map && !two_pass_dedupe) {
-            // more beams than table directions, PADDED table: march each distinct direction once and write
-            // the beams that share it from the same wave (k_scan_dirs_agent)
-            const uint32_t tpa = (uint32_t)h->dir_stride / 64u;
+        const bool cnt = j.lookups_total != nullptr;
+        // agent-aligned launch geometry: whole 64-ray tasks per agent, so every wave belongs to one agent (and one map)
+        auto agent_grid = [&](uint32_t tpa, dim3 &grid, uint32_t &wpb) {
             (void)rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
             j.n_tasks = (uint32_t)count * tpa;
             j.first_pose = (uint32_t)begin;
-            const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave, wpb = (uint32_t)h->scan_block / 64u;
-            const dim3 grid((waves + wpb - 1) / wpb), block(h->scan_block);
-            const bool cnt = j.lookups_total != nullptr;
-            if (h->k.ident_rot) {
-                if (cnt) hipLaunchKernelGGL((k_scan_dirs_agent<true, true>), grid, block, 0, st, j, h->k, tpa);
-                else hipLaunchKernelGGL((k_scan_dirs_agent<true, false>), grid, block, 0, st, j, h->k, tpa);
-            } else {
-                if (cnt) hipLaunchKernelGGL((k_scan_dirs_agent<false, true>), grid, block, 0, st, j, h->k, tpa);
-                else hipLaunchKernelGGL((k_scan_dirs_agent<false, false>), grid, block, 0, st, j, h->k, tpa);
-            }
-        } else if (h->dir_stride > 0) {
+            wpb = (uint32_t)h->scan_block / 64u;
+            const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave;
+            grid = dim3((waves + wpb - 1) / wpb);
+        };
+        const dim3 block(h->scan_block);
+        dim3 grid;
+        uint32_t wpb = 1;
+        switch (scan) {
+        case SCAN_DIRS: {
+            // more beams than table directions, PADDED table: march each distinct direction once and write
+            // the beams that share it from the same wave (k_scan_dirs_agent)
+            const uint32_t tpa = (uint32_t)h->dir_stride / 64u;
+            agent_grid(tpa, grid, wpb);
+#define DIRS_SCAN(PM, ID)                                                                                                                    \
+    do {                                                                                                                                     \
+        if (cnt) hipLaunchKernelGGL((k_scan_dirs_agent<PM, ID, true>), grid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);     \
+        else hipLaunchKernelGGL((k_scan_dirs_agent<PM, ID, false>), grid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);        \
+    } while (0)
+            if (h->multi_map) DIRS_SCAN(true, false);
+            else if (h->k.ident_rot) DIRS_SCAN(false, true);
+            else DIRS_SCAN(false, false);
+#undef DIRS_SCAN
+            break;
+        }
+#ifdef F110_EXPERIMENTAL
+        case SCAN_TWO_PASS: {
+            if (!h->d_dir_ranges) TRY(dmalloc(h, &h->d_dir_ranges, (size_t)N * h->dir_stride));
             RayJob jd = j;  // pass 1: one ray per (agent, distinct direction)
             jd.n_rays = (uint32_t)N * (uint32_t)h->dir_stride;
             jd.ranges = h->d_dir_ranges;
@@ -1678,54 +1835,77 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             jd.div_magic = h->dir_magic;
             jd.div_shift = h->dir_shift;
             const dim3 gd = rays_grid(jd, h->scan_block, h->scan_tasks_per_wave);
-            hipLaunchKernelGGL(fn, gd, dim3(h->scan_block), 0, st, jd, h->k);
+            hipLaunchKernelGGL(pick_rays<true>(h->k, h->cfg.map_layout), gd, block, 0, st, jd, h->k);
             j.dir_stride = h->dir_stride;  // pass 2: every beam picks its direction's range
             j.dir_ranges = h->d_dir_ranges;
             j.lookups_total = nullptr;
             hipLaunchKernelGGL(k_expand_beams, grid1d(j.n_rays, 256), dim3(256), 0, st, j, h->k);
-        } else if (h->multi_map || agent_aligned(h)) {
-            // whole 64-ray tasks per agent, so every wave belongs to one agent (and one map)
+            break;
+        }
+        case SCAN_WINDOW: {
+            // one workgroup per agent, its neighbourhood of the table staged in LDS
             const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
-            (void)rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
-            j.n_tasks = (uint32_t)count * tpa;
-            j.first_pose = (uint32_t)begin;
-            const uint32_t waves = (j.n_tasks + j.tasks_per_wave - 1) / j.tasks_per_wave, wpb = (uint32_t)h->scan_block / 64u;
-            const dim3 grid((waves + wpb - 1) / wpb), block(h->scan_block);
-            const bool cnt = j.lookups_total != nullptr;
-            static const bool no_window = std::getenv("F110_NO_WINDOW") != nullptr;
-            if (h->cfg.map_layout == F110_MAP_WINDOW_LDS && h->d_wcodes && !h->multi_map && !no_window) {
-                // one workgroup per agent, its neighbourhood of the table staged in LDS
-                j.win_codes = h->d_wcodes;
-                j.win_lut = h->d_wlut;
-                j.win_pitch = h->wcode_pitch;
-                const dim3 wgrid((unsigned)count), wblock(256);
-                if (h->k.ident_rot) {
-                    if (cnt) hipLaunchKernelGGL((k_scan_rays_window<true, true>), wgrid, wblock, 0, st, j, h->k, tpa);
-                    else hipLaunchKernelGGL((k_scan_rays_window<true, false>), wgrid, wblock, 0, st, j, h->k, tpa);
-                } else {
-                    if (cnt) hipLaunchKernelGGL((k_scan_rays_window<false, true>), wgrid, wblock, 0, st, j, h->k, tpa);
-                    else hipLaunchKernelGGL((k_scan_rays_window<false, false>), wgrid, wblock, 0, st, j, h->k, tpa);
-                }
-            } else if (h->task_order && !h->multi_map && !cnt && begin == 0 && count == N && !h->use_graph && (h->scan_block % 64) == 0) {
-                // longest-first: last step's long tasks are served by the first blocks of the launch
-                const uint32_t parity = h->task_epoch & 1u;
-                j.sched = h->d_tsched + parity;
-                j.epoch_r = h->task_epoch - 1u;
-                j.epoch_w = h->task_epoch;
-                j.long_blocks = (h->task_cap + wpb - 1) / wpb;
-                h->task_epoch += 1u;
-                const dim3 sgrid(grid.x + j.long_blocks);
-                if (h->k.ident_rot)
-                    hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true>), sgrid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
-                else
-                    hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, true>), sgrid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+            agent_grid(tpa, grid, wpb);
+            j.win_codes = h->d_wcodes;
+            j.win_lut = h->d_wlut;
+            j.win_pitch = h->wcode_pitch;
+            const dim3 wgrid((unsigned)count), wblock(256);
+            if (h->k.ident_rot) {
+                if (cnt) hipLaunchKernelGGL((k_scan_rays_window<true, true>), wgrid, wblock, 0, st, j, h->k, tpa);
+                else hipLaunchKernelGGL((k_scan_rays_window<true, false>), wgrid, wblock, 0, st, j, h->k, tpa);
             } else {
-#define AGENT_SCAN(PM, ID)                                                                                                         \
-    do {                                                                                                                           \
-        if (cnt)                                                                                                                   \
-            hipLaunchKernelGGL((k_scan_rays_agent<PM, ID, true>), grid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa); \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((k_scan_rays_agent<PM, ID, false>), grid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa); \
+                if (cnt) hipLaunchKernelGGL((k_scan_rays_window<false, true>), wgrid, wblock, 0, st, j, h->k, tpa);
+                else hipLaunchKernelGGL((k_scan_rays_window<false, false>), wgrid, wblock, 0, st, j, h->k, tpa);
+            }
+            break;
+        }
+#endif
+        case SCAN_AGENT_SCHED: {
+            // longest-first: last step's long tasks are served by the first blocks of the launch
+            const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
+            agent_grid(tpa, grid, wpb);
+            const uint32_t parity = h->task_epoch & 1u;
+            j.sched = h->d_tsched + parity;
+            j.epoch_r = h->task_epoch - 1u;
+            j.epoch_w = h->task_epoch;
+            j.long_blocks = (h->task_cap + wpb - 1) / wpb;
+            h->task_epoch += 1u;
+            const dim3 sgrid(grid.x + j.long_blocks);
+            if (h->k.ident_rot)
+                hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true>), sgrid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+            else
+                hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, true>), sgrid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+            break;
+        }
+        case SCAN_AGENT: {
+            const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
+            agent_grid(tpa, grid, wpb);
+            size_t lds = 0;
+#ifdef F110_EXPERIMENTAL
+            // fusion-feasibility probes: the occupancy a kernel with k_finalize_pair's 118 VGPRs
+            // would run at (LDS reservation per one-wave workgroup caps the CU at 16 waves), and the price of a
+            // per-env completion counter
+            if (h->exp.scan_occupancy == 4 && h->scan_block == 64) lds = 10 * 1024;
+            if (h->exp.scan_env_counter && !h->multi_map && !cnt) {
+                if (!h->d_env_done) {
+                    TRY(dmalloc(h, &h->d_env_done, (size_t)h->cfg.num_envs));
+                    HIPCHK(h, hipMemsetAsync(h->d_env_done, 0, sizeof(uint32_t) * h->cfg.num_envs, st));
+                }
+                j.env_done = h->d_env_done;
+                j.tasks_per_env = tpa * (uint32_t)A;
+                if (h->k.ident_rot)
+                    hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, false, true>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                else
+                    hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, false, true>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                break;
+            }
+#endif
+#define AGENT_SCAN(PM, ID)                                                                                                           \
+    do {                                                                                                                             \
+        if (cnt)                                                                                                                     \
+            hipLaunchKernelGGL((k_scan_rays_agent<PM, ID, true>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa); \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_scan_rays_agent<PM, ID, false>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa); \
     } while (0)
             if (h->multi_map)
                 AGENT_SCAN(true, false);
@@ -1734,33 +1914,50 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             else
                 AGENT_SCAN(false, false);
 #undef AGENT_SCAN
-            }
-        } else {
-            const dim3 grid = rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
-            hipLaunchKernelGGL(fn, grid, dim3(h->scan_block), 0, st, j, h->k);
+            break;
+        }
+        default: {   // SCAN_FLAT: ray = agent * B + beam (row-major table, few beams, or — product build — beams
+                     // beyond the table directions on a map the PADDED layout cannot hold)
+            const dim3 fgrid = rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
+            hipLaunchKernelGGL(pick_rays<true>(h->k, h->cfg.map_layout), fgrid, block, 0, st, j, h->k);
+            break;
+        }
         }
     }
     if (ev) HIPCHK(h, hipEventRecord(ev[2], st));
-    if (multi && !fused && collide_mode == 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_collided, 0));
+    if (side_collide) HIPCHK(h, hipStreamWaitEvent(st, h->ev_collided, 0));
     if (multi) {
-        static const int forced = std::getenv("F110_FINALIZE_LANES") ? std::atoi(std::getenv("F110_FINALIZE_LANES")) : 0;
         // few lanes per agent pay off when opponent windows are short (~36 beams); cars that have
         // crashed into each other see windows of up to all beams, so the narrow forms are used only
         // when finished envs are re-seated inside the step (f110_set_auto_reseat)
         const bool narrow = h->dev.reseat_poses != nullptr;
         // (with the pair test inside the kernel a group also carries that prologue: 16 lanes from 8192 agents up)
-        const int lanes = forced ? forced : (narrow && N >= 131072 ? 8 : (narrow && N >= (pair_in_finalize ? 8192 : 32768) ? 16 : 64));
-        if (pair_in_finalize) {
+        int lanes = narrow && N >= 131072 ? 8 : (narrow && N >= (pair_in_finalize ? 8192 : 32768) ? 16 : 64);
+        bool flat = pair_in_finalize && kFinalizeFlatDefault;
+#ifdef F110_EXPERIMENTAL
+        if (h->exp.finalize_lanes) lanes = h->exp.finalize_lanes;
+        if (h->exp.finalize_flat >= 0) flat = pair_in_finalize && h->exp.finalize_flat != 0;
+#endif
+        if (pair_in_finalize && flat) {
+            // the window loop flattened over the workgroup: AG agents per 256 threads (256 / AG lanes each in the prologue)
+            if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_flat<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
+            else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_flat<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
+            else hipLaunchKernelGGL(k_finalize_pair_flat<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
+        } else if (pair_in_finalize) {
             if (lanes == 8) hipLaunchKernelGGL(k_finalize_pair<8>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
             else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
+#ifdef F110_EXPERIMENTAL
             else if (lanes == 32) hipLaunchKernelGGL(k_finalize_pair<32>, dim3((count + 7) / 8), dim3(256), 0, st, dev, B);
+#endif
             else hipLaunchKernelGGL(k_finalize_pair<64>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
         } else if (lanes == 8)
             hipLaunchKernelGGL(k_finalize<8>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
         else if (lanes == 16)
             hipLaunchKernelGGL(k_finalize<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
+#ifdef F110_EXPERIMENTAL
         else if (lanes == 32)
             hipLaunchKernelGGL(k_finalize<32>, dim3((count + 7) / 8), dim3(256), 0, st, dev, B);
+#endif
         else
             hipLaunchKernelGGL(k_finalize<64>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
     } else {
@@ -1812,7 +2009,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     const bool prof = h->profiling && h->prof_used + 4 <= 4 * 65536;
     // the env groups need the agent-aligned scan (a launch per agent range); per-kernel profiling
     // brackets the kernels of ONE stream, so a profiled step runs as one block on the main stream
-    const bool grouped = h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0;
+    const bool grouped = kExperimental && h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0;
     if (!grouped) {
         TRY(join_groups(h));
         h->main_dirty = true;
@@ -1822,26 +2019,25 @@ int f110_step_device(f110_sim *h, const double *d_actions)
                 if (!(ev[i] = prof_event(h))) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
         }
         const int cmode = h->collide_mode;
+#ifdef F110_EXPERIMENTAL
         if (h->use_graph && !prof) {
             // the four launches and the fork/join of the side stream as ONE graph submission.  A graph is
             // valid for one set of launch arguments: every value a launch depends on is part of the key
             // (the agent arrays incl. re-seat / noise pointers, the scan constants, the action buffer, which
-            // optional kernels run); a handful of graphs cover a training loop (one per action buffer).
+            // optional kernels run, the switches); anything else that a launch reads through a pointer the
+            // handle may free and re-allocate (maps, beam tables, parameters) drops the cache (graphs_clear)
             if (!cold_consts(h)) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
             const int flags = (h->lookups_on ? 1 : 0) | (h->path_stats_on ? 2 : 0) | (cmode << 2) |
                               ((h->dev.noise_rng && (h->dev.noise_rng == 2 || h->noise_ub >= (long long)h->dev.noise_rows)) ? 16 : 0);
             hipGraphExec_t exec = nullptr;
             for (auto &g : h->graphs)
-                if (g.actions == d_actions && g.flags == flags && std::memcmp(&g.dev, &h->dev, sizeof(AgentArrays)) == 0 &&
-                    std::memcmp(&g.k, &h->k, sizeof(ScanConst)) == 0) {
+                if (g.actions == d_actions && g.flags == flags && g.noise_scale == h->noise_gen.scale && std::memcmp(&g.exp, &h->exp, sizeof(ExpSwitches)) == 0 &&
+                    std::memcmp(&g.dev, &h->dev, sizeof(AgentArrays)) == 0 && std::memcmp(&g.k, &h->k, sizeof(ScanConst)) == 0) {
                     exec = g.exec;
                     break;
                 }
             if (!exec) {
-                if (h->graphs.size() >= 64) {
-                    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-                    h->graphs.clear();
-                }
+                if (h->graphs.size() >= 64) TRY(graphs_clear(h));
                 hipGraph_t graph = nullptr;
                 HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
                 const int rc = step_range(h, h->stream, 0, N, d_actions, cmode, nullptr);
@@ -1854,16 +2050,21 @@ int f110_step_device(f110_sim *h, const double *d_actions)
                 f110_sim::StepGraph g;
                 g.dev = h->dev;
                 g.k = h->k;
+                g.exp = h->exp;
+                g.noise_scale = h->noise_gen.scale;
                 g.actions = d_actions;
                 g.flags = flags;
                 g.exec = exec;
                 h->graphs.push_back(g);
             }
             HIPCHK(h, hipGraphLaunch(exec, h->stream));
-        } else {
+        } else
+#endif
+        {
             TRY(step_range(h, h->stream, 0, N, d_actions, cmode, prof ? ev : nullptr));
         }
     } else {
+#ifdef F110_EXPERIMENTAL
         if (h->main_dirty) {
             HIPCHK(h, hipEventRecord(h->ev_main, h->stream));
             for (hipStream_t gs : h->gstreams) HIPCHK(h, hipStreamWaitEvent(gs, h->ev_main, 0));
@@ -1877,6 +2078,9 @@ int f110_step_device(f110_sim *h, const double *d_actions)
             TRY(step_range(h, h->gstreams[g], e0 * A, (e1 - e0) * A, d_actions, mode == 0 ? 2 : mode, nullptr));
         }
         h->groups_busy = true;
+#else
+        (void)A;
+#endif
     }
     h->noise_ub += 1;
     HIPCHK(h, hipGetLastError());

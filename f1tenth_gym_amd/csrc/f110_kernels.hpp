@@ -306,6 +306,9 @@ struct RayJob {
     // longest-first task order (k_scan_rays_agent<.., SCHED>): see TaskSched
     const struct TaskSched *sched;
     uint32_t epoch_r, epoch_w, long_blocks, pad_sched;
+    // fusion-feasibility probe (experimental build): per-env count of finished scan tasks, reset by the last arriver
+    uint32_t *env_done;
+    uint32_t tasks_per_env, pad_env;
     // k_scan_rays_window: 1-byte codes of the padded table (row-major, `win_pitch` bytes per row, a multiple
     // of 16) and the 256-entry exact value LUT (entry 255 unused: code 255 = "read the float64 table")
     const uint8_t *win_codes;
@@ -511,7 +514,24 @@ struct MapFast {
 };
 static_assert(sizeof(MapFast) == 64, "MapFast is read as one 64-byte scalar load");
 
-template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false>
+// the per-env map's constants through the scalar cache (one 64-byte record), pinned to SGPRs
+__device__ __forceinline__ void load_map_fast(ScanConst &km, const MapFast *__restrict__ maps_fast, int slot)
+{
+    typedef const __attribute__((address_space(4))) MapFast *cmap_t;
+    const cmap_t m0 = (cmap_t)(maps_fast) + slot;
+    const uint64_t pa = (uint64_t)m0->pad;
+    km.pad = (const double *)(((uint64_t)(uint32_t)uniform_i32((int)(pa >> 32)) << 32) | (uint32_t)uniform_i32((int)pa));
+    km.pad_cx = uniform_f64(m0->pad_cx);
+    km.pad_cy = uniform_f64(m0->pad_cy);
+    km.pad_axx = uniform_f64(m0->pad_axx);
+    km.pad_axy = uniform_f64(m0->pad_axy);
+    km.pad_ayx = uniform_f64(m0->pad_ayx);
+    km.pad_ayy = uniform_f64(m0->pad_ayy);
+    km.pad_row_bytes = uniform_i32((int)m0->pad_row_bytes);
+    km.pad_max_samples = uniform_i32(m0->pad_max_samples);
+}
+
+template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false>
 __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
                                                           const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
@@ -551,7 +571,6 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         const int b = (int)((task - pl * tasks_per_agent) * 64u + lane);
         if (b >= (int)B) continue;
         typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
-        typedef const __attribute__((address_space(4))) MapFast *cmap_t;
         const chdr_t h0 = (chdr_t)(j.hdr) + p;
         const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
         const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
@@ -559,18 +578,8 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         ScanConst km = k;   // PER_ENV_MAP: only the fields set here differ
         const ScanConst *cold = j.k_cold;
         if (PER_ENV_MAP) {
-            const cmap_t m0 = (cmap_t)(maps_fast) + slot;
             cold = maps_full + slot;
-            const uint64_t pa = (uint64_t)m0->pad;
-            km.pad = (const double *)(((uint64_t)(uint32_t)uniform_i32((int)(pa >> 32)) << 32) | (uint32_t)uniform_i32((int)pa));
-            km.pad_cx = uniform_f64(m0->pad_cx);
-            km.pad_cy = uniform_f64(m0->pad_cy);
-            km.pad_axx = uniform_f64(m0->pad_axx);
-            km.pad_axy = uniform_f64(m0->pad_axy);
-            km.pad_ayx = uniform_f64(m0->pad_ayx);
-            km.pad_ayy = uniform_f64(m0->pad_ayy);
-            km.pad_row_bytes = uniform_i32((int)m0->pad_row_bytes);
-            km.pad_max_samples = uniform_i32(m0->pad_max_samples);
+            load_map_fast(km, maps_fast, slot);
         }
         // the beam's noise sample is requested before the march so that its latency hides under it:
         // row of the table / row cache, or (row -2) the row k_noise_rows left in this agent's scans[]
@@ -600,10 +609,18 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
             }
         }
         finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
+        if (ENVCNT && lane == 0u) {
+            // probe: what a per-env completion counter costs (one returning agent-scope atomic per task; the
+            // arrival that completes the env resets the counter, as a fused finalize would before it runs)
+            const uint32_t env = p / (j.tasks_per_env / tasks_per_agent);
+            const uint32_t old = __hip_atomic_fetch_add(j.env_done + env, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1u == j.tasks_per_env) __hip_atomic_store(j.env_done + env, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
 }
 
+#ifdef F110_EXPERIMENTAL   // measured and rejected: not part of the product library
 // ---- K2w: the step's ray march with the agent's neighbourhood staged in LDS ------------------------
 // north_star's "occupancy grid in LDS".  One workgroup = one agent: the kWin x kWin cells around the
 // lidar (1-byte codes of the padded table, 16 KB) and the exact 256-entry value LUT (2 KB) are staged
@@ -707,6 +724,8 @@ __global__ void __launch_bounds__(256) k_scan_rays_window(RayJob j, ScanConst k,
     }
 }
 
+#endif  // F110_EXPERIMENTAL
+
 // iTTC + store for one beam whose noise sample has been added already
 __device__ __forceinline__ void finish_beam_with(const RayJob &j, uint32_t p, int b, uint32_t ray, double r, double vel)
 {
@@ -734,8 +753,9 @@ __device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_
 // gets its own noise sample and iTTC test.  Replaces the (march to a [N][dir_stride] buffer,
 // k_expand_beams) pair: one launch less and no 1.6 GB round trip of intermediate ranges per step.
 // Bit-identical to marching every beam (beams that share a table index from one origin are one ray).
-template <bool IDENT, bool COUNT>
-__global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, uint32_t tasks_per_agent)
+template <bool PER_ENV_MAP, bool IDENT, bool COUNT>
+__global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
+                                                          const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
     const uint32_t B = (uint32_t)k.num_beams;
     const uint32_t tpw = j.tasks_per_wave;
@@ -760,6 +780,13 @@ __global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, 
         const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
         const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
         const int row = uniform_i32(h0->noise_row), fast = uniform_i32(h0->fast), i0 = uniform_i32(h0->i0);
+        ScanConst km = k;   // PER_ENV_MAP: this agent's track (f110_set_env_maps), constants through the scalar cache
+        const ScanConst *cold = j.k_cold;
+        if (PER_ENV_MAP) {
+            const int slot = uniform_i32(h0->map_slot);
+            cold = maps_full + slot;
+            load_map_fast(km, maps_fast, slot);
+        }
         double r_dir = 0.;
         if (s0 + (int)lane < n_dirs) {
             int didx = i0 + s0 + (int)lane;
@@ -769,11 +796,11 @@ __global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, 
             bool exact = fast == 0;
             if (fast) {
                 double ux, uy, cux, cuy;
-                padded_position<IDENT>(k, x, y, ux, uy);
-                padded_rate<IDENT>(k, cs.x, cs.y, cux, cuy);
-                exact = !march_padded<false>(k, ux, uy, cux, cuy, d0, r_dir, hr, hc, nl);
+                padded_position<IDENT>(km, x, y, ux, uy);
+                padded_rate<IDENT>(km, cs.x, cs.y, cux, cuy);
+                exact = !march_padded<false>(km, ux, uy, cux, cuy, d0, r_dir, hr, hc, nl);
             }
-            if (exact) r_dir = march_exact_cold<IDENT>(j.k_cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
+            if (exact) r_dir = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
             if (COUNT) nl_acc += (uint32_t)nl;
         }
         // first beam whose table index is direction s0 (relative indices never decrease with the beam):
@@ -805,6 +832,7 @@ __global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, 
     if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
 }
 
+#ifdef F110_EXPERIMENTAL   // two-pass dedupe: superseded by k_scan_dirs_agent
 // ---- K2b: beam expansion of the dedupe pass ---------------------------------------------------
 // More beams than table directions (BASELINE config 5: 4096 beams, theta_dis = 2000 -> 1497
 // distinct directions per scan): beams that share a table index from the same origin are the same
@@ -824,6 +852,8 @@ __global__ void __launch_bounds__(256) k_expand_beams(RayJob j, ScanConst k)
     const double r = j.dir_ranges[(size_t)p * j.dir_stride + s];
     finish_beam(j, B, p, b, ray, r, hd.row, hd.vel);
 }
+
+#endif  // F110_EXPERIMENTAL
 
 // ---- scan noise generated on the device --------------------------------------------
 // rng.normal(0., std, num_beams) of laser_models.py:450-452 — NumPy's PCG64 + ziggurat, restated in
@@ -1092,6 +1122,128 @@ __global__ void __launch_bounds__(256) k_finalize_pair(AgentArrays a, int32_t B)
     }
     if (a.reseat_poses && tid == 0) {
         // the ego's collisions value of this step: the pair flag (the same test for both agents) OR its wall flag
+        const int ego = (i & ~1) + a.reseat_ego;
+        if (hit || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
+    }
+}
+
+// ---- K3f: k_finalize_pair with the window loop flattened over the workgroup (round 3) ---------------------
+// k_finalize_pair gives every agent a fixed share of lanes for its opponent window, so a wave runs as many
+// passes as its widest window needs (a follower sees ~50 beams of the car ahead, the leader none, a car
+// about to be hit a few hundred) and the rest of its lanes idle through them.  Here a 256-thread workgroup
+// takes AG agents: the prologue (pair test, window) runs 256 / AG lanes per agent exactly as before and
+// leaves each agent's record in LDS; an exclusive scan of the AG window lengths turns them into one list of
+// (agent, beam) items, and the 256 threads walk that list — every pass has all lanes busy whatever the
+// split between agents.  Same functions on the same operands per beam: bit-identical to k_finalize_pair.
+template <int AG>
+__global__ void __launch_bounds__(256) k_finalize_pair_flat(AgentArrays a, int32_t B)
+{
+    constexpr int L = 256 / AG;   // lanes per agent in the prologue (lanes 0-5 carry work: L >= 8)
+    static_assert(L >= 8 && (AG & (AG - 1)) == 0 && AG <= 32, "AG is a power of two, at most 32");
+    __shared__ double s_rec[AG][12];   // ex, ey, eth, the opponent's box (8), pad
+    __shared__ int s_lo[AG], s_cnt[AG], s_off[AG + 1];
+    const int slot = threadIdx.x / L, tid = threadIdx.x & (L - 1);
+    const int first = a.agent_begin + (int)blockIdx.x * AG, end = a.agent_begin + a.agent_count;
+    const bool live = first + slot < end;
+    const int i = live ? first + slot : end - 1;   // idle groups shadow the last agent (no stores) so shuffles stay whole
+    const int N = a.n_agents_total;
+    const int me = i & 1, o = i ^ 1;
+    const int wall = a.in_collision[i];
+    const double ex = a.state[i], ey = a.state[(size_t)N + i];
+    const double th_live = a.state[4 * (size_t)N + i];
+    const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
+    const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
+    const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
+    const double eth = wall ? 0.0 : th_live;
+    double v[8];
+    box_vertices(ox, oy, oth, blen, bwid, v);
+    int idx = 0, cl = 0, ch = B - 1, hit = 0;
+    {
+        const double head = atan2(sin(eth), cos(eth));
+        const double px = tid == 0 ? v[0] : (tid == 1 ? v[2] : (tid == 2 ? v[4] : (tid == 3 ? v[6] : ox)));
+        const double py = tid == 0 ? v[1] : (tid == 1 ? v[3] : (tid == 2 ? v[5] : (tid == 3 ? v[7] : oy)));
+        const double dx = px - ex, dy = py - ey;
+        const double norm = sqrt(dx * dx + dy * dy);
+        const double qx = tid < 4 ? dx / norm : dx, qy = tid < 4 ? dy / norm : dy;
+        const double dir = atan2(qy, qx);
+        if (tid < 4) {
+            idx = vertex_beam_from_angles(head, dir, a.scan_angles, B, a.angle_inc);
+        } else if (tid == 4) {
+            disc_beam_range_from(norm, eth, dir, head, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
+        } else if (tid == 5) {
+            const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+            const double cdx = ox - ex, cdy = oy - ey;
+            if (cdx * cdx + cdy * cdy <= reach * reach) {
+                double mine[8], other[8];
+                box_vertices(ex, ey, th_live, a.box_length, a.box_width, mine);
+                box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
+                hit = (me == 0 ? gjk_overlap(mine, other) : gjk_overlap(other, mine)) ? 1 : 0;
+            }
+        }
+    }
+    const int i0 = __shfl(idx, 0, L), i1 = __shfl(idx, 1, L), i2 = __shfl(idx, 2, L), i3 = __shfl(idx, 3, L);
+    cl = __shfl(cl, 4, L);
+    ch = __shfl(ch, 4, L);
+    hit = __shfl(hit, 5, L);
+    int ref_lo = i0 < i1 ? i0 : i1, t2 = i2 < i3 ? i2 : i3;
+    ref_lo = ref_lo < t2 ? ref_lo : t2;
+    int ref_hi = i0 > i1 ? i0 : i1;
+    t2 = i2 > i3 ? i2 : i3;
+    ref_hi = ref_hi > t2 ? ref_hi : t2;
+    const int lo = ref_lo > cl ? ref_lo : cl, hi = ref_hi < ch ? ref_hi : ch;
+    if (tid == 0) {
+        if (live) {
+            if (wall) {
+                a.state[3 * (size_t)N + i] = 0.;
+                a.state[4 * (size_t)N + i] = 0.;
+                a.state[5 * (size_t)N + i] = 0.;
+                a.state[6 * (size_t)N + i] = 0.;
+            }
+            a.collisions[i] = (hit || wall) ? 1.0 : 0.0;
+            a.collision_idx[i] = hit ? (double)(1 - me) : -1.0;
+            a.step_count[i] += 1;
+        }
+        s_lo[slot] = lo;
+        s_cnt[slot] = (live && hi >= lo) ? hi - lo + 1 : 0;
+        s_rec[slot][0] = ex;
+        s_rec[slot][1] = ey;
+        s_rec[slot][2] = eth;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s_rec[slot][3 + c] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // exclusive scan of the AG window lengths (AG <= 32: one wave)
+        const int lane = (int)threadIdx.x;
+        int c = lane < AG ? s_cnt[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < AG; d <<= 1) {
+            const int up = __shfl_up(c, d);
+            if (lane >= d) c += up;
+        }
+        if (lane < AG) s_off[lane + 1] = c;
+        if (lane == 0) s_off[0] = 0;
+    }
+    __syncthreads();
+    const int total = s_off[AG];
+    for (int item = (int)threadIdx.x; item < total; item += 256) {
+        int ag = 0;   // the largest ag with s_off[ag] <= item (its window is not empty: item < s_off[ag + 1])
+#pragma unroll
+        for (int st = AG / 2; st; st >>= 1)
+            if (s_off[ag + st] <= item) ag += st;
+        const int b = s_lo[ag] + (item - s_off[ag]);
+        const double bex = s_rec[ag][0], bey = s_rec[ag][1], beth = s_rec[ag][2];
+        double bv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bv[c] = s_rec[ag][3 + c];
+        double *sc = a.scans + (size_t)(first + ag) * B;
+        const double bt = beth + a.scan_angles[b];
+        const double r0 = sc[b];
+        double v3x, v3y;
+        sincos(bt + kPi / 2., &v3y, &v3x);
+        const double r = box_range(bex, bey, v3x, v3y, bv, r0);
+        if (r < r0) sc[b] = r;
+    }
+    if (a.reseat_poses && tid == 0 && live) {
         const int ego = (i & ~1) + a.reseat_ego;
         if (hit || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
     }
@@ -1565,6 +1717,7 @@ __global__ void k_build_padded(const double *__restrict__ rowmajor, int H, int W
     pad[i] = inside ? rowmajor[(size_t)r * W + c] : rowmajor[(size_t)H * W - 1];
 }
 
+#ifdef F110_EXPERIMENTAL   // tiled / byte-code / window layouts
 __global__ void k_retile(const double *__restrict__ rowmajor, int H, int W, int tiles_w, int tiles_h, double *__restrict__ tiled)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1629,6 +1782,8 @@ __global__ void k_build_codes_padded(const double *__restrict__ pad, int Hp, int
     }
     codes[t] = code;
 }
+
+#endif  // F110_EXPERIMENTAL
 
 // examples/waypoint_follow.py: PurePursuitPlanner.plan, 16 lanes per pose (4 poses per wave).  The
 // lanes of a group split the segments of the waypoint polyline: the nearest-point search is a

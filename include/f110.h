@@ -48,7 +48,9 @@ enum {
 
 enum { F110_INTEGRATOR_RK4 = 1, F110_INTEGRATOR_EULER = 2 }; /* base_classes.py:40-42 */
 
-/* distance-table layouts in HBM (DESIGN.md §data layout) */
+/* distance-table layouts in HBM (DESIGN.md §data layout).  libf110_hip.so, the product, has
+ * F110_MAP_ROWMAJOR_F64 and F110_MAP_PADDED_F64; the other three were built, measured and not adopted and
+ * exist in libf110_hip_exp.so (built with -DF110_EXPERIMENTAL) only — f110_create of the product refuses them. */
 enum {
     F110_MAP_ROWMAJOR_F64 = 0, /* dt[r][c] as the reference stores it */
     F110_MAP_TILED_F64 = 1,    /* 4x4-cell tiles, one 128-byte line per tile */
@@ -78,8 +80,8 @@ typedef struct f110_config {
     int32_t map_layout;    /* F110_MAP_* */
     int32_t scan_block;    /* threads per scan workgroup (0 = default) */
     int32_t scan_tasks_per_wave; /* consecutive 64-ray tasks each wave walks (0 = default) */
-    int32_t step_groups;   /* independent env blocks stepped on streams of their own (0 = automatic) */
-    int32_t step_graph;    /* 1: submit the step as one captured HIP graph (0 = separate launches) */
+    int32_t step_groups;   /* experimental build: independent env blocks stepped on streams of their own (product: 0 or 1) */
+    int32_t step_graph;    /* experimental build: 1 = submit the step as one captured HIP graph (product: 0) */
     double fov, eps, max_range;
     double time_step, lidar_dist, ttc_thresh;
     double params[F110_NPARAMS]; /* initial vehicle params for every agent slot */
@@ -96,6 +98,16 @@ int f110_device_pci_bus_id(int32_t device, char *out, int32_t len);
 /* "csrc=<sha256 prefix of the kernel sources this library was built from>": profiles/ entries and
  * bench.py's roofline record carry the same hash, so a reader can tie a number to the code */
 const char *f110_build_info(void);
+
+/* 1 for libf110_hip_exp.so (-DF110_EXPERIMENTAL), 0 for the product library */
+int f110_is_experimental(void);
+/* The switchboard of the experimental build — every variant that was measured against the default and not
+ * adopted, for the A/B tests and the profiles.  The product library refuses every key
+ * (F110_ERR_STATE) and reads no environment variable; a step of the product has ONE dispatch per (agents per
+ * env, beams) case.  Keys: scan_flat, dedupe_two_pass, no_window, finalize_lanes (0|8|16|32|64),
+ * finalize_flat (-1|0|1), collide_mode (0 side stream | 1 fused into k_integrate | 2 in line | 3 inside
+ * k_finalize), step_graph, task_order, task_thr, scan_occupancy, scan_env_counter (fusion probes). */
+int f110_exp_set(f110_sim *h, const char *key, int32_t value);
 
 int f110_create(const f110_config *cfg, f110_sim **out);
 void f110_destroy(f110_sim *h);
@@ -124,7 +136,7 @@ int f110_set_beam_tables(f110_sim *h, const double *h_scan_angles, const double 
  * f110_set_map_* is slot 0; f110_add_map_* registers further maps (same arguments, same exact-EDT
  * pipeline) and returns their slot; f110_set_env_maps assigns a slot to every env (h_env_map
  * [num_envs]; NULL = everybody back on slot 0).  Needs map_layout = F110_MAP_PADDED_F64 with every
- * map fitting it and num_beams below the dedupe threshold.  Changing slot 0 or adding maps takes
+ * map fitting it (any beam count).  Changing slot 0 or adding maps takes
  * effect at the next f110_set_env_maps.  Unit entry points (f110_scan_batch ...) keep using slot 0. */
 int f110_add_map_image(f110_sim *h, const uint8_t *h_img, int32_t height, int32_t width,
                        double resolution, double origin_x, double origin_y, double origin_yaw,

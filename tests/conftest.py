@@ -10,3 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    """A test that reaches a layout / step form / switch of the experimental build while the product library
+    is loaded (the default) is skipped, not failed: the same test runs for real under
+    F110_LIB_VARIANT=experimental (tests/test_gpu_round3.py::test_gpu_suite_on_the_experimental_build)."""
+    outcome = yield
+    if outcome.excinfo is not None:
+        from f1tenth_gym_amd._ffi import ExperimentalOnly
+        if isinstance(outcome.excinfo[1], ExperimentalOnly):
+            outcome.force_exception(pytest.skip.Exception("experimental build only: %s" % outcome.excinfo[1], _use_item_location=True))

@@ -18,13 +18,14 @@ def _header_symbols():
 
 def test_library_builds_and_exports_every_declared_symbol():
     from f1tenth_gym_amd import build, _ffi
-    lib_path = build.build()
-    assert os.path.isfile(lib_path)
-    L = C.CDLL(lib_path)
     names = _header_symbols()
     assert len(names) >= 40
-    for n in names:
-        assert hasattr(L, n), "libf110_hip.so does not export %s" % n
+    for lib_path, is_exp in zip(build.build_all(), (0, 1)):   # the product and the experimental build: one ABI
+        assert os.path.isfile(lib_path)
+        L = C.CDLL(lib_path)
+        for n in names:
+            assert hasattr(L, n), "%s does not export %s" % (os.path.basename(lib_path), n)
+        assert L.f110_is_experimental() == is_exp
     # the ctypes binding covers the same set
     assert sorted(_ffi.PROTOTYPES) == names
     assert _ffi.lib().f110_abi_version() == _ffi.ABI_VERSION == 1
@@ -51,6 +52,19 @@ def test_no_gpu_fails_loudly():
     assert _ffi.lib().f110_create(C.byref(cfg), C.byref(h)) == _ffi.ERR_INVALID   # abi_version 0
     assert "ABI version" in _ffi.last_error()
     assert _ffi.lib().f110_step(None, None) == _ffi.ERR_INVALID
+
+
+def test_product_library_reads_no_environment():
+    """nine getenv switches lived in the shared library; the product build has none (the lab has
+    f110_exp_set), and refuses the experimental switchboard"""
+    from f1tenth_gym_amd import build
+    for src in build.DEPS:
+        assert "getenv" not in open(src).read(), src
+    blob = open(build.build(), "rb").read()
+    assert b"getenv" not in blob
+    L = C.CDLL(build.build())
+    L.f110_last_error.restype = C.c_char_p
+    assert L.f110_exp_set(None, b"finalize_flat", 1) != 0
 
 
 def test_product_never_imports_the_oracle():

@@ -625,11 +625,10 @@ def test_pair_test_in_finalize_is_bit_identical(amd, monkeypatch, lanes):
     (k_finalize_pair, the default for A = 2: no side stream, no events) against k_collide on the side
     stream + k_finalize: every array incl. collision_idx identical, through wall hits, car-to-car
     contacts, the fused re-seat and resets, for every lanes-per-agent form"""
-    monkeypatch.setenv("F110_FINALIZE_LANES", lanes)
     E, A, T = 200, 2, 120
-    monkeypatch.setenv("F110_COLLIDE_MODE", "0")
+    monkeypatch.setenv("F110_EXP", "finalize_lanes=%s,collide_mode=0" % lanes)   # switches of the experimental build
     a = _pair(amd, E, A)
-    monkeypatch.setenv("F110_COLLIDE_MODE", "3")
+    monkeypatch.setenv("F110_EXP", "finalize_lanes=%s,collide_mode=3" % lanes)
     b = _pair(amd, E, A)
     poses = bench_start_poses(E, A, gap_wp=3)     # 0.6 m apart: contacts happen
     rng = np.random.default_rng(21)
@@ -666,10 +665,9 @@ def test_longest_first_task_order_is_invisible(amd, monkeypatch, thr):
     so that most tasks go through the list, and with the default one — against forced off: not a bit may
     change, through resets, re-seat arming, lookup counting (which suspends the ordering) and 70 steps"""
     E, A, T = 300, 2, 70
-    monkeypatch.setenv("F110_TASK_ORDER", "0")
+    monkeypatch.setenv("F110_EXP", "task_order=0")   # switches of the experimental build
     a = _pair(amd, E, A)
-    monkeypatch.setenv("F110_TASK_ORDER", "1")
-    monkeypatch.setenv("F110_TASK_THR", thr)
+    monkeypatch.setenv("F110_EXP", "task_order=1,task_thr=%s" % thr)
     b = _pair(amd, E, A)
     poses = bench_start_poses(E, A)
     rng = np.random.default_rng(8)

@@ -1,0 +1,87 @@
+#!/bin/bash
+# Round-3 GPU sessions (one gpurun call each; every phase is bounded):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_r3.sh test finalize probes tracks preroll'
+#   gpurun --timeout 1500 -- 'bash tools/gpu_r3.sh bench prof pmc'
+cd "${GRAFT_REPO_ROOT:-.}"
+R="$PWD"; export TMPDIR=/tmp
+OUT=$R/gpurun_out; mkdir -p $OUT
+{ rocminfo | grep -E "Marketing Name|gfx9|Compute Unit" | head -8; nproc; lscpu | grep "Model name" | head -1; } > $OUT/box.txt 2>&1
+python -c "import __graft_entry__ as g; print(g.build())" > $OUT/build.log 2>&1
+H="--only-headline --steps 300 --warmup 30"
+X="env F110_LIB_VARIANT=experimental"
+line() { grep -h '^{' "$1" 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    print('%-34s %8.2f M/s  %.4f ms/step  resets %d' % ('$2', d['value']/1e6, d['ms_per_step'], d['config']['env_resets_in_timed_region']))
+"; }
+for MODE in "$@"; do
+case $MODE in
+test)
+  timeout 2400 python -m pytest tests -m gpu -q --maxfail=10 -x --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
+  tail -40 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log
+  ;;
+testfast)   # the product-library run only (the nested experimental-build run is the slow half)
+  F110_NESTED_SUITE=1 timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 -x --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  tail -30 $OUT/pytest_gpu.log
+  ;;
+finalize)
+  # A = 2 finalize: fixed lanes per agent vs the window loop flattened over the workgroup
+  for n in 1024 4096 16384 65536; do for f in 0 1; do
+    F110_EXP=finalize_flat=$f timeout 200 $X python bench.py $H --agents $n > $OUT/fin_n${n}_f${f}.log 2>&1; line $OUT/fin_n${n}_f${f}.log "agents $n finalize_flat $f"
+  done; done
+  for l in 8 16 64; do
+    F110_EXP=finalize_flat=1,finalize_lanes=$l timeout 200 $X python bench.py $H --agents 65536 > $OUT/fin_flat_l$l.log 2>&1; line $OUT/fin_flat_l$l.log "65536 flat AG-by-lanes $l"
+  done
+  ;;
+probes)
+  # fusion feasibility: the scan kernel at the occupancy a fused (118-VGPR) kernel would have,
+  # and with a per-env completion counter
+  for n in 4096 65536; do
+    F110_EXP=task_order=0 timeout 200 $X python bench.py $H --agents $n > $OUT/probe_n${n}_base.log 2>&1; line $OUT/probe_n${n}_base.log "agents $n base (no task order)"
+    F110_EXP=task_order=0,scan_occupancy=4 timeout 200 $X python bench.py $H --agents $n > $OUT/probe_n${n}_occ4.log 2>&1; line $OUT/probe_n${n}_occ4.log "agents $n scan at 4 waves/SIMD"
+    F110_EXP=task_order=0,scan_env_counter=1 timeout 200 $X python bench.py $H --agents $n > $OUT/probe_n${n}_cnt.log 2>&1; line $OUT/probe_n${n}_cnt.log "agents $n + per-env counter"
+  done
+  ;;
+tracks)
+  timeout 400 python tools/debug/track_scaling.py 65536 1080 > $OUT/track_scaling.log 2>&1; cat $OUT/track_scaling.log | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('tracks %2d %-18s %.4f ms/step' % (d['tracks'], d['assignment'], d['ms_per_step']))
+    else: print(l.rstrip())"
+  ;;
+preroll)
+  # how long until the batch is in its steady regime: 20 timed steps after P un-timed ones
+  for p in 0 100 300 500 1000 2000; do
+    timeout 200 python bench.py --only-headline --steps 20 --warmup 5 --preroll $p > $OUT/preroll_$p.log 2>&1; line $OUT/preroll_$p.log "preroll $p (20 steps)"
+  done
+  timeout 200 python bench.py --only-headline --steps 1000 --warmup 100 --preroll 0 > $OUT/preroll_steady.log 2>&1; line $OUT/preroll_steady.log "steady 100+1000"
+  ;;
+bench)
+  timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo "bench exit $?" >> $OUT/bench_default.log
+  tail -c 7000 $OUT/bench_default.log
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --secondary 0 --no-config5 --fixed-pose-steps 0 > $OUT/bench_driver_form.log 2>&1; line $OUT/bench_driver_form.log "driver form --steps 20 --warmup 5"
+  ;;
+prof)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats -o stats -- python $R/bench.py $H > $OUT/prof_stats.log 2>&1
+  python $R/tools/summarize_prof.py stats $OUT/prof_stats $OUT/kernel_stats.txt; rm -rf $OUT/prof_stats
+  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats4k -o stats -- python $R/bench.py $H --agents 4096 > $OUT/prof_stats4k.log 2>&1
+  python $R/tools/summarize_prof.py stats $OUT/prof_stats4k $OUT/kernel_stats_4096.txt; rm -rf $OUT/prof_stats4k
+  cd "$R"; cat $OUT/kernel_stats.txt | head -30
+  ;;
+pmc)
+  cd /tmp
+  i=0
+  for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_TA_BUSY GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays|k_finalize|k_integrate|k_collide" -T -f csv -d $OUT/pmc_$i -o p -- python $R/bench.py $H > $OUT/pmc_$i.log 2>&1
+    python $R/tools/summarize_prof.py pmc $OUT/pmc_$i $OUT/pmc_pass$i.json
+    rm -rf $OUT/pmc_$i
+  done
+  cd "$R"
+  ;;
+esac
+done
