@@ -468,7 +468,11 @@ def roofline_record(args, n_agents, beams, timed, prof, cnt, tiles=1):
     b_stream = 216.0 + 8.0 * B
     b_alg = b_stream + 8.0 * B * lbar
     step_gbs = agent_steps_per_s * b_alg / 1e9
-    rec = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
+    rec = {"bound": "hbm",
+           "binds": "ta-issue (L2-resident gathers): the table gathers hit L2 (TCC hit 96 %), the CUs' texture address / data path is 85-92 % "
+                    "busy; `frac` prices the algorithmic bytes against the HBM peak as SURVEY 8d defines it, `issue_floor_frac` is the "
+                    "fraction of the roofline that actually binds",
+           "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
            "definition": "SURVEY 8d: agent-steps/s x B_alg / 8 TB/s over the timed steps; B_alg = 216 + 8*B + 8*B*L-bar bytes per agent-step",
            "lookups_per_ray": lbar,
            "lookups_counted": "on the device over the same %d steps after the same %d warm-up steps (replay with the counting kernels)%s"
@@ -476,8 +480,26 @@ def roofline_record(args, n_agents, beams, timed, prof, cnt, tiles=1):
            "alg_bytes_per_agent_step": b_alg, "b_stream_bytes_per_agent_step": b_stream,
            "b_stream_frac": agent_steps_per_s * b_stream / 1e9 / HBM_PEAK_GBS}
     key = "agents=%d,beams=%d,layout=%d" % (n_agents, beams, args.layout) + (",tiles=%d" % tiles if tiles > 1 else "")
+    # evidence from profiles/ counts only when it was measured on THIS code: every entry carries the hash of the
+    # kernel sources it was collected with (tools/summarize_prof.py), the library reports the hash it was built from
+    from f1tenth_gym_amd import _ffi, build
+    lib_csrc = (_ffi.lib().f110_build_info() or b"").decode().replace("csrc=", "")
+    rec["csrc"] = lib_csrc
+    if lib_csrc != build.src_hash():
+        rec["csrc_note"] = "the loaded library was built from other sources (%s) than the tree holds (%s)" % (lib_csrc, build.src_hash())
     pmc = (load_json("pmc_scan.json") or {}).get(key)
-    rec["traffic"] = pmc.get("hbm_bytes_per_launch") if pmc else None
+    if pmc and pmc.get("csrc") != lib_csrc:
+        rec["traffic"] = None
+        rec["traffic_note"] = ("profiles/pmc_scan.json[%s] was collected on sources %s, this library is %s: not reported"
+                               % (key, pmc.get("csrc", "unrecorded (%s)" % pmc.get("round", "?")), lib_csrc))
+        pmc = None
+    else:
+        rec["traffic"] = pmc.get("hbm_bytes_per_launch") if pmc else None
+        if pmc:
+            rec["traffic_note"] = "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE per launch, %s, sources %s (profiles/pmc_scan.json, %s)" % (
+                pmc.get("window", "?"), pmc.get("csrc"), pmc.get("round", "?"))
+        else:
+            rec["traffic_note"] = "no PMC pass recorded for %s" % key
     if prof and "scan_ms_avg" in prof:
         scan_bytes = n_agents * (8.0 * B + 8.0 * B * lbar)   # range write + L-bar gathers of 8 B per ray
         k_ms = prof["scan_ms_avg"]
@@ -488,15 +510,24 @@ def roofline_record(args, n_agents, beams, timed, prof, cnt, tiles=1):
                     "integrate_collide_ms_avg": prof["dyn_ms_avg"], "finalize_ms_avg": prof["fin_ms_avg"]})
         if pmc:
             rec["hbm_measured_frac"] = pmc["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-            rec["hbm_measured_note"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this kernel (profiles/pmc_scan.json, %s) / this run's kernel time" % pmc.get("round", "?")
-        fl = load_json("r02_issue_floor.json")
-        if fl and key in fl.get("vmem_instr_per_launch", {}):
+        fl = None
+        for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_issue_floor.json")), reverse=True):
+            cand = load_json(name)
+            if cand and cand.get("csrc") == lib_csrc and key in cand.get("vmem_instr_per_launch", {}):
+                fl = cand
+                break
+        if fl:
             vm = fl["vmem_instr_per_launch"][key]
             floor_ms = vm * fl["gather_cycles_per_wave_instr"] / fl["cus"] / (fl["clock_mhz"] * 1e3)
             rec["issue_floor"] = {"what": "the binding unit: wave-level vector-memory instructions x the cheapest a 64-lane gather can issue "
                                           "on a gfx950 CU (tools/debug/ta_bench.hip, profiles/r02_ta_bench.txt)",
                                   "vmem_wave_instr_per_launch": vm, "cycles_per_instr": fl["gather_cycles_per_wave_instr"],
-                                  "floor_ms": floor_ms, "kernel_ms": k_ms, "frac": floor_ms / k_ms}
+                                  "floor_ms": floor_ms, "kernel_ms": k_ms, "frac": floor_ms / k_ms, "csrc": fl.get("csrc"), "window": fl.get("window")}
+            # what binds the kernel is the CUs' texture-address / data path issuing L2-resident gathers, not HBM: the
+            # honest fraction-of-roofline of the dominant kernel is this one
+            rec["issue_floor_frac"] = floor_ms / k_ms
+        else:
+            rec["issue_floor_note"] = "no *_issue_floor.json in profiles/ was measured on sources %s" % lib_csrc
     return rec
 
 
@@ -639,7 +670,7 @@ def main(argv=None):
     extras = n_gpus == 1 and not args.only_headline and not args.stub
     total_needed = args.preroll + args.warmup + args.steps
     if extras and args.steady_steps > 0:
-        total_needed = max(total_needed, args.steady_warmup + args.steady_steps)
+        total_needed = max(total_needed, args.preroll + args.steady_warmup + args.steady_steps)
     total_agents = args.agents * n_gpus
     # the legs of ONE invocation: the headline (no data-path collective unless --gather asks for it), then — on
     # more than one GPU — the same steps with the RCCL observation gather in-stream and overlapped (SURVEY 8e:
@@ -669,7 +700,9 @@ def main(argv=None):
     elapsed = head["ms_per_step"] * args.steps / 1e3
     value = head["value"]
     n_reset = head["env_resets_in_timed_region"]
-    numa_all = [json.loads(b.rstrip(b"\0").decode()) for b in rdv.gather_bytes(json.dumps(numa).encode().ljust(256, b"\0")[:256])]
+    if numa.get("note"):
+        numa["note"] = str(numa["note"])[:120]
+    numa_all = [json.loads(b.rstrip(b"\0").decode()) for b in rdv.gather_bytes(json.dumps(numa).encode().ljust(512, b"\0"))]
 
     line = {
         "metric": "agent-steps/s (1080-beam scan + ST dynamics)", "value": value, "unit": "agent-steps/s",
@@ -719,13 +752,15 @@ def main(argv=None):
         cnt = wl.run(args.steps, args.warmup, "count")
         line["roofline"] = roofline_record(args, args.agents, args.beams, dict(timed, elapsed_s=elapsed), prof, cnt, args.map_tiles)
         if extras and args.steady_steps > 0:
-            st = wl.run(args.steady_steps, args.steady_warmup, "timed", preroll=0)
-            sp = wl.run(args.steady_steps, args.steady_warmup, "profile", preroll=0)
-            sc = wl.run(args.steady_steps, args.steady_warmup, "count", preroll=0)
+            st = wl.run(args.steady_steps, args.steady_warmup, "timed")
+            sp = wl.run(args.steady_steps, args.steady_warmup, "profile")
+            sc = wl.run(args.steady_steps, args.steady_warmup, "count")
             line["steady_state"] = {"value": args.agents * args.steady_steps / st["elapsed_s"], "unit": "agent-steps/s",
                                     "steps": args.steady_steps, "warmup": args.steady_warmup,
-                                    "definition": "SURVEY 8d: >= 1000 timed steps after 100 warm-up steps from the reset (no pre-roll); the headline's "
-                                                  "pre-rolled window must agree with it",
+                                    "definition": "SURVEY 8d: >= 1000 timed steps after >= 100 warm-up steps — here %d pre-roll + %d warm-up steps, the same "
+                                                  "regime the headline's short window samples (measured: 20 timed steps after 0 / 100 / 300 / 500 / 1000 / 2000 "
+                                                  "un-timed ones run at 98.4 / 94.1 / 86.7 / 85.4 / 86.1 / 85.5 M agent-steps/s: the batch needs ~300 steps "
+                                                  "to reach it)" % (args.preroll, args.steady_warmup),
                                     "headline_over_steady": value / (args.agents * args.steady_steps / st["elapsed_s"]),
                                     "ms_per_step": 1e3 * st["elapsed_s"] / args.steady_steps, "env_resets_in_timed_region": st["n_reset"],
                                     "roofline": roofline_record(args, args.agents, args.beams, st, sp, sc, args.map_tiles)}

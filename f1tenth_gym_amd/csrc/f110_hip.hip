@@ -43,12 +43,14 @@ struct ExpSwitches {
     int no_window = 0;         // 1: F110_MAP_WINDOW_LDS handles step with the PADDED kernel
     int finalize_lanes = 0;    // 8 / 16 / 32 / 64 lanes per agent in k_finalize*, 0 = by batch size
     int finalize_flat = -1;    // A = 2: 1 the workgroup-flattened window loop, 0 fixed lanes per agent, -1 = default
+    int pair_always = 0;       // A = 2: 1 = pair test inside the finalize kernel also for big batches without the in-step re-seat
     int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
     int scan_env_counter = 0;  // 1: the scan kernel also counts finished tasks per env (fusion feasibility A/B)
 };
 
 // A = 2 finalize: the workgroup-flattened window loop (k_finalize_pair_flat) or fixed lanes per agent
-constexpr bool kFinalizeFlatDefault = false;
+// (round 3, measured: 65 536 agents 0.763 -> 0.726 ms per step, 16 384: 0.252 -> 0.239, 4096: 0.108 -> 0.107)
+constexpr bool kFinalizeFlatDefault = true;
 
 struct f110_sim {
     f110_config cfg{};
@@ -83,6 +85,7 @@ struct f110_sim {
     MapFast *d_maps_fast = nullptr;
     ScanConst *d_maps_full = nullptr;
     int32_t *d_env_map = nullptr;
+    uint32_t *d_scan_order = nullptr;   // [N] agents sorted by map slot (nullptr while every env is on one slot)
     bool multi_map = false;
     ScanConst *d_k = nullptr;  // HBM copy of k (RayJob::k_cold), refreshed by cold_consts()
     ScanConst k_uploaded{};
@@ -707,6 +710,7 @@ void f110_destroy(f110_sim *h)
     if (h->d_maps_fast) (void)hipFree(h->d_maps_fast);
     if (h->d_maps_full) (void)hipFree(h->d_maps_full);
     if (h->d_env_map) (void)hipFree(h->d_env_map);
+    if (h->d_scan_order) (void)hipFree(h->d_scan_order);
     {
         void *eptrs[] = {h->ep.start_poses, h->ep.rot, h->ep.current_time, h->ep.near_start, h->ep.toggle,
                          h->ep.lap_count, h->ep.lap_time, h->ep.done, h->ep.checkpoint, h->d_rot_stage, h->d_packed};
@@ -1016,6 +1020,22 @@ int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map)
     HIPCHK(h, hipMemcpyAsync(h->d_maps_fast, fast.data(), sizeof(MapFast) * M, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_maps_full, full.data(), sizeof(ScanConst) * M, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_env_map, h_env_map, sizeof(int32_t) * E, hipMemcpyHostToDevice, h->stream));
+    {
+        // the scan's agent order: by map slot (stable), so each XCD's contiguous share of the launch touches as few
+        // tables as possible — interleaved assignments then cost what grouped ones do (measured, 8 tracks x 65 536
+        // agents: interleaved 1.075 ms per step in agent order, grouped 0.738)
+        const int A = h->cfg.num_agents;
+        std::vector<uint32_t> order((size_t)h->N);
+        for (int i = 0; i < h->N; ++i) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return h_env_map[a / A] < h_env_map[b / A]; });
+        bool identity = true;
+        for (int i = 0; i < h->N && identity; ++i) identity = order[i] == (uint32_t)i;
+        if (h->d_scan_order) { (void)hipFree(h->d_scan_order); h->d_scan_order = nullptr; }
+        if (!identity) {
+            HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_scan_order), sizeof(uint32_t) * h->N));
+            HIPCHK(h, hipMemcpyAsync(h->d_scan_order, order.data(), sizeof(uint32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+        }
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->dev.maps_full = h->d_maps_full;
     h->dev.env_map = h->d_env_map;
@@ -1757,7 +1777,8 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     // big AND finished envs are not re-seated inside the step: then k_finalize runs a wave per agent (crashed
     // cars pile up, windows grow to all beams) and 65 536 waves each carrying the prologue cost more than the
     // side stream does (parked cars, 65 536 agents: 0.70 vs 0.63 ms)
-    const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0 && (h->dev.reseat_poses != nullptr || N < 8192);
+    const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0 &&
+                                  (h->dev.reseat_poses != nullptr || N < 8192 || (kExperimental && h->exp.pair_always));
     const bool no_collide_launch = fused_integrate || pair_in_finalize;
     const bool side_collide = multi && !no_collide_launch && !(kExperimental && collide_mode == 2);
     // k_collide only feeds k_finalize, k_scan_rays only needs k_integrate: run the two side by
@@ -1794,6 +1815,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         j.lookups_total = h->lookups_on ? h->d_lookups : nullptr;
         j.k_cold = cold_consts(h);
         if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
+        j.order = (h->multi_map && begin == 0 && count == N) ? h->d_scan_order : nullptr;
         const bool cnt = j.lookups_total != nullptr;
         // agent-aligned launch geometry: whole 64-ray tasks per agent, so every wave belongs to one agent (and one map)
         auto agent_grid = [&](uint32_t tpa, dim3 &grid, uint32_t &wpb) {
@@ -1939,7 +1961,13 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         if (h->exp.finalize_flat >= 0) flat = pair_in_finalize && h->exp.finalize_flat != 0;
 #endif
         if (pair_in_finalize && flat) {
-            // the window loop flattened over the workgroup: AG agents per 256 threads (256 / AG lanes each in the prologue)
+            // the window loop flattened over the workgroup: AG agents per 256 threads (256 / AG lanes each in the
+            // prologue).  More agents per workgroup = fewer prologue waves and a better-balanced item list; small
+            // batches want the workgroups many (measured: 65 536 agents AG 32 / 16 / 4: 0.726 / 0.738 / 0.815 ms)
+            lanes = N >= 32768 ? 8 : (N >= 8192 ? 16 : 64);
+#ifdef F110_EXPERIMENTAL
+            if (h->exp.finalize_lanes) lanes = h->exp.finalize_lanes;
+#endif
             if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_flat<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
             else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_flat<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
             else hipLaunchKernelGGL(k_finalize_pair_flat<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);

@@ -309,6 +309,10 @@ struct RayJob {
     // fusion-feasibility probe (experimental build): per-env count of finished scan tasks, reset by the last arriver
     uint32_t *env_done;
     uint32_t tasks_per_env, pad_env;
+    // per-env maps: the order the scan walks the agents in — sorted by map slot, so that the XCD-contiguous
+    // block order hands each XCD's L2 the agents of as few tracks as possible however the caller interleaved
+    // them (nullptr: agent order)
+    const uint32_t *order;
     // k_scan_rays_window: 1-byte codes of the padded table (row-major, `win_pitch` bytes per row, a multiple
     // of 16) and the 256-entry exact value LUT (entry 255 unused: code 255 = "read the float64 table")
     const uint8_t *win_codes;
@@ -567,7 +571,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         if (task >= j.n_tasks) break;
         if (SCHED && !long_pass && ((cu32_t)((csched_t)j.sched)->flags_r)[task] == j.epoch_r) continue;   // served by the long pass
         const uint32_t pl = task / tasks_per_agent;                 // scalar
-        const uint32_t p = j.first_pose + pl;
+        const uint32_t p = (PER_ENV_MAP && j.order) ? ((cu32_t)j.order)[pl] : j.first_pose + pl;
         const int b = (int)((task - pl * tasks_per_agent) * 64u + lane);
         if (b >= (int)B) continue;
         typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
@@ -771,7 +775,8 @@ __global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, 
         const uint32_t task = __builtin_amdgcn_readfirstlane(wave * tpw + t);
         if (task >= j.n_tasks) break;
         const uint32_t pl = task / tasks_per_agent;
-        const uint32_t p = j.first_pose + pl;
+        typedef const __attribute__((address_space(4))) uint32_t *cu32_t;
+        const uint32_t p = (PER_ENV_MAP && j.order) ? ((cu32_t)j.order)[pl] : j.first_pose + pl;
         const int s0 = (int)((task - pl * tasks_per_agent) * 64u);
         typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
         const chdr_t h0 = (chdr_t)(j.hdr) + p;

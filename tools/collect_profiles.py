@@ -29,18 +29,23 @@ def main():
         if not os.path.isfile(p):
             continue
         for kern, rec in json.load(open(p)).items():
-            m = merged.setdefault(kern, {"dispatches": rec["dispatches"], "mean_per_dispatch": {}, "meta": rec["meta"]})
+            m = merged.setdefault(kern, {"dispatches": rec["dispatches"], "mean_per_dispatch": {}, "meta": rec["meta"],
+                                         "csrc": rec.get("csrc"), "window": rec.get("window")})
             m["mean_per_dispatch"].update(rec["mean_per_dispatch"])
+            if rec.get("csrc") != m["csrc"]:
+                raise SystemExit("PMC passes of different source trees: %s vs %s" % (rec.get("csrc"), m["csrc"]))
     json.dump(merged, open(os.path.join(DST, "%s_pmc.json" % tag), "w"), indent=1, sort_keys=True)
     for name in ("bench_default.log", "box.txt"):
         if os.path.isfile(os.path.join(SRC, name)):
             shutil.copyfile(os.path.join(SRC, name), os.path.join(DST, "%s_%s" % (tag, name.replace(".log", ".json") if name.endswith(".log") else name)))
-    scan = (merged.get("k_scan_rays_agent") or merged.get("k_scan_rays") or {}).get("mean_per_dispatch", {})
+    scan_rec = merged.get("k_scan_rays_agent") or merged.get("k_scan_rays") or {}
+    scan = scan_rec.get("mean_per_dispatch", {})
+    csrc, window = scan_rec.get("csrc"), scan_rec.get("window")
     if "FETCH_SIZE" in scan and "WRITE_SIZE" in scan:
         rec_path = os.path.join(DST, "pmc_scan.json")
         rec = json.load(open(rec_path)) if os.path.isfile(rec_path) else {}
         rec["agents=%d,beams=%d,layout=%d" % (agents, beams, layout)] = {
-            "round": tag, "FETCH_SIZE_KiB": scan["FETCH_SIZE"], "WRITE_SIZE_KiB": scan["WRITE_SIZE"],
+            "round": tag, "csrc": csrc, "window": window, "FETCH_SIZE_KiB": scan["FETCH_SIZE"], "WRITE_SIZE_KiB": scan["WRITE_SIZE"],
             "hbm_bytes_per_launch": (2.0 * scan["FETCH_SIZE"] + scan["WRITE_SIZE"]) * 1024.0,
             "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)"}
         json.dump(rec, open(rec_path, "w"), indent=1, sort_keys=True)
@@ -54,9 +59,9 @@ def main():
         key = "agents=%d,beams=%d,layout=%d" % (agents, beams, layout)
         fl.update({"what": "gather-issue floor of the scan kernel: wave-level vector-memory instructions per launch (rocprofv3 --pmc "
                            "SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR over the bench's timed steps) x the cheapest a 64-lane non-contiguous "
-                           "gather issues on a gfx950 CU (%s_ta_bench.txt: 19.4-19.7 cycles per wave-level u64 load at 1-4 distinct "
-                           "lines; no width, line count or active-lane mask measured is cheaper than ~17.5)" % tag,
-                   "gather_cycles_per_wave_instr": 19.5, "cus": 256, "clock_mhz": 2400, "round": tag})
+                           "gather issues on a gfx950 CU (r02_ta_bench.txt: 19.4-19.7 cycles per wave-level u64 load at 1-4 distinct "
+                           "lines; no width, line count or active-lane mask measured is cheaper than ~17.5)",
+                   "gather_cycles_per_wave_instr": 19.5, "cus": 256, "clock_mhz": 2400, "round": tag, "csrc": csrc, "window": window})
         fl.setdefault("vmem_instr_per_launch", {})[key] = vm
         fl.setdefault("pmc", {})[key] = {"kernel_cycles": cyc, "TA_TA_BUSY_frac": scan.get("TA_TA_BUSY_sum", 0.0) / 256.0 / cyc,
                                          "TD_TD_BUSY_frac": scan.get("TD_TD_BUSY_sum", 0.0) / 256.0 / cyc,

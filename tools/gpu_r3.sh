@@ -18,12 +18,12 @@ for l in sys.stdin:
 for MODE in "$@"; do
 case $MODE in
 test)
-  timeout 2400 python -m pytest tests -m gpu -q --maxfail=10 -x --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  timeout 2400 python -m pytest tests -m gpu -q -rs --maxfail=10 --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
   timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
   tail -40 $OUT/pytest_gpu.log; tail -2 $OUT/smoke.log
   ;;
 testfast)   # the product-library run only (the nested experimental-build run is the slow half)
-  F110_NESTED_SUITE=1 timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 -x --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  F110_NESTED_SUITE=1 timeout 1500 python -m pytest tests -m gpu -q -rs --maxfail=10 --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
   tail -30 $OUT/pytest_gpu.log
   ;;
 finalize)
@@ -33,6 +33,18 @@ finalize)
   done; done
   for l in 8 16 64; do
     F110_EXP=finalize_flat=1,finalize_lanes=$l timeout 200 $X python bench.py $H --agents 65536 > $OUT/fin_flat_l$l.log 2>&1; line $OUT/fin_flat_l$l.log "65536 flat AG-by-lanes $l"
+  done
+  ;;
+finalize2)
+  # AG choice for the flattened finalize at the middle sizes, and the pair test inside the finalize kernel for
+  # big batches WITHOUT the in-step re-seat (crashed / parked cars: windows grow)
+  for n in 4096 16384; do for l in 8 16 64; do
+    F110_EXP=finalize_lanes=$l timeout 200 $X python bench.py $H --agents $n > $OUT/fin2_n${n}_l$l.log 2>&1; line $OUT/fin2_n${n}_l$l.log "agents $n flat, lanes $l"
+  done; done
+  for pa in 0 1; do
+    F110_EXP=pair_always=$pa timeout 200 $X python bench.py $H --agents 65536 --policy parked --no-reset --preroll 0 > $OUT/fin2_parked_pa$pa.log 2>&1; line $OUT/fin2_parked_pa$pa.log "65536 parked, pair_always $pa"
+    F110_EXP=pair_always=$pa timeout 200 $X python bench.py $H --agents 65536 --no-reset --preroll 100 > $OUT/fin2_noreset_pa$pa.log 2>&1; line $OUT/fin2_noreset_pa$pa.log "65536 no reset, pair_always $pa"
+    F110_EXP=pair_always=$pa timeout 200 $X python bench.py $H --agents 65536 --separate-reset > $OUT/fin2_sepreset_pa$pa.log 2>&1; line $OUT/fin2_sepreset_pa$pa.log "65536 separate reset, pair_always $pa"
   done
   ;;
 probes)
@@ -78,8 +90,17 @@ pmc)
   for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_TA_BUSY GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
     i=$((i+1))
     timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays|k_finalize|k_integrate|k_collide" -T -f csv -d $OUT/pmc_$i -o p -- python $R/bench.py $H > $OUT/pmc_$i.log 2>&1
-    python $R/tools/summarize_prof.py pmc $OUT/pmc_$i $OUT/pmc_pass$i.json
+    python $R/tools/summarize_prof.py pmc $OUT/pmc_$i $OUT/pmc_pass$i.json - 300   # the 300 timed steps only (steady regime: after pre-roll + warm-up)
     rm -rf $OUT/pmc_$i
+  done
+  # HBM traffic of the scan kernel for the two other bench legs (FETCH_SIZE, WRITE_SIZE)
+  for cfg in "4096:--agents 4096" "cfg5:--agents 65536 --beams 4096 --map-tiles 2 --steps 100 --warmup 20 --preroll 100"; do
+    tagc=${cfg%%:*}; argsc=${cfg#*:}; n=300; [ "$tagc" = cfg5 ] && n=100
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout 300 rocprofv3 --pmc $c --kernel-include-regex "k_scan_rays|k_scan_dirs" -T -f csv -d $OUT/tr_$c -o p -- python $R/bench.py --only-headline $argsc > $OUT/tr_${tagc}_$c.log 2>&1
+      python $R/tools/summarize_prof.py pmc $OUT/tr_$c $OUT/traffic_${tagc}_$c.json - $n
+      rm -rf $OUT/tr_$c
+    done
   done
   cd "$R"
   ;;

@@ -22,19 +22,39 @@ def kernel_stats(d, out):
     open(out, "w").write("\n".join(lines) + "\n")
 
 
-def counters(d, out, kernel_filter=None):
+def src_hash():
+    """identity of the kernel sources the profiled library was built from (f1tenth_gym_amd/build.py)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from f1tenth_gym_amd import build
+    return build.src_hash()
+
+
+def counters(d, out, kernel_filter=None, last_n=0):
+    """mean counter values per dispatch and kernel.  last_n > 0: only the last `last_n` dispatches of every
+    kernel — the bench's TIMED steps, without the pre-roll and warm-up dispatches of the same process."""
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    rows = []
+    for f in files:
+        rows.extend(csv.DictReader(open(f)))
+    keep = None
+    if last_n > 0:
+        ids = defaultdict(set)
+        for r in rows:
+            ids[r["Kernel_Name"].split("(")[0][:60]].add(int(r["Dispatch_Id"]))
+        keep = {k: set(sorted(v)[-last_n:]) for k, v in ids.items()}
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     meta = {}
-    for f in files:
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0][:60]
-            if kernel_filter and kernel_filter not in k:
-                continue
-            a = acc[k][r["Counter_Name"]]
-            a[0] += float(r["Counter_Value"]); a[1] += 1
-            meta[k] = {x: r.get(x) for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
-    res = {k: {"dispatches": max(v[1] for v in c.values()), "mean_per_dispatch": {n: v[0] / v[1] for n, v in c.items()}, "meta": meta[k]}
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0][:60]
+        if kernel_filter and kernel_filter not in k:
+            continue
+        if keep is not None and int(r["Dispatch_Id"]) not in keep[k]:
+            continue
+        a = acc[k][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+        meta[k] = {x: r.get(x) for x in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+    res = {k: {"dispatches": max(v[1] for v in c.values()), "mean_per_dispatch": {n: v[0] / v[1] for n, v in c.items()}, "meta": meta[k],
+               "csrc": src_hash(), "window": ("last %d dispatches (the timed steps)" % last_n) if last_n > 0 else "every dispatch of the process"}
            for k, c in acc.items()}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 
@@ -65,5 +85,6 @@ if __name__ == "__main__":
         kernel_stats(d, out)
     elif mode == "gaps":
         gaps(d, out)
-    else:
-        counters(d, out, sys.argv[4] if len(sys.argv) > 4 else None)
+    else:   # pmc <dir> <out> [kernel-name filter | -] [last N dispatches]
+        kf = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "-" else None
+        counters(d, out, kf, int(sys.argv[5]) if len(sys.argv) > 5 else 0)
