@@ -129,8 +129,11 @@ struct f110_sim {
     // longest-first order of the scan tasks (TaskSched, small batches): double-buffered flags / lists / counters
     bool task_order = false;
     uint32_t *d_tflags[2] = {nullptr, nullptr}, *d_tlist[2] = {nullptr, nullptr}, *d_tcount = nullptr;
+    uint32_t *d_rflags[2] = {nullptr, nullptr}, *d_rlist[2] = {nullptr, nullptr};   // the ray-level lists (TaskSched::r*)
     TaskSched *d_tsched = nullptr;   // [2]
     uint32_t task_epoch = 2, task_cap = 0, task_thr = 96;   // epochs start above the flags' initial 0
+    uint32_t ray_cap = 0, ray_thr = 64, ray_waves = 2048;
+    bool ray_pass = true;
     ExpSwitches exp;
     uint32_t *d_env_done = nullptr;   // [num_envs] scan_env_counter probe
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
@@ -353,21 +356,28 @@ static int task_order_setup(f110_sim *h, bool on)
         h->task_order = false;
         return F110_OK;
     }
+    const size_t n_rays = (size_t)h->N * (size_t)h->cfg.num_beams;
     if (!h->d_tsched) {
         h->task_cap = (uint32_t)std::max<size_t>(64, n_tasks / 32);
+        h->ray_cap = (uint32_t)std::max<size_t>(256, n_rays / 512);
         for (int q = 0; q < 2; ++q) {
             TRY(dmalloc(h, &h->d_tflags[q], n_tasks));
             TRY(dmalloc(h, &h->d_tlist[q], (size_t)h->task_cap));
-            HIPCHK(h, hipMemset(h->d_tflags[q], 0, sizeof(uint32_t) * n_tasks));
+            HIPCHK(h, hipMemsetAsync(h->d_tflags[q], 0, sizeof(uint32_t) * n_tasks, h->stream));
+            TRY(dmalloc(h, &h->d_rflags[q], n_rays));
+            TRY(dmalloc(h, &h->d_rlist[q], (size_t)h->ray_cap));
+            HIPCHK(h, hipMemsetAsync(h->d_rflags[q], 0, sizeof(uint32_t) * n_rays, h->stream));
         }
-        TRY(dmalloc(h, &h->d_tcount, 2));
-        HIPCHK(h, hipMemset(h->d_tcount, 0, 2 * sizeof(uint32_t)));
+        TRY(dmalloc(h, &h->d_tcount, 4));   // {task count 0, 1, ray count 0, 1}
+        HIPCHK(h, hipMemsetAsync(h->d_tcount, 0, 4 * sizeof(uint32_t), h->stream));
         TRY(dmalloc(h, &h->d_tsched, 2));
     }
     TaskSched ts[2];
     for (int q = 0; q < 2; ++q)   // struct q is used at steps of parity q: it reads what parity q^1 wrote
-        ts[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr};
-    HIPCHK(h, hipMemcpy(h->d_tsched, ts, sizeof ts, hipMemcpyHostToDevice));
+        ts[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr,
+                          h->d_rflags[q ^ 1], h->d_rflags[q], h->d_rlist[q ^ 1], h->d_rlist[q], h->d_tcount + 2 + (q ^ 1), h->d_tcount + 2 + q, h->ray_cap, h->ray_thr};
+    HIPCHK(h, hipMemcpyAsync(h->d_tsched, ts, sizeof ts, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     h->task_order = true;
     return F110_OK;
 }
@@ -419,6 +429,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
         if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(h, F110_ERR_INVALID, "finalize_lanes must be 0, 8, 16, 32 or 64");
         h->exp.finalize_lanes = value;
     } else if (k == "finalize_flat") h->exp.finalize_flat = value;
+    else if (k == "pair_always") h->exp.pair_always = value;
     else if (k == "scan_occupancy") h->exp.scan_occupancy = value;
     else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
     else if (k == "collide_mode") {
@@ -429,7 +440,12 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "task_thr") {
         h->task_thr = (uint32_t)value;
         if (h->task_order) return task_order_setup(h, true);
-    } else
+    } else if (k == "ray_pass") h->ray_pass = value != 0;
+    else if (k == "ray_thr") {
+        h->ray_thr = (uint32_t)value;
+        if (h->task_order) return task_order_setup(h, true);
+    } else if (k == "ray_waves") h->ray_waves = (uint32_t)std::max(64, value);
+    else
         return fail(h, F110_ERR_INVALID, "f110_exp_set: unknown key '%s'", key);
     return F110_OK;
 }
@@ -579,7 +595,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         CKH(hipMemcpy(h->d_zig_f, kZigF, sizeof kZigF, hipMemcpyHostToDevice));
         CKH(hipMemcpy(h->d_jump, jt.a, sizeof jt.a, hipMemcpyHostToDevice));
         CKH(hipMemcpy(h->d_jump + 65, jt.g, sizeof jt.g, hipMemcpyHostToDevice));
-        CKH(hipMemset(h->d_lookups, 0, 2 * sizeof(unsigned long long)));
+        CKH(hipMemsetAsync(h->d_lookups, 0, 2 * sizeof(unsigned long long), h->stream));
         h->noise_gen = NoiseGen{h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_jump + 65, 0.0};
     }
     {
@@ -693,7 +709,7 @@ void f110_destroy(f110_sim *h)
     for (hipEvent_t ge : h->gevents) (void)hipEventDestroy(ge);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     {
-        void *rp[] = {h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_tsched, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
+        void *rp[] = {h->d_rflags[0], h->d_rflags[1], h->d_rlist[0], h->d_rlist[1], h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_tsched, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
         for (void *p : rp)
             if (p) (void)hipFree(p);
     }
@@ -1198,7 +1214,7 @@ int f110_set_noise_rng(f110_sim *h, const uint64_t *state_inc, int32_t per_agent
     const size_t N = (size_t)h->N;
     h->noise_gen.scale = std_dev;
     TRY(dmalloc(h, &h->d_rng_state, N));
-    HIPCHK(h, hipMemset(h->d_rng_state, 0, sizeof(U128) * N));
+    HIPCHK(h, hipMemsetAsync(h->d_rng_state, 0, sizeof(U128) * N, h->stream));
     h->dev.rng_state = h->d_rng_state;
     if (per_agent) {
         // h_state_inc [N][4]: two U128 {hi, lo} per agent — the layout of rng_seed
@@ -1400,7 +1416,7 @@ int f110_comm_set_overlap(f110_sim *h, int32_t enable)
         const size_t count = (size_t)h->N * h->cfg.num_beams;
         if (!h->scan_bufs[1]) {
             TRY(dmalloc(h, &h->scan_bufs[1], count));
-            HIPCHK(h, hipMemset(h->scan_bufs[1], 0, sizeof(double) * count));
+            HIPCHK(h, hipMemsetAsync(h->scan_bufs[1], 0, sizeof(double) * count, h->stream));
             HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_step_done, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_gather_done[0], hipEventDisableTiming));
@@ -1414,7 +1430,8 @@ int f110_comm_set_overlap(f110_sim *h, int32_t enable)
     } else if (!enable && h->comm_overlap) {
         if (h->comm_stream) HIPCHK(h, hipStreamSynchronize(h->comm_stream));
         if (h->scans_cur != 0) {   // back on the buffer the handle owns by name
-            HIPCHK(h, hipMemcpy(h->scan_bufs[0], h->scan_bufs[1], sizeof(double) * (size_t)h->N * h->cfg.num_beams, hipMemcpyDeviceToDevice));
+            HIPCHK(h, hipMemcpyAsync(h->scan_bufs[0], h->scan_bufs[1], sizeof(double) * (size_t)h->N * h->cfg.num_beams, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
             h->scans_cur = 0;
         }
         h->dev.scans = h->scan_bufs[0];
@@ -1433,8 +1450,7 @@ static int comm_gather(f110_sim *h, void *d_recv_scans, void *d_recv_scal)
     const size_t N = (size_t)h->N, count = N * h->cfg.num_beams, scount = N * kObsScalars;
     const int cur = h->comm_overlap ? h->scans_cur : 0;
     if (d_recv_scal && !h->obs_scal[cur]) {
-        TRY(dmalloc(h, &h->obs_scal[cur], scount));
-        HIPCHK(h, hipMemset(h->obs_scal[cur], 0, sizeof(double) * scount));
+        TRY(dmalloc(h, &h->obs_scal[cur], scount));   // (k_pack_obs writes every element before the gather reads it)
     }
     auto gather_on = [&](hipStream_t st, const double *scans) -> int {
         ncclResult_t rc = r->GroupStart();
@@ -1891,8 +1907,9 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             j.epoch_r = h->task_epoch - 1u;
             j.epoch_w = h->task_epoch;
             j.long_blocks = (h->task_cap + wpb - 1) / wpb;
+            j.ray_blocks = h->ray_pass ? (std::min(h->ray_cap, h->ray_waves) + wpb - 1) / wpb : 0u;
             h->task_epoch += 1u;
-            const dim3 sgrid(grid.x + j.long_blocks);
+            const dim3 sgrid(grid.x + j.long_blocks + j.ray_blocks);
             if (h->k.ident_rot)
                 hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true>), sgrid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
             else

@@ -233,7 +233,10 @@ __global__ void __launch_bounds__(AF ? 64 : 256) k_integrate(AgentArrays a, Scan
         a.ray_hdr[i] = hd;
     }
     a.in_collision[i] = 0;  // raised by k_scan_rays when any beam's iTTC is under the threshold
-    if (a.sched_count_zero && i == a.agent_begin) *a.sched_count_zero = 0u;
+    if (a.sched_count_zero && i == a.agent_begin) {
+        a.sched_count_zero[0] = 0u;   // this step's task list ...
+        a.sched_count_zero[2] = 0u;   // ... and ray list (TaskSched::count_w / rcount_w)
+    }
     if constexpr (AF != 0) {
         // groups are env-aligned and AF divides 64: the AF lanes of an env are all here, in one wave.
         // Every lane takes part in every shuffle (a lane masked off would read as zero).
@@ -291,6 +294,19 @@ struct TaskSched {
     const uint32_t *count_r;
     uint32_t *count_w;   // zeroed by k_integrate of the same step
     uint32_t cap, thr;
+    // The same idea one level down (round 3): a RAY that took more than `rthr` lookups in the previous step is
+    // listed by its number, stamped in rflags (one epoch word per ray), skipped by the lane that would
+    // normally march it, and marched by a wave of its own at the front of the launch — all 64 lanes compute
+    // the same values, so the table sample travels the scalar path (s_load through the scalar cache), which
+    // answers faster than the texture path a divergent gather needs.  The scan of a small batch ends when
+    // its longest ray ends; this shortens exactly that chain.  rcount_w sits two words behind count_w.
+    const uint32_t *rflags_r;
+    uint32_t *rflags_w;
+    const uint32_t *rlist_r;
+    uint32_t *rlist_w;
+    const uint32_t *rcount_r;
+    uint32_t *rcount_w;
+    uint32_t rcap, rthr;
 };
 
 struct RayJob {
@@ -305,7 +321,7 @@ struct RayJob {
     unsigned long long *lookups_total;  // COUNT variants: table lookups of every marched ray, summed (or nullptr)
     // longest-first task order (k_scan_rays_agent<.., SCHED>): see TaskSched
     const struct TaskSched *sched;
-    uint32_t epoch_r, epoch_w, long_blocks, pad_sched;
+    uint32_t epoch_r, epoch_w, long_blocks, ray_blocks;
     // fusion-feasibility probe (experimental build): per-env count of finished scan tasks, reset by the last arriver
     uint32_t *env_done;
     uint32_t tasks_per_env, pad_env;
@@ -518,6 +534,37 @@ struct MapFast {
 };
 static_assert(sizeof(MapFast) == 64, "MapFast is read as one 64-byte scalar load");
 
+// march_padded for ONE ray marched by a whole wave (every lane holds the same values): identical arithmetic,
+// but the table sample is a scalar load — its address comes out of the VALU through v_readfirstlane and the
+// value comes back through the scalar cache, ~2x sooner than a 64-lane gather travels the texture path.
+__device__ __forceinline__ bool march_padded_uniform(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
+                                                     int &lookups)
+{
+    typedef const __attribute__((address_space(4))) char *cbase_t;
+    const cbase_t base = (cbase_t)(k.pad);
+    double total = d;
+    int n = 1;
+    bool redo = false;
+    while ((d > k.eps) & (total <= k.max_range) & !redo) {
+        ux = fma(d, cux, ux);
+        uy = fma(d, cuy, uy);
+        const uint32_t wx = low_word(ux + kFixBig);
+        const uint32_t wy = low_word(uy + kFixBig);
+        uint32_t off = mul24(wy >> kFixFracBits, (uint32_t)k.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
+        if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {   // march_padded's guard band, verbatim
+            redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
+            off = mul24((uint32_t)(int)floor(uy), (uint32_t)k.pad_row_bytes) + ((uint32_t)(int)floor(ux) << 3);
+        }
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+        d = *reinterpret_cast<const __attribute__((address_space(4))) double *>(base + so);
+        total += d;
+        ++n;
+    }
+    lookups = n;
+    range = (total > k.max_range) ? k.max_range : total;
+    return !(redo | (n > k.pad_max_samples));
+}
+
 // the per-env map's constants through the scalar cache (one 64-byte record), pinned to SGPRs
 __device__ __forceinline__ void load_map_fast(ScanConst &km, const MapFast *__restrict__ maps_fast, int slot)
 {
@@ -548,6 +595,50 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
     bool long_pass = false;
     uint32_t long_task = 0;
     if (SCHED) {
+        if (blk < j.ray_blocks) {
+            // ---- ray pass: last step's longest RAYS, one per wave, newest list entries (= the rays that finished
+            // last, i.e. the longest) first
+            const csched_t sc = (csched_t)j.sched;
+            const uint32_t nw = j.ray_blocks * (blockDim.x >> 6);
+            uint32_t cnt = *(cu32_t)sc->rcount_r;
+            cnt = cnt < sc->rcap ? cnt : sc->rcap;
+            typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
+            for (uint32_t w = __builtin_amdgcn_readfirstlane((blk * blockDim.x + threadIdx.x) >> 6); w < cnt; w += nw) {
+                const uint32_t ray = ((cu32_t)sc->rlist_r)[cnt - 1u - w];
+                if (ray >= j.n_rays || ((cu32_t)sc->rflags_r)[ray] != j.epoch_r) continue;   // (every slot below cnt was written this epoch; belt and braces)
+                const uint32_t p = ray / B;
+                const int b = (int)(ray - p * B);
+                const chdr_t h0 = (chdr_t)(j.hdr) + p;
+                const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
+                const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
+                const int row = uniform_i32(h0->noise_row), fast = uniform_i32(h0->fast);
+                const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;
+                const double nz = row != -1 ? nrow[b] : 0.0;
+                const double2 cs = k.cs[beam_dir_index(k, start, b)];
+                int hr = -1, hc = -1, nl;
+                double r = 0.;
+                bool exact = fast == 0;
+                if (fast) {
+                    double ux, uy, cux, cuy;
+                    padded_position<IDENT>(k, x, y, ux, uy);
+                    padded_rate<IDENT>(k, cs.x, cs.y, cux, cuy);
+                    exact = !march_padded_uniform(k, ux, uy, cux, cuy, d0, r, nl);
+                }
+                if (exact) r = march_exact_cold<IDENT>(j.k_cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
+                if (lane == 0u) {
+                    if (nl > (int)sc->rthr) {   // still long: stays on the list
+                        const uint32_t pos = atomicAdd(sc->rcount_w, 1u);
+                        if (pos < sc->rcap) {
+                            sc->rlist_w[pos] = ray;
+                            sc->rflags_w[ray] = j.epoch_w;
+                        }
+                    }
+                    finish_beam_with(j, p, b, ray, row != -1 ? r + nz : r, vel);
+                }
+            }
+            return;
+        }
+        blk -= j.ray_blocks;
         if (blk < j.long_blocks) {   // the first blocks of the launch serve last step's long tasks, one per wave
             const csched_t sc = (csched_t)j.sched;
             const uint32_t wl = __builtin_amdgcn_readfirstlane((blk * blockDim.x + threadIdx.x) >> 6);
@@ -561,7 +652,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         }
     }
     if (!long_pass) {
-        const uint32_t nb = gridDim.x - (SCHED ? j.long_blocks : 0u), q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
+        const uint32_t nb = gridDim.x - (SCHED ? j.long_blocks + j.ray_blocks : 0u), q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
         blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // XCD-contiguous, as k_scan_rays
     }
     const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
@@ -574,6 +665,10 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         const uint32_t p = (PER_ENV_MAP && j.order) ? ((cu32_t)j.order)[pl] : j.first_pose + pl;
         const int b = (int)((task - pl * tasks_per_agent) * 64u + lane);
         if (b >= (int)B) continue;
+        // a ray the ray pass marches (stamped in the previous step) is skipped by its lane; the stamp is requested
+        // here and looked at after the noise sample and the direction have been requested too (one round trip)
+        uint32_t ray_stamp = 0u;
+        if (SCHED && j.ray_blocks) ray_stamp = ((csched_t)j.sched)->rflags_r[p * B + (uint32_t)b];
         typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
         const chdr_t h0 = (chdr_t)(j.hdr) + p;
         const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
@@ -590,10 +685,11 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;   // scalar
         const double nz = row != -1 ? nrow[b] : 0.0;
         const double2 cs = k.cs[beam_dir_index(k, start, b)];
-        int hr = -1, hc = -1, nl;
+        const bool mine = !(SCHED && j.ray_blocks && ray_stamp == j.epoch_r);   // false: the ray pass has this ray
+        int hr = -1, hc = -1, nl = 0;
         double r = 0.;
-        bool exact = fast == 0;
-        if (fast) {
+        bool exact = mine && fast == 0;
+        if (mine && fast) {
             double ux, uy, cux, cuy;
             padded_position<IDENT>(km, x, y, ux, uy);
             padded_rate<IDENT>(km, cs.x, cs.y, cux, cuy);
@@ -601,10 +697,25 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         }
         if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
         if (COUNT) nl_acc += (uint32_t)nl;   // measurement variant only (bench.py's L-bar)
+        if (SCHED && j.ray_blocks) {
+            // this step's long rays go on the ray list for the next step: one atomic per wave that has any
+            const csched_t sc = (csched_t)j.sched;
+            const bool listed = nl > (int)sc->rthr;
+            const uint64_t lm = __ballot(listed);
+            if (lm != 0ull) {
+                uint32_t pos = 0u;
+                if (lane == (uint32_t)__builtin_ctzll(lm)) pos = atomicAdd(sc->rcount_w, (uint32_t)popc_u64(lm));
+                pos = (uint32_t)__shfl((int)pos, __builtin_ctzll(lm)) + (uint32_t)popc_u64(lm & ((1ull << lane) - 1ull));
+                if (listed && pos < sc->rcap) {
+                    sc->rlist_w[pos] = p * B + (uint32_t)b;
+                    sc->rflags_w[p * B + (uint32_t)b] = j.epoch_w;
+                }
+            }
+        }
         if (SCHED) {
             const csched_t sc = (csched_t)j.sched;
             if (__ballot(nl > (int)sc->thr) != 0ull && lane == 0u) {
-                // lane 0 (beam task*64, always a valid beam) appends the task for the next step
+                // lane 0 (beam task*64, always a valid beam; nl = 0 if the ray pass has its ray) appends the task for the next step
                 const uint32_t pos = atomicAdd(sc->count_w, 1u);
                 if (pos < sc->cap) {
                     sc->list_w[pos] = task;
@@ -612,7 +723,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
                 }
             }
         }
-        finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
+        if (mine) finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
         if (ENVCNT && lane == 0u) {
             // probe: what a per-env completion counter costs (one returning agent-scope atomic per task; the
             // arrival that completes the env resets the counter, as a fused finalize would before it runs)

@@ -110,6 +110,45 @@ def test_flattened_finalize_is_bit_identical(amd, lanes):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("thr,waves,cache", [(4, 64, 0), (24, 2048, 0), (64, 2048, 16)])
+def test_ray_pass_is_invisible(amd, thr, waves, cache):
+    """small batches: a ray that was long in the previous step is marched by a wave of its own at the front of the
+    next scan launch (scalar-path samples) and skipped by the lane that would normally march it.  Forced on with
+    a threshold so low that most rays take that path and the list overflows its capacity (thr 4), with few waves
+    serving many rays each, with the noise rows living in scans[] (row cache of 16 rows: RayHdr::noise_row == -2,
+    where a ray marched twice would add its noise twice) — against the ray pass switched off: not a bit may
+    change, through resets, re-seat arming and lookup counting (which suspends the ordering)"""
+    E, A, T = 300, 2, 60
+    a = _sim(amd, E, A, exp={"task_order": 1, "ray_pass": 0})
+    b = _sim(amd, E, A, exp={"task_order": 1, "ray_pass": 1, "ray_thr": thr, "ray_waves": waves})
+    poses = bench_start_poses(E, A)
+    rng = np.random.default_rng(8)
+    st = []
+    for s in (a, b):
+        s.set_noise_rng(12345, 0.01, cache_rows=cache)
+        s.reset(poses)
+        d = s.device_array((E * A, 3)); d.upload(poses); st.append(d)
+    for t in range(T):
+        if t % 10 == 0:
+            act = _actions(rng, E * A)
+        if t == 25:
+            for s, d in zip((a, b), st):
+                s.set_auto_reseat(d, 0, None)
+        if t == 40:
+            for s in (a, b):
+                s.scan_lookup_count(enable=True, read=True)
+        if t == 44:
+            assert a.scan_lookup_count(enable=False) == b.scan_lookup_count(enable=False)
+        a.step(act); b.step(act)
+        oa, ob = a.get(*ALL), b.get(*ALL)
+        for kk in oa:
+            assert np.array_equal(oa[kk], ob[kk]), (kk, t)
+        if t == 35:
+            mask = (rng.random(E) < 0.3).astype(np.uint8)
+            a.reset(poses, mask); b.reset(poses, mask)
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("probe", [{"scan_occupancy": 4}, {"scan_env_counter": 1}])
 def test_fusion_probes_do_not_change_results(amd, probe):
     """the two probes behind DESIGN 4.4's fusion-feasibility numbers (scan kernel at 4 waves/SIMD; per-env
@@ -333,6 +372,7 @@ def test_device_arrays_and_pinned_blocks_have_owners(amd):
     """DeviceArray: context manager, free() twice, collected without free(), alive at close(); a pinned block
     stays valid for the arrays that view it after the handle is closed (use-after-free)"""
     s = _sim(amd, 4, 2)
+    gc.collect()                     # earlier tests' garbage first, so that the numbers below are this test's
     free0 = s.device_mem_info()[0]
     with s.device_array((1 << 20,)) as d:
         d.upload(np.arange(1 << 20, dtype=np.float64))
@@ -340,10 +380,10 @@ def test_device_arrays_and_pinned_blocks_have_owners(amd):
         assert s.device_mem_info()[0] < free0
     assert d.ptr is None
     d.free()
-    assert s.device_mem_info()[0] == free0
+    assert s.device_mem_info()[0] >= free0
     s.device_array((1 << 20,))      # dropped on the floor
     gc.collect()
-    assert s.device_mem_info()[0] == free0
+    assert s.device_mem_info()[0] >= free0
     keep = s.device_array((1 << 20,))   # still alive at close(): given back by close()
     pin = s.pinned_empty((1000,))
     pin[:] = np.arange(1000.0)

@@ -33,8 +33,11 @@ d_act = s.device_array((E * A, 2)); d_act.upload(np.stack([rng.uniform(-0.2, 0.2
 d_start = s.device_array((E * A, 3)); d_start.upload(poses)
 out = []
 free, total = s.device_mem_info()
-for k in (0, 1, 2, 4, 8, 16):
-    for assign in (("single-map kernel",) if k == 0 else (("one slot",) if k == 1 else ("interleaved", "grouped"))):
+# two sweeps, the second in reverse order (clock / thermal state drifts over a run); the faster of the two counts
+sweep = [(k, a) for k in (0, 1, 2, 4, 8, 16) for a in (("single-map kernel",) if k == 0 else (("one slot",) if k == 1 else ("interleaved", "grouped")))]
+best = {}
+for k, assign in sweep + sweep[::-1]:
+    if True:
         if k == 0:
             s.set_env_maps(None)
         elif assign == "grouped":
@@ -50,8 +53,11 @@ for k in (0, 1, 2, 4, 8, 16):
         s.sync(); dt = (time.perf_counter() - t0) / 150
         rec = {"agents": N, "beams": BEAMS, "tracks": max(k, 1), "assignment": assign, "ms_per_step": dt * 1e3, "agent_steps_per_s": N / dt,
                "csrc": build.src_hash()}
-        out.append(rec)
-        print(json.dumps(rec)); sys.stdout.flush()
+        if (k, assign) not in best or rec["ms_per_step"] < best[(k, assign)]["ms_per_step"]:
+            best[(k, assign)] = rec
+out = [best[c] for c in sweep]
+for rec in out:
+    print(json.dumps(rec)); sys.stdout.flush()
 base = out[0]["ms_per_step"]
 for r in out:
     r["vs_single_map"] = r["ms_per_step"] / base

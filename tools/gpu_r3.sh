@@ -47,6 +47,21 @@ finalize2)
     F110_EXP=pair_always=$pa timeout 200 $X python bench.py $H --agents 65536 --separate-reset > $OUT/fin2_sepreset_pa$pa.log 2>&1; line $OUT/fin2_sepreset_pa$pa.log "65536 separate reset, pair_always $pa"
   done
   ;;
+ray)
+  # configs[1]: the ray-level pass (last step's longest rays on waves of their own, scalar-path samples)
+  for n in 1024 2048 4096 8192; do for r in 0 1; do
+    F110_EXP=ray_pass=$r timeout 200 $X python bench.py $H --agents $n > $OUT/ray_n${n}_r$r.log 2>&1; line $OUT/ray_n${n}_r$r.log "agents $n ray_pass $r"
+  done; done
+  for thr in 16 32 48 96 128; do
+    F110_EXP=ray_pass=1,ray_thr=$thr timeout 200 $X python bench.py $H --agents 4096 > $OUT/ray_thr$thr.log 2>&1; line $OUT/ray_thr$thr.log "4096 ray_thr $thr"
+  done
+  for w in 512 1024 4096 8192; do
+    F110_EXP=ray_pass=1,ray_waves=$w timeout 200 $X python bench.py $H --agents 4096 > $OUT/ray_w$w.log 2>&1; line $OUT/ray_w$w.log "4096 ray_waves $w"
+  done
+  for tt in 24 48 200; do
+    F110_EXP=ray_pass=1,task_thr=$tt timeout 200 $X python bench.py $H --agents 4096 > $OUT/ray_tt$tt.log 2>&1; line $OUT/ray_tt$tt.log "4096 ray_pass 1, task_thr $tt"
+  done
+  ;;
 probes)
   # fusion feasibility: the scan kernel at the occupancy a fused (118-VGPR) kernel would have,
   # and with a per-env completion counter
@@ -57,7 +72,7 @@ probes)
   done
   ;;
 tracks)
-  timeout 400 python tools/debug/track_scaling.py 65536 1080 > $OUT/track_scaling.log 2>&1; cat $OUT/track_scaling.log | python -c "
+  timeout 600 python tools/debug/track_scaling.py 65536 1080 > $OUT/track_scaling.log 2>&1; cat $OUT/track_scaling.log | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
