@@ -129,11 +129,11 @@ struct f110_sim {
     // longest-first order of the scan tasks (TaskSched, small batches): double-buffered flags / lists / counters
     bool task_order = false;
     uint32_t *d_tflags[2] = {nullptr, nullptr}, *d_tlist[2] = {nullptr, nullptr}, *d_tcount = nullptr;
-    uint32_t *d_rflags[2] = {nullptr, nullptr}, *d_rlist[2] = {nullptr, nullptr};   // the ray-level lists (TaskSched::r*)
+    uint32_t *d_rflags[2] = {nullptr, nullptr}, *d_rlist[2] = {nullptr, nullptr}, *d_rtask[2] = {nullptr, nullptr};   // the ray-level lists (TaskSched::r*)
     TaskSched *d_tsched = nullptr;   // [2]
     uint32_t task_epoch = 2, task_cap = 0, task_thr = 96;   // epochs start above the flags' initial 0
-    uint32_t ray_cap = 0, ray_thr = 64, ray_waves = 2048;
-    bool ray_pass = true;
+    uint32_t ray_cap = 0, ray_thr = 96, ray_waves = 2048;
+    bool ray_pass = false;   // until it is measured to pay (f110_exp_set ray_pass)
     ExpSwitches exp;
     uint32_t *d_env_done = nullptr;   // [num_envs] scan_env_counter probe
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
@@ -366,6 +366,8 @@ static int task_order_setup(f110_sim *h, bool on)
             HIPCHK(h, hipMemsetAsync(h->d_tflags[q], 0, sizeof(uint32_t) * n_tasks, h->stream));
             TRY(dmalloc(h, &h->d_rflags[q], n_rays));
             TRY(dmalloc(h, &h->d_rlist[q], (size_t)h->ray_cap));
+            TRY(dmalloc(h, &h->d_rtask[q], n_tasks));
+            HIPCHK(h, hipMemsetAsync(h->d_rtask[q], 0, sizeof(uint32_t) * n_tasks, h->stream));
             HIPCHK(h, hipMemsetAsync(h->d_rflags[q], 0, sizeof(uint32_t) * n_rays, h->stream));
         }
         TRY(dmalloc(h, &h->d_tcount, 4));   // {task count 0, 1, ray count 0, 1}
@@ -375,7 +377,7 @@ static int task_order_setup(f110_sim *h, bool on)
     TaskSched ts[2];
     for (int q = 0; q < 2; ++q)   // struct q is used at steps of parity q: it reads what parity q^1 wrote
         ts[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr,
-                          h->d_rflags[q ^ 1], h->d_rflags[q], h->d_rlist[q ^ 1], h->d_rlist[q], h->d_tcount + 2 + (q ^ 1), h->d_tcount + 2 + q, h->ray_cap, h->ray_thr};
+                          h->d_rflags[q ^ 1], h->d_rflags[q], h->d_rtask[q ^ 1], h->d_rtask[q], h->d_rlist[q ^ 1], h->d_rlist[q], h->d_tcount + 2 + (q ^ 1), h->d_tcount + 2 + q, h->ray_cap, h->ray_thr};
     HIPCHK(h, hipMemcpyAsync(h->d_tsched, ts, sizeof ts, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->task_order = true;
@@ -709,7 +711,7 @@ void f110_destroy(f110_sim *h)
     for (hipEvent_t ge : h->gevents) (void)hipEventDestroy(ge);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     {
-        void *rp[] = {h->d_rflags[0], h->d_rflags[1], h->d_rlist[0], h->d_rlist[1], h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_tsched, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
+        void *rp[] = {h->d_rtask[0], h->d_rtask[1], h->d_rflags[0], h->d_rflags[1], h->d_rlist[0], h->d_rlist[1], h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_tsched, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
         for (void *p : rp)
             if (p) (void)hipFree(p);
     }

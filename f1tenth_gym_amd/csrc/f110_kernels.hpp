@@ -296,12 +296,14 @@ struct TaskSched {
     uint32_t cap, thr;
     // The same idea one level down (round 3): a RAY that took more than `rthr` lookups in the previous step is
     // listed by its number, stamped in rflags (one epoch word per ray), skipped by the lane that would
-    // normally march it, and marched by a wave of its own at the front of the launch — all 64 lanes compute
-    // the same values, so the table sample travels the scalar path (s_load through the scalar cache), which
-    // answers faster than the texture path a divergent gather needs.  The scan of a small batch ends when
-    // its longest ray ends; this shortens exactly that chain.  rcount_w sits two words behind count_w.
+    // normally march it, and marched by a wave of its own at the front of the launch, which reads the table a
+    // 16 x 16-cell block at a time (march_padded_block): one memory round trip per ~10 samples of a ray that
+    // creeps along a wall instead of one per sample.  The scan of a small batch ends when its longest ray
+    // ends; this shortens exactly that chain.  rcount_w sits two words behind count_w.
     const uint32_t *rflags_r;
     uint32_t *rflags_w;
+    const uint32_t *rtask_r;   // [n_tasks] epoch stamps: some ray of this task is on the ray list (only then do the
+    uint32_t *rtask_w;         //           task's lanes look at their per-ray stamps)
     const uint32_t *rlist_r;
     uint32_t *rlist_w;
     const uint32_t *rcount_r;
@@ -534,14 +536,21 @@ struct MapFast {
 };
 static_assert(sizeof(MapFast) == 64, "MapFast is read as one 64-byte scalar load");
 
-// march_padded for ONE ray marched by a whole wave (every lane holds the same values): identical arithmetic,
-// but the table sample is a scalar load — its address comes out of the VALU through v_readfirstlane and the
-// value comes back through the scalar cache, ~2x sooner than a 64-lane gather travels the texture path.
-__device__ __forceinline__ bool march_padded_uniform(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
-                                                     int &lookups)
+// march_padded for ONE ray marched by a whole wave (every lane holds the same position): identical arithmetic,
+// but the table is read a 16 x 16-cell block at a time — lane l keeps the cells of rows (l >> 4) + 4 q,
+// q = 0..3, column (l & 15) of the block in four registers, one load instruction per row group, all in flight
+// together — and a sample that lands inside the block is a v_readlane, not a trip to L2.  A ray that creeps
+// along a wall takes ~10 samples per block, so its dependent chain is one memory round trip per ~10 samples
+// instead of one per sample.  The block is placed with the current cell near its trailing edge along the ray.
+__device__ __forceinline__ bool march_padded_block(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
+                                                   int &lookups)
 {
-    typedef const __attribute__((address_space(4))) char *cbase_t;
-    const cbase_t base = (cbase_t)(k.pad);
+    const uint32_t lane = threadIdx.x & 63u;
+    const char *base = reinterpret_cast<const char *>(k.pad);
+    const int lead_c = cux >= 0. ? 2 : 13, lead_r = cuy >= 0. ? 2 : 13;   // (uniform)
+    const uint32_t lane_off = (lane >> 4) * (uint32_t)k.pad_row_bytes + ((lane & 15u) << 3);
+    int bc = -0x10000, br = -0x10000;   // block origin: none yet
+    double v0 = 0., v1 = 0., v2 = 0., v3 = 0.;
     double total = d;
     int n = 1;
     bool redo = false;
@@ -550,13 +559,33 @@ __device__ __forceinline__ bool march_padded_uniform(const ScanConst &k, double 
         uy = fma(d, cuy, uy);
         const uint32_t wx = low_word(ux + kFixBig);
         const uint32_t wy = low_word(uy + kFixBig);
-        uint32_t off = mul24(wy >> kFixFracBits, (uint32_t)k.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
+        int cc = (int)(wx >> kFixFracBits), cr = (int)(wy >> kFixFracBits);
         if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {   // march_padded's guard band, verbatim
             redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
-            off = mul24((uint32_t)(int)floor(uy), (uint32_t)k.pad_row_bytes) + ((uint32_t)(int)floor(ux) << 3);
+            cc = (int)floor(ux);
+            cr = (int)floor(uy);
         }
-        const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
-        d = *reinterpret_cast<const __attribute__((address_space(4))) double *>(base + so);
+        cc = __builtin_amdgcn_readfirstlane(cc);
+        cr = __builtin_amdgcn_readfirstlane(cr);
+        int dc = cc - bc, dr = cr - br;
+        if ((((uint32_t)dc) | ((uint32_t)dr)) >= 16u) {   // wave-uniform: fetch the block around (and ahead of) this cell
+            bc = cc - lead_c;
+            br = cr - lead_r;
+            bc = bc < 0 ? 0 : (bc > k.pad_width - 16 ? k.pad_width - 16 : bc);
+            br = br < 0 ? 0 : (br > k.pad_height - 16 ? k.pad_height - 16 : br);
+            const char *p0 = base + (mul24((uint32_t)br, (uint32_t)k.pad_row_bytes) + ((uint32_t)bc << 3)) + lane_off;
+            const uint32_t r4 = 4u * (uint32_t)k.pad_row_bytes;
+            v0 = *reinterpret_cast<const double *>(p0);
+            v1 = *reinterpret_cast<const double *>(p0 + r4);
+            v2 = *reinterpret_cast<const double *>(p0 + 2u * r4);
+            v3 = *reinterpret_cast<const double *>(p0 + 3u * r4);
+            dc = cc - bc;
+            dr = cr - br;
+        }
+        const int q = dr >> 2;
+        const double vq = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
+        const int src = ((dr & 3) << 4) | dc;
+        d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(vq), src), __builtin_amdgcn_readlane(__double2loint(vq), src));
         total += d;
         ++n;
     }
@@ -622,7 +651,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
                     double ux, uy, cux, cuy;
                     padded_position<IDENT>(k, x, y, ux, uy);
                     padded_rate<IDENT>(k, cs.x, cs.y, cux, cuy);
-                    exact = !march_padded_uniform(k, ux, uy, cux, cuy, d0, r, nl);
+                    exact = !march_padded_block(k, ux, uy, cux, cuy, d0, r, nl);
                 }
                 if (exact) r = march_exact_cold<IDENT>(j.k_cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
                 if (lane == 0u) {
@@ -631,6 +660,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
                         if (pos < sc->rcap) {
                             sc->rlist_w[pos] = ray;
                             sc->rflags_w[ray] = j.epoch_w;
+                            sc->rtask_w[p * tasks_per_agent + ((uint32_t)b >> 6)] = j.epoch_w;
                         }
                     }
                     finish_beam_with(j, p, b, ray, row != -1 ? r + nz : r, vel);
@@ -668,7 +698,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         // a ray the ray pass marches (stamped in the previous step) is skipped by its lane; the stamp is requested
         // here and looked at after the noise sample and the direction have been requested too (one round trip)
         uint32_t ray_stamp = 0u;
-        if (SCHED && j.ray_blocks) ray_stamp = ((csched_t)j.sched)->rflags_r[p * B + (uint32_t)b];
+        if (SCHED && j.ray_blocks && ((cu32_t)((csched_t)j.sched)->rtask_r)[task] == j.epoch_r) ray_stamp = ((csched_t)j.sched)->rflags_r[p * B + (uint32_t)b];
         typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
         const chdr_t h0 = (chdr_t)(j.hdr) + p;
         const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
@@ -709,6 +739,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
                 if (listed && pos < sc->rcap) {
                     sc->rlist_w[pos] = p * B + (uint32_t)b;
                     sc->rflags_w[p * B + (uint32_t)b] = j.epoch_w;
+                    sc->rtask_w[task] = j.epoch_w;   // (every listed lane stores the same word)
                 }
             }
         }
