@@ -43,6 +43,7 @@ struct ExpSwitches {
     int no_window = 0;         // 1: F110_MAP_WINDOW_LDS handles step with the PADDED kernel
     int finalize_lanes = 0;    // 8 / 16 / 32 / 64 lanes per agent in k_finalize*, 0 = by batch size
     int finalize_flat = -1;    // A = 2: 1 the workgroup-flattened window loop, 0 fixed lanes per agent, -1 = default
+    int long_prio = 0;         // 1: the longest-first pass's waves raise their issue priority (s_setprio 3)
     int pair_always = 0;       // A = 2: 1 = pair test inside the finalize kernel also for big batches without the in-step re-seat
     int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
     int scan_env_counter = 0;  // 1: the scan kernel also counts finished tasks per env (fusion feasibility A/B)
@@ -432,6 +433,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
         h->exp.finalize_lanes = value;
     } else if (k == "finalize_flat") h->exp.finalize_flat = value;
     else if (k == "pair_always") h->exp.pair_always = value;
+    else if (k == "long_prio") h->exp.long_prio = value;
     else if (k == "scan_occupancy") h->exp.scan_occupancy = value;
     else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
     else if (k == "collide_mode") {
@@ -1741,9 +1743,8 @@ static int noise_cache_extend(f110_sim *h, int upto)
 // One step of the agents [begin, begin + count) (an env-aligned block) on stream `st`.
 // Product build, one dispatch per (agents per env, beams) case:
 //   A = 1                      k_integrate -> scan -> k_finalize_solo
-//   A = 2 (re-seat armed, or a small batch)
-//                              k_integrate -> scan -> k_finalize_pair[_flat]   (pair test + window inside the last kernel)
-//   otherwise                  k_integrate -> { scan || k_collide on the side stream } -> k_finalize
+//   A = 2                      k_integrate -> scan -> k_finalize_pair_flat     (pair test + window inside the last kernel)
+//   A > 2                      k_integrate -> { scan || k_collide on the side stream } -> k_finalize
 // and the scan kernel by table / beam count: k_scan_rays_agent (PADDED table; longest-first order for small
 // batches), k_scan_dirs_agent (more beams than table directions), k_scan_rays (row-major table, few beams).
 // The experimental build adds collide_mode 1 (pair tests fused into k_integrate) / 2 (k_collide in line), the
@@ -1791,12 +1792,12 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     }
 #endif
     if (!fused_integrate) hipLaunchKernelGGL(k_integrate<0>, grid1d(count, 256), dim3(256), 0, st, dev, h->k, d_actions);
-    // A = 2: the pair test and the opponent window inside k_finalize (k_finalize_pair) — unless the batch is
-    // big AND finished envs are not re-seated inside the step: then k_finalize runs a wave per agent (crashed
-    // cars pile up, windows grow to all beams) and 65 536 waves each carrying the prologue cost more than the
-    // side stream does (parked cars, 65 536 agents: 0.70 vs 0.63 ms)
+    // A = 2: the pair test and the opponent window inside the finalize kernel (k_finalize_pair_flat): one stream, no
+    // events.  (Round 2 kept the side-stream form for big batches stepped without the in-step re-seat — crashed cars
+    // pile up, their windows grow to all beams, and fixed lanes per agent then serialise — the flattened window loop
+    // balances that inside the workgroup: 65 536 parked cars 0.624 -> 0.579 ms, crashed cars piling up 0.899 -> 0.852.)
     const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0 &&
-                                  (h->dev.reseat_poses != nullptr || N < 8192 || (kExperimental && h->exp.pair_always));
+                                  (kFinalizeFlatDefault || h->dev.reseat_poses != nullptr || N < 8192 || (kExperimental && h->exp.pair_always));
     const bool no_collide_launch = fused_integrate || pair_in_finalize;
     const bool side_collide = multi && !no_collide_launch && !(kExperimental && collide_mode == 2);
     // k_collide only feeds k_finalize, k_scan_rays only needs k_integrate: run the two side by
@@ -1831,6 +1832,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         j.div_magic = h->step_magic;
         j.div_shift = h->step_shift;
         j.lookups_total = h->lookups_on ? h->d_lookups : nullptr;
+        j.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;   // (step form: only the ray pass counts here)
         j.k_cold = cold_consts(h);
         if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
         j.order = (h->multi_map && begin == 0 && count == N) ? h->d_scan_order : nullptr;
@@ -1909,7 +1911,8 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             j.epoch_r = h->task_epoch - 1u;
             j.epoch_w = h->task_epoch;
             j.long_blocks = (h->task_cap + wpb - 1) / wpb;
-            j.ray_blocks = h->ray_pass ? (std::min(h->ray_cap, h->ray_waves) + wpb - 1) / wpb : 0u;
+            j.ray_blocks = (kExperimental && h->ray_pass) ? (std::min(h->ray_cap, h->ray_waves) + wpb - 1) / wpb : 0u;
+            j.long_prio = (uint32_t)h->exp.long_prio;
             h->task_epoch += 1u;
             const dim3 sgrid(grid.x + j.long_blocks + j.ray_blocks);
             if (h->k.ident_rot)
@@ -1990,14 +1993,16 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_flat<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
             else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_flat<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
             else hipLaunchKernelGGL(k_finalize_pair_flat<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
-        } else if (pair_in_finalize) {
+        }
+#ifdef F110_EXPERIMENTAL
+        else if (pair_in_finalize) {   // round 2's form: fixed lanes per agent (A/B)
             if (lanes == 8) hipLaunchKernelGGL(k_finalize_pair<8>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
             else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
-#ifdef F110_EXPERIMENTAL
             else if (lanes == 32) hipLaunchKernelGGL(k_finalize_pair<32>, dim3((count + 7) / 8), dim3(256), 0, st, dev, B);
-#endif
             else hipLaunchKernelGGL(k_finalize_pair<64>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
-        } else if (lanes == 8)
+        }
+#endif
+        else if (lanes == 8)
             hipLaunchKernelGGL(k_finalize<8>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
         else if (lanes == 16)
             hipLaunchKernelGGL(k_finalize<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);

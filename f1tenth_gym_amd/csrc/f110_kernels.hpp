@@ -286,6 +286,13 @@ __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
 // launch.  flags_r[task] == epoch_r marks "on the list" (the normal blocks skip those tasks); this step's
 // long tasks go to list_w / flags_w for the next step (stamped epoch_w; stale stamps never match again, so
 // nothing is ever cleared).  Stale or missing entries only cost speed: every task is marched exactly once.
+// the ray-level pass below was measured not to pay: it exists in the experimental build only
+#ifdef F110_EXPERIMENTAL
+constexpr bool kRayPassBuilt = true;
+#else
+constexpr bool kRayPassBuilt = false;
+#endif
+
 struct TaskSched {
     const uint32_t *flags_r;
     uint32_t *flags_w;
@@ -326,7 +333,7 @@ struct RayJob {
     uint32_t epoch_r, epoch_w, long_blocks, ray_blocks;
     // fusion-feasibility probe (experimental build): per-env count of finished scan tasks, reset by the last arriver
     uint32_t *env_done;
-    uint32_t tasks_per_env, pad_env;
+    uint32_t tasks_per_env, long_prio;
     // per-env maps: the order the scan walks the agents in — sorted by map slot, so that the XCD-contiguous
     // block order hands each XCD's L2 the agents of as few tracks as possible however the caller interleaved
     // them (nullptr: agent order)
@@ -539,22 +546,32 @@ static_assert(sizeof(MapFast) == 64, "MapFast is read as one 64-byte scalar load
 // march_padded for ONE ray marched by a whole wave (every lane holds the same position): identical arithmetic,
 // but the table is read a 16 x 16-cell block at a time — lane l keeps the cells of rows (l >> 4) + 4 q,
 // q = 0..3, column (l & 15) of the block in four registers, one load instruction per row group, all in flight
-// together — and a sample that lands inside the block is a v_readlane, not a trip to L2.  A ray that creeps
-// along a wall takes ~10 samples per block, so its dependent chain is one memory round trip per ~10 samples
-// instead of one per sample.  The block is placed with the current cell near its trailing edge along the ray.
+// together — and a sample that lands inside the block is a v_readlane, not a trip through the memory system.
+// A ray that creeps along a wall takes 5-13 samples per block.  The block the ray will enter next (13 cells
+// further along its direction) is requested as soon as the current one is entered, so that its (cold: nobody
+// else has touched those lines) fetch runs under the samples of the current block; a sample that jumps further
+// than a block (open space: the step is the distance to the nearest wall) is read on its own.
 __device__ __forceinline__ bool march_padded_block(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
-                                                   int &lookups)
+                                                   int &lookups, int &blocks)
 {
+    blocks = 0;
     const uint32_t lane = threadIdx.x & 63u;
     const char *base = reinterpret_cast<const char *>(k.pad);
-    const int lead_c = cux >= 0. ? 2 : 13, lead_r = cuy >= 0. ? 2 : 13;   // (uniform)
+    const int lead_c = cux >= 0. ? 2 : 13, lead_r = cuy >= 0. ? 2 : 13;   // (uniform) the entry cell sits near the trailing edge
+    const double cmax = fmax(fabs(cux), fabs(cuy));                      // cells per metre along the dominant axis
+    const int step_c = __builtin_amdgcn_readfirstlane((int)rint(13.0 * cux / cmax));
+    const int step_r = __builtin_amdgcn_readfirstlane((int)rint(13.0 * cuy / cmax));
+    const double far = 12.0 / cmax;                                      // a step longer than this leaves any block
     const uint32_t lane_off = (lane >> 4) * (uint32_t)k.pad_row_bytes + ((lane & 15u) << 3);
-    int bc = -0x10000, br = -0x10000;   // block origin: none yet
-    double v0 = 0., v1 = 0., v2 = 0., v3 = 0.;
+    const uint32_t r4 = 4u * (uint32_t)k.pad_row_bytes;
+    int bc = -0x10000, br = -0x10000, nbc = -0x10000, nbr = -0x10000;   // origins of the current / the requested block
+    double v0 = 0., v1 = 0., v2 = 0., v3 = 0., n0 = 0., n1 = 0., n2 = 0., n3 = 0.;
+    auto origin = [&](int c, int lead, int hi) { c -= lead; return c < 0 ? 0 : (c > hi ? hi : c); };
     double total = d;
     int n = 1;
     bool redo = false;
     while ((d > k.eps) & (total <= k.max_range) & !redo) {
+        const bool jump = d > far;
         ux = fma(d, cux, ux);
         uy = fma(d, cuy, uy);
         const uint32_t wx = low_word(ux + kFixBig);
@@ -568,17 +585,38 @@ __device__ __forceinline__ bool march_padded_block(const ScanConst &k, double ux
         cc = __builtin_amdgcn_readfirstlane(cc);
         cr = __builtin_amdgcn_readfirstlane(cr);
         int dc = cc - bc, dr = cr - br;
-        if ((((uint32_t)dc) | ((uint32_t)dr)) >= 16u) {   // wave-uniform: fetch the block around (and ahead of) this cell
-            bc = cc - lead_c;
-            br = cr - lead_r;
-            bc = bc < 0 ? 0 : (bc > k.pad_width - 16 ? k.pad_width - 16 : bc);
-            br = br < 0 ? 0 : (br > k.pad_height - 16 ? k.pad_height - 16 : br);
-            const char *p0 = base + (mul24((uint32_t)br, (uint32_t)k.pad_row_bytes) + ((uint32_t)bc << 3)) + lane_off;
-            const uint32_t r4 = 4u * (uint32_t)k.pad_row_bytes;
-            v0 = *reinterpret_cast<const double *>(p0);
-            v1 = *reinterpret_cast<const double *>(p0 + r4);
-            v2 = *reinterpret_cast<const double *>(p0 + 2u * r4);
-            v3 = *reinterpret_cast<const double *>(p0 + 3u * r4);
+        if ((((uint32_t)dc) | ((uint32_t)dr)) >= 16u) {   // wave-uniform: not in the current block
+            const int ndc = cc - nbc, ndr = cr - nbr;
+            const bool in_next = (((uint32_t)ndc) | ((uint32_t)ndr)) < 16u;
+            if (!in_next && __builtin_amdgcn_readfirstlane((int)jump)) {
+                // a long step in open space: one cell, no block
+                d = *reinterpret_cast<const double *>(base + (mul24((uint32_t)cr, (uint32_t)k.pad_row_bytes) + ((uint32_t)cc << 3)));
+                total += d;
+                ++n;
+                continue;
+            }
+            if (in_next) {   // the requested block becomes the current one (its loads have had a block's worth of samples to land)
+                bc = nbc; br = nbr;
+                v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+            } else {
+                bc = origin(cc, lead_c, k.pad_width - 16);
+                br = origin(cr, lead_r, k.pad_height - 16);
+                const char *p0 = base + (mul24((uint32_t)br, (uint32_t)k.pad_row_bytes) + ((uint32_t)bc << 3)) + lane_off;
+                v0 = *reinterpret_cast<const double *>(p0);
+                v1 = *reinterpret_cast<const double *>(p0 + r4);
+                v2 = *reinterpret_cast<const double *>(p0 + 2u * r4);
+                v3 = *reinterpret_cast<const double *>(p0 + 3u * r4);
+                ++blocks;
+            }
+            {   // request the block after this one
+                nbc = origin(cc + step_c, lead_c, k.pad_width - 16);
+                nbr = origin(cr + step_r, lead_r, k.pad_height - 16);
+                const char *p1 = base + (mul24((uint32_t)nbr, (uint32_t)k.pad_row_bytes) + ((uint32_t)nbc << 3)) + lane_off;
+                n0 = *reinterpret_cast<const double *>(p1);
+                n1 = *reinterpret_cast<const double *>(p1 + r4);
+                n2 = *reinterpret_cast<const double *>(p1 + 2u * r4);
+                n3 = *reinterpret_cast<const double *>(p1 + 3u * r4);
+            }
             dc = cc - bc;
             dr = cr - br;
         }
@@ -624,7 +662,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
     bool long_pass = false;
     uint32_t long_task = 0;
     if (SCHED) {
-        if (blk < j.ray_blocks) {
+        if (kRayPassBuilt && blk < j.ray_blocks) {
             // ---- ray pass: last step's longest RAYS, one per wave, newest list entries (= the rays that finished
             // last, i.e. the longest) first
             const csched_t sc = (csched_t)j.sched;
@@ -644,14 +682,19 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
                 const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;
                 const double nz = row != -1 ? nrow[b] : 0.0;
                 const double2 cs = k.cs[beam_dir_index(k, start, b)];
-                int hr = -1, hc = -1, nl;
+                int hr = -1, hc = -1, nl, nblk = 0;
                 double r = 0.;
                 bool exact = fast == 0;
                 if (fast) {
                     double ux, uy, cux, cuy;
                     padded_position<IDENT>(k, x, y, ux, uy);
                     padded_rate<IDENT>(k, cs.x, cs.y, cux, cuy);
-                    exact = !march_padded_block(k, ux, uy, cux, cuy, d0, r, nl);
+                    exact = !march_padded_block(k, ux, uy, cux, cuy, d0, r, nl, nblk);
+                }
+                if (j.path_stats && lane == 0u) {   // diagnostics: rays / block fetches / samples of the ray pass
+                    atomicAdd(&j.path_stats[0], 1ull);
+                    atomicAdd(&j.path_stats[1], (unsigned long long)nblk);
+                    atomicAdd(&j.path_stats[2], (unsigned long long)nl);
                 }
                 if (exact) r = march_exact_cold<IDENT>(j.k_cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
                 if (lane == 0u) {
@@ -677,6 +720,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
             long_pass = true;
             long_task = ((cu32_t)sc->list_r)[wl];
             tpw = 1u;
+            if (j.long_prio) __builtin_amdgcn_s_setprio(3);   // (experiment: instruction-issue priority for the waves the launch waits for)
         } else {
             blk -= j.long_blocks;
         }
@@ -698,7 +742,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         // a ray the ray pass marches (stamped in the previous step) is skipped by its lane; the stamp is requested
         // here and looked at after the noise sample and the direction have been requested too (one round trip)
         uint32_t ray_stamp = 0u;
-        if (SCHED && j.ray_blocks && ((cu32_t)((csched_t)j.sched)->rtask_r)[task] == j.epoch_r) ray_stamp = ((csched_t)j.sched)->rflags_r[p * B + (uint32_t)b];
+        if (SCHED && kRayPassBuilt && j.ray_blocks && ((cu32_t)((csched_t)j.sched)->rtask_r)[task] == j.epoch_r) ray_stamp = ((csched_t)j.sched)->rflags_r[p * B + (uint32_t)b];
         typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
         const chdr_t h0 = (chdr_t)(j.hdr) + p;
         const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
@@ -715,7 +759,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;   // scalar
         const double nz = row != -1 ? nrow[b] : 0.0;
         const double2 cs = k.cs[beam_dir_index(k, start, b)];
-        const bool mine = !(SCHED && j.ray_blocks && ray_stamp == j.epoch_r);   // false: the ray pass has this ray
+        const bool mine = !(SCHED && kRayPassBuilt && j.ray_blocks && ray_stamp == j.epoch_r);   // false: the ray pass has this ray
         int hr = -1, hc = -1, nl = 0;
         double r = 0.;
         bool exact = mine && fast == 0;
@@ -727,7 +771,7 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         }
         if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
         if (COUNT) nl_acc += (uint32_t)nl;   // measurement variant only (bench.py's L-bar)
-        if (SCHED && j.ray_blocks) {
+        if (SCHED && kRayPassBuilt && j.ray_blocks) {
             // this step's long rays go on the ray list for the next step: one atomic per wave that has any
             const csched_t sc = (csched_t)j.sched;
             const bool listed = nl > (int)sc->rthr;
