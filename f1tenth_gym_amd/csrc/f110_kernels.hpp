@@ -731,6 +731,11 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
     }
     const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
     uint32_t nl_acc = 0;
+    // PER_ENV_MAP: the map record is (re)loaded only when the slot changes — the wave's consecutive tasks belong to
+    // one or two agents, and the scan order groups the agents by slot (f110_set_env_maps)
+    ScanConst km = k;
+    const ScanConst *cold = j.k_cold;
+    int cur_slot = -1;
     for (uint32_t t = 0; t < tpw; ++t) {
         const uint32_t task = __builtin_amdgcn_readfirstlane(long_pass ? long_task : wave * tpw + t);
         if (task >= j.n_tasks) break;
@@ -748,11 +753,10 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
         const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
         const int row = uniform_i32(h0->noise_row), slot = uniform_i32(h0->map_slot), fast = uniform_i32(h0->fast);
-        ScanConst km = k;   // PER_ENV_MAP: only the fields set here differ
-        const ScanConst *cold = j.k_cold;
-        if (PER_ENV_MAP) {
+        if (PER_ENV_MAP && slot != cur_slot) {   // wave-uniform
             cold = maps_full + slot;
             load_map_fast(km, maps_fast, slot);
+            cur_slot = slot;
         }
         // the beam's noise sample is requested before the march so that its latency hides under it:
         // row of the table / row cache, or (row -2) the row k_noise_rows left in this agent's scans[]
@@ -957,6 +961,9 @@ __global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, 
     }
     const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
     uint32_t nl_acc = 0;
+    ScanConst km = k;   // PER_ENV_MAP: this agent's track (f110_set_env_maps), reloaded when the slot changes
+    const ScanConst *cold = j.k_cold;
+    int cur_slot = -1;
     for (uint32_t t = 0; t < tpw; ++t) {
         const uint32_t task = __builtin_amdgcn_readfirstlane(wave * tpw + t);
         if (task >= j.n_tasks) break;
@@ -971,12 +978,13 @@ __global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, 
         const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
         const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
         const int row = uniform_i32(h0->noise_row), fast = uniform_i32(h0->fast), i0 = uniform_i32(h0->i0);
-        ScanConst km = k;   // PER_ENV_MAP: this agent's track (f110_set_env_maps), constants through the scalar cache
-        const ScanConst *cold = j.k_cold;
         if (PER_ENV_MAP) {
             const int slot = uniform_i32(h0->map_slot);
-            cold = maps_full + slot;
-            load_map_fast(km, maps_fast, slot);
+            if (slot != cur_slot) {   // wave-uniform
+                cold = maps_full + slot;
+                load_map_fast(km, maps_fast, slot);
+                cur_slot = slot;
+            }
         }
         double r_dir = 0.;
         if (s0 + (int)lane < n_dirs) {
