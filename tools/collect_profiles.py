@@ -70,6 +70,43 @@ def main():
                                          "TCP_hit_frac": 1.0 - scan.get("TCP_TCC_READ_REQ_sum", 0.0) / max(scan.get("TCP_TOTAL_CACHE_ACCESSES_sum", 1.0), 1.0),
                                          "TCC_hit_frac": scan.get("TCC_HIT_sum", 0.0) / max(scan.get("TCC_REQ_sum", 1.0), 1.0)}
         json.dump(fl, open(fl_path, "w"), indent=1, sort_keys=True)
+    # HBM traffic of the scan kernel for the bench's other legs (tools/gpu_r3.sh pmc: traffic_<tag>_{FETCH,WRITE}_SIZE.json)
+    rec_path = os.path.join(DST, "pmc_scan.json")
+    rec = json.load(open(rec_path)) if os.path.isfile(rec_path) else {}
+    for leg, key in (("4096", "agents=4096,beams=1080,layout=3"), ("cfg5", "agents=65536,beams=4096,layout=3,tiles=2")):
+        vals, meta = {}, {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            q = os.path.join(SRC, "traffic_%s_%s.json" % (leg, c))
+            if os.path.isfile(q):
+                for kern, r in json.load(open(q)).items():
+                    if kern.startswith(("k_scan_rays", "k_scan_dirs")) and c in r["mean_per_dispatch"]:
+                        vals[c] = r["mean_per_dispatch"][c]; meta = r
+        if len(vals) == 2:
+            rec[key] = {"round": tag, "csrc": meta.get("csrc"), "window": meta.get("window"), "FETCH_SIZE_KiB": vals["FETCH_SIZE"],
+                        "WRITE_SIZE_KiB": vals["WRITE_SIZE"], "hbm_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+                        "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)"}
+    json.dump(rec, open(rec_path, "w"), indent=1, sort_keys=True)
+    # other summaries of the session, as they are
+    for src, dst in (("kernel_stats_4096.txt", "%s_kernel_stats_4096.txt"), ("track_scaling_65536_1080.json", "%s_track_scaling.json"),
+                     ("ray_bench.txt", "%s_ray_bench.txt"), ("bench_driver_form.log", "%s_bench_driver_form.json")):
+        if os.path.isfile(os.path.join(SRC, src)):
+            shutil.copyfile(os.path.join(SRC, src), os.path.join(DST, dst % tag))
+    # the A/B sweeps (one JSON line per bench run) as one table
+    import glob
+    rows = []
+    for f in sorted(glob.glob(os.path.join(SRC, "fin_*.log")) + glob.glob(os.path.join(SRC, "fin2_*.log")) + glob.glob(os.path.join(SRC, "probe_*.log")) +
+                    glob.glob(os.path.join(SRC, "ray_*.log")) + glob.glob(os.path.join(SRC, "preroll_*.log"))):
+        for line in open(f):
+            if line.startswith("{"):
+                d = json.loads(line)
+                rows.append("%-28s %9.3f M agent-steps/s  %.4f ms/step  agents %6d  resets %d" % (
+                    os.path.basename(f)[:-4], d["value"] / 1e6, d["ms_per_step"], d["config"]["agents_per_gpu"], d["config"]["env_resets_in_timed_region"]))
+    if rows:
+        hdr = ("# A/B sweeps of round 3 (tools/gpu_r3.sh finalize finalize2 probes ray preroll): bench.py --only-headline --steps 300 --warmup 30,\n"
+               "# experimental build, F110_EXP switches as named by the file: fin_n<agents>_f<finalize_flat>, fin_flat_l<lanes>, fin2_n<agents>_l<lanes>,\n"
+               "# fin2_<workload>_pa<pair_always>, probe_n<agents>_{base,occ4,cnt} (task_order off; scan at 4 waves/SIMD; + per-env completion counter),\n"
+               "# ray_n<agents>_r<ray_pass>, ray_thr<N>, ray_w<waves>, ray_tt<task_thr>, preroll_<P> (20 timed steps after P un-timed ones)\n# csrc %s\n" % csrc)
+        open(os.path.join(DST, "%s_ab_sweeps.txt" % tag), "w").write(hdr + "\n".join(rows) + "\n")
     print("profiles/%s_* written" % tag)
 
 

@@ -94,9 +94,9 @@ bench)
 prof)
   cd /tmp
   timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats -o stats -- python $R/bench.py $H > $OUT/prof_stats.log 2>&1
-  python $R/tools/summarize_prof.py stats $OUT/prof_stats $OUT/kernel_stats.txt; rm -rf $OUT/prof_stats
+  python $R/tools/summarize_prof.py stats $OUT/prof_stats $OUT/kernel_stats.txt 300; rm -rf $OUT/prof_stats
   timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats4k -o stats -- python $R/bench.py $H --agents 4096 > $OUT/prof_stats4k.log 2>&1
-  python $R/tools/summarize_prof.py stats $OUT/prof_stats4k $OUT/kernel_stats_4096.txt; rm -rf $OUT/prof_stats4k
+  python $R/tools/summarize_prof.py stats $OUT/prof_stats4k $OUT/kernel_stats_4096.txt 300; rm -rf $OUT/prof_stats4k
   cd "$R"; cat $OUT/kernel_stats.txt | head -30
   ;;
 pmc)

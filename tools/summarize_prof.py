@@ -9,16 +9,33 @@ import sys
 from collections import defaultdict
 
 
-def kernel_stats(d, out):
+def kernel_stats(d, out, last_n=0):
+    """rocprofv3 --kernel-trace --stats: the tool's own per-kernel table (every dispatch of the process) and, with
+    last_n > 0, the same statistics over the LAST last_n dispatches of every kernel from the trace — the bench's
+    timed steps, without its pre-roll and warm-up launches (what roofline.kernel_ms_avg is measured over)."""
     files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
-    lines = []
+    lines = ["# csrc %s" % src_hash()]
     for f in files:
         rows = list(csv.DictReader(open(f)))
-        lines.append("# %s" % os.path.basename(f))
+        lines.append("# %s — every dispatch of the process" % os.path.basename(f))
         lines.append("%-70s %8s %12s %12s %12s %12s %7s" % ("Name", "Calls", "Total(ns)", "Avg(ns)", "Min(ns)", "Max(ns)", "Pct"))
         for r in rows:
             lines.append("%-70s %8s %12s %12.1f %12s %12s %7s" % (r["Name"][:70], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"]),
                                                                 r["MinNs"], r["MaxNs"], r["Percentage"]))
+    if last_n > 0:
+        per = defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                per[r["Kernel_Name"].split("(")[0]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        lines.append("# the last %d dispatches of every kernel that has that many (the timed steps), from the kernel trace" % last_n)
+        lines.append("%-70s %8s %12s %12s %12s %12s" % ("Name", "Calls", "Total(ns)", "Avg(ns)", "Min(ns)", "Max(ns)"))
+        tot = {}
+        for k, v in per.items():
+            if len(v) >= last_n:
+                dur = [x[1] for x in sorted(v)[-last_n:]]
+                tot[k] = dur
+        for k, dur in sorted(tot.items(), key=lambda kv: -sum(kv[1])):
+            lines.append("%-70s %8d %12d %12.1f %12d %12d" % (k[:70], len(dur), sum(dur), sum(dur) / len(dur), min(dur), max(dur)))
     open(out, "w").write("\n".join(lines) + "\n")
 
 
@@ -81,8 +98,8 @@ def gaps(d, out):
 
 if __name__ == "__main__":
     mode, d, out = sys.argv[1:4]
-    if mode == "stats":
-        kernel_stats(d, out)
+    if mode == "stats":   # stats <dir> <out> [last N dispatches]
+        kernel_stats(d, out, int(sys.argv[4]) if len(sys.argv) > 4 else 0)
     elif mode == "gaps":
         gaps(d, out)
     else:   # pmc <dir> <out> [kernel-name filter | -] [last N dispatches]
