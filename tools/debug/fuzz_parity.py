@@ -79,5 +79,6 @@ def run(seed, verbose=True, tol=1e-9, stop_when_diverged=False):
 
 if __name__ == "__main__":
     a, b = int(sys.argv[1]), int(sys.argv[2])
-    bad = [sd for sd in range(a, b) if not run(sd)]
+    # (as the suite runs it: a seed whose random actions blow a car's state past 1e6 is compared up to that step)
+    bad = [sd for sd in range(a, b) if not run(sd, stop_when_diverged=True)]
     print("failed seeds:", bad)
