@@ -427,8 +427,10 @@ class Workload(object):
         o = sim.get("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions")
         scal = np.stack([o["poses_x"], o["poses_y"], o["poses_theta"], o["linear_vels_x"], np.zeros(self.N), o["ang_vels_z"], o["collisions"]])
         theirs = rdv.gather_bytes(self.digest(o["scans"]) + self.digest(scal))
-        got_s, got_c = self.d_alls[slot].download(), self.d_scals[slot].download()
-        ok = all(self.digest(got_s[r]) + self.digest(got_c[r]) == theirs[r] for r in range(rdv.world))
+        ok = True
+        for r in range(rdv.world):   # one rank's block at a time: the receive buffer is world x 570 MB
+            got = self.digest(self.d_alls[slot].download_part(r, 1)) + self.digest(self.d_scals[slot].download_part(r, 1))
+            ok = ok and got == theirs[r]
         return bool(ok)
 
     def close(self):
@@ -620,10 +622,10 @@ def cpu_baseline(args, seconds):
 
 
 def stub_run(args, rdv, steps, leg="headline"):
-    """tests (no GPU): every rank 'steps' by sleeping; rank r pretends to be slower by r ms, the gather legs by 2 / 1 ms"""
+    """tests (no GPU): every rank 'steps' by sleeping; rank r pretends to be slower by r ms, the gather legs by 50 / 25 %"""
     rdv.barrier()
     t0 = time.perf_counter()
-    time.sleep(0.001 * steps + 0.001 * rdv.rank + {"headline": 0.0, "gather": 0.002, "gather_overlap": 0.001}[leg])
+    time.sleep(0.001 * steps * {"headline": 1.0, "gather": 1.5, "gather_overlap": 1.25}[leg] + 0.001 * rdv.rank)
     mine = time.perf_counter() - t0
     rdv.barrier()
     return {"elapsed_s": time.perf_counter() - t0, "rank_s": mine, "n_reset": rdv.rank + 1, "steps": steps, "warmup": args.warmup,

@@ -121,6 +121,14 @@ class DeviceArray(object):
         check(_ffi.lib().f110_memcpy_d2h(self.sim._h, out.ctypes.data, self.ptr, self.nbytes), self.sim._h)
         return out
 
+    def download_part(self, first_row, n_rows):
+        """rows [first_row, first_row + n_rows) along the leading axis (a receive buffer of many ranks' blocks is
+        read back one block at a time instead of as one multi-GB host array)"""
+        row_bytes = (int(np.prod(self.shape[1:])) if len(self.shape) > 1 else 1) * self.dtype.itemsize
+        out = np.empty((int(n_rows),) + self.shape[1:], dtype=self.dtype)
+        check(_ffi.lib().f110_memcpy_d2h(self.sim._h, out.ctypes.data, self.ptr + int(first_row) * row_bytes, out.nbytes), self.sim._h)
+        return out
+
     def free(self):
         if self._fin is not None:
             self.sim._device_arrays.discard(self._fin)

@@ -104,7 +104,7 @@ def test_bench_main_as_two_launched_ranks_with_stub_step():
     assert abs(mg["per_gpu_value"] - line["value"] / 2) < 1e-9 * line["value"]
     for leg in ("gather", "gather_overlap"):
         assert mg[leg]["gather_ok"] is True and len(mg[leg]["per_rank_ms_per_step"]) == 2
-        assert mg[leg]["value"] < line["value"]                # the stub's gather legs are slower by 2 / 1 ms
+        assert mg[leg]["value"] < line["value"]                # the stub's gather legs are slower by 50 / 25 %
         assert mg[leg]["bytes_gathered_per_rank_per_step"] == 8 * 1000 * (1080 + 7) * 2
     assert mg["gather_overlap"]["value"] > mg["gather"]["value"]
     assert mg["rccl_ranks"] is None                          # no communicator in the stub
