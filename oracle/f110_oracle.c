@@ -319,6 +319,20 @@ void orc_get_scan(const orc_scan_cfg *c, const double pose[3], double *scan, int
     }
 }
 
+/* analysis aid (tools/debug/regroup_potential.py): table lookups of every beam of one scan */
+void orc_get_scan_counts(const orc_scan_cfg *c, const double pose[3], int32_t *counts)
+{
+    double theta_index = orc_theta_index_start(c, pose[2]);
+    int i;
+    for (i = 0; i < c->num_beams; i++) {
+        int64_t n = 0;
+        (void)orc_trace_ray(c, pose[0], pose[1], theta_index, 0, &n);
+        counts[i] = (int32_t)n;
+        theta_index += c->theta_index_increment;
+        while (theta_index >= c->theta_dis) theta_index -= c->theta_dis;
+    }
+}
+
 void orc_beam_dir_indices(const orc_scan_cfg *c, double pose_theta, int *idx)
 {
     double theta_index = orc_theta_index_start(c, pose_theta);
