@@ -87,6 +87,7 @@ def parse_args(argv=None):
                     help="N > 1: skip the two extra legs (observation gather in-stream, and overlapped) that follow the headline")
     ap.add_argument("--gather-legs", action="store_true", help="run the gather legs at N = 1 too (a device copy there)")
     ap.add_argument("--no-numa", action="store_true", help="do not pin the rank to its GPU's NUMA node")
+    ap.add_argument("--gather-timeout", type=float, default=300.0, help="watchdog (s) per gather leg: communicator init + the leg's steps")
     ap.add_argument("--noise", choices=["rng", "table", "off"], default="rng",
                     help="rng: drawn on the device (default); table: NumPy's rows uploaded (A/B); off")
     ap.add_argument("--no-noise", action="store_true", help="same as --noise off")
@@ -623,6 +624,8 @@ def cpu_baseline(args, seconds):
 
 def stub_run(args, rdv, steps, leg="headline"):
     """tests (no GPU): every rank 'steps' by sleeping; rank r pretends to be slower by r ms, the gather legs by 50 / 25 %"""
+    if os.environ.get("F110_BENCH_STUB_FAIL") == leg and rdv.rank == rdv.world - 1:
+        raise RuntimeError("stub: the %s leg fails on rank %d" % (leg, rdv.rank))   # tests: a leg that dies on one rank
     rdv.barrier()
     t0 = time.perf_counter()
     time.sleep(0.001 * steps * {"headline": 1.0, "gather": 1.5, "gather_overlap": 1.25}[leg] + 0.001 * rdv.rank)
@@ -630,6 +633,23 @@ def stub_run(args, rdv, steps, leg="headline"):
     rdv.barrier()
     return {"elapsed_s": time.perf_counter() - t0, "rank_s": mine, "n_reset": rdv.rank + 1, "steps": steps, "warmup": args.warmup,
             "preroll": args.preroll, "gather_ok": None if leg == "headline" else True}
+
+
+def guarded(fn, timeout_s):
+    """fn() in a worker thread (ctypes calls release the GIL) -> (result, None) | (None, what went wrong / 'timed out')"""
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn()
+        except BaseException as ex:  # noqa: BLE001
+            box["e"] = "%s: %s" % (type(ex).__name__, ex)
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return None, "no answer within %d s" % timeout_s
+    return box.get("v"), box.get("e")
 
 
 def leg_record(rdv, total_agents, t):
@@ -684,20 +704,11 @@ def main(argv=None):
     if args.stub:
         timed = stub_run(args, rdv, args.steps)
         head = leg_record(rdv, total_agents, timed)
-        if gather_legs:
-            for name in ("gather", "gather_overlap"):
-                legs[name] = leg_record(rdv, total_agents, stub_run(args, rdv, args.steps, name))
     else:
         wl = Workload(args, rdv, args.agents, total_needed)
         timed = wl.run(args.steps, args.warmup, "timed")
         head = leg_record(rdv, total_agents, timed)
-        if gather_legs:
-            for name, overlap in (("gather", False), ("gather_overlap", True)):
-                wl.set_gather(True, overlap)
-                legs[name] = leg_record(rdv, total_agents, wl.run(args.steps, args.warmup, "timed"))
-            rccl_ranks = wl.sim.comm_info()[0]
-            wl.set_gather(False)
-        elif args.gather:
+        if args.gather:
             rccl_ranks = wl.sim.comm_info()[0]
     elapsed = head["ms_per_step"] * args.steps / 1e3
     value = head["value"]
@@ -735,11 +746,8 @@ def main(argv=None):
                       "per_rank_ms_per_step_max": head["per_rank_ms_per_step_max"], "per_gpu_value": value / n_gpus,
                       "rccl_ranks": rccl_ranks, "numa": numa_all,
                       "legs": "headline = no collective on the step path" + ("; gather = f110_comm_all_gather_obs after every step on the step's stream; "
-                              "gather_overlap = the same on a stream of its own beside the next step (double-buffered observation)" if legs else "")},
+                              "gather_overlap = the same on a stream of its own beside the next step (double-buffered observation)" if gather_legs else "")},
     }
-    for name, rec in legs.items():
-        line["multi_gpu"][name] = dict(rec, per_gpu_value=rec["value"] / n_gpus,
-                                       bytes_gathered_per_rank_per_step=8 * args.agents * (args.beams + 7) * n_gpus)
     if args.gather:
         line["config"]["gather_ok"] = head["gather_ok"]
 
@@ -767,6 +775,38 @@ def main(argv=None):
                                     "ms_per_step": 1e3 * st["elapsed_s"] / args.steady_steps, "env_resets_in_timed_region": st["n_reset"],
                                     "roofline": roofline_record(args, args.agents, args.beams, st, sp, sc, args.map_tiles)}
         wl.rdv = rdv
+
+    if gather_legs:
+        # The two gather legs come LAST and under a watchdog: the headline (and rank 0's replays of it) are already
+        # in `line`, so whatever the communicator does on this node — refuses to initialise, or never returns — the
+        # run still ends with its one line, `multi_gpu.gather_error` saying what happened.
+        rdv.barrier()     # (the other ranks have been waiting here for rank 0's replays)
+        err = None
+        try:
+            for name, overlap in (("gather", False), ("gather_overlap", True)):
+                if args.stub:
+                    res = stub_run(args, rdv, args.steps, name)
+                else:
+                    res, e = guarded(lambda: (wl.set_gather(True, overlap), wl.run(args.steps, args.warmup, "timed"))[1], args.gather_timeout)
+                    if e:
+                        raise RuntimeError("%s leg: %s" % (name, e))
+                legs[name] = leg_record(rdv, total_agents, res)
+            if not args.stub:
+                rccl_ranks = wl.sim.comm_info()[0]
+                wl.set_gather(False)
+        except BaseException as ex:  # noqa: BLE001 — incl. "peer went away" when another rank gave up
+            err = "%s: %s" % (type(ex).__name__, ex)
+        line["multi_gpu"]["rccl_ranks"] = rccl_ranks
+        for name, rec in legs.items():
+            line["multi_gpu"][name] = dict(rec, per_gpu_value=rec["value"] / n_gpus,
+                                           bytes_gathered_per_rank_per_step=8 * args.agents * (args.beams + 7) * n_gpus)
+        if err:
+            line["multi_gpu"]["gather_error"] = err[:400]
+            if rdv.rank == 0:
+                print(json.dumps(line))
+                sys.stdout.flush()
+            os._exit(0)   # a collective may be stuck on this handle's streams: no orderly teardown is possible
+
     if wl is not None:
         wl.close()
 

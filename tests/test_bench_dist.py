@@ -122,6 +122,31 @@ def test_bench_self_launches_its_ranks():
     assert line["n_gpus"] == 2 and line["config"]["agents_total"] == 1024
 
 
+def test_a_failing_gather_leg_cannot_take_the_headline_with_it():
+    """the gather legs run last and under a watchdog: when one dies on some rank (here: rank 1 raises in the
+    overlapped leg, rank 0 then finds its peer gone) every rank still exits 0 and rank 0 still prints the line —
+    the headline, the leg that did complete, and `gather_error`"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.guarded(lambda: 7, 5.0) == (7, None)
+    assert bench.guarded(lambda: 1 / 0, 5.0)[1].startswith("ZeroDivisionError")
+    import time
+    assert "no answer within" in bench.guarded(lambda: time.sleep(3), 0.2)[1]
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   F110_BENCH_STUB_FAIL="gather_overlap")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2",
+                                       "--agents", "100", "--stub"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    line = _bench_line(outs[0][0])
+    mg = line["multi_gpu"]
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "gather" in mg and "gather_overlap" not in mg and mg["gather_error"]
+
+
 def test_bench_single_rank_has_no_gather_legs_unless_asked():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "F110_BENCH_RDV")}
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "1", "--agents", "64", "--stub"]
