@@ -43,6 +43,7 @@ struct ExpSwitches {
     int no_window = 0;         // 1: F110_MAP_WINDOW_LDS handles step with the PADDED kernel
     int finalize_lanes = 0;    // 8 / 16 / 32 / 64 lanes per agent in k_finalize*, 0 = by batch size
     int finalize_flat = -1;    // A = 2: 1 the workgroup-flattened window loop, 0 fixed lanes per agent, -1 = default
+    int finalize_roles = -1;   // A = 2: 1 the prologue dealt by role (k_finalize_pair_roles), 0 by agent (k_finalize_pair_flat), -1 = default
     int long_prio = 0;         // 1: the longest-first pass's waves raise their issue priority (s_setprio 3)
     int pair_always = 0;       // A = 2: 1 = pair test inside the finalize kernel also for big batches without the in-step re-seat
     int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
@@ -52,6 +53,12 @@ struct ExpSwitches {
 // A = 2 finalize: the workgroup-flattened window loop (k_finalize_pair_flat) or fixed lanes per agent
 // (round 3, measured: 65 536 agents 0.763 -> 0.726 ms per step, 16 384: 0.252 -> 0.239, 4096: 0.108 -> 0.107)
 constexpr bool kFinalizeFlatDefault = true;
+// ... and its prologue dealt by role (k_finalize_pair_roles) or by agent (k_finalize_pair_flat, experimental build)
+#ifdef F110_EXPERIMENTAL
+constexpr bool kFinalizeRolesDefault = true;
+#else
+constexpr bool kFinalizeRolesDefault = true;   // the product has only this form
+#endif
 
 struct f110_sim {
     f110_config cfg{};
@@ -434,6 +441,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     } else if (k == "finalize_flat") h->exp.finalize_flat = value;
     else if (k == "pair_always") h->exp.pair_always = value;
     else if (k == "long_prio") h->exp.long_prio = value;
+    else if (k == "finalize_roles") h->exp.finalize_roles = value;
     else if (k == "scan_occupancy") h->exp.scan_occupancy = value;
     else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
     else if (k == "collide_mode") {
@@ -1743,7 +1751,7 @@ static int noise_cache_extend(f110_sim *h, int upto)
 // One step of the agents [begin, begin + count) (an env-aligned block) on stream `st`.
 // Product build, one dispatch per (agents per env, beams) case:
 //   A = 1                      k_integrate -> scan -> k_finalize_solo
-//   A = 2                      k_integrate -> scan -> k_finalize_pair_flat     (pair test + window inside the last kernel)
+//   A = 2                      k_integrate -> scan -> k_finalize_pair_roles    (pair test + window inside the last kernel)
 //   A > 2                      k_integrate -> { scan || k_collide on the side stream } -> k_finalize
 // and the scan kernel by table / beam count: k_scan_rays_agent (PADDED table; longest-first order for small
 // batches), k_scan_dirs_agent (more beams than table directions), k_scan_rays (row-major table, few beams).
@@ -1985,14 +1993,26 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         if (pair_in_finalize && flat) {
             // the window loop flattened over the workgroup: AG agents per 256 threads (256 / AG lanes each in the
             // prologue).  More agents per workgroup = fewer prologue waves and a better-balanced item list; small
-            // batches want the workgroups many (measured: 65 536 agents AG 32 / 16 / 4: 0.726 / 0.738 / 0.815 ms)
-            lanes = N >= 32768 ? 8 : (N >= 8192 ? 16 : 64);
+            // batches want the workgroups many (measured: 65 536 agents AG 32 / 16 / 4: 0.726 / 0.738 / 0.815 ms;
+            // 4096 agents AG 16 / 4: 0.1047 / 0.1053)
+            lanes = N >= 32768 ? 8 : (N >= 4096 ? 16 : 64);
 #ifdef F110_EXPERIMENTAL
             if (h->exp.finalize_lanes) lanes = h->exp.finalize_lanes;
 #endif
-            if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_flat<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
+            bool roles = kFinalizeRolesDefault;
+#ifdef F110_EXPERIMENTAL
+            if (h->exp.finalize_roles >= 0) roles = h->exp.finalize_roles != 0;
+#endif
+            if (roles) {
+                if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_roles<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
+                else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_roles<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
+                else hipLaunchKernelGGL(k_finalize_pair_roles<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
+            }
+#ifdef F110_EXPERIMENTAL
+            else if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_flat<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
             else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_flat<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
             else hipLaunchKernelGGL(k_finalize_pair_flat<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
+#endif
         }
 #ifdef F110_EXPERIMENTAL
         else if (pair_in_finalize) {   // round 2's form: fixed lanes per agent (A/B)

@@ -1448,6 +1448,151 @@ __global__ void __launch_bounds__(256) k_finalize_pair_flat(AgentArrays a, int32
     }
 }
 
+// ---- K3r: k_finalize_pair_flat with the prologue laid out by ROLE instead of by agent (round 3) -----------
+// In k_finalize_pair_flat every wave carries all three pieces of the prologue one after the other (divergent
+// branches: corner -> beam index on lanes 0-3 of an agent's group, disc cull on lane 4, pair test on lane 5), so
+// the kernel's vector-ALU work — which is what bounds it (12.6 M wave-instructions x 8 cycles of float64 per
+// launch at 65 536 agents = its 42 us) — is four times one prologue per workgroup.  Here the workgroup's threads
+// are dealt by role: the 4 AG corners fill waves 0-1 completely, the AG disc culls sit in wave 2, the AG / 2
+// pair tests (ONE per env: both agents' calls are the same gjk_overlap(box(2e), box(2e + 1)) on the same
+// numbers) in wave 3; each wave runs only its own piece, the pieces run side by side on the CU's four SIMDs,
+// results meet in LDS.  Same functions on the same operands: bit-identical.  The window loop is unchanged.
+template <int AG>
+__global__ void __launch_bounds__(256) k_finalize_pair_roles(AgentArrays a, int32_t B)
+{
+    static_assert((AG & (AG - 1)) == 0 && AG >= 2 && 4 * AG <= 128, "AG is a power of two, 2..32");
+    __shared__ double s_rec[AG][12];   // ex, ey, eth, the opponent's box (8), pad
+    __shared__ int s_idx[AG][4], s_cl[AG], s_ch[AG], s_hit[AG / 2];
+    __shared__ int s_lo[AG], s_cnt[AG], s_off[AG + 1];
+    const int t = (int)threadIdx.x;
+    const int first = a.agent_begin + (int)blockIdx.x * AG, end = a.agent_begin + a.agent_count;
+    const int N = a.n_agents_total;
+    int role = -1, slot = 0, sub = 0;
+    if (t < 4 * AG) {                        // waves 0-1: box corner `sub` of agent `slot`'s opponent -> beam index
+        role = 0; slot = t >> 2; sub = t & 3;
+    } else if (t >= 128 && t < 128 + AG) {   // wave 2: disc cull of agent `slot`
+        role = 1; slot = t - 128;
+    } else if (t >= 192 && t < 192 + AG / 2) {   // wave 3: the pair test of env (slot, slot + 1)
+        role = 2; slot = 2 * (t - 192);
+    }
+    if (role >= 0 && first + slot < end) {
+        const int i = first + slot, me = i & 1, o = i ^ 1;
+        const double ex = a.state[i], ey = a.state[(size_t)N + i];
+        const double th_live = a.state[4 * (size_t)N + i];   // == the :574 snapshot heading: nothing has zeroed it yet
+        const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
+        if (role == 2) {
+            // collision_multiple on the env's one pair, boxes with the Simulator's length / width (:549); i is the
+            // even agent: gjk_overlap(mine, other) here is gjk_overlap(other, mine) of the odd agent's call
+            int hit = 0;
+            const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+            const double cdx = ox - ex, cdy = oy - ey;
+            if (cdx * cdx + cdy * cdy <= reach * reach) {
+                double mine[8], other[8];
+                box_vertices(ex, ey, th_live, a.box_length, a.box_width, mine);
+                box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
+                hit = gjk_overlap(mine, other) ? 1 : 0;
+            }
+            s_hit[slot >> 1] = hit;
+        } else {
+            const int wall = a.in_collision[i];
+            const double eth = wall ? 0.0 : th_live;
+            const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
+            const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
+            double v[8];   // the opponent drawn with MY length / width (RaceCar.ray_cast_agents :223)
+            box_vertices(ox, oy, oth, blen, bwid, v);
+            const double head = atan2(sin(eth), cos(eth));
+            const double px = role == 1 ? ox : (sub == 0 ? v[0] : (sub == 1 ? v[2] : (sub == 2 ? v[4] : v[6])));
+            const double py = role == 1 ? oy : (sub == 0 ? v[1] : (sub == 1 ? v[3] : (sub == 2 ? v[5] : v[7])));
+            const double dx = px - ex, dy = py - ey;
+            const double norm = sqrt(dx * dx + dy * dy);
+            const double qx = role == 0 ? dx / norm : dx, qy = role == 0 ? dy / norm : dy;
+            const double dir = atan2(qy, qx);
+            if (role == 0) {
+                s_idx[slot][sub] = vertex_beam_from_angles(head, dir, a.scan_angles, B, a.angle_inc);
+                if (sub == 0) {
+                    s_rec[slot][0] = ex;
+                    s_rec[slot][1] = ey;
+                    s_rec[slot][2] = eth;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) s_rec[slot][3 + c] = v[c];
+                }
+            } else {
+                int cl, ch;
+                disc_beam_range_from(norm, eth, dir, head, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
+                s_cl[slot] = cl;
+                s_ch[slot] = ch;
+            }
+        }
+    }
+    __syncthreads();
+    int my_hit = 0;
+    const bool agent_thread = t < AG && first + t < end;
+    if (t < AG) {
+        int lo = 0, cnt = 0;
+        if (agent_thread) {
+            const int i = first + t, me = i & 1;
+            const int i0 = s_idx[t][0], i1 = s_idx[t][1], i2 = s_idx[t][2], i3 = s_idx[t][3];
+            const int cl = s_cl[t], ch = s_ch[t];
+            my_hit = s_hit[t >> 1];
+            int ref_lo = i0 < i1 ? i0 : i1, t2 = i2 < i3 ? i2 : i3;
+            ref_lo = ref_lo < t2 ? ref_lo : t2;
+            int ref_hi = i0 > i1 ? i0 : i1;
+            t2 = i2 > i3 ? i2 : i3;
+            ref_hi = ref_hi > t2 ? ref_hi : t2;
+            lo = ref_lo > cl ? ref_lo : cl;
+            const int hi = ref_hi < ch ? ref_hi : ch;
+            cnt = hi >= lo ? hi - lo + 1 : 0;
+            const int wall = a.in_collision[i];
+            if (wall) {
+                a.state[3 * (size_t)N + i] = 0.;
+                a.state[4 * (size_t)N + i] = 0.;
+                a.state[5 * (size_t)N + i] = 0.;
+                a.state[6 * (size_t)N + i] = 0.;
+            }
+            a.collisions[i] = (my_hit || wall) ? 1.0 : 0.0;
+            a.collision_idx[i] = my_hit ? (double)(1 - me) : -1.0;
+            a.step_count[i] += 1;
+        }
+        s_lo[t] = lo;
+        s_cnt[t] = cnt;
+    }
+    __syncthreads();
+    if (t < 64) {   // exclusive scan of the AG window lengths (AG <= 32: one wave)
+        int c = t < AG ? s_cnt[t] : 0;
+#pragma unroll
+        for (int d = 1; d < AG; d <<= 1) {
+            const int up = __shfl_up(c, d);
+            if (t >= d) c += up;
+        }
+        if (t < AG) s_off[t + 1] = c;
+        if (t == 0) s_off[0] = 0;
+    }
+    __syncthreads();
+    const int total = s_off[AG];
+    for (int item = t; item < total; item += 256) {
+        int ag = 0;   // the largest ag with s_off[ag] <= item (its window is not empty: item < s_off[ag + 1])
+#pragma unroll
+        for (int st = AG / 2; st; st >>= 1)
+            if (s_off[ag + st] <= item) ag += st;
+        const int b = s_lo[ag] + (item - s_off[ag]);
+        const double bex = s_rec[ag][0], bey = s_rec[ag][1], beth = s_rec[ag][2];
+        double bv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bv[c] = s_rec[ag][3 + c];
+        double *sc = a.scans + (size_t)(first + ag) * B;
+        const double bt = beth + a.scan_angles[b];
+        const double r0 = sc[b];
+        double v3x, v3y;
+        sincos(bt + kPi / 2., &v3y, &v3x);
+        const double r = box_range(bex, bey, v3x, v3y, bv, r0);
+        if (r < r0) sc[b] = r;
+    }
+    if (a.reseat_poses && agent_thread) {
+        const int i = first + t, ego = (i & ~1) + a.reseat_ego;
+        if (my_hit || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
+    }
+}
+
 // single-agent envs: no opponents, one lane per agent is enough
 __global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
 {

@@ -105,7 +105,7 @@ int f110_is_experimental(void);
  * adopted, for the A/B tests and the profiles.  The product library refuses every key
  * (F110_ERR_STATE) and reads no environment variable; a step of the product has ONE dispatch per (agents per
  * env, beams) case.  Keys: scan_flat, dedupe_two_pass, no_window, finalize_lanes (0|8|16|32|64),
- * finalize_flat (-1|0|1), pair_always, collide_mode (0 side stream | 1 fused into k_integrate | 2 in line | 3 inside
+ * finalize_flat (-1|0|1), finalize_roles (-1|0|1), pair_always, collide_mode (0 side stream | 1 fused into k_integrate | 2 in line | 3 inside
  * k_finalize), step_graph, task_order, task_thr, ray_pass, ray_thr, ray_waves, scan_occupancy, scan_env_counter (fusion probes). */
 int f110_exp_set(f110_sim *h, const char *key, int32_t value);
 

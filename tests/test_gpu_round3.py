@@ -77,14 +77,16 @@ def test_product_library_refuses_the_lab(amd):
 
 
 # ---------------------------------------------------------------------------- flattened finalize
+@pytest.mark.parametrize("roles", [1, 0])
 @pytest.mark.parametrize("lanes", [0, 8, 16, 64])
-def test_flattened_finalize_is_bit_identical(amd, lanes):
-    """k_finalize_pair_flat (AG = 32 / 16 / 4 agents per workgroup, the window loop flattened over the 256
-    threads) against k_finalize_pair with fixed lanes per agent: every array identical through wall hits,
-    car-to-car contacts (wide windows), the fused re-seat, resets and a partly filled last workgroup"""
+def test_flattened_finalize_is_bit_identical(amd, lanes, roles):
+    """k_finalize_pair_roles / k_finalize_pair_flat (AG = 32 / 16 / 4 agents per workgroup, the window loop
+    flattened over the 256 threads; the prologue dealt by role — the product's kernel — or by agent) against
+    k_finalize_pair with fixed lanes per agent: every array identical through wall hits, car-to-car contacts
+    (wide windows), the fused re-seat, resets and a partly filled last workgroup"""
     E, A, T = 203, 2, 110
     a = _sim(amd, E, A, exp={"finalize_flat": 0, "finalize_lanes": lanes})
-    b = _sim(amd, E, A, exp={"finalize_flat": 1, "finalize_lanes": lanes})
+    b = _sim(amd, E, A, exp={"finalize_flat": 1, "finalize_roles": roles, "finalize_lanes": lanes})
     poses = bench_start_poses(E, A, gap_wp=3)     # 0.6 m apart: contacts happen
     rng = np.random.default_rng(21)
     st = []

@@ -35,6 +35,14 @@ finalize)
     F110_EXP=finalize_flat=1,finalize_lanes=$l timeout 200 $X python bench.py $H --agents 65536 > $OUT/fin_flat_l$l.log 2>&1; line $OUT/fin_flat_l$l.log "65536 flat AG-by-lanes $l"
   done
   ;;
+roles)
+  for n in 1024 4096 16384 65536; do for r in 0 1; do
+    F110_EXP=finalize_roles=$r timeout 200 $X python bench.py $H --agents $n > $OUT/roles_n${n}_r$r.log 2>&1; line $OUT/roles_n${n}_r$r.log "agents $n finalize_roles $r"
+  done; done
+  F110_EXP=finalize_roles=1,finalize_lanes=16 timeout 200 $X python bench.py $H --agents 65536 > $OUT/roles_l16.log 2>&1; line $OUT/roles_l16.log "65536 roles, AG 16"
+  F110_EXP=finalize_roles=1,finalize_lanes=16 timeout 200 $X python bench.py $H --agents 4096 > $OUT/roles_4096_l16.log 2>&1; line $OUT/roles_4096_l16.log "4096 roles, AG 16"
+  F110_EXP=finalize_roles=1,finalize_lanes=8 timeout 200 $X python bench.py $H --agents 16384 > $OUT/roles_16384_l8.log 2>&1; line $OUT/roles_16384_l8.log "16384 roles, AG 32"
+  ;;
 finalize2)
   # AG choice for the flattened finalize at the middle sizes, and the pair test inside the finalize kernel for
   # big batches WITHOUT the in-step re-seat (crashed / parked cars: windows grow)
