@@ -356,7 +356,7 @@ class Workload(object):
         self.d_all = self.d_alls[0]
         sim.comm_set_overlap(bool(overlap))
 
-    def one(self, t):
+    def one(self, t, gather=True):
         sim = self.sim
         if self.d_zero is not None:
             sim.step_device(self.d_zero)
@@ -365,7 +365,7 @@ class Workload(object):
             sim.step_device(self.d_plan)
         else:
             sim.step_device(self.d_sets[t // 20])
-        if self.d_all is not None:
+        if self.d_all is not None and gather:
             sim.comm_all_gather_obs(self.d_alls[t % self.n_recv], self.d_scals[t % self.n_recv])
         if not self.no_reset and not self.fused_reset:
             sim.reset_collided_device(self.d_start, 0, self.d_count)
@@ -383,7 +383,7 @@ class Workload(object):
         if self.fused_reset:
             sim.set_auto_reseat(self.d_start, 0, self.d_count)
         for t in range(first):
-            self.one(t)
+            self.one(t, gather=t >= preroll)   # the pre-roll only ages the batch: no need to move 570 MB per rank per step for it
         sim.sync()
         self.d_count.upload(np.zeros(1, dtype=np.int32))
         if mode == "profile":
