@@ -1,4 +1,7 @@
 #!/bin/bash
+# HISTORICAL (round 2).  The F110_* environment switches used below were read by the library in round 2; since
+# round 3 the product library reads no environment and the A/B switches live in the experimental build behind
+# f110_exp_set (F110_LIB_VARIANT=experimental F110_EXP="key=value,...", see tools/gpu_r3.sh for the current sweeps).
 # Round-2 GPU sessions (one gpurun call each; GPU minutes are scarce, so every phase is bounded):
 #   gpurun --timeout 1500 -- 'bash tools/gpu_r2.sh test ab'
 #   gpurun --timeout 1500 -- 'bash tools/gpu_r2.sh bench prof pmc'
