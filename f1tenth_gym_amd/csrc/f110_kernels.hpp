@@ -1265,7 +1265,9 @@ __global__ void __launch_bounds__(256) k_finalize_pair(AgentArrays a, int32_t B)
         // direction to "my point" — a box corner (normalised, :296-300) for lanes 0-3, the box centre
         // (as it is, disc_beam_range) for lane 4 — in one call.  The same operations on the same operands
         // as the two functions, only not twice.
-        const double head = atan2(sin(eth), cos(eth));
+        double ce_, se_;
+        cos_sin(eth, ce_, se_);
+        const double head = atan2(se_, ce_);
         const double px = tid == 0 ? v[0] : (tid == 1 ? v[2] : (tid == 2 ? v[4] : (tid == 3 ? v[6] : ox)));
         const double py = tid == 0 ? v[1] : (tid == 1 ? v[3] : (tid == 2 ? v[5] : (tid == 3 ? v[7] : oy)));
         const double dx = px - ex, dy = py - ey;
@@ -1358,7 +1360,9 @@ __global__ void __launch_bounds__(256) k_finalize_pair_flat(AgentArrays a, int32
     box_vertices(ox, oy, oth, blen, bwid, v);
     int idx = 0, cl = 0, ch = B - 1, hit = 0;
     {
-        const double head = atan2(sin(eth), cos(eth));
+        double ce_, se_;
+        cos_sin(eth, ce_, se_);
+        const double head = atan2(se_, ce_);
         const double px = tid == 0 ? v[0] : (tid == 1 ? v[2] : (tid == 2 ? v[4] : (tid == 3 ? v[6] : ox)));
         const double py = tid == 0 ? v[1] : (tid == 1 ? v[3] : (tid == 2 ? v[5] : (tid == 3 ? v[7] : oy)));
         const double dx = px - ex, dy = py - ey;
@@ -1500,7 +1504,9 @@ __global__ void __launch_bounds__(256) k_finalize_pair_roles(AgentArrays a, int3
             const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
             double v[8];   // the opponent drawn with MY length / width (RaceCar.ray_cast_agents :223)
             box_vertices(ox, oy, oth, blen, bwid, v);
-            const double head = atan2(sin(eth), cos(eth));
+            double ce_, se_;
+        cos_sin(eth, ce_, se_);
+        const double head = atan2(se_, ce_);
             const double px = role == 1 ? ox : (sub == 0 ? v[0] : (sub == 1 ? v[2] : (sub == 2 ? v[4] : v[6])));
             const double py = role == 1 ? oy : (sub == 0 ? v[1] : (sub == 1 ? v[3] : (sub == 2 ? v[5] : v[7])));
             const double dx = px - ex, dy = py - ey;

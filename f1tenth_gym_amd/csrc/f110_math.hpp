@@ -28,6 +28,20 @@ struct VehicleParams {
     double v[NPARAMS];
 };
 
+// cos and sin of ONE angle.  On the device a single argument reduction serves both (ocml's sincos returns what its
+// sin and its cos return — the ray-cast has relied on that since round 1); the host instantiation (tests/host_harness)
+// makes the two libm calls the oracle makes.  A float64 sin or cos is ~250 dependent instructions of a kernel that is
+// a dependent chain (k_integrate) or bound by its vector-ALU work (the finalize kernels): one call instead of two.
+F110_HD void cos_sin(double a, double &c, double &s)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(a, &s, &c);
+#else
+    c = cos(a);
+    s = sin(a);
+#endif
+}
+
 // ------------------------------------------------------------------ dynamic_models.py
 // accl_constraints :29-60
 F110_HD double clamp_accel(double vel, double accl, const VehicleParams &p)
@@ -55,8 +69,10 @@ F110_HD void rhs_kinematic(const double *x, double sv_in, double accl_in, const 
     const double lwb = p.v[P_LF] + p.v[P_LR];
     const double u0 = clamp_steer_rate(x[2], sv_in, p);
     const double u1 = clamp_accel(x[3], accl_in, p);
-    f[0] = x[3] * cos(x[4]);
-    f[1] = x[3] * sin(x[4]);
+    double c4, s4;
+    cos_sin(x[4], c4, s4);
+    f[0] = x[3] * c4;
+    f[1] = x[3] * s4;
     f[2] = u0;
     f[3] = u1;
     f[4] = x[3] / lwb * tan(x[2]);
@@ -83,8 +99,10 @@ F110_HD void rhs_single_track(const double *x, double sv_in, double accl_in, con
     const double rear = g * lr - u1 * h;   // (g*lr - u[1]*h)
     const double front = g * lf + u1 * h;  // (g*lf + u[1]*h)
     const double wb = lr + lf;
-    f[0] = x[3] * cos(x[6] + x[4]);
-    f[1] = x[3] * sin(x[6] + x[4]);
+    double cb, sb;
+    cos_sin(x[6] + x[4], cb, sb);
+    f[0] = x[3] * cb;
+    f[1] = x[3] * sb;
     f[2] = u0;
     f[3] = u1;
     f[4] = x[5];
@@ -164,9 +182,19 @@ F110_HD void advance_vehicle(double *st, double &buf0, double &buf1, int &buf_cn
         st[4] = st[4] - kTwoPi;
     else if (st[4] < 0)
         st[4] = st[4] + kTwoPi;
-    // :407-409
-    scan_pose[0] = st[0] + lidar_dist * cos(st[4]);
-    scan_pose[1] = st[1] + lidar_dist * sin(st[4]);
+    // :407-409.  With the lidar on the reference point (lidar_dist == 0., the default of F110Env) the products are
+    // +-0. and x + (+-0.) == x for every x except -0. — the two trig calls are skipped exactly then (finite heading,
+    // no negative zero among the coordinates): the same bits, ~500 instructions off k_integrate's chain
+    const bool on_axle = lidar_dist == 0.0 && fabs(st[4]) < 1e300 && !(st[0] == 0.0 && signbit(st[0])) && !(st[1] == 0.0 && signbit(st[1]));
+    if (on_axle) {
+        scan_pose[0] = st[0];
+        scan_pose[1] = st[1];
+    } else {
+        double ch, sh;
+        cos_sin(st[4], ch, sh);
+        scan_pose[0] = st[0] + lidar_dist * ch;
+        scan_pose[1] = st[1] + lidar_dist * sh;
+    }
     scan_pose[2] = st[4];
 }
 
@@ -628,7 +656,9 @@ F110_HD int vertex_beam_index(double ex, double ey, double etheta, double vx, do
     const double dx = vx - ex, dy = vy - ey;
     const double norm = sqrt(dx * dx + dy * dy);
     const double ux = dx / norm, uy = dy / norm;
-    return vertex_beam_from_angles(atan2(sin(etheta), cos(etheta)), atan2(uy, ux), scan_angles, num_beams, angle_inc);
+    double ce, se;
+    cos_sin(etheta, ce, se);
+    return vertex_beam_from_angles(atan2(se, ce), atan2(uy, ux), scan_angles, num_beams, angle_inc);
 }
 
 // Conservative beam-index range whose rays can touch a disc (centre c, radius R) seen from the
@@ -682,7 +712,9 @@ F110_HD void disc_beam_range(double ex, double ey, double eth, double cx, double
         ch = num_beams - 1;
         return;
     }
-    disc_beam_range_from(dist, eth, atan2(dy, dx), atan2(sin(eth), cos(eth)), R, scan_angles, num_beams, angle_inc, cl, ch);
+    double ce, se;
+    cos_sin(eth, ce, se);
+    disc_beam_range_from(dist, eth, atan2(dy, dx), atan2(se, ce), R, scan_angles, num_beams, angle_inc, cl, ch);
 }
 
 // get_blocked_view_indices :282-315 (min/max of the four vertex beam indices) intersected with
@@ -724,7 +756,8 @@ F110_HD double box_range(double ex, double ey, double v3x, double v3y, const dou
 // get_vertices :218-260 — order [rl, rr, fr, fl]; v[2*i], v[2*i+1]
 F110_HD void box_vertices(double x, double y, double th, double length, double width, double *v)
 {
-    const double c = cos(th), s = sin(th);
+    double c, s;
+    cos_sin(th, c, s);
     const double hx = length / 2, hy = width / 2;
     const double bx[4] = {-hx, -hx, hx, hx};
     const double by[4] = {hy, -hy, -hy, hy};
