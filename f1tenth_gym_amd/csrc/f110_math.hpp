@@ -543,7 +543,9 @@ F110_HD double march_exact_cold(const ScanConst *kc_in, double x, double y, doub
 F110_HD double scan_start_index(const ScanConst &k, double pose_theta)
 {
     double ti = k.theta_dis * (pose_theta - k.fov / 2.) / (2. * kPi);
-    ti = fmod(ti, (double)k.theta_dis);
+    // fmod(x, y) == x whenever |x| < |y| (exactly): with the yaw wrapped to [0, 2 pi] that is every call, and the
+    // library fmod is a loop of a few hundred dependent instructions on k_integrate's chain
+    if (!(fabs(ti) < (double)k.theta_dis)) ti = fmod(ti, (double)k.theta_dis);
     while (ti < 0) ti += k.theta_dis;
     return ti;
 }
