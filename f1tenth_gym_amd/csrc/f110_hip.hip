@@ -1923,10 +1923,16 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             j.long_prio = (uint32_t)h->exp.long_prio;
             h->task_epoch += 1u;
             const dim3 sgrid(grid.x + j.long_blocks + j.ray_blocks);
+            size_t slds = 0;
+#ifdef F110_EXPERIMENTAL
+            // probe: fewer waves per SIMD (an LDS reservation per one-wave workgroup) so that last step's long tasks,
+            // which start first, march at the idle chip's latency — does the shorter chain beat the lost throughput?
+            if (h->exp.scan_occupancy > 0 && h->scan_block == 64) slds = (size_t)(160 * 1024 / (4 * h->exp.scan_occupancy)) & ~(size_t)255;
+#endif
             if (h->k.ident_rot)
-                hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true>), sgrid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
             else
-                hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, true>), sgrid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
             break;
         }
         case SCAN_AGENT: {
@@ -1937,7 +1943,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             // fusion-feasibility probes: the occupancy a kernel with k_finalize_pair's 118 VGPRs
             // would run at (LDS reservation per one-wave workgroup caps the CU at 16 waves), and the price of a
             // per-env completion counter
-            if (h->exp.scan_occupancy == 4 && h->scan_block == 64) lds = 10 * 1024;
+            if (h->exp.scan_occupancy > 0 && h->scan_block == 64) lds = (size_t)(160 * 1024 / (4 * h->exp.scan_occupancy)) & ~(size_t)255;
             if (h->exp.scan_env_counter && !h->multi_map && !cnt) {
                 if (!h->d_env_done) {
                     TRY(dmalloc(h, &h->d_env_done, (size_t)h->cfg.num_envs));
