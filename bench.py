@@ -29,7 +29,9 @@ Each rank pins itself to its GPU's NUMA node (f1tenth_gym_amd/numa.py).  With N 
 reports three legs (`multi_gpu`): the headline without any collective, the same steps with the RCCL
 observation gather (scans + 7 scalars per agent, f110_comm_all_gather_obs) on the step's stream, and
 with the gather overlapped with the next step — each with every rank's own ms per step (min / max),
-the communicator size as RCCL reports it, and the per-GPU rate.
+the communicator size as RCCL reports it, and the per-GPU rate; at --gpus 8 also BASELINE configs[3] to the
+letter (262144 agents over the node, without / with the gather).  The gather legs run last, under a watchdog:
+whatever RCCL does on the node, the line with the headline is printed.
 
 The JSON line carries, besides the contract's fields:
   roofline      SURVEY §8d: whole-step ALGORITHMIC bytes (216 + 8B + 8B*L-bar per agent-step) x
@@ -87,6 +89,8 @@ def parse_args(argv=None):
                     help="N > 1: skip the two extra legs (observation gather in-stream, and overlapped) that follow the headline")
     ap.add_argument("--gather-legs", action="store_true", help="run the gather legs at N = 1 too (a device copy there)")
     ap.add_argument("--no-numa", action="store_true", help="do not pin the rank to its GPU's NUMA node")
+    ap.add_argument("--config3-legs", action="store_true",
+                    help="also run BASELINE configs[3] to the letter (262144 agents over the node, without / with the gather); automatic at --gpus 8")
     ap.add_argument("--gather-timeout", type=float, default=300.0, help="watchdog (s) per gather leg: communicator init + the leg's steps")
     ap.add_argument("--noise", choices=["rng", "table", "off"], default="rng",
                     help="rng: drawn on the device (default); table: NumPy's rows uploaded (A/B); off")
@@ -699,7 +703,6 @@ def main(argv=None):
     # "report scaling both with and without it")
     gather_legs = (n_gpus > 1 or args.gather_legs) and not args.no_gather_legs and not args.gather and not args.only_headline
     wl = None
-    legs = {}
     rccl_ranks = None
     if args.stub:
         timed = stub_run(args, rdv, args.steps)
@@ -777,29 +780,54 @@ def main(argv=None):
         wl.rdv = rdv
 
     if gather_legs:
-        # The two gather legs come LAST and under a watchdog: the headline (and rank 0's replays of it) are already
-        # in `line`, so whatever the communicator does on this node — refuses to initialise, or never returns — the
+        # The gather legs come LAST and under a watchdog: the headline (and rank 0's replays of it) are already in
+        # `line`, so whatever the communicator does on this node — refuses to initialise, or never returns — the
         # run still ends with its one line, `multi_gpu.gather_error` saying what happened.
         rdv.barrier()     # (the other ranks have been waiting here for rank 0's replays)
         err = None
-        try:
+
+        def gather_pair(work, agents_per_rank, out):
+            """the same steps with the observation gather in the step's stream, then overlapped; -> rccl_ranks"""
             for name, overlap in (("gather", False), ("gather_overlap", True)):
                 if args.stub:
                     res = stub_run(args, rdv, args.steps, name)
                 else:
-                    res, e = guarded(lambda: (wl.set_gather(True, overlap), wl.run(args.steps, args.warmup, "timed"))[1], args.gather_timeout)
+                    res, e = guarded(lambda: (work.set_gather(True, overlap), work.run(args.steps, args.warmup, "timed"))[1], args.gather_timeout)
                     if e:
                         raise RuntimeError("%s leg: %s" % (name, e))
-                legs[name] = leg_record(rdv, total_agents, res)
-            if not args.stub:
-                rccl_ranks = wl.sim.comm_info()[0]
-                wl.set_gather(False)
+                rec = leg_record(rdv, agents_per_rank * n_gpus, res)
+                out[name] = dict(rec, per_gpu_value=rec["value"] / n_gpus, bytes_gathered_per_rank_per_step=8 * agents_per_rank * (args.beams + 7) * n_gpus)
+            if args.stub:
+                return None
+            n = work.sim.comm_info()[0]
+            work.set_gather(False)
+            return n
+        try:
+            rccl_ranks = gather_pair(wl, args.agents, line["multi_gpu"])
+            line["multi_gpu"]["rccl_ranks"] = rccl_ranks
+            c3_agents = 262144 // n_gpus
+            if (n_gpus == 8 or args.config3_legs) and c3_agents != args.agents and c3_agents % args.agents_per_env == 0:
+                # BASELINE configs[3] to the letter: 262 144 agents over the node (32 768 per GPU at 8), without and
+                # with the gather — the legs above keep the scaling curve's 65 536 agents per GPU
+                c3 = {"workload": "262144 agents sharded x%d = %d per GPU, RCCL gather of the observation (BASELINE configs[3])" % (n_gpus, c3_agents)}
+                if wl is not None:
+                    wl.close()
+                    wl = None
+                w3 = None if args.stub else Workload(args, rdv, c3_agents, args.preroll + args.warmup + args.steps)
+                if args.stub:
+                    res = stub_run(args, rdv, args.steps)
+                else:
+                    res, e = guarded(lambda: w3.run(args.steps, args.warmup, "timed"), args.gather_timeout)
+                    if e:
+                        raise RuntimeError("configs[3] leg: %s" % e)
+                rec = leg_record(rdv, c3_agents * n_gpus, res)
+                c3["no_gather"] = dict(rec, per_gpu_value=rec["value"] / n_gpus)
+                gather_pair(w3, c3_agents, c3)
+                line["multi_gpu"]["configs3"] = c3
+                if w3 is not None:
+                    w3.close()
         except BaseException as ex:  # noqa: BLE001 — incl. "peer went away" when another rank gave up
             err = "%s: %s" % (type(ex).__name__, ex)
-        line["multi_gpu"]["rccl_ranks"] = rccl_ranks
-        for name, rec in legs.items():
-            line["multi_gpu"][name] = dict(rec, per_gpu_value=rec["value"] / n_gpus,
-                                           bytes_gathered_per_rank_per_step=8 * args.agents * (args.beams + 7) * n_gpus)
         if err:
             line["multi_gpu"]["gather_error"] = err[:400]
             if rdv.rank == 0:

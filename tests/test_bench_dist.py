@@ -122,6 +122,21 @@ def test_bench_self_launches_its_ranks():
     assert line["n_gpus"] == 2 and line["config"]["agents_total"] == 1024
 
 
+def test_configs3_to_the_letter_legs():
+    """BASELINE configs[3] — 262 144 agents over the node with the observation gather — runs inside the same
+    invocation (automatically at --gpus 8, on request elsewhere): without the gather, with it, overlapped"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "F110_BENCH_RDV")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2", "--agents", "512",
+                          "--stub", "--config3-legs"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1000:]
+    c3 = _bench_line(out.stdout)["multi_gpu"]["configs3"]
+    assert "131072 per GPU" in c3["workload"]
+    for leg in ("no_gather", "gather", "gather_overlap"):
+        assert c3[leg]["value"] > 0 and len(c3[leg]["per_rank_ms_per_step"]) == 2
+    assert c3["gather"]["bytes_gathered_per_rank_per_step"] == 8 * 131072 * 1087 * 2
+    assert c3["no_gather"]["value"] > c3["gather_overlap"]["value"] > c3["gather"]["value"]
+
+
 def test_a_failing_gather_leg_cannot_take_the_headline_with_it():
     """the gather legs run last and under a watchdog: when one dies on some rank (here: rank 1 raises in the
     overlapped leg, rank 0 then finds its peer gone) every rank still exits 0 and rank 0 still prints the line —
