@@ -48,6 +48,8 @@ struct ExpSwitches {
     int pair_always = 0;       // A = 2: 1 = pair test inside the finalize kernel also for big batches without the in-step re-seat
     int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
     int scan_env_counter = 0;  // 1: the scan kernel also counts finished tasks per env (fusion feasibility A/B)
+    int integrate_xcd = 0;     // 1: k_integrate walks its blocks in the scan's XCD-contiguous order (L2 locality probe)
+    uint64_t scan_trace = 0;   // device address of a caller-owned [waves][8] uint64 buffer: clock stamps, hardware id, samples of every scan wave (0 = off)
 };
 
 // A = 2 finalize: the workgroup-flattened window loop (k_finalize_pair_flat) or fixed lanes per agent
@@ -138,8 +140,11 @@ struct f110_sim {
     bool task_order = false;
     uint32_t *d_tflags[2] = {nullptr, nullptr}, *d_tlist[2] = {nullptr, nullptr}, *d_tcount = nullptr;
     uint32_t *d_rflags[2] = {nullptr, nullptr}, *d_rlist[2] = {nullptr, nullptr}, *d_rtask[2] = {nullptr, nullptr};   // the ray-level lists (TaskSched::r*)
-    TaskSched *d_tsched = nullptr;   // [2]
+    TaskSched tsched[2]{};           // [parity], passed to the scan by value
+    bool sched_allocated = false;
+    uint32_t task_cap_alloc = 0;
     uint32_t task_epoch = 2, task_cap = 0, task_thr = 96;   // epochs start above the flags' initial 0
+    uint32_t task_cap_div = 32, task_rev = 0;                // list capacity = tasks / task_cap_div; 1 = newest list entries first
     uint32_t ray_cap = 0, ray_thr = 96, ray_waves = 2048;
     bool ray_pass = false;   // until it is measured to pay (f110_exp_set ray_pass)
     ExpSwitches exp;
@@ -365,12 +370,12 @@ static int task_order_setup(f110_sim *h, bool on)
         return F110_OK;
     }
     const size_t n_rays = (size_t)h->N * (size_t)h->cfg.num_beams;
-    if (!h->d_tsched) {
-        h->task_cap = (uint32_t)std::max<size_t>(64, n_tasks / 32);
+    if (!h->sched_allocated) {
+        h->task_cap_alloc = (uint32_t)std::max<size_t>(64, kExperimental ? n_tasks : n_tasks / h->task_cap_div);
         h->ray_cap = (uint32_t)std::max<size_t>(256, n_rays / 512);
         for (int q = 0; q < 2; ++q) {
             TRY(dmalloc(h, &h->d_tflags[q], n_tasks));
-            TRY(dmalloc(h, &h->d_tlist[q], (size_t)h->task_cap));
+            TRY(dmalloc(h, &h->d_tlist[q], (size_t)h->task_cap_alloc));
             HIPCHK(h, hipMemsetAsync(h->d_tflags[q], 0, sizeof(uint32_t) * n_tasks, h->stream));
             TRY(dmalloc(h, &h->d_rflags[q], n_rays));
             TRY(dmalloc(h, &h->d_rlist[q], (size_t)h->ray_cap));
@@ -380,13 +385,12 @@ static int task_order_setup(f110_sim *h, bool on)
         }
         TRY(dmalloc(h, &h->d_tcount, 4));   // {task count 0, 1, ray count 0, 1}
         HIPCHK(h, hipMemsetAsync(h->d_tcount, 0, 4 * sizeof(uint32_t), h->stream));
-        TRY(dmalloc(h, &h->d_tsched, 2));
+        h->sched_allocated = true;
     }
-    TaskSched ts[2];
+    h->task_cap = std::min<uint32_t>(h->task_cap_alloc, (uint32_t)std::max<size_t>(64, n_tasks / h->task_cap_div));
     for (int q = 0; q < 2; ++q)   // struct q is used at steps of parity q: it reads what parity q^1 wrote
-        ts[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr,
+        h->tsched[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr,
                           h->d_rflags[q ^ 1], h->d_rflags[q], h->d_rtask[q ^ 1], h->d_rtask[q], h->d_rlist[q ^ 1], h->d_rlist[q], h->d_tcount + 2 + (q ^ 1), h->d_tcount + 2 + q, h->ray_cap, h->ray_thr};
-    HIPCHK(h, hipMemcpyAsync(h->d_tsched, ts, sizeof ts, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->task_order = true;
     return F110_OK;
@@ -444,12 +448,19 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "finalize_roles") h->exp.finalize_roles = value;
     else if (k == "scan_occupancy") h->exp.scan_occupancy = value;
     else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
+    else if (k == "integrate_xcd") h->exp.integrate_xcd = value;
+    else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
+    else if (k == "scan_trace_lo") h->exp.scan_trace = (h->exp.scan_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "collide_mode") {
         if (value < 0 || value > 3) return fail(h, F110_ERR_INVALID, "collide_mode must be 0..3");
         h->collide_mode = value;
     } else if (k == "step_graph") h->use_graph = value != 0;
     else if (k == "task_order") return task_order_setup(h, value != 0);
-    else if (k == "task_thr") {
+    else if (k == "task_cap_div" || k == "task_rev") {
+        if (k == "task_rev") h->task_rev = value != 0;
+        else h->task_cap_div = (uint32_t)std::max(1, value);
+        if (h->task_order) return task_order_setup(h, true);
+    } else if (k == "task_thr") {
         h->task_thr = (uint32_t)value;
         if (h->task_order) return task_order_setup(h, true);
     } else if (k == "ray_pass") h->ray_pass = value != 0;
@@ -611,10 +622,15 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         h->noise_gen = NoiseGen{h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_jump + 65, 0.0};
     }
     {
-        // longest-first task order: for batches whose scan lasts as long as its longest ray (one task per wave)
-        // (measured: 4096 agents 0.110 -> 0.103 ms, 8192: 0.159 -> 0.155, 1024: 0.073 -> 0.071; 16 384: a loss)
+        // longest-first task order: for batches whose scan ends with its longest rays.  Window re-measured in round 3
+        // with both kernels at 8 waves per SIMD (product kernel, list on / off): 512 agents 8.50 / 8.68 M agent-steps/s,
+        // 1024: 15.4 / 15.2, 2048: 27.5 / 26.1, 4096: 43.7 / 39.9, 8192: 60.9 / 57.8, 12 288: 69.7 / 67.4,
+        // 16 384: 75.2 / 73.6, 24 576: 81.0 / 83.0, 32 768: 82.6 / 86.3
         const size_t n_tasks = (size_t)N * (((size_t)B + 63) / 64);
-        if (n_tasks >= 4096 && n_tasks < 160000) CK(task_order_setup(h, true));
+#ifndef F110_TASK_ORDER_MAX_TASKS
+#define F110_TASK_ORDER_MAX_TASKS 340000
+#endif
+        if (n_tasks >= 12000 && n_tasks < F110_TASK_ORDER_MAX_TASKS) CK(task_order_setup(h, true));
     }
     CKH(hipMemsetAsync(d.state, 0, sizeof(double) * 7 * N, h->stream));
     CKH(hipMemsetAsync(d.steer_buf, 0, sizeof(double) * 2 * N, h->stream));
@@ -721,7 +737,7 @@ void f110_destroy(f110_sim *h)
     for (hipEvent_t ge : h->gevents) (void)hipEventDestroy(ge);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     {
-        void *rp[] = {h->d_rtask[0], h->d_rtask[1], h->d_rflags[0], h->d_rflags[1], h->d_rlist[0], h->d_rlist[1], h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_tsched, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
+        void *rp[] = {h->d_rtask[0], h->d_rtask[1], h->d_rflags[0], h->d_rflags[1], h->d_rlist[0], h->d_rlist[1], h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
         for (void *p : rp)
             if (p) (void)hipFree(p);
     }
@@ -1784,6 +1800,9 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     // (the longest-first list counter) follow the same answer
     const ScanKind scan = pick_scan(h, begin, count);
     dev.sched_count_zero = scan == SCAN_AGENT_SCHED ? h->d_tcount + (h->task_epoch & 1u) : nullptr;
+#ifdef F110_EXPERIMENTAL
+    dev.integrate_xcd = h->exp.integrate_xcd;
+#endif
     if (dev.noise_rng && (dev.noise_rng == 2 || h->noise_ub >= (long long)dev.noise_rows)) {
         const int apb = dev.noise_rng == 2 ? 16 : 64;   // per-agent streams: every agent needs a row, keep the waves many
         hipLaunchKernelGGL(k_noise_rows, dim3((count + apb - 1) / apb), dim3(256), 0, st, dev, h->noise_gen, B, apb);
@@ -1841,6 +1860,9 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         j.div_shift = h->step_shift;
         j.lookups_total = h->lookups_on ? h->d_lookups : nullptr;
         j.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;   // (step form: only the ray pass counts here)
+#ifdef F110_EXPERIMENTAL
+        j.trace = reinterpret_cast<unsigned long long *>(h->exp.scan_trace);
+#endif
         j.k_cold = cold_consts(h);
         if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
         j.order = (h->multi_map && begin == 0 && count == N) ? h->d_scan_order : nullptr;
@@ -1915,12 +1937,13 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
             agent_grid(tpa, grid, wpb);
             const uint32_t parity = h->task_epoch & 1u;
-            j.sched = h->d_tsched + parity;
+            j.sched = h->tsched[parity];
             j.epoch_r = h->task_epoch - 1u;
             j.epoch_w = h->task_epoch;
             j.long_blocks = (h->task_cap + wpb - 1) / wpb;
             j.ray_blocks = (kExperimental && h->ray_pass) ? (std::min(h->ray_cap, h->ray_waves) + wpb - 1) / wpb : 0u;
             j.long_prio = (uint32_t)h->exp.long_prio;
+            j.long_rev = h->task_rev;
             h->task_epoch += 1u;
             const dim3 sgrid(grid.x + j.long_blocks + j.ray_blocks);
             size_t slds = 0;

@@ -68,6 +68,7 @@ struct AgentArrays {
     int32_t *reseat_count;           // device counter or nullptr
     int32_t reseat_ego, pad_reseat;
     uint32_t *sched_count_zero;  // longest-first scan order: this step's list counter, zeroed here (or nullptr)
+    int32_t integrate_xcd;       // probe (experimental build): k_integrate's blocks in the scan's XCD-contiguous order
     int32_t *opp_window;     // [N][A][4] beam range each opponent can occupy: {lo, hi} for the live
                              //           heading and {lo0, hi0} for heading 0 (after a wall hit)
     double *opp_verts;       // [N][A][8] the opponent's box drawn with the ego's length/width
@@ -163,7 +164,14 @@ __device__ __forceinline__ void collide_agent(const AgentArrays &a, int32_t B, i
 template <int AF>
 __global__ void __launch_bounds__(AF ? 64 : 256) k_integrate(AgentArrays a, ScanConst k, const double *__restrict__ actions)
 {
-    const int i = a.agent_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    uint32_t blk = blockIdx.x;
+#ifdef F110_EXPERIMENTAL
+    if (a.integrate_xcd) {   // the XCD that will scan an agent also integrates it: does its header stay in that XCD's L2?
+        const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, ii = blk >> 3;
+        blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + ii;
+    }
+#endif
+    const int i = a.agent_begin + (int)(blk * blockDim.x + threadIdx.x);
     const int N = a.n_agents_total;
     if (i >= a.agent_begin + a.agent_count) return;
     const VehicleParams vp = load_params(a.params + (size_t)(a.params_per_agent ? i : i % a.agents_per_env) * NPARAMS);
@@ -329,11 +337,16 @@ struct RayJob {
     uint32_t first_pose, pad_first; // k_scan_rays_agent: the launch covers agents first_pose .. (env group)
     unsigned long long *lookups_total;  // COUNT variants: table lookups of every marched ray, summed (or nullptr)
     // longest-first task order (k_scan_rays_agent<.., SCHED>): see TaskSched
-    const struct TaskSched *sched;
+    TaskSched sched;   // by value: the kernel argument segment is the one read a wave never waits long for
     uint32_t epoch_r, epoch_w, long_blocks, ray_blocks;
     // fusion-feasibility probe (experimental build): per-env count of finished scan tasks, reset by the last arriver
     uint32_t *env_done;
     uint32_t tasks_per_env, long_prio;
+    uint32_t long_rev, pad_rev;   // 1: the long pass walks last step's list from its newest entry (the tasks that finished last)
+    // timeline probe (experimental build, k_scan_rays_agent): [launch waves][8] = {begin, end (100 MHz clock), HW_ID | XCC_ID << 32,
+    // lock-step samples marched | long pass << 32, task loop entered, first task's stamp + header arrived, its direction /
+    // noise operands arrived (march begins), last march done} written by every wave that reaches the end of the kernel; nullptr = off
+    unsigned long long *trace;
     // per-env maps: the order the scan walks the agents in — sorted by map slot, so that the XCD-contiguous
     // block order hands each XCD's L2 the agents of as few tracks as possible however the caller interleaved
     // them (nullptr: agent order)
@@ -649,30 +662,37 @@ __device__ __forceinline__ void load_map_fast(ScanConst &km, const MapFast *__re
     km.pad_max_samples = uniform_i32(m0->pad_max_samples);
 }
 
+#ifndef F110_SCAN_WAVES_EXPR
+#define F110_SCAN_WAVES_EXPR 8
+#endif
 template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false>
-__global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_SCAN_WAVES_EXPR))) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
                                                           const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
     const uint32_t B = (uint32_t)k.num_beams;
     uint32_t tpw = j.tasks_per_wave;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t blk = blockIdx.x;
-    typedef const __attribute__((address_space(4))) TaskSched *csched_t;
     typedef const __attribute__((address_space(4))) uint32_t *cu32_t;
     bool long_pass = false;
     uint32_t long_task = 0;
+#ifdef F110_EXPERIMENTAL
+    const unsigned long long trace_begin = j.trace ? wall_clock64() : 0ull;
+    unsigned long long trace_loop = 0ull, trace_hdr = 0ull, trace_ops = 0ull, trace_marched = 0ull;
+    uint32_t trace_samples = 0;
+#endif
     if (SCHED) {
         if (kRayPassBuilt && blk < j.ray_blocks) {
             // ---- ray pass: last step's longest RAYS, one per wave, newest list entries (= the rays that finished
             // last, i.e. the longest) first
-            const csched_t sc = (csched_t)j.sched;
+            const TaskSched &sc = j.sched;
             const uint32_t nw = j.ray_blocks * (blockDim.x >> 6);
-            uint32_t cnt = *(cu32_t)sc->rcount_r;
-            cnt = cnt < sc->rcap ? cnt : sc->rcap;
+            uint32_t cnt = *(cu32_t)sc.rcount_r;
+            cnt = cnt < sc.rcap ? cnt : sc.rcap;
             typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
             for (uint32_t w = __builtin_amdgcn_readfirstlane((blk * blockDim.x + threadIdx.x) >> 6); w < cnt; w += nw) {
-                const uint32_t ray = ((cu32_t)sc->rlist_r)[cnt - 1u - w];
-                if (ray >= j.n_rays || ((cu32_t)sc->rflags_r)[ray] != j.epoch_r) continue;   // (every slot below cnt was written this epoch; belt and braces)
+                const uint32_t ray = ((cu32_t)sc.rlist_r)[cnt - 1u - w];
+                if (ray >= j.n_rays || ((cu32_t)sc.rflags_r)[ray] != j.epoch_r) continue;   // (every slot below cnt was written this epoch; belt and braces)
                 const uint32_t p = ray / B;
                 const int b = (int)(ray - p * B);
                 const chdr_t h0 = (chdr_t)(j.hdr) + p;
@@ -698,12 +718,12 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
                 }
                 if (exact) r = march_exact_cold<IDENT>(j.k_cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
                 if (lane == 0u) {
-                    if (nl > (int)sc->rthr) {   // still long: stays on the list
-                        const uint32_t pos = atomicAdd(sc->rcount_w, 1u);
-                        if (pos < sc->rcap) {
-                            sc->rlist_w[pos] = ray;
-                            sc->rflags_w[ray] = j.epoch_w;
-                            sc->rtask_w[p * tasks_per_agent + ((uint32_t)b >> 6)] = j.epoch_w;
+                    if (nl > (int)sc.rthr) {   // still long: stays on the list
+                        const uint32_t pos = atomicAdd(sc.rcount_w, 1u);
+                        if (pos < sc.rcap) {
+                            sc.rlist_w[pos] = ray;
+                            sc.rflags_w[ray] = j.epoch_w;
+                            sc.rtask_w[p * tasks_per_agent + ((uint32_t)b >> 6)] = j.epoch_w;
                         }
                     }
                     finish_beam_with(j, p, b, ray, row != -1 ? r + nz : r, vel);
@@ -713,12 +733,13 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         }
         blk -= j.ray_blocks;
         if (blk < j.long_blocks) {   // the first blocks of the launch serve last step's long tasks, one per wave
-            const csched_t sc = (csched_t)j.sched;
+            const TaskSched &sc = j.sched;
             const uint32_t wl = __builtin_amdgcn_readfirstlane((blk * blockDim.x + threadIdx.x) >> 6);
-            const uint32_t cnt = *(cu32_t)sc->count_r;
-            if (wl >= (cnt < sc->cap ? cnt : sc->cap)) return;
+            uint32_t cnt = *(cu32_t)sc.count_r;
+            cnt = cnt < sc.cap ? cnt : sc.cap;
+            if (wl >= cnt) return;
             long_pass = true;
-            long_task = ((cu32_t)sc->list_r)[wl];
+            long_task = ((cu32_t)sc.list_r)[j.long_rev ? cnt - 1u - wl : wl];
             tpw = 1u;
             if (j.long_prio) __builtin_amdgcn_s_setprio(3);   // (experiment: instruction-issue priority for the waves the launch waits for)
         } else {
@@ -736,23 +757,36 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
     ScanConst km = k;
     const ScanConst *cold = j.k_cold;
     int cur_slot = -1;
+#ifdef F110_EXPERIMENTAL
+    if (j.trace) trace_loop = wall_clock64();
+#endif
     for (uint32_t t = 0; t < tpw; ++t) {
         const uint32_t task = __builtin_amdgcn_readfirstlane(long_pass ? long_task : wave * tpw + t);
         if (task >= j.n_tasks) break;
-        if (SCHED && !long_pass && ((cu32_t)((csched_t)j.sched)->flags_r)[task] == j.epoch_r) continue;   // served by the long pass
         const uint32_t pl = task / tasks_per_agent;                 // scalar
         const uint32_t p = (PER_ENV_MAP && j.order) ? ((cu32_t)j.order)[pl] : j.first_pose + pl;
-        const int b = (int)((task - pl * tasks_per_agent) * 64u + lane);
-        if (b >= (int)B) continue;
-        // a ray the ray pass marches (stamped in the previous step) is skipped by its lane; the stamp is requested
-        // here and looked at after the noise sample and the direction have been requested too (one round trip)
-        uint32_t ray_stamp = 0u;
-        if (SCHED && kRayPassBuilt && j.ray_blocks && ((cu32_t)((csched_t)j.sched)->rtask_r)[task] == j.epoch_r) ray_stamp = ((csched_t)j.sched)->rflags_r[p * B + (uint32_t)b];
+        // the task's two cold words — its stamp on last step's long list and its agent's header, both written by
+        // other kernels on other XCDs — are requested together: one memory round trip, not two in a row (a small
+        // batch is bound by its per-task latency chain: tools/debug/scan_timeline.py).  Measured and NOT done: keeping
+        // the header in SGPRs while consecutive tasks belong to one agent (65 536 agents 92.1 -> 86.9 M agent-steps/s:
+        // the loop-carried scalars cost more than the scalar-cache hit they save), and requesting the next task's
+        // direction / noise operands before this task's march (92.1 -> 91.7).
+        const uint32_t stamp = (SCHED && !long_pass) ? ((cu32_t)j.sched.flags_r)[task] : 0u;
         typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
         const chdr_t h0 = (chdr_t)(j.hdr) + p;
         const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
         const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
         const int row = uniform_i32(h0->noise_row), slot = uniform_i32(h0->map_slot), fast = uniform_i32(h0->fast);
+#ifdef F110_EXPERIMENTAL
+        if (j.trace && trace_hdr == 0ull) trace_hdr = wall_clock64();   // (reading the clock waits for the scalar loads above)
+#endif
+        if (SCHED && !long_pass && stamp == j.epoch_r) continue;   // served by the long pass
+        const int b = (int)((task - pl * tasks_per_agent) * 64u + lane);
+        if (b >= (int)B) continue;
+        // a ray the ray pass marches (stamped in the previous step) is skipped by its lane; the stamp is requested
+        // here and looked at after the noise sample and the direction have been requested too (one round trip)
+        uint32_t ray_stamp = 0u;
+        if (SCHED && kRayPassBuilt && j.ray_blocks && ((cu32_t)j.sched.rtask_r)[task] == j.epoch_r) ray_stamp = j.sched.rflags_r[p * B + (uint32_t)b];
         if (PER_ENV_MAP && slot != cur_slot) {   // wave-uniform
             cold = maps_full + slot;
             load_map_fast(km, maps_fast, slot);
@@ -762,7 +796,13 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         // row of the table / row cache, or (row -2) the row k_noise_rows left in this agent's scans[]
         const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;   // scalar
         const double nz = row != -1 ? nrow[b] : 0.0;
-        const double2 cs = k.cs[beam_dir_index(k, start, b)];
+        double2 cs = k.cs[beam_dir_index(k, start, b)];
+#ifdef F110_EXPERIMENTAL
+        if (j.trace && trace_ops == 0ull) {
+            asm volatile("" : "+v"(cs.x), "+v"(cs.y));   // (the direction has arrived)
+            trace_ops = wall_clock64();
+        }
+#endif
         const bool mine = !(SCHED && kRayPassBuilt && j.ray_blocks && ray_stamp == j.epoch_r);   // false: the ray pass has this ray
         int hr = -1, hc = -1, nl = 0;
         double r = 0.;
@@ -775,30 +815,42 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         }
         if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
         if (COUNT) nl_acc += (uint32_t)nl;   // measurement variant only (bench.py's L-bar)
+#ifdef F110_EXPERIMENTAL
+        if (j.trace) {
+            asm volatile("" : "+v"(r));
+            trace_marched = wall_clock64();
+        }
+        if (j.trace) {   // the task's lock-step length = its longest ray
+            int m = 0;   // max over the lanes that hold a beam, bit by bit (ten compares; a cheap probe distorts least)
+            for (int bit = 1 << 10; bit; bit >>= 1)
+                if (__ballot(nl >= (m | bit)) != 0ull) m |= bit;
+            trace_samples += (uint32_t)m;
+        }
+#endif
         if (SCHED && kRayPassBuilt && j.ray_blocks) {
             // this step's long rays go on the ray list for the next step: one atomic per wave that has any
-            const csched_t sc = (csched_t)j.sched;
-            const bool listed = nl > (int)sc->rthr;
+            const TaskSched &sc = j.sched;
+            const bool listed = nl > (int)sc.rthr;
             const uint64_t lm = __ballot(listed);
             if (lm != 0ull) {
                 uint32_t pos = 0u;
-                if (lane == (uint32_t)__builtin_ctzll(lm)) pos = atomicAdd(sc->rcount_w, (uint32_t)popc_u64(lm));
+                if (lane == (uint32_t)__builtin_ctzll(lm)) pos = atomicAdd(sc.rcount_w, (uint32_t)popc_u64(lm));
                 pos = (uint32_t)__shfl((int)pos, __builtin_ctzll(lm)) + (uint32_t)popc_u64(lm & ((1ull << lane) - 1ull));
-                if (listed && pos < sc->rcap) {
-                    sc->rlist_w[pos] = p * B + (uint32_t)b;
-                    sc->rflags_w[p * B + (uint32_t)b] = j.epoch_w;
-                    sc->rtask_w[task] = j.epoch_w;   // (every listed lane stores the same word)
+                if (listed && pos < sc.rcap) {
+                    sc.rlist_w[pos] = p * B + (uint32_t)b;
+                    sc.rflags_w[p * B + (uint32_t)b] = j.epoch_w;
+                    sc.rtask_w[task] = j.epoch_w;   // (every listed lane stores the same word)
                 }
             }
         }
         if (SCHED) {
-            const csched_t sc = (csched_t)j.sched;
-            if (__ballot(nl > (int)sc->thr) != 0ull && lane == 0u) {
+            const TaskSched &sc = j.sched;
+            if (__ballot(nl > (int)sc.thr) != 0ull && lane == 0u) {
                 // lane 0 (beam task*64, always a valid beam; nl = 0 if the ray pass has its ray) appends the task for the next step
-                const uint32_t pos = atomicAdd(sc->count_w, 1u);
-                if (pos < sc->cap) {
-                    sc->list_w[pos] = task;
-                    sc->flags_w[task] = j.epoch_w;
+                const uint32_t pos = atomicAdd(sc.count_w, 1u);
+                if (pos < sc.cap) {
+                    sc.list_w[pos] = task;
+                    sc.flags_w[task] = j.epoch_w;
                 }
             }
         }
@@ -812,6 +864,22 @@ __global__ void __launch_bounds__(256) k_scan_rays_agent(RayJob j, ScanConst k, 
         }
     }
     if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
+#ifdef F110_EXPERIMENTAL
+    if (j.trace && lane == 0u) {
+        uint32_t hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        unsigned long long *rec = j.trace + 8ull * ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+        rec[0] = trace_begin;
+        rec[1] = wall_clock64();
+        rec[2] = (unsigned long long)hw_id | ((unsigned long long)xcc_id << 32);
+        rec[3] = (unsigned long long)trace_samples | ((unsigned long long)(long_pass ? 1u : 0u) << 32);
+        rec[4] = trace_loop;
+        rec[5] = trace_hdr;
+        rec[6] = trace_ops;
+        rec[7] = trace_marched;
+    }
+#endif
 }
 
 #ifdef F110_EXPERIMENTAL   // measured and rejected: not part of the product library
@@ -947,8 +1015,11 @@ __device__ __forceinline__ void finish_beam(const RayJob &j, uint32_t B, uint32_
 // gets its own noise sample and iTTC test.  Replaces the (march to a [N][dir_stride] buffer,
 // k_expand_beams) pair: one launch less and no 1.6 GB round trip of intermediate ranges per step.
 // Bit-identical to marching every beam (beams that share a table index from one origin are one ray).
+#ifndef F110_DIRS_WAVES_EXPR
+#define F110_DIRS_WAVES_EXPR 8
+#endif
 template <bool PER_ENV_MAP, bool IDENT, bool COUNT>
-__global__ void __launch_bounds__(256) k_scan_dirs_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_DIRS_WAVES_EXPR))) k_scan_dirs_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
                                                           const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
     const uint32_t B = (uint32_t)k.num_beams;

@@ -173,8 +173,9 @@ def test_fusion_probes_do_not_change_results(amd, probe):
 def test_scan_choice_is_one_decision(amd):
     """the predicate that made k_integrate zero the longest-first list counter differed from the
     one that picked the SCHED kernel (WINDOW_LDS layout + no_window).  One decision now: a small batch on the
-    window layout with the window switched off equals the PADDED layout bit for bit."""
-    E, A, T = 300, 2, 30
+    window layout with the window switched off equals the PADDED layout bit for bit.  (800 envs x 2 agents x 17 tasks:
+    inside the longest-first window, which starts at 12 000 tasks.)"""
+    E, A, T = 800, 2, 30
     a = _sim(amd, E, A, map_layout=3); b = _sim(amd, E, A, map_layout=4, exp={"no_window": 1})
     poses = bench_start_poses(E, A)
     rng = np.random.default_rng(5)

@@ -70,6 +70,31 @@ ray)
     F110_EXP=ray_pass=1,task_thr=$tt timeout 200 $X python bench.py $H --agents 4096 > $OUT/ray_tt$tt.log 2>&1; line $OUT/ray_tt$tt.log "4096 ray_pass 1, task_thr $tt"
   done
   ;;
+latency)
+  # small batches are bound by the per-task latency chain (tools/debug/scan_timeline.py): sizes, the timeline, and
+  # k_integrate in the scan's XCD order
+  timeout 600 python tools/debug/tpw_sweep.py 1024,2048,4096,8192,16384,65536 0 > $OUT/latency_sizes.txt 2>&1; cat $OUT/latency_sizes.txt
+  for n in 1024 4096 16384; do for ix in 0 1; do
+    F110_EXP=integrate_xcd=$ix timeout 200 $X python bench.py $H --agents $n > $OUT/lat_n${n}_ix$ix.log 2>&1; line $OUT/lat_n${n}_ix$ix.log "agents $n integrate_xcd $ix"
+  done; done
+  timeout 300 $X python tools/debug/scan_timeline.py 4096 -1 2 > $OUT/scan_timeline_4096.txt 2>&1; tail -42 $OUT/scan_timeline_4096.txt
+  ;;
+lists)
+  # longest-first list: threshold, capacity (tasks / div) and walking order, small batches
+  for n in 4096 1024; do
+    for cfgs in "task_thr=96" "task_thr=64" "task_thr=48,task_cap_div=8" "task_thr=32,task_cap_div=4" "task_thr=24,task_cap_div=2" "task_thr=96,task_rev=1" "task_thr=48,task_cap_div=8,task_rev=1" "task_thr=32,task_cap_div=4,task_rev=1" "task_thr=24,task_cap_div=2,task_rev=1" "task_thr=16,task_cap_div=2,task_rev=1"; do
+      F110_EXP=$cfgs timeout 200 $X python bench.py $H --agents $n > $OUT/lists_tmp.log 2>&1; line $OUT/lists_tmp.log "agents $n $cfgs"
+    done
+  done
+  ;;
+order)
+  # longest-first window: does the list pay above 160 000 tasks now that both kernels run 8 waves per SIMD?
+  for n in 8192 16384 32768 65536; do for o in 0 1; do
+    F110_EXP=task_order=$o timeout 200 $X python bench.py $H --agents $n > $OUT/order_tmp.log 2>&1; line $OUT/order_tmp.log "agents $n task_order $o"
+  done; done
+  F110_EXP=task_order=1,task_thr=150 timeout 200 $X python bench.py $H --agents 65536 > $OUT/order_tmp.log 2>&1; line $OUT/order_tmp.log "agents 65536 task_order 1 thr 150"
+  F110_EXP=task_order=1,task_thr=150 timeout 200 $X python bench.py $H --agents 16384 > $OUT/order_tmp.log 2>&1; line $OUT/order_tmp.log "agents 16384 task_order 1 thr 150"
+  ;;
 probes)
   # fusion feasibility: the scan kernel at the occupancy a fused (118-VGPR) kernel would have,
   # and with a per-env completion counter
