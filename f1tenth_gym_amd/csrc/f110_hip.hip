@@ -48,7 +48,6 @@ struct ExpSwitches {
     int pair_always = 0;       // A = 2: 1 = pair test inside the finalize kernel also for big batches without the in-step re-seat
     int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
     int scan_env_counter = 0;  // 1: the scan kernel also counts finished tasks per env (fusion feasibility A/B)
-    int integrate_xcd = 0;     // 1: k_integrate walks its blocks in the scan's XCD-contiguous order (L2 locality probe)
     uint64_t scan_trace = 0;   // device address of a caller-owned [waves][8] uint64 buffer: clock stamps, hardware id, samples of every scan wave (0 = off)
 };
 
@@ -448,7 +447,6 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "finalize_roles") h->exp.finalize_roles = value;
     else if (k == "scan_occupancy") h->exp.scan_occupancy = value;
     else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
-    else if (k == "integrate_xcd") h->exp.integrate_xcd = value;
     else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
     else if (k == "scan_trace_lo") h->exp.scan_trace = (h->exp.scan_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "collide_mode") {
@@ -542,12 +540,13 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     if (cfg->scan_tasks_per_wave > 0) {
         h->scan_tasks_per_wave = cfg->scan_tasks_per_wave;
     } else {
-        // default: 4 consecutive tasks per wave once the batch fills every wave slot ~8 times over
+        // default: 3 consecutive tasks per wave once the batch fills every wave slot ~8 times over
         // (amortises the per-wave set-up); small batches are bound by their longest rays and want
-        // the finer granularity (4096 agents: +5 %, 1024: +12 % with 1 task per wave)
+        // the finer granularity (4096 agents: +5 %, 1024: +12 % with 1 task per wave).  Round 3, 3 / 4 / 6 / 8 / 17
+        // tasks per wave: 65 536 agents 95.7 / 95.2 / 95.1 / 94.3 / 88.4 M agent-steps/s, 32 768: 87.6 / 86.2 / 85.9 / 83.3 / 77.9
         const size_t tasks = ((size_t)N * (size_t)B + 63) / 64, slots = (size_t)h->num_cus * 32;
         const size_t t = tasks / (slots * 8);
-        h->scan_tasks_per_wave = t < 1 ? 1 : (t > 4 ? 4 : (int)t);
+        h->scan_tasks_per_wave = t < 1 ? 1 : (t > 3 ? 3 : (int)t);
     }
     CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CKH(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
@@ -1800,9 +1799,6 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     // (the longest-first list counter) follow the same answer
     const ScanKind scan = pick_scan(h, begin, count);
     dev.sched_count_zero = scan == SCAN_AGENT_SCHED ? h->d_tcount + (h->task_epoch & 1u) : nullptr;
-#ifdef F110_EXPERIMENTAL
-    dev.integrate_xcd = h->exp.integrate_xcd;
-#endif
     if (dev.noise_rng && (dev.noise_rng == 2 || h->noise_ub >= (long long)dev.noise_rows)) {
         const int apb = dev.noise_rng == 2 ? 16 : 64;   // per-agent streams: every agent needs a row, keep the waves many
         hipLaunchKernelGGL(k_noise_rows, dim3((count + apb - 1) / apb), dim3(256), 0, st, dev, h->noise_gen, B, apb);

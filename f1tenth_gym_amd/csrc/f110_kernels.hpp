@@ -68,7 +68,6 @@ struct AgentArrays {
     int32_t *reseat_count;           // device counter or nullptr
     int32_t reseat_ego, pad_reseat;
     uint32_t *sched_count_zero;  // longest-first scan order: this step's list counter, zeroed here (or nullptr)
-    int32_t integrate_xcd;       // probe (experimental build): k_integrate's blocks in the scan's XCD-contiguous order
     int32_t *opp_window;     // [N][A][4] beam range each opponent can occupy: {lo, hi} for the live
                              //           heading and {lo0, hi0} for heading 0 (after a wall hit)
     double *opp_verts;       // [N][A][8] the opponent's box drawn with the ego's length/width
@@ -164,14 +163,7 @@ __device__ __forceinline__ void collide_agent(const AgentArrays &a, int32_t B, i
 template <int AF>
 __global__ void __launch_bounds__(AF ? 64 : 256) k_integrate(AgentArrays a, ScanConst k, const double *__restrict__ actions)
 {
-    uint32_t blk = blockIdx.x;
-#ifdef F110_EXPERIMENTAL
-    if (a.integrate_xcd) {   // the XCD that will scan an agent also integrates it: does its header stay in that XCD's L2?
-        const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, ii = blk >> 3;
-        blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + ii;
-    }
-#endif
-    const int i = a.agent_begin + (int)(blk * blockDim.x + threadIdx.x);
+    const int i = a.agent_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int N = a.n_agents_total;
     if (i >= a.agent_begin + a.agent_count) return;
     const VehicleParams vp = load_params(a.params + (size_t)(a.params_per_agent ? i : i % a.agents_per_env) * NPARAMS);

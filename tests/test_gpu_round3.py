@@ -112,6 +112,51 @@ def test_flattened_finalize_is_bit_identical(amd, lanes, roles):
     a.close(); b.close()
 
 
+def _set_trace(s, ptr):
+    s.exp_set("scan_trace_hi", int(np.array(ptr >> 32, dtype=np.uint32).view(np.int32)))
+    s.exp_set("scan_trace_lo", int(np.array(ptr & 0xffffffff, dtype=np.uint32).view(np.int32)))
+
+
+def test_scan_timeline_probe_and_list_switches_are_invisible(amd):
+    """the wave-by-wave timeline of the scan launch (tools/debug/scan_timeline.py: every wave stamps begin / end /
+    phase clocks, its CU and its lock-step samples into a caller-owned buffer) and the longest-first list's capacity
+    and walking order change no result; the records it leaves are coherent"""
+    E, A, T = 400, 2, 24
+    B, tpa = 1080, 17
+    a = _sim(amd, E, A, exp={"task_order": 1})
+    b = _sim(amd, E, A, exp={"task_order": 1, "task_thr": 8, "task_cap_div": 2, "task_rev": 1})
+    poses = bench_start_poses(E, A)
+    rng = np.random.default_rng(21)
+    for s in (a, b):
+        s.set_noise_rng(12345, 0.01); s.reset(poses)
+    n_waves = E * A * tpa + E * A * tpa // 2 + 4096
+    tr = b.device_array((n_waves, 8), dtype=np.uint64)
+    for t in range(T):
+        if t % 8 == 0:
+            act = _actions(rng, E * A)
+        if t == 10:
+            tr.upload(np.zeros((n_waves, 8), dtype=np.uint64)); _set_trace(b, tr.ptr)
+        if t == 12:
+            _set_trace(b, 0)
+        a.step(act); b.step(act)
+        oa, ob = a.get(*ALL), b.get(*ALL)
+        for kk in oa:
+            assert np.array_equal(oa[kk], ob[kk]), (kk, t)
+    r = tr.download()
+    live = r[r[:, 1] != 0]
+    assert E * A * tpa * 0.5 < len(live) <= n_waves            # (the last traced launch; listed tasks' normal waves end too)
+    begin, end, loop, hdr, ops, marched = (live[:, c].astype(np.int64) for c in (0, 1, 4, 5, 6, 7))
+    assert (begin <= loop).all() and (loop <= end).all()
+    worked = ops != 0
+    assert worked.sum() > E * A * tpa * 0.5
+    assert (loop[worked] <= hdr[worked]).all() and (hdr[worked] <= ops[worked]).all() and (ops[worked] <= marched[worked]).all() and (marched[worked] <= end[worked]).all()
+    samples = (live[:, 3] & 0xffffffff).astype(np.int64)
+    assert 0 < samples[worked].max() < 2000 and samples[worked].mean() > 2
+    assert ((live[:, 3] >> 32) != 0).sum() > 0                   # some waves served the list
+    assert len(np.unique(live[:, 2])) > 64                       # many distinct (CU, SIMD, slot) ids
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("thr,waves,cache", [(4, 64, 0), (24, 2048, 0), (64, 2048, 16)])
 def test_ray_pass_is_invisible(amd, thr, waves, cache):
     """small batches: a ray that was long in the previous step is marched by a wave of its own at the front of the

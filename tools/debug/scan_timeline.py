@@ -34,9 +34,8 @@ n_waves = N * ((B + 63) // 64) + 65536
 tr = s.device_array((n_waves, 8), dtype=np.uint64)
 
 def set_trace(ptr):
-    s.exp_set("scan_trace_hi", np.int32(np.uint32(ptr >> 32)).item() if ptr >> 32 < 2**31 else int(np.array(ptr >> 32, dtype=np.uint32).view(np.int32)))
-    lo = ptr & 0xffffffff
-    s.exp_set("scan_trace_lo", int(np.array(lo, dtype=np.uint32).view(np.int32)))
+    s.exp_set("scan_trace_hi", int(np.array(ptr >> 32, dtype=np.uint32).view(np.int32)))
+    s.exp_set("scan_trace_lo", int(np.array(ptr & 0xffffffff, dtype=np.uint32).view(np.int32)))
 
 for step in range(STEPS):
     tr.upload(np.zeros((n_waves, 8), dtype=np.uint64))

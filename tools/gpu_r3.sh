@@ -71,12 +71,8 @@ ray)
   done
   ;;
 latency)
-  # small batches are bound by the per-task latency chain (tools/debug/scan_timeline.py): sizes, the timeline, and
-  # k_integrate in the scan's XCD order
+  # small batches are bound by the per-task latency chain (tools/debug/scan_timeline.py): sizes and the timeline
   timeout 600 python tools/debug/tpw_sweep.py 1024,2048,4096,8192,16384,65536 0 > $OUT/latency_sizes.txt 2>&1; cat $OUT/latency_sizes.txt
-  for n in 1024 4096 16384; do for ix in 0 1; do
-    F110_EXP=integrate_xcd=$ix timeout 200 $X python bench.py $H --agents $n > $OUT/lat_n${n}_ix$ix.log 2>&1; line $OUT/lat_n${n}_ix$ix.log "agents $n integrate_xcd $ix"
-  done; done
   timeout 300 $X python tools/debug/scan_timeline.py 4096 -1 2 > $OUT/scan_timeline_4096.txt 2>&1; tail -42 $OUT/scan_timeline_4096.txt
   ;;
 lists)
