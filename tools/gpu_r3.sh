@@ -77,9 +77,10 @@ latency)
   ;;
 lists)
   # longest-first list: threshold, capacity (tasks / div) and walking order, small batches
+  echo "# experimental build, bench.py $H, F110_EXP as named" > $OUT/late_lists.txt
   for n in 4096 1024; do
     for cfgs in "task_thr=96" "task_thr=64" "task_thr=48,task_cap_div=8" "task_thr=32,task_cap_div=4" "task_thr=24,task_cap_div=2" "task_thr=96,task_rev=1" "task_thr=48,task_cap_div=8,task_rev=1" "task_thr=32,task_cap_div=4,task_rev=1" "task_thr=24,task_cap_div=2,task_rev=1" "task_thr=16,task_cap_div=2,task_rev=1"; do
-      F110_EXP=$cfgs timeout 200 $X python bench.py $H --agents $n > $OUT/lists_tmp.log 2>&1; line $OUT/lists_tmp.log "agents $n $cfgs"
+      F110_EXP=$cfgs timeout 200 $X python bench.py $H --agents $n > $OUT/lists_tmp.log 2>&1; line $OUT/lists_tmp.log "agents $n $cfgs" | tee -a $OUT/late_lists.txt
     done
   done
   ;;
@@ -90,6 +91,22 @@ order)
   done; done
   F110_EXP=task_order=1,task_thr=150 timeout 200 $X python bench.py $H --agents 65536 > $OUT/order_tmp.log 2>&1; line $OUT/order_tmp.log "agents 65536 task_order 1 thr 150"
   F110_EXP=task_order=1,task_thr=150 timeout 200 $X python bench.py $H --agents 16384 > $OUT/order_tmp.log 2>&1; line $OUT/order_tmp.log "agents 16384 task_order 1 thr 150"
+  ;;
+variants)
+  # compile-time A/Bs of the PRODUCT library (built here, next to the tree's): no register hint on the scan kernels
+  # (7 waves per SIMD for the longest-first and per-env-map kernels, the compiler's own allocation for the rest), and
+  # no longest-first list at any size
+  FL="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DF110_SRC_HASH=\"probe\""
+  /opt/rocm/bin/hipcc $FL -DF110_SCAN_WAVES_EXPR=1 -DF110_DIRS_WAVES_EXPR=1 f1tenth_gym_amd/csrc/f110_hip.hip -o f1tenth_gym_amd/probe_a_no_register_hint.so > /dev/null 2>&1 &
+  /opt/rocm/bin/hipcc $FL -DF110_TASK_ORDER_MAX_TASKS=0 f1tenth_gym_amd/csrc/f110_hip.hip -o f1tenth_gym_amd/probe_b_no_longest_first.so > /dev/null 2>&1 &
+  wait
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  (probe_zz_tree = the product library as built from the tree)"
+    echo "# bench.py --only-headline --steps 400 --warmup 20 --agents N"
+    timeout 900 python tools/debug/lib_variants.py 1024,2048,4096,8192,16384,65536
+    echo "# ... --agents 65536 --beams 4096 --map-tiles 2 --steps 60 --preroll 100 (BASELINE configs[4])"
+    timeout 600 python tools/debug/lib_variants.py 65536 --beams 4096 --map-tiles 2 --steps 60 --preroll 100; } > $OUT/late_variants.txt 2>&1
+  rm -f f1tenth_gym_amd/probe_*.so
+  cat $OUT/late_variants.txt
   ;;
 probes)
   # fusion feasibility: the scan kernel at the occupancy a fused (118-VGPR) kernel would have,
