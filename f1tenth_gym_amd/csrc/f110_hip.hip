@@ -72,6 +72,7 @@ struct f110_sim {
     bool has_map = false;
     uint32_t step_magic = 0, step_shift = 0;  // ray -> agent division constants of the step launch
     int scan_tasks_per_wave = 1, num_cus = 256;  // consecutive 64-ray tasks per wave
+    bool scan_tasks_auto = false;                // chosen by batch size (f110_config.scan_tasks_per_wave = 0)
     double ttc_side_max = INFINITY, ttc_cos_max = INFINITY;  // see f110_set_beam_tables
     uint8_t *d_codes = nullptr;
     double *d_dir_ranges = nullptr;  // dedupe pass output [N][dir_stride]
@@ -547,6 +548,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         const size_t tasks = ((size_t)N * (size_t)B + 63) / 64, slots = (size_t)h->num_cus * 32;
         const size_t t = tasks / (slots * 8);
         h->scan_tasks_per_wave = t < 1 ? 1 : (t > 3 ? 3 : (int)t);
+        h->scan_tasks_auto = true;
     }
     CKH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CKH(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
@@ -1864,8 +1866,8 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         j.order = (h->multi_map && begin == 0 && count == N) ? h->d_scan_order : nullptr;
         const bool cnt = j.lookups_total != nullptr;
         // agent-aligned launch geometry: whole 64-ray tasks per agent, so every wave belongs to one agent (and one map)
-        auto agent_grid = [&](uint32_t tpa, dim3 &grid, uint32_t &wpb) {
-            (void)rays_grid(j, h->scan_block, h->scan_tasks_per_wave);
+        auto agent_grid = [&](uint32_t tpa, dim3 &grid, uint32_t &wpb, int tpw) {
+            (void)rays_grid(j, h->scan_block, tpw);
             j.n_tasks = (uint32_t)count * tpa;
             j.first_pose = (uint32_t)begin;
             wpb = (uint32_t)h->scan_block / 64u;
@@ -1880,7 +1882,9 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             // more beams than table directions, PADDED table: march each distinct direction once and write
             // the beams that share it from the same wave (k_scan_dirs_agent)
             const uint32_t tpa = (uint32_t)h->dir_stride / 64u;
-            agent_grid(tpa, grid, wpb);
+            // (a direction task ends with ~3 coalesced write passes: four per wave, where the beam kernel wants three —
+            // BASELINE configs[4] 42.8 M agent-steps/s at 3, 45.2 M at 4)
+            agent_grid(tpa, grid, wpb, h->scan_tasks_auto && h->scan_tasks_per_wave == 3 ? 4 : h->scan_tasks_per_wave);
 #define DIRS_SCAN(PM, ID)                                                                                                                    \
     do {                                                                                                                                     \
         if (cnt) hipLaunchKernelGGL((k_scan_dirs_agent<PM, ID, true>), grid, block, 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);     \
@@ -1913,7 +1917,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         case SCAN_WINDOW: {
             // one workgroup per agent, its neighbourhood of the table staged in LDS
             const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
-            agent_grid(tpa, grid, wpb);
+            agent_grid(tpa, grid, wpb, h->scan_tasks_per_wave);
             j.win_codes = h->d_wcodes;
             j.win_lut = h->d_wlut;
             j.win_pitch = h->wcode_pitch;
@@ -1931,7 +1935,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         case SCAN_AGENT_SCHED: {
             // longest-first: last step's long tasks are served by the first blocks of the launch
             const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
-            agent_grid(tpa, grid, wpb);
+            agent_grid(tpa, grid, wpb, h->scan_tasks_per_wave);
             const uint32_t parity = h->task_epoch & 1u;
             j.sched = h->tsched[parity];
             j.epoch_r = h->task_epoch - 1u;
@@ -1956,7 +1960,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         }
         case SCAN_AGENT: {
             const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
-            agent_grid(tpa, grid, wpb);
+            agent_grid(tpa, grid, wpb, h->scan_tasks_per_wave);
             size_t lds = 0;
 #ifdef F110_EXPERIMENTAL
             // fusion-feasibility probes: the occupancy a kernel with k_finalize_pair's 118 VGPRs
