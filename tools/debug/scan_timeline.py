@@ -2,7 +2,7 @@
 Every wave of k_scan_rays_agent records its begin / end on the 100 MHz clock, the CU it ran on and how many lock-step
 samples it marched.  Answers: when do waves start, how long does each take against its samples, how full is the
 chip over the launch, which waves end last.
-    F110_LIB_VARIANT=experimental python tools/debug/scan_timeline.py [agents=4096] [task_order=-1 (default)] [steps=3]"""
+    F110_LIB_VARIANT=experimental python tools/debug/scan_timeline.py [agents=4096] [task_order=-1 (default)] [steps=3] [tasks per wave=0 (default)]"""
 import os, sys
 os.environ.setdefault("F110_LIB_VARIANT", "experimental")
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
@@ -15,10 +15,11 @@ import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 TORD = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+TPW = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 A, B = 2, 1080
 E = N // A
 exp = {} if TORD < 0 else {"task_order": TORD}
-s = amd.BatchSim(num_envs=E, num_agents=A, exp=exp)
+s = amd.BatchSim(num_envs=E, num_agents=A, exp=exp, scan_tasks_per_wave=TPW)
 s.set_map_image(*load_map_image("example_map"))
 s.set_noise_rng(12345, 0.01); s.noise_prepare(800)
 poses0 = bench.start_poses_for(bench.shard_envs(E, 0), A).reshape(N, 3)
@@ -85,7 +86,7 @@ for step in range(STEPS):
         for nm, sg in zip(names, seg):
             print("     %-52s %6.0f / %6.0f / %6.0f" % (nm, sg.mean(), np.median(sg), np.percentile(sg, 90)))
         print("     march per sample: %.0f ns;  gap between a slot's waves (launch span * slots / waves - duration): %.0f ns" % (
-            seg[3].sum() / max(samples[m].sum(), 1), span * 256 * 4 * 7 / float(live.sum()) - dur.mean()))
+            seg[3].sum() / max(samples[m].sum(), 1), span * 256 * 4 * 8 / float(live.sum()) - dur.mean()))
     if lp.any():
         m = lp
         sl, ic = np.polyfit(samples[m], dur[m], 1)
