@@ -48,6 +48,7 @@ struct ExpSwitches {
     int pair_always = 0;       // A = 2: 1 = pair test inside the finalize kernel also for big batches without the in-step re-seat
     int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
     int scan_env_counter = 0;  // 1: the scan kernel also counts finished tasks per env (fusion feasibility A/B)
+    int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
     uint64_t scan_trace = 0;   // device address of a caller-owned [waves][8] uint64 buffer: clock stamps, hardware id, samples of every scan wave (0 = off)
 };
 
@@ -448,6 +449,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "finalize_roles") h->exp.finalize_roles = value;
     else if (k == "scan_occupancy") h->exp.scan_occupancy = value;
     else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
+    else if (k == "integrate_duo") h->exp.integrate_duo = value;
     else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
     else if (k == "scan_trace_lo") h->exp.scan_trace = (h->exp.scan_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "collide_mode") {
@@ -1816,7 +1818,16 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         fused_integrate = true;
     }
 #endif
-    if (!fused_integrate) hipLaunchKernelGGL(k_integrate<0>, grid1d(count, 256), dim3(256), 0, st, dev, h->k, d_actions);
+    if (!fused_integrate) {
+        bool duo = true;   // the integration in two waves per 64 agents (k_integrate_duo)
+#ifdef F110_EXPERIMENTAL
+        if (h->exp.integrate_duo >= 0) duo = h->exp.integrate_duo != 0;
+#endif
+        if (duo) hipLaunchKernelGGL(k_integrate_duo, grid1d(count, 64), dim3(128), 0, st, dev, h->k, d_actions);
+#ifdef F110_EXPERIMENTAL
+        else hipLaunchKernelGGL(k_integrate<0>, grid1d(count, 256), dim3(256), 0, st, dev, h->k, d_actions);
+#endif
+    }
     // A = 2: the pair test and the opponent window inside the finalize kernel (k_finalize_pair_flat): one stream, no
     // events.  (Round 2 kept the side-stream form for big batches stepped without the in-step re-seat — crashed cars
     // pile up, their windows grow to all beams, and fixed lanes per agent then serialise — the flattened window loop

@@ -153,28 +153,10 @@ __device__ __forceinline__ void collide_agent(const AgentArrays &a, int32_t B, i
     a.collision_idx[i] = (double)partner;
 }
 
-// ---- K1: integrate every agent one time step ------------------------------------------
-// AF = 0: integration only (k_collide follows on a side stream, hidden under the scan).
-// AF = 2 / 4 (agents per env): the pair tests run in the same lane right after the integration,
-// the partners' post-integration poses (the :574 snapshot) arriving by lane shuffle — the agents
-// of an env are neighbouring lanes of one wave.  Used when the step runs as several env groups on
-// their own streams: one launch and no event fork/join per group, and the longer dependent chain
-// hides under the other groups' scans.
-template <int AF>
-__global__ void __launch_bounds__(AF ? 64 : 256) k_integrate(AgentArrays a, ScanConst k, const double *__restrict__ actions)
+// what k_integrate leaves behind for one agent: state, delay buffer, lidar pose, pose snapshot, the ray header
+__device__ __forceinline__ void integrate_store(const AgentArrays &a, const ScanConst &k, int i, int N, const double *st, double b0, double b1,
+                                                int cnt, const double *sp)
 {
-    const int i = a.agent_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int N = a.n_agents_total;
-    if (i >= a.agent_begin + a.agent_count) return;
-    const VehicleParams vp = load_params(a.params + (size_t)(a.params_per_agent ? i : i % a.agents_per_env) * NPARAMS);
-    double st[7];
-#pragma unroll
-    for (int c = 0; c < 7; ++c) st[c] = a.state[(size_t)c * N + i];
-    double b0 = a.steer_buf[i], b1 = a.steer_buf[(size_t)N + i];
-    int cnt = a.buf_cnt[i];
-    const double2 act = reinterpret_cast<const double2 *>(actions)[i];
-    double sp[3];
-    advance_vehicle(st, b0, b1, cnt, act.x, act.y, vp, a.time_step, a.integrator, a.lidar_dist, sp);
 #pragma unroll
     for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = st[c];
     a.steer_buf[i] = b0;
@@ -237,6 +219,31 @@ __global__ void __launch_bounds__(AF ? 64 : 256) k_integrate(AgentArrays a, Scan
         a.sched_count_zero[0] = 0u;   // this step's task list ...
         a.sched_count_zero[2] = 0u;   // ... and ray list (TaskSched::count_w / rcount_w)
     }
+}
+
+// ---- K1: integrate every agent one time step ------------------------------------------
+// AF = 0: integration only (k_collide follows on a side stream, hidden under the scan).
+// AF = 2 / 4 (agents per env): the pair tests run in the same lane right after the integration,
+// the partners' post-integration poses (the :574 snapshot) arriving by lane shuffle — the agents
+// of an env are neighbouring lanes of one wave.  Used when the step runs as several env groups on
+// their own streams: one launch and no event fork/join per group, and the longer dependent chain
+// hides under the other groups' scans.
+template <int AF>
+__global__ void __launch_bounds__(AF ? 64 : 256) k_integrate(AgentArrays a, ScanConst k, const double *__restrict__ actions)
+{
+    const int i = a.agent_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int N = a.n_agents_total;
+    if (i >= a.agent_begin + a.agent_count) return;
+    const VehicleParams vp = load_params(a.params + (size_t)(a.params_per_agent ? i : i % a.agents_per_env) * NPARAMS);
+    double st[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) st[c] = a.state[(size_t)c * N + i];
+    double b0 = a.steer_buf[i], b1 = a.steer_buf[(size_t)N + i];
+    int cnt = a.buf_cnt[i];
+    const double2 act = reinterpret_cast<const double2 *>(actions)[i];
+    double sp[3];
+    advance_vehicle(st, b0, b1, cnt, act.x, act.y, vp, a.time_step, a.integrator, a.lidar_dist, sp);
+    integrate_store(a, k, i, N, st, b0, b1, cnt, sp);
     if constexpr (AF != 0) {
         // groups are env-aligned and AF divides 64: the AF lanes of an env are all here, in one wave.
         // Every lane takes part in every shuffle (a lane masked off would read as zero).
@@ -254,6 +261,64 @@ __global__ void __launch_bounds__(AF ? 64 : 256) k_integrate(AgentArrays a, Scan
             oth = pth[jj];
         });
     }
+}
+
+// ---- K1 in two waves (round 3; what the product launches when the pair tests are not fused in) ---------------
+// k_integrate is one dependent float64 chain per wave (one wave per SIMD at every batch size: its time is its
+// instruction count, ~12 cycles each).  The low-speed branch of the right-hand side — tan and cos of the steering
+// angle, a quarter of a stage's instructions in a wave that has lanes on both sides of |v| = 0.5, which is nearly
+// every wave of a batch that re-seats crashed cars — depends on (steer, v) only, and THEIR derivatives depend on
+// nothing else (low_speed_trig_ahead).  So a second wave of the workgroup walks (steer, v) through the stages on its
+// own, one stage ahead of the integration, and leaves tan / cos in LDS; the first wave picks them up behind one
+// workgroup barrier per stage.  Same operations on the same values: bit-identical to k_integrate<0>.
+struct LowTrigShared {
+    double (*tn)[64];
+    double (*cd)[64];
+    int lane;
+    __device__ __forceinline__ void begin_stage(int) const { __syncthreads(); }
+    __device__ __forceinline__ void operator()(int stage, double, double &t, double &c) const
+    {
+        t = tn[stage][lane];
+        c = cd[stage][lane];
+    }
+};
+struct LowTrigEmit {
+    double (*tn)[64];
+    double (*cd)[64];
+    int lane;
+    __device__ __forceinline__ void operator()(int stage, double t, double c) const
+    {
+        tn[stage][lane] = t;
+        cd[stage][lane] = c;
+    }
+    __device__ __forceinline__ void end_stage(int) const { __syncthreads(); }
+};
+
+__global__ void __launch_bounds__(128) k_integrate_duo(AgentArrays a, ScanConst k, const double *__restrict__ actions)
+{
+    __shared__ double s_tn[4][64], s_cd[4][64];
+    const int lane = (int)(threadIdx.x & 63u);
+    const bool ahead = threadIdx.x >= 64u;   // wave 1: the low-speed branch's trigonometry; wave 0: everything else
+    const int N = a.n_agents_total;
+    const int i_raw = a.agent_begin + (int)(blockIdx.x * 64u) + lane;
+    const bool live = i_raw < a.agent_begin + a.agent_count;
+    const int i = live ? i_raw : a.agent_begin;   // (lanes past the end shadow the first agent: every lane meets every barrier)
+    const VehicleParams vp = load_params(a.params + (size_t)(a.params_per_agent ? i : i % a.agents_per_env) * NPARAMS);
+    const double2 act = reinterpret_cast<const double2 *>(actions)[i];
+    if (ahead) {
+        low_speed_trig_ahead(a.state[(size_t)2 * N + i], a.state[(size_t)3 * N + i], a.steer_buf[(size_t)N + i], a.buf_cnt[i], act.y, vp,
+                             a.time_step, a.integrator, LowTrigEmit{s_tn, s_cd, lane});
+        return;
+    }
+    double st[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) st[c] = a.state[(size_t)c * N + i];
+    double b0 = a.steer_buf[i], b1 = a.steer_buf[(size_t)N + i];
+    int cnt = a.buf_cnt[i];
+    double sp[3];
+    advance_vehicle_with(st, b0, b1, cnt, act.x, act.y, vp, a.time_step, a.integrator, a.lidar_dist, sp, LowTrigShared{s_tn, s_cd, lane});
+    if (!live) return;
+    integrate_store(a, k, i, N, st, b0, b1, cnt, sp);
 }
 
 // ---- K1b: pairwise body collisions inside each env (separate launch, side stream) ------------

@@ -78,8 +78,21 @@ F110_HD void rhs_kinematic(const double *x, double sv_in, double accl_in, const 
     f[4] = x[3] / lwb * tan(x[2]);
 }
 
+// Where the low-speed branch's tan(steer) and cos(steer) come from: computed in place (everywhere but k_integrate), or
+// handed over by the kernel's second wave, which runs one stage ahead (LowTrigShared in f110_kernels.hpp).
+struct LowTrigDirect {
+    F110_HD void begin_stage(int /*stage*/) const {}   // (called by every lane at the top of every stage)
+    F110_HD void operator()(int /*stage*/, double steer, double &tn, double &cd) const
+    {
+        tn = tan(steer);
+        cd = cos(steer);
+    }
+};
+
 // vehicle_dynamics_st :123-176 — x[0..6] = (x, y, steer, v, yaw, yaw_rate, slip)
-F110_HD void rhs_single_track(const double *x, double sv_in, double accl_in, const VehicleParams &p, double *f)
+template <class LowTrig>
+F110_HD void rhs_single_track_with(const double *x, double sv_in, double accl_in, const VehicleParams &p, double *f, int stage,
+                                   const LowTrig &low_trig)
 {
     const double g = 9.81;
     const double u0 = clamp_steer_rate(x[2], sv_in, p);
@@ -97,11 +110,11 @@ F110_HD void rhs_single_track(const double *x, double sv_in, double accl_in, con
     f[1] = x[3] * sa;
     if (low) {
         const double lwb = p.v[P_LF] + p.v[P_LR];
-        const double tn = tan(x[2]);
+        double tn, cd;
+        low_trig(stage, x[2], tn, cd);
         f[2] = clamp_steer_rate(x[2], u0, p);   // vehicle_dynamics_ks :108-109 on the already constrained inputs
         f[3] = clamp_accel(x[3], u1, p);
         f[4] = x[3] / lwb * tn;
-        const double cd = cos(x[2]);
         f[5] = u1 / lwb * tn + x[3] / (lwb * (cd * cd)) * u0;
         f[6] = 0.;
         return;
@@ -126,6 +139,11 @@ F110_HD void rhs_single_track(const double *x, double sv_in, double accl_in, con
     f[6] = s1 - s2 + s3;
 }
 
+F110_HD void rhs_single_track(const double *x, double sv_in, double accl_in, const VehicleParams &p, double *f)
+{
+    rhs_single_track_with(x, sv_in, accl_in, p, f, 0, LowTrigDirect());
+}
+
 // pid :178-221
 F110_HD void speed_steer_controller(double speed, double steer, double cur_speed, double cur_steer,
                                     const VehicleParams &p, double &accl, double &sv)
@@ -143,9 +161,10 @@ F110_HD void speed_steer_controller(double speed, double steer, double cur_speed
 
 // ------------------------------------------------------------------ base_classes.py
 // RaceCar.update_pose :256-409 minus the scan.  buf[0] = newest delayed steer command.
-F110_HD void advance_vehicle(double *st, double &buf0, double &buf1, int &buf_cnt, double raw_steer,
-                             double speed_cmd, const VehicleParams &p, double dt, int integrator,
-                             double lidar_dist, double *scan_pose)
+template <class LowTrig>
+F110_HD void advance_vehicle_with(double *st, double &buf0, double &buf1, int &buf_cnt, double raw_steer,
+                                  double speed_cmd, const VehicleParams &p, double dt, int integrator,
+                                  double lidar_dist, double *scan_pose, const LowTrig &low_trig)
 {
     // :271-278 two-step steering delay
     double steer = 0.;
@@ -172,7 +191,8 @@ F110_HD void advance_vehicle(double *st, double &buf0, double &buf1, int &buf_cn
         for (int i = 0; i < 7; ++i) tmp[i] = st[i];
 #pragma unroll 1
         for (int sidx = 0; sidx < stages; ++sidx) {
-            rhs_single_track(tmp, sv, accl, p, kk);
+            low_trig.begin_stage(sidx);
+            rhs_single_track_with(tmp, sv, accl, p, kk, sidx, low_trig);
             const double wgt = (sidx == 1 || sidx == 2) ? 2.0 : 1.0;
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
@@ -204,6 +224,40 @@ F110_HD void advance_vehicle(double *st, double &buf0, double &buf1, int &buf_cn
         scan_pose[1] = st[1] + lidar_dist * sh;
     }
     scan_pose[2] = st[4];
+}
+
+F110_HD void advance_vehicle(double *st, double &buf0, double &buf1, int &buf_cnt, double raw_steer,
+                             double speed_cmd, const VehicleParams &p, double dt, int integrator,
+                             double lidar_dist, double *scan_pose)
+{
+    advance_vehicle_with(st, buf0, buf1, buf_cnt, raw_steer, speed_cmd, p, dt, integrator, lidar_dist, scan_pose, LowTrigDirect());
+}
+
+// The steering angle and the velocity through the RK4 stages, on their own: their derivatives — the constrained
+// steering rate and acceleration, constrained a second time inside the low-speed branch (:152-160 -> :108-109) —
+// depend on nothing else, so a second wave can walk (x[2], x[3]) ahead of the integration and have the low-speed
+// branch's tan / cos ready (k_integrate).  Same operations in the same order as advance_vehicle_with's loop.
+// emit(stage, tan, cos) is called by the lanes whose stage takes the low-speed branch, emit.end_stage(stage) by all.
+template <class Emit>
+F110_HD void low_speed_trig_ahead(double steer0, double vel0, double buf1, int buf_cnt, double speed_cmd, const VehicleParams &p,
+                                  double dt, int integrator, const Emit &emit)
+{
+    const double steer = (buf_cnt < 2) ? 0. : buf1;   // :271-278 (the command that leaves the delay buffer this step)
+    double accl, sv;
+    speed_steer_controller(speed_cmd, steer, vel0, steer0, p, accl, sv);
+    const int stages = (integrator == 1) ? 4 : 1;
+    double x2 = steer0, x3 = vel0;
+    for (int sidx = 0; sidx < stages; ++sidx) {
+        const bool low = fabs(x3) < 0.5;
+        if (low) emit(sidx, tan(x2), cos(x2));
+        emit.end_stage(sidx);   // (every lane, every stage)
+        const double u0 = clamp_steer_rate(x2, sv, p), u1 = clamp_accel(x3, accl, p);
+        const double f2 = low ? clamp_steer_rate(x2, u0, p) : u0;
+        const double f3 = low ? clamp_accel(x3, u1, p) : u1;
+        const double h2 = (sidx < 2) ? f2 / 2 : f2, h3 = (sidx < 2) ? f3 / 2 : f3;
+        x2 = steer0 + dt * h2;
+        x3 = vel0 + dt * h3;
+    }
 }
 
 // ------------------------------------------------------------------ laser_models.py

@@ -107,7 +107,7 @@ int f110_is_experimental(void);
  * env, beams) case.  Keys: scan_flat, dedupe_two_pass, no_window, finalize_lanes (0|8|16|32|64),
  * finalize_flat (-1|0|1), finalize_roles (-1|0|1), pair_always, collide_mode (0 side stream | 1 fused into k_integrate | 2 in line | 3 inside
  * k_finalize), step_graph, task_order, task_thr, task_cap_div (list capacity = tasks / div), task_rev (walk the list from its newest
- * entry), ray_pass, ray_thr, ray_waves, scan_occupancy, scan_env_counter (fusion probes), scan_trace_hi / scan_trace_lo (the two
+ * entry), ray_pass, ray_thr, ray_waves, scan_occupancy, scan_env_counter (fusion probes), integrate_duo (-1|0|1: k_integrate in one wave or two per 64 agents), scan_trace_hi / scan_trace_lo (the two
  * halves of the device address of a caller-owned [launch waves][8] uint64 buffer that every wave of the step's scan kernel stamps with
  * its begin / end clock, CU and samples: tools/debug/scan_timeline.py; 0 = off). */
 int f110_exp_set(f110_sim *h, const char *key, int32_t value);

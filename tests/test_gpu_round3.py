@@ -112,6 +112,34 @@ def test_flattened_finalize_is_bit_identical(amd, lanes, roles):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("E,A,integrator,lidar_dist", [(300, 2, 1, 0.0), (37, 3, 1, 0.275), (65, 1, 2, 0.0)])
+def test_integrate_in_two_waves_is_invisible(amd, E, A, integrator, lidar_dist):
+    """k_integrate_duo (a second wave walks steer / velocity one RK4 stage ahead and leaves the low-speed branch's
+    tan / cos in LDS) against the one-wave kernel: the same operations on the same values, so not a bit may differ —
+    from standstill (every lane in the low-speed branch) through the |v| = 0.5 crossing, with resets, agent counts
+    that do not fill the last workgroup, Euler, an offset lidar"""
+    T = 60
+    kw = dict(integrator=integrator, lidar_dist=lidar_dist)   # (1 = RK4, 2 = Euler: f110.h)
+    a = _sim(amd, E, A, exp={"integrate_duo": 0}, **kw); b = _sim(amd, E, A, exp={"integrate_duo": 1}, **kw)
+    poses = bench_start_poses(E, A)
+    rng = np.random.default_rng(33)
+    for s in (a, b):
+        s.set_noise_rng(12345, 0.01); s.reset(poses)
+    for t in range(T):
+        if t % 6 == 0:
+            act = np.stack([rng.uniform(-0.4, 0.4, E * A), rng.uniform(-1.0, 4.0, E * A)], axis=1)   # slow: many lanes stay near |v| = 0.5
+        a.step(act); b.step(act)
+        oa, ob = a.get(*ALL), b.get(*ALL)
+        for kk in oa:
+            assert np.array_equal(oa[kk], ob[kk]), (kk, t)
+        if t == 30:
+            mask = (rng.random(E) < 0.4).astype(np.uint8)
+            a.reset(poses, mask); b.reset(poses, mask)
+    v = a.get("state")["state"][:, 3]
+    assert (np.abs(v) < 0.5).any() and (np.abs(v) >= 0.5).any()      # both branches were live at the end
+    a.close(); b.close()
+
+
 def _set_trace(s, ptr):
     s.exp_set("scan_trace_hi", int(np.array(ptr >> 32, dtype=np.uint32).view(np.int32)))
     s.exp_set("scan_trace_lo", int(np.array(ptr & 0xffffffff, dtype=np.uint32).view(np.int32)))

@@ -108,6 +108,12 @@ variants)
   rm -f f1tenth_gym_amd/probe_*.so
   cat $OUT/late_variants.txt
   ;;
+duo)
+  # k_integrate in two waves per 64 agents (the low-speed branch's tan / cos one stage ahead) against one
+  for n in 1024 4096 16384 65536; do for d in 0 1; do
+    F110_EXP=integrate_duo=$d timeout 200 $X python bench.py $H --agents $n > $OUT/duo_tmp.log 2>&1; line $OUT/duo_tmp.log "agents $n integrate_duo $d" | tee -a $OUT/late_duo.txt
+  done; done
+  ;;
 probes)
   # fusion feasibility: the scan kernel at the occupancy a fused (118-VGPR) kernel would have,
   # and with a per-env completion counter
