@@ -1,6 +1,6 @@
 """long-run identity check of round 3's step (experimental build): the product's dispatch — pair test inside the
 workgroup-flattened finalize, device-drawn noise with episodes that outlive a 256-row cache — against round 1's form
-(k_collide on the side stream + k_finalize with fixed lanes, uploaded NumPy noise rows), same inputs, many steps,
+(k_collide on the side stream + k_finalize with fixed lanes, the one-wave k_integrate, no longest-first list, uploaded NumPy noise rows), same inputs, many steps,
 every array compared at checkpoints.
     gpurun -- 'F110_LIB_VARIANT=experimental python tools/debug/soak_round3.py 32768 3000'"""
 import sys, os, time, numpy as np
@@ -15,7 +15,7 @@ img, res, origin = load_map_image("example_map")
 poses = bench_start_poses(E, A)
 sims = []
 for which in ("product dispatch", "round-1 form"):
-    s = amd.BatchSim(num_envs=E, num_agents=A, exp=({} if which == "product dispatch" else {"finalize_flat": 0, "collide_mode": 0}))
+    s = amd.BatchSim(num_envs=E, num_agents=A, exp=({} if which == "product dispatch" else {"finalize_flat": 0, "collide_mode": 0, "integrate_duo": 0, "task_order": 0}))
     s.set_map_image(img, res, origin)
     if which == "product dispatch":
         s.set_noise_rng(12345, 0.01, cache_rows=256)

@@ -114,6 +114,21 @@ duo)
     F110_EXP=integrate_duo=$d timeout 200 $X python bench.py $H --agents $n > $OUT/duo_tmp.log 2>&1; line $OUT/duo_tmp.log "agents $n integrate_duo $d" | tee -a $OUT/late_duo.txt
   done; done
   ;;
+soak)
+  # long-run identity of the product's dispatch against round 1's form, random-configuration fuzz against the oracle, VecEnv rate
+  C=$(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')
+  { echo "# round-3 soak and fuzz evidence, csrc $C"
+    echo "## tools/debug/soak_round3.py 32768 3000 (experimental build): the product's dispatch vs round 1's form, 65 536 agents, 3000 steps"
+    timeout 900 $X python tools/debug/soak_round3.py 32768 3000 2>&1 | tail -16
+    echo "## tools/debug/fuzz_parity.py 0 250 (product build) — HIP vs oracle over random configurations: flags / step counters exact, floats |a-b| <= 1e-9*|b| + 1e-12"
+    timeout 1200 python tools/debug/fuzz_parity.py 0 250 2>&1 | tail -2
+    echo "## tools/debug/fuzz_parity.py 250 400 (experimental build, all five layouts)"
+    timeout 1200 $X python tools/debug/fuzz_parity.py 250 400 2>&1 | tail -2
+    echo "## tools/debug/fuzz_units.py 1 2 3 (product build): unit entry points vs oracle"
+    timeout 600 python tools/debug/fuzz_units.py 1 2 3 2>&1 | tail -20; } > $OUT/soak_fuzz.txt 2>&1
+  tail -30 $OUT/soak_fuzz.txt
+  { echo "# csrc $C  tools/debug/vecenv_rate.py"; timeout 600 python tools/debug/vecenv_rate.py 2>&1 | tail -6; } > $OUT/vecenv_rate.txt 2>&1; cat $OUT/vecenv_rate.txt
+  ;;
 probes)
   # fusion feasibility: the scan kernel at the occupancy a fused (118-VGPR) kernel would have,
   # and with a per-env completion counter
