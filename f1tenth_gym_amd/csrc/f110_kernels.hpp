@@ -1727,6 +1727,191 @@ __global__ void __launch_bounds__(256) k_finalize_pair_roles(AgentArrays a, int3
     }
 }
 
+// ---- K3m: the same for envs of MORE than two agents (round 3) ---------------------------------------------
+// k_finalize_pair_roles generalised: a workgroup holds G whole envs of A agents.  What k_collide + k_finalize did
+// with one lane per agent (a serial loop over the A - 1 opponents: box, GJK, two beam windows, 80 bytes of windows
+// and boxes through HBM per ordered pair, a side stream with an event fork / join around the scan) becomes one
+// kernel behind the scan:
+//   records   every ORDERED pair (agent i, opponent o) of the workgroup's envs, R = G A (A - 1) <= kMaxRec: the four
+//             corners of o's box (drawn with i's length / width, RaceCar.ray_cast_agents :223) -> beam indices on
+//             threads 0-127 (four per record), the disc cull on threads 128-191 (one per record);
+//   pairs     every UNORDERED pair (p < q) of an env, P = G A (A - 1) / 2: collision_multiple's GJK in the reference's
+//             (lower, higher) argument order on threads 192-255 — once, not once per side;
+//   agents    flags (Simulator's collision OR :588-589; collision_idx = the LARGEST colliding partner, the reference's
+//             last writer), check_ttc's side effects, step count, re-seat: thread a of the first G A;
+//   windows   all records' beam windows flattened into one item list over the 256 threads, as in the pair kernel.  Two
+//             opponents of one agent may cover the same beam; the reference takes them one after the other, each
+//             keeping the smaller range (:206-227), i.e. the minimum — ranges are non-negative doubles, whose bit
+//             patterns order like unsigned integers, so the items settle it with atomicMin on the pattern: no rounds,
+//             no order, the same value.
+// Same functions on the same operands as collide_agent / k_finalize: bit-identical (test_finalize_multi_*).
+constexpr int kMaxRec = 64;
+__global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B, int G)
+{
+    __shared__ double s_rec[kMaxRec][12];   // ex, ey, eth, the opponent's box (8), pad
+    __shared__ int s_idx[kMaxRec][4], s_cl[kMaxRec], s_ch[kMaxRec], s_hit[kMaxRec];
+    __shared__ int s_lo[kMaxRec], s_cnt[kMaxRec], s_off[kMaxRec + 1], s_agent[kMaxRec], s_ahit[kMaxRec];
+    const int t = (int)threadIdx.x;
+    const int A = a.agents_per_env, N = a.n_agents_total;
+    const int per_env = A * (A - 1), pairs_env = per_env / 2;
+    const int first = a.agent_begin + (int)blockIdx.x * G * A, end = a.agent_begin + a.agent_count;
+    int envs = (end - first) / A;
+    envs = envs < G ? envs : G;                 // (whole envs only: ranges are env-aligned)
+    const int R = envs * per_env, P = envs * pairs_env, AGN = envs * A;
+    if (t < 128) {
+        // corner `sub` of record `rec`'s opponent box -> beam index
+        for (int q = t; q < 4 * R; q += 128) {
+            const int rec = q >> 2, sub = q & 3;
+            const int e = rec / per_env, w = rec - e * per_env, me = w / (A - 1), k = w - me * (A - 1), oj = k < me ? k : k + 1;
+            const int i = first + e * A + me, o = first + e * A + oj;
+            const double ex = a.state[i], ey = a.state[(size_t)N + i];
+            const double th_live = a.state[4 * (size_t)N + i];   // == the :574 snapshot heading: nothing has zeroed it yet
+            const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
+            const int wall = a.in_collision[i];
+            const double eth = wall ? 0.0 : th_live;
+            const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
+            const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
+            double v[8];
+            box_vertices(ox, oy, oth, blen, bwid, v);
+            double ce_, se_;
+            cos_sin(eth, ce_, se_);
+            const double head = atan2(se_, ce_);
+            const double px = sub == 0 ? v[0] : (sub == 1 ? v[2] : (sub == 2 ? v[4] : v[6]));
+            const double py = sub == 0 ? v[1] : (sub == 1 ? v[3] : (sub == 2 ? v[5] : v[7]));
+            const double dx = px - ex, dy = py - ey;
+            const double norm = sqrt(dx * dx + dy * dy);
+            const double dir = atan2(dy / norm, dx / norm);
+            s_idx[rec][sub] = vertex_beam_from_angles(head, dir, a.scan_angles, B, a.angle_inc);
+            if (sub == 0) {
+                s_rec[rec][0] = ex;
+                s_rec[rec][1] = ey;
+                s_rec[rec][2] = eth;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) s_rec[rec][3 + c] = v[c];
+                s_agent[rec] = e * A + me;
+            }
+        }
+    } else if (t < 192) {
+        // the disc cull of record `rec`
+        for (int rec = t - 128; rec < R; rec += 64) {
+            const int e = rec / per_env, w = rec - e * per_env, me = w / (A - 1), k = w - me * (A - 1), oj = k < me ? k : k + 1;
+            const int i = first + e * A + me, o = first + e * A + oj;
+            const double ex = a.state[i], ey = a.state[(size_t)N + i];
+            const double th_live = a.state[4 * (size_t)N + i];
+            const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o];
+            const int wall = a.in_collision[i];
+            const double eth = wall ? 0.0 : th_live;
+            const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
+            const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
+            double ce_, se_;
+            cos_sin(eth, ce_, se_);
+            const double head = atan2(se_, ce_);
+            const double dx = ox - ex, dy = oy - ey;
+            const double norm = sqrt(dx * dx + dy * dy);
+            const double dir = atan2(dy, dx);
+            int cl, ch;
+            disc_beam_range_from(norm, eth, dir, head, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
+            s_cl[rec] = cl;
+            s_ch[rec] = ch;
+        }
+    } else {
+        // collision_multiple's pair (p < q) of env e, boxes with the Simulator's length / width (:549)
+        const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+        for (int pr = t - 192; pr < P; pr += 64) {
+            const int e = pr / pairs_env;
+            int w = pr - e * pairs_env, p = 0;
+            while (w >= A - 1 - p) { w -= A - 1 - p; ++p; }   // row p of the upper triangle holds A - 1 - p pairs
+            const int q = p + 1 + w;
+            const int ip = first + e * A + p, iq = first + e * A + q;
+            const double px = a.snap_pose[ip], py = a.snap_pose[(size_t)N + ip], pth = a.snap_pose[2 * (size_t)N + ip];
+            const double qx = a.snap_pose[iq], qy = a.snap_pose[(size_t)N + iq], qth = a.snap_pose[2 * (size_t)N + iq];
+            int hit = 0;
+            const double cdx = qx - px, cdy = qy - py;
+            if (cdx * cdx + cdy * cdy <= reach * reach) {
+                double lower[8], higher[8];
+                box_vertices(px, py, pth, a.box_length, a.box_width, lower);
+                box_vertices(qx, qy, qth, a.box_length, a.box_width, higher);
+                hit = gjk_overlap(lower, higher) ? 1 : 0;
+            }
+            s_hit[pr] = hit;
+        }
+    }
+    __syncthreads();
+    int my_hit = 0;
+    const bool agent_thread = t < AGN;
+    if (agent_thread) {
+        const int e = t / A, me = t - e * A, i = first + t;
+        int partner = -1;
+        for (int j = 0; j < A; ++j) {   // ascending: ends at the largest colliding index
+            if (j == me) continue;
+            const int p = me < j ? me : j, q = me < j ? j : me;
+            const int pr = e * pairs_env + p * (A - 1) - (p * (p - 1)) / 2 + (q - p - 1);   // rows 0..p-1 hold p (A - 1) - p (p - 1) / 2 pairs
+            if (s_hit[pr]) partner = j;
+        }
+        my_hit = partner >= 0;
+        const int wall = a.in_collision[i];
+        if (wall) {
+            a.state[3 * (size_t)N + i] = 0.;
+            a.state[4 * (size_t)N + i] = 0.;
+            a.state[5 * (size_t)N + i] = 0.;
+            a.state[6 * (size_t)N + i] = 0.;
+        }
+        a.collisions[i] = (my_hit || wall) ? 1.0 : 0.0;
+        a.collision_idx[i] = (double)partner;
+        a.step_count[i] += 1;
+        s_ahit[t] = my_hit;
+    }
+    if (t >= 64 && t < 128) {   // (another wave) every record's window = corner hull clipped by the disc cull
+        const int rec = t - 64;
+        int lo = 0, cnt = 0;
+        if (rec < R) {
+            const int i0 = s_idx[rec][0], i1 = s_idx[rec][1], i2 = s_idx[rec][2], i3 = s_idx[rec][3];
+            int ref_lo = i0 < i1 ? i0 : i1, t2 = i2 < i3 ? i2 : i3;
+            ref_lo = ref_lo < t2 ? ref_lo : t2;
+            int ref_hi = i0 > i1 ? i0 : i1;
+            t2 = i2 > i3 ? i2 : i3;
+            ref_hi = ref_hi > t2 ? ref_hi : t2;
+            const int cl = s_cl[rec], ch = s_ch[rec];
+            lo = ref_lo > cl ? ref_lo : cl;
+            const int hi = ref_hi < ch ? ref_hi : ch;
+            cnt = hi >= lo ? hi - lo + 1 : 0;
+        }
+        s_lo[rec] = lo;
+        int c = cnt;   // inclusive scan over the wave's 64 records
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(c, d);
+            if (rec >= d) c += up;
+        }
+        s_off[rec + 1] = c;
+        if (rec == 0) s_off[0] = 0;
+    }
+    __syncthreads();
+    const int total = s_off[kMaxRec];
+    for (int item = t; item < total; item += 256) {
+        int rec = 0;   // the largest rec with s_off[rec] <= item (its window is not empty: item < s_off[rec + 1])
+#pragma unroll
+        for (int st = kMaxRec / 2; st; st >>= 1)
+            if (s_off[rec + st] <= item) rec += st;
+        const int b = s_lo[rec] + (item - s_off[rec]);
+        const double bex = s_rec[rec][0], bey = s_rec[rec][1], beth = s_rec[rec][2];
+        double bv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bv[c] = s_rec[rec][3 + c];
+        double *sc = a.scans + (size_t)(first + s_agent[rec]) * B;
+        const double bt = beth + a.scan_angles[b];
+        const double r0 = sc[b];   // (possibly already lowered by another opponent's item: the minimum does not care)
+        double v3x, v3y;
+        sincos(bt + kPi / 2., &v3y, &v3x);
+        const double r = box_range(bex, bey, v3x, v3y, bv, r0);
+        if (r < r0) atomicMin(reinterpret_cast<unsigned long long *>(sc + b), (unsigned long long)__double_as_longlong(r));
+    }
+    if (a.reseat_poses && agent_thread) {
+        const int e = t / A, i = first + t, ego_t = e * A + a.reseat_ego, ego = first + ego_t;
+        if (s_ahit[ego_t] || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
+    }
+}
+
 // single-agent envs: no opponents, one lane per agent is enough
 __global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
 {

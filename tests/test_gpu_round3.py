@@ -140,6 +140,41 @@ def test_integrate_in_two_waves_is_invisible(amd, E, A, integrator, lidar_dist):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("E,A", [(130, 3), (101, 4), (37, 5), (9, 8), (1, 3)])
+def test_finalize_multi_is_invisible(amd, E, A):
+    """envs of 3..8 agents: pair tests, opponent windows and the ray-cast inside ONE finalize kernel (k_finalize_multi:
+    every ordered pair of an env a record, windows flattened, overlapping opponents settled by an integer atomicMin on
+    the range's bit pattern) against round 1's form (k_collide on the side stream + k_finalize): not a bit may
+    differ — cars that start nose to tail, crash into each other and into walls, re-seat, partial last workgroups"""
+    T = 80
+    a = _sim(amd, E, A, exp={"collide_mode": 0}); b = _sim(amd, E, A)
+    poses = bench_start_poses(E, A, gap_wp=4)      # close: opponents fill each other's windows, pairs collide early
+    rng = np.random.default_rng(40 + A)
+    for s in (a, b):
+        s.set_noise_rng(12345, 0.01); s.reset(poses)
+    st = [s.device_array((E * A, 3)) for s in (a, b)]
+    for d in st:
+        d.upload(poses)
+    n_pair = n_wall = n_multi = 0
+    for t in range(T):
+        if t % 8 == 0:
+            act = _actions(rng, E * A)
+        if t == 40:
+            for s, d in zip((a, b), st):
+                s.set_auto_reseat(d, 0, None)
+        a.step(act); b.step(act)
+        oa, ob = a.get(*ALL), b.get(*ALL)
+        for kk in oa:
+            assert np.array_equal(oa[kk], ob[kk]), (kk, t, A)
+        n_pair += int((oa["collision_idx"] >= 0).sum()); n_wall += int(oa["in_collision"].sum())
+        n_multi += int(((oa["collision_idx"] >= 0).reshape(E, A).sum(axis=1) > 2).sum())
+        if t == 25:
+            mask = (rng.random(E) < 0.5).astype(np.uint8)
+            a.reset(poses, mask); b.reset(poses, mask)
+    assert n_pair > 0 and (n_wall > 0 or E < 5), (n_pair, n_wall)
+    a.close(); b.close()
+
+
 def _set_trace(s, ptr):
     s.exp_set("scan_trace_hi", int(np.array(ptr >> 32, dtype=np.uint32).view(np.int32)))
     s.exp_set("scan_trace_lo", int(np.array(ptr & 0xffffffff, dtype=np.uint32).view(np.int32)))
