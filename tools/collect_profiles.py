@@ -92,7 +92,7 @@ def main():
         if os.path.isfile(os.path.join(SRC, src)):
             shutil.copyfile(os.path.join(SRC, src), os.path.join(DST, dst % tag))
     # the late-round-3 latency work: sizes, the wave-by-wave timeline, compile-time variants, list switches
-    for src in ("latency_sizes.txt", "scan_timeline_4096.txt", "late_variants.txt", "late_lists.txt", "late_duo.txt", "soak_fuzz.txt", "vecenv_rate.txt"):
+    for src in ("latency_sizes.txt", "scan_timeline_4096.txt", "late_variants.txt", "late_lists.txt", "late_duo.txt", "late_many_agents.txt", "soak_fuzz.txt", "vecenv_rate.txt"):
         if os.path.isfile(os.path.join(SRC, src)):
             body = open(os.path.join(SRC, src)).read()
             open(os.path.join(DST, "%s_%s" % (tag, src)), "w").write(("" if "# csrc" in body else "# csrc %s\n" % csrc) + body)
