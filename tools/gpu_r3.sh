@@ -138,7 +138,7 @@ many)
     done
     for a in 3 4 8; do
       n=65520; [ $a != 3 ] && n=65536
-      F110_EXP=collide_mode=0 timeout 300 $X python bench.py --only-headline --agents $n --agents-per-env $a --steps 200 --warmup 20 > $OUT/many_tmp.log 2>&1; line $OUT/many_tmp.log "A=$a k_collide + k_finalize (round 1's form)"
+      F110_EXP=collide_mode=0 timeout 300 $X python bench.py --only-headline --agents $n --agents-per-env $a --steps 200 --warmup 20 > $OUT/many_tmp.log 2>&1; line $OUT/many_tmp.log "A=$a k_collide + k_finalize, round-1 form"
     done; } > $OUT/late_many_agents.txt 2>&1
   cat $OUT/late_many_agents.txt
   ;;
