@@ -142,6 +142,12 @@ many)
     done; } > $OUT/late_many_agents.txt 2>&1
   cat $OUT/late_many_agents.txt
   ;;
+agsweep)
+  # agents per workgroup of the A = 2 finalize kernel (finalize_lanes 8 / 16 / 64 -> AG 32 / 16 / 4), small batches
+  for n in 1024 2048 4096 8192 16384; do for l in 8 16 64; do
+    F110_EXP=finalize_lanes=$l timeout 200 $X python bench.py $H --agents $n > $OUT/ag_tmp.log 2>&1; line $OUT/ag_tmp.log "agents $n finalize_lanes $l" | tee -a $OUT/late_agsweep.txt
+  done; done
+  ;;
 probes)
   # fusion feasibility: the scan kernel at the occupancy a fused (118-VGPR) kernel would have,
   # and with a per-env completion counter
