@@ -772,7 +772,7 @@ def main(argv=None):
                                     "steps": args.steady_steps, "warmup": args.steady_warmup,
                                     "definition": "SURVEY 8d: >= 1000 timed steps after >= 100 warm-up steps — here %d pre-roll + %d warm-up steps, the same "
                                                   "regime the headline's short window samples (measured: 20 timed steps after 0 / 100 / 300 / 500 / 1000 / 2000 "
-                                                  "un-timed ones run at 98.4 / 94.1 / 86.7 / 85.4 / 86.1 / 85.5 M agent-steps/s: the batch needs ~300 steps "
+                                                  "un-timed ones run at 103.0 / 102.9 / 96.0 / 95.0 / 95.4 / 95.0 M agent-steps/s: the batch needs ~300 steps "
                                                   "to reach it)" % (args.preroll, args.steady_warmup),
                                     "headline_over_steady": value / (args.agents * args.steady_steps / st["elapsed_s"]),
                                     "ms_per_step": 1e3 * st["elapsed_s"] / args.steady_steps, "env_resets_in_timed_region": st["n_reset"],
