@@ -90,6 +90,10 @@ def main():
     for src, dst in (("kernel_stats_4096.txt", "%s_kernel_stats_4096.txt"), ("track_scaling_65536_1080.json", "%s_track_scaling.json"),
                      ("ray_bench.txt", "%s_ray_bench.txt"), ("bench_driver_form.log", "%s_bench_driver_form.json")):
         if os.path.isfile(os.path.join(SRC, src)):
+            body = open(os.path.join(SRC, src)).read()
+            if csrc and '"csrc"' in body and csrc not in body:
+                print("skipped %s: measured on other sources than the PMC passes (%s)" % (src, csrc))
+                continue
             shutil.copyfile(os.path.join(SRC, src), os.path.join(DST, dst % tag))
     # the late-round-3 latency work: sizes, the wave-by-wave timeline, compile-time variants, list switches
     for src in ("latency_sizes.txt", "scan_timeline_4096.txt", "late_variants.txt", "late_lists.txt", "late_duo.txt", "late_many_agents.txt", "soak_fuzz.txt", "vecenv_rate.txt"):
@@ -106,7 +110,7 @@ def main():
                 d = json.loads(line)
                 rows.append("%-28s %9.3f M agent-steps/s  %.4f ms/step  agents %6d  resets %d" % (
                     os.path.basename(f)[:-4], d["value"] / 1e6, d["ms_per_step"], d["config"]["agents_per_gpu"], d["config"]["env_resets_in_timed_region"]))
-    if rows:
+    if rows and any(not r.startswith("preroll_") for r in rows):   # (a session that only re-ran the pre-roll ramp does not replace the table)
         hdr = ("# A/B sweeps of round 3 (tools/gpu_r3.sh finalize finalize2 probes ray preroll): bench.py --only-headline --steps 300 --warmup 30,\n"
                "# experimental build, F110_EXP switches as named by the file: fin_n<agents>_f<finalize_flat>, fin_flat_l<lanes>, fin2_n<agents>_l<lanes>,\n"
                "# fin2_<workload>_pa<pair_always>, probe_n<agents>_{base,occ4,cnt} (task_order off; scan at 4 waves/SIMD; + per-env completion counter),\n"
