@@ -86,6 +86,20 @@ def main():
                         "WRITE_SIZE_KiB": vals["WRITE_SIZE"], "hbm_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
                         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)"}
     json.dump(rec, open(rec_path, "w"), indent=1, sort_keys=True)
+    # ... and their gather-issue floors (traffic_<tag>_VMEM.json: SQ_INSTS_VMEM_RD / _WR of the leg's scan kernel)
+    fl_path = os.path.join(DST, "%s_issue_floor.json" % tag)
+    if os.path.isfile(fl_path):
+        fl = json.load(open(fl_path))
+        for leg, key in (("4096", "agents=4096,beams=1080,layout=3"), ("cfg5", "agents=65536,beams=4096,layout=3,tiles=2")):
+            q = os.path.join(SRC, "traffic_%s_VMEM.json" % leg)
+            if not os.path.isfile(q):
+                continue
+            for kern, r in json.load(open(q)).items():
+                m = r["mean_per_dispatch"]
+                if kern.startswith(("k_scan_rays", "k_scan_dirs")) and "SQ_INSTS_VMEM_RD" in m and r.get("csrc") == fl.get("csrc"):
+                    fl["vmem_instr_per_launch"][key] = m["SQ_INSTS_VMEM_RD"] + m.get("SQ_INSTS_VMEM_WR", 0.0)
+                    fl.setdefault("pmc", {})[key] = {"kernel": kern, "waves": m.get("SQ_WAVES"), "window": r.get("window")}
+        json.dump(fl, open(fl_path, "w"), indent=1, sort_keys=True)
     # other summaries of the session, as they are
     for src, dst in (("kernel_stats_4096.txt", "%s_kernel_stats_4096.txt"), ("track_scaling_65536_1080.json", "%s_track_scaling.json"),
                      ("ray_bench.txt", "%s_ray_bench.txt"), ("bench_driver_form.log", "%s_bench_driver_form.json")):

@@ -148,6 +148,16 @@ agsweep)
     F110_EXP=finalize_lanes=$l timeout 200 $X python bench.py $H --agents $n > $OUT/ag_tmp.log 2>&1; line $OUT/ag_tmp.log "agents $n finalize_lanes $l" | tee -a $OUT/late_agsweep.txt
   done; done
   ;;
+pmclegs)
+  cd /tmp
+  for cfg in "4096:--agents 4096" "cfg5:--agents 65536 --beams 4096 --map-tiles 2 --steps 100 --warmup 20 --preroll 100"; do
+    tagc=${cfg%%:*}; argsc=${cfg#*:}; n=300; [ "$tagc" = cfg5 ] && n=100
+    timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --kernel-include-regex "k_scan_rays|k_scan_dirs" -T -f csv -d $OUT/tr_vm -o p -- python $R/bench.py --only-headline $argsc > $OUT/tr_${tagc}_vm.log 2>&1
+    python $R/tools/summarize_prof.py pmc $OUT/tr_vm $OUT/traffic_${tagc}_VMEM.json - $n
+    rm -rf $OUT/tr_vm
+  done
+  cd "$R"; cat $OUT/traffic_4096_VMEM.json | head -30
+  ;;
 probes)
   # fusion feasibility: the scan kernel at the occupancy a fused (118-VGPR) kernel would have,
   # and with a per-env completion counter
@@ -202,6 +212,10 @@ pmc)
       python $R/tools/summarize_prof.py pmc $OUT/tr_$c $OUT/traffic_${tagc}_$c.json - $n
       rm -rf $OUT/tr_$c
     done
+    # ... and its wave-level vector-memory instructions (the gather-issue floor of that leg)
+    timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --kernel-include-regex "k_scan_rays|k_scan_dirs" -T -f csv -d $OUT/tr_vm -o p -- python $R/bench.py --only-headline $argsc > $OUT/tr_${tagc}_vm.log 2>&1
+    python $R/tools/summarize_prof.py pmc $OUT/tr_vm $OUT/traffic_${tagc}_VMEM.json - $n
+    rm -rf $OUT/tr_vm
   done
   cd "$R"
   ;;
