@@ -158,6 +158,30 @@ pmclegs)
   done
   cd "$R"; cat $OUT/traffic_4096_VMEM.json | head -30
   ;;
+pmccfg5)
+  cd /tmp
+  i=0
+  for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_TA_BUSY GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_dirs" -T -f csv -d $OUT/pc5_$i -o p -- python $R/bench.py --only-headline --agents 65536 --beams 4096 --map-tiles 2 --steps 100 --warmup 20 --preroll 100 > $OUT/pc5_$i.log 2>&1
+    python $R/tools/summarize_prof.py pmc $OUT/pc5_$i $OUT/pmc_cfg5_pass$i.json - 100
+    rm -rf $OUT/pc5_$i
+  done
+  cd "$R"; python - <<'PYEOF'
+import json, glob
+m = {}
+for f in sorted(glob.glob("gpurun_out/pmc_cfg5_pass*.json")):
+    for k, r in json.load(open(f)).items():
+        m.update(r["mean_per_dispatch"]); meta = r["meta"]
+cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+tasks = 65536 * 24
+print("kernel cycles %.0f (%.3f ms at 2.4 GHz)  VGPR %s SGPR %s" % (cyc, cyc / 2.4e6, meta.get("VGPR_Count"), meta.get("SGPR_Count")))
+print("per task: VALU %.1f  SALU %.1f  VMEM rd %.2f wr %.2f  LDS %.2f" % (m["SQ_INSTS_VALU"] / tasks, m["SQ_INSTS_SALU"] / tasks, m["SQ_INSTS_VMEM_RD"] / tasks, m["SQ_INSTS_VMEM_WR"] / tasks, m["SQ_INSTS_LDS"] / tasks))
+print("TA busy %.3f  TD busy %.3f  VALU active (SQ_ACTIVE_INST_VALU / 4 / waves-cycles) %.3f" % (m["TA_TA_BUSY_sum"] / 256.0 / cyc, m["TD_TD_BUSY_sum"] / 256.0 / cyc, m["SQ_ACTIVE_INST_VALU"] / (1024.0 * cyc)))
+print("TCP hit %.3f  TCC hit %.3f  waves %d  wave cycles per wave %.0f" % (1 - m["TCP_TCC_READ_REQ_sum"] / m["TCP_TOTAL_CACHE_ACCESSES_sum"], m["TCC_HIT_sum"] / m["TCC_REQ_sum"], m["SQ_WAVES"], 4 * m["SQ_WAVE_CYCLES"] / m["SQ_WAVES"]))
+json.dump(m, open("gpurun_out/pmc_cfg5.json", "w"), indent=1, sort_keys=True)
+PYEOF
+  ;;
 probes)
   # fusion feasibility: the scan kernel at the occupancy a fused (118-VGPR) kernel would have,
   # and with a per-env completion counter
