@@ -1732,7 +1732,8 @@ __global__ void __launch_bounds__(256) k_finalize_pair_roles(AgentArrays a, int3
 // with one lane per agent (a serial loop over the A - 1 opponents: box, GJK, two beam windows, 80 bytes of windows
 // and boxes through HBM per ordered pair, a side stream with an event fork / join around the scan) becomes one
 // kernel behind the scan:
-//   records   every ORDERED pair (agent i, opponent o) of the workgroup's envs, R = G A (A - 1) <= kMaxRec: the four
+//   records   every ORDERED pair (agent i, opponent o) of the workgroup's envs, R = G A (A - 1) <= MAXREC (64 for A <= 8,
+//             256 with one env per workgroup for A <= 16): the four
 //             corners of o's box (drawn with i's length / width, RaceCar.ray_cast_agents :223) -> beam indices on
 //             threads 0-127 (four per record), the disc cull on threads 128-191 (one per record);
 //   pairs     every UNORDERED pair (p < q) of an env, P = G A (A - 1) / 2: collision_multiple's GJK in the reference's
@@ -1745,12 +1746,15 @@ __global__ void __launch_bounds__(256) k_finalize_pair_roles(AgentArrays a, int3
 //             patterns order like unsigned integers, so the items settle it with atomicMin on the pattern: no rounds,
 //             no order, the same value.
 // Same functions on the same operands as collide_agent / k_finalize: bit-identical (test_finalize_multi_*).
-constexpr int kMaxRec = 64;
+constexpr int kMaxRec = 64;      // A <= 8: a workgroup's record table
+constexpr int kMaxRecBig = 256;  // 9 <= A <= 16: one env per workgroup, up to 240 records
+template <int MAXREC>
 __global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B, int G)
 {
-    __shared__ double s_rec[kMaxRec][12];   // ex, ey, eth, the opponent's box (8), pad
-    __shared__ int s_idx[kMaxRec][4], s_cl[kMaxRec], s_ch[kMaxRec], s_hit[kMaxRec];
-    __shared__ int s_lo[kMaxRec], s_cnt[kMaxRec], s_off[kMaxRec + 1], s_agent[kMaxRec], s_ahit[kMaxRec];
+    static_assert(MAXREC == 64 || MAXREC == 256, "record table sizes");
+    __shared__ double s_rec[MAXREC][12];   // ex, ey, eth, the opponent's box (8), pad
+    __shared__ int s_idx[MAXREC][4], s_cl[MAXREC], s_ch[MAXREC], s_hit[MAXREC];
+    __shared__ int s_lo[MAXREC], s_off[MAXREC + 1], s_agent[MAXREC], s_ahit[MAXREC], s_wsum[4];
     const int t = (int)threadIdx.x;
     const int A = a.agents_per_env, N = a.n_agents_total;
     const int per_env = A * (A - 1), pairs_env = per_env / 2;
@@ -1861,8 +1865,9 @@ __global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B
         a.step_count[i] += 1;
         s_ahit[t] = my_hit;
     }
-    if (t >= 64 && t < 128) {   // (another wave) every record's window = corner hull clipped by the disc cull
-        const int rec = t - 64;
+    const int wrec = MAXREC == 64 ? t - 64 : t;   // 64 records: wave 1 (beside the agents' wave); 256: every thread one record
+    if (wrec >= 0 && wrec < MAXREC) {   // every record's window = corner hull clipped by the disc cull
+        const int rec = wrec;
         int lo = 0, cnt = 0;
         if (rec < R) {
             const int i0 = s_idx[rec][0], i1 = s_idx[rec][1], i2 = s_idx[rec][2], i3 = s_idx[rec][3];
@@ -1881,17 +1886,26 @@ __global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int up = __shfl_up(c, d);
-            if (rec >= d) c += up;
+            if ((rec & 63) >= d) c += up;
         }
         s_off[rec + 1] = c;
         if (rec == 0) s_off[0] = 0;
+        if (MAXREC > 64 && (rec & 63) == 63) s_wsum[rec >> 6] = c;
     }
     __syncthreads();
-    const int total = s_off[kMaxRec];
+    if (MAXREC > 64) {   // the later waves' records start behind the earlier waves' totals
+        if (t >= 64 && t < MAXREC) {
+            int base = 0;
+            for (int w = 0; w < (t >> 6); ++w) base += s_wsum[w];
+            s_off[t + 1] += base;
+        }
+        __syncthreads();
+    }
+    const int total = s_off[MAXREC];
     for (int item = t; item < total; item += 256) {
         int rec = 0;   // the largest rec with s_off[rec] <= item (its window is not empty: item < s_off[rec + 1])
 #pragma unroll
-        for (int st = kMaxRec / 2; st; st >>= 1)
+        for (int st = MAXREC / 2; st; st >>= 1)
             if (s_off[rec + st] <= item) rec += st;
         const int b = s_lo[rec] + (item - s_off[rec]);
         const double bex = s_rec[rec][0], bey = s_rec[rec][1], beth = s_rec[rec][2];

@@ -140,9 +140,9 @@ def test_integrate_in_two_waves_is_invisible(amd, E, A, integrator, lidar_dist):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("E,A", [(130, 3), (101, 4), (37, 5), (9, 8), (1, 3)])
+@pytest.mark.parametrize("E,A", [(130, 3), (101, 4), (37, 5), (9, 8), (1, 3), (7, 9), (5, 12), (3, 16)])
 def test_finalize_multi_is_invisible(amd, E, A):
-    """envs of 3..8 agents: pair tests, opponent windows and the ray-cast inside ONE finalize kernel (k_finalize_multi:
+    """envs of 3..16 agents: pair tests, opponent windows and the ray-cast inside ONE finalize kernel (k_finalize_multi:
     every ordered pair of an env a record, windows flattened, overlapping opponents settled by an integer atomicMin on
     the range's bit pattern) against round 1's form (k_collide on the side stream + k_finalize): not a bit may
     differ — cars that start nose to tail, crash into each other and into walls, re-seat, partial last workgroups"""

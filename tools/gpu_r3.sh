@@ -132,11 +132,11 @@ soak)
 many)
   # envs of 1 / 3 / 4 agents (k_finalize_solo / k_finalize_multi) and, experimental build, round 1's form for 3 / 4
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  bench.py --only-headline --agents 65520|65536 --agents-per-env A --steps 200 --warmup 20"
-    for a in 1 3 4 6 8; do
-      n=65520; [ $a = 4 ] && n=65536; [ $a = 8 ] && n=65536
+    for a in 1 3 4 6 8 12 16; do
+      n=65520; [ $a = 4 ] && n=65536; [ $a = 8 ] && n=65536; [ $a = 16 ] && n=65536
       timeout 300 python bench.py --only-headline --agents $n --agents-per-env $a --steps 200 --warmup 20 > $OUT/many_tmp.log 2>&1; line $OUT/many_tmp.log "A=$a product"
     done
-    for a in 3 4 8; do
+    for a in 3 4 8 16; do
       n=65520; [ $a != 3 ] && n=65536
       F110_EXP=collide_mode=0 timeout 300 $X python bench.py --only-headline --agents $n --agents-per-env $a --steps 200 --warmup 20 > $OUT/many_tmp.log 2>&1; line $OUT/many_tmp.log "A=$a k_collide + k_finalize, round-1 form"
     done; } > $OUT/late_many_agents.txt 2>&1
