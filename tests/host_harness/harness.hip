@@ -40,6 +40,48 @@ void hh_advance(double *st, double *buf, int *cnt, double steer, double speed, c
     advance_vehicle(st, buf[0], buf[1], *cnt, steer, speed, vp, dt, integ, lidar_dist, scan_pose);
 }
 
+// k_integrate_duo's decomposition on the host: the "second wave" (low_speed_trig_ahead) walks (steer, v) through the
+// stages and leaves the low-speed branch's tan / cos in a table, the "first wave" integrates taking them from there.
+// which[s] = 1 where stage s took the low-speed branch (the table entry was produced AND consumed).
+struct HostTrigTable {
+    double tn[4], cd[4];
+    mutable int produced[4], consumed[4];
+};
+struct HostTrigEmit {
+    HostTrigTable *t;
+    void operator()(int stage, double tn, double cd) const
+    {
+        t->tn[stage] = tn;
+        t->cd[stage] = cd;
+        t->produced[stage] = 1;
+    }
+    void end_stage(int) const {}
+};
+struct HostTrigTake {
+    const HostTrigTable *t;
+    void begin_stage(int) const {}
+    void operator()(int stage, double, double &tn, double &cd) const
+    {
+        tn = t->tn[stage];
+        cd = t->cd[stage];
+        t->consumed[stage] = 1;
+    }
+};
+void hh_advance_duo(double *st, double *buf, int *cnt, double steer, double speed, const double *p, double dt, int integ, double lidar_dist,
+                    double *scan_pose, int *which)
+{
+    VehicleParams vp;
+    for (int i = 0; i < NPARAMS; ++i) vp.v[i] = p[i];
+    HostTrigTable tab;
+    for (int s = 0; s < 4; ++s) {
+        tab.tn[s] = tab.cd[s] = -12345.0;   // (a stage that consumes what was never produced shows)
+        tab.produced[s] = tab.consumed[s] = 0;
+    }
+    low_speed_trig_ahead(st[2], st[3], buf[1], *cnt, speed, vp, dt, integ, HostTrigEmit{&tab});
+    advance_vehicle_with(st, buf[0], buf[1], *cnt, steer, speed, vp, dt, integ, lidar_dist, scan_pose, HostTrigTake{&tab});
+    for (int s = 0; s < 4; ++s) which[s] = tab.produced[s] * 2 + tab.consumed[s];
+}
+
 // guard-band re-marches of the PADDED layout since the last call to hh_padded_stats
 static long long g_pad_fast = 0, g_pad_guard = 0, g_pad_far = 0;
 void hh_padded_stats(long long *out)

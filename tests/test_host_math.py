@@ -81,6 +81,44 @@ def test_advance_vehicle(hh, name, integ, ld):
         assert rel_err(sp, g[name + "_scan_pose"][i]) < 1e-12
 
 
+@pytest.mark.parametrize("integ", [1, 2])
+def test_two_wave_integration_is_the_one_wave_integration(hh, integ):
+    """k_integrate_duo's decomposition, on the host: a second walker takes (steer, v) through the RK4 stages alone
+    (low_speed_trig_ahead) and leaves the low-speed branch's tan / cos in a table; the integration takes them from
+    there.  Bit-identical to advance_vehicle for random states on both sides of |v| = 0.5 (and crossing it inside a
+    step), every delay-buffer fill, steering at its limits, both integrators — and a stage consumes a table entry
+    exactly when the walker produced one."""
+    g = gold("update_pose")
+    p, pp = d(g["params"])
+    rng = np.random.default_rng(77 + integ)
+    n_low = n_high = n_cross = 0
+    for i in range(6000):
+        st0 = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-0.45, 0.45), 0.0, rng.uniform(-7, 7), rng.uniform(-2, 2), rng.uniform(-0.3, 0.3)])
+        kind = i % 4
+        st0[3] = (rng.uniform(-0.6, 0.6), rng.uniform(0.4, 0.6) * rng.choice([-1, 1]), rng.uniform(-6, 12), 0.0)[kind]
+        if i % 7 == 0:
+            st0[2] = rng.choice([-0.4189, 0.4189])          # at the steering limits (the rate constraint's 0 branch)
+        c0 = int(rng.integers(0, 3))
+        buf0 = np.concatenate([rng.uniform(-0.4, 0.4, c0), np.zeros(2 - c0)])
+        steer, speed = rng.uniform(-0.5, 0.5), rng.uniform(-3, 15)
+        outs = []
+        for fn in ("hh_advance", "hh_advance_duo"):
+            st = st0.copy(); buf = buf0.copy(); cnt = C.c_int(c0); sp = np.empty(3); which = np.zeros(4, dtype=np.intc)
+            args = [st.ctypes.data_as(_dp), buf.ctypes.data_as(_dp), C.byref(cnt), C.c_double(steer), C.c_double(speed), pp, C.c_double(0.01), integ,
+                    C.c_double(0.275 if i % 5 == 0 else 0.0), sp.ctypes.data_as(_dp)]
+            if fn == "hh_advance_duo":
+                args.append(which.ctypes.data_as(_ip))
+            getattr(hh, fn)(*args)
+            outs.append((st, buf, cnt.value, sp, which))
+        (s1, b1, c1, p1, _), (s2, b2, c2, p2, which) = outs
+        assert np.array_equal(s1, s2) and np.array_equal(b1, b2) and c1 == c2 and np.array_equal(p1, p2), (i, st0)
+        stages = 4 if integ == 1 else 1
+        assert all(w in (0, 3) for w in which[:stages]) and all(w == 0 for w in which[stages:]), which   # produced <=> consumed
+        low = [w == 3 for w in which[:stages]]
+        n_low += all(low); n_high += not any(low); n_cross += any(low) and not all(low)
+    assert n_low > 500 and n_high > 500 and (n_cross > 20 or integ == 2), (n_low, n_high, n_cross)
+
+
 def _hh_scan(hh, layout, dt, res, origin, sines, cosines, B, fov, pose, theta_dis=2000):
     dt_, dtp = d(dt); s_, sp = d(sines); c_, cp = d(cosines); pose_, pp = d(pose)
     ranges = np.empty(B); hits = np.empty((B, 2), dtype=np.intc); idx = np.empty(B, dtype=np.intc)
