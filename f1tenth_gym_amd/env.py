@@ -109,8 +109,10 @@ class F110Env(_EnvBase):
         self.poses_x, self.poses_y, self.poses_theta = [], [], []
         self.collisions = np.zeros((self.num_agents,))
         self._lap = _LapLogic(1, self.num_agents, self.ego_idx)
+        # f110_env.py:192 does NOT hand ego_idx to its Simulator: obs['ego_idx'] is 0 whatever the env's
+        # ego_idx is (pinned by tests/golden/env_episode_2agents.npz); ego_idx only steers _check_done
         self.sim = Simulator(self.params, self.num_agents, self.seed, time_step=self.timestep,
-                             ego_idx=self.ego_idx, integrator=self.integrator, lidar_dist=self.lidar_dist,
+                             integrator=self.integrator, lidar_dist=self.lidar_dist,
                              device_id=kwargs.get('device_id', 0),
                              map_layout=kwargs.get('map_layout', _ffi.MAP_DEFAULT))
         self.sim.set_map(self.map_path, self.map_ext)

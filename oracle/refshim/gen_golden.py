@@ -396,6 +396,151 @@ def gen_sim(ns):
     print("    wall hits at steps:", np.nonzero(incol.any(axis=1))[0][:10], " gjk:", np.nonzero(cols.any(axis=1))[0][:5])
 
 
+# ------------------------------------------------------------------- multi-agent sim rollout
+def gen_sim_multi(ns):
+    """Simulator.step with A = 3, 4 and 8 cars on example_map (base_classes.py:553-612 loops over A
+    agents; collision_models.py:184-212 all pairs; base_classes.py:206-227 every opponent per ego).
+    The cars start as a bunched train on the raceline (0.8 m apart, alternating lateral offsets, so that
+    the opponent windows of an ego overlap and every car but the last has one exactly behind it, where
+    the bearing wraps at +-pi); the rear cars are faster than the front ones (rear-end GJK contacts,
+    several pairs at once) and one car in the middle is steered into the wall (iTTC hit, heading zeroed
+    while the others still ray-cast it)."""
+    bc = ns.base_classes
+    w = raceline()
+    out = {}
+    for A, k0, T in ((3, 40, 220), (4, 300, 220), (8, 520, 240)):
+        ref_loader.fresh_racecar_class(ns)
+        sim = bc.Simulator(dict(DEFAULT_PARAMS), A, 12345, time_step=0.01, integrator=bc.Integrator.RK4)
+        sim.set_map(EXAMPLE_MAP + ".yaml", ".png")
+        start = np.empty((A, 3))
+        for i in range(A):
+            k = (k0 + 4 * i) % w.shape[0]
+            th = w[k, 3] + np.pi / 2
+            lat = 0.12 * (1 if i % 2 else -1)
+            start[i] = [w[k, 1] - lat * np.sin(th), w[k, 2] + lat * np.cos(th), th]
+        sim.reset(start)
+        rng = np.random.default_rng(900 + A)
+        acts = np.empty((T, A, 2)); states = np.empty((T, A, 7)); cols = np.empty((T, A))
+        incol = np.empty((T, A), dtype=np.int32); cidx = np.empty((T, A)); snap = np.empty((T, A, 3))
+        sub = np.empty((T, A, 45)); ssum = np.empty((T, A))
+        full_steps = [0, 90, T - 1]
+        a = np.zeros((A, 2))
+        waller = A // 2
+        for t in range(T):
+            if t % 25 == 0:
+                for i in range(A):
+                    a[i] = [rng.uniform(-0.06, 0.06), 6.5 - 5.0 * i / (A - 1) + rng.uniform(-0.4, 0.4)]
+            if t >= 110:
+                a[waller] = [0.41, 5.0]
+            acts[t] = a
+            obs = sim.step(a)
+            states[t] = np.array([ag.state for ag in sim.agents])
+            cols[t] = obs['collisions']; cidx[t] = sim.collision_idx
+            incol[t] = [int(ag.in_collision) for ag in sim.agents]
+            snap[t] = sim.agent_poses
+            for i in range(A):
+                sc = np.asarray(obs['scans'][i])
+                sub[t, i] = sc[::24]; ssum[t, i] = sc.sum()
+            if t in full_steps:
+                out["a%d_scans_t%d" % (A, t)] = np.array(obs['scans'])
+        out.update({"a%d_start" % A: start, "a%d_actions" % A: acts, "a%d_states" % A: states,
+                    "a%d_collisions" % A: cols, "a%d_in_collision" % A: incol, "a%d_collision_idx" % A: cidx,
+                    "a%d_agent_poses" % A: snap, "a%d_scans_sub24" % A: sub, "a%d_scans_sum" % A: ssum,
+                    "a%d_full_steps" % A: np.array(full_steps)})
+        gjk_steps = np.nonzero((cidx >= 0).any(axis=1))[0]
+        print("    A=%d: wall hits at %s (agents %s); gjk contact steps %d (first %s), pairs seen %s" % (
+            A, np.nonzero(incol.any(axis=1))[0][:4], np.nonzero(incol.any(axis=0))[0], len(gjk_steps), gjk_steps[:3],
+            sorted({(int(i), int(j)) for row in cidx for i, j in enumerate(row) if j >= 0})[:10]))
+    ref_loader.fresh_racecar_class(ns)
+    save("sim_rollout_multi", params=pvec(DEFAULT_PARAMS), seed=np.array([12345]), agent_counts=np.array([3, 4, 8]), **out)
+
+
+# ------------------------------------------------------------------- env, 2 agents, ego_idx = 1
+def gen_env2(ns):
+    """F110Env(num_agents=2, ego_idx=1) — the reference's default agent count (f110_env.py:133-136)
+    with the ego in slot 1 — through three episodes on example_map, each started by env.reset:
+      0  both cars leave the start zone and reverse back into it twice at different speeds, with
+         different start headings (the zone of BOTH cars is laid out in the EGO's start frame,
+         f110_env.py:331): toggles of both cars, done only when both reach 4 (:244);
+      1  car 0 (not the ego) is steered into the wall first — collisions[0] = 1 and the episode goes
+         on — then the ego hits the wall: done on collisions[ego_idx] (:244);
+      2  car 0 rear-ends the ego: GJK sets both flags, done."""
+    ns = ref_loader.load_reference(with_env=True)
+    ref_loader.fresh_racecar_class(ns)
+    env = ns.f110_env.F110Env(map=EXAMPLE_MAP, map_ext='.png', num_agents=2, ego_idx=1, seed=12345)
+    w = raceline()
+    obs_ego = []
+    keys = ("x", "y", "th", "v", "w", "lap_time", "lap_count", "done", "toggle", "near", "col", "ckpt", "scan_sum")
+    out = {}
+
+    def pose_at(k, lat=0.0, dth=0.0):
+        th = w[k, 3] + np.pi / 2
+        return [w[k, 1] - lat * np.sin(th), w[k, 2] + lat * np.cos(th), th + dth]
+
+    def run(ep, start, policy, max_steps):
+        rec = {k: [] for k in keys}
+        acts = []
+
+        def log(obs, done, info):
+            rec["x"].append(list(obs['poses_x'])); rec["y"].append(list(obs['poses_y']))
+            rec["th"].append(list(obs['poses_theta'])); rec["v"].append(list(obs['linear_vels_x']))
+            rec["w"].append(list(obs['ang_vels_z']))
+            rec["lap_time"].append(np.array(obs['lap_times'], dtype=float).copy())
+            rec["lap_count"].append(np.array(obs['lap_counts'], dtype=float).copy())
+            rec["done"].append(bool(done)); rec["toggle"].append(np.array(env.toggle_list, dtype=float).copy())
+            rec["near"].append(np.array(env.near_starts, dtype=bool).copy())
+            rec["col"].append(np.array(obs['collisions'], dtype=float).copy())
+            rec["ckpt"].append(np.array(info['checkpoint_done'], dtype=bool).copy())
+            rec["scan_sum"].append([float(np.sum(s)) for s in obs['scans']])
+        start = np.array(start)
+        obs, r, done, info = env.reset(start.copy())
+        obs_ego.append(obs['ego_idx'])   # F110Env does not hand ego_idx to its Simulator (f110_env.py:192): the obs says 0
+        log(obs, done, info)
+        t = 0
+        while t < max_steps and not done:
+            a = policy(t, env)
+            acts.append(a.copy())
+            obs, r, done, info = env.step(a)
+            log(obs, done, info)
+            t += 1
+        out["ep%d_start" % ep] = start
+        out["ep%d_actions" % ep] = np.array(acts)
+        for k in keys:
+            out["ep%d_%s" % (ep, k)] = np.array(rec[k])
+        print("    episode %d: %d steps, toggles %s, collisions %s, done %s" % (ep, t, env.toggle_list, rec["col"][-1], done))
+        return rec
+
+    # episode 0: laps.  the cars sit side by side (1 m apart, mid-track); car 0's heading is 0.5 rad off the ego's
+    def laps(t, env):
+        a = np.zeros((2, 2))
+        for i, sp in ((0, 1.8), (1, 2.6)):
+            a[i, 1] = sp if env.toggle_list[i] % 2 == 0 else -sp
+        return a
+    rec = run(0, [pose_at(0, lat=0.45, dth=-0.5), pose_at(0, lat=1.45)], laps, 4000)
+    print("      collision steps:", np.nonzero(np.array(rec["col"]).any(axis=1))[0][:10])
+    assert rec["done"][-1] and not np.any(np.array(rec["col"])) and np.all(rec["toggle"][-1] >= 4)
+    first_both = [int(np.argmax(np.array(rec["toggle"])[:, i] >= 4)) for i in range(2)]
+    assert first_both[0] != first_both[1], "cars should finish at different steps"
+
+    # episode 1: the non-ego car hits the wall first, the ego later
+    def walls(t, env):
+        return np.array([[0.41 if t >= 40 else 0.0, 5.0], [0.41 if t >= 200 else 0.0, 4.0]])
+    rec = run(1, [pose_at(120, lat=0.0), pose_at(160, lat=0.0)], walls, 1500)
+    col = np.array(rec["col"])
+    first0 = int(np.argmax(col[:, 0] > 0)); first1 = int(np.argmax(col[:, 1] > 0))
+    assert col[:, 0].any() and first0 < first1 and rec["done"][-1] and not rec["done"][first0], (first0, first1)
+
+    # episode 2: car 0 rear-ends the ego
+    def ram(t, env):
+        return np.array([[0.0, 7.0], [0.0, 1.0]])
+    rec = run(2, [pose_at(400, lat=0.0), pose_at(408, lat=0.0)], ram, 1500)
+    col = np.array(rec["col"])
+    assert rec["done"][-1] and col[-1, 0] == 1 and col[-1, 1] == 1
+    ref_loader.fresh_racecar_class(ns)
+    assert set(obs_ego) == {0}
+    save("env_episode_2agents", ego_idx=np.array([1]), obs_ego_idx=np.array([obs_ego[0]]), seed=np.array([12345]), **out)
+
+
 # ----------------------------------------------------------------------------------- env
 def gen_env(ns):
     """F110Env episode (1 agent, example_map): drive out of the start zone and reverse back
@@ -530,7 +675,7 @@ def gen_planner(ns):
 
 GROUPS = {"planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
-          "sim": gen_sim, "env": gen_env, "waypoint_follow": gen_waypoint_follow}
+          "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "waypoint_follow": gen_waypoint_follow}
 
 
 def main(argv):
