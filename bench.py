@@ -265,8 +265,11 @@ def start_poses_for(env_ids, num_agents, gap_wp=10):
     w = raceline()
     n = w.shape[0]
     poses = np.empty((len(env_ids), num_agents, 3))
+    order = os.environ.get("F110_BENCH_START_ORDER", "")   # experiment only (tools/debug): "sorted" lays the envs out along the track
     for a in range(num_agents):
         k = ((env_ids * 7919) % n - a * gap_wp) % n
+        if order == "sorted":
+            k = (np.sort((env_ids * 7919) % n) - a * gap_wp) % n
         poses[:, a, 0] = w[k, 1]
         poses[:, a, 1] = w[k, 2]
         poses[:, a, 2] = w[k, 3] + np.pi / 2

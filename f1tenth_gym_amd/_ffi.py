@@ -58,6 +58,17 @@ class EpisodeViews(C.Structure):
                 ("lap_counts", C.c_void_p), ("toggles", C.c_void_p), ("current_time", C.c_void_p)]
 
 
+class HostBlock(C.Structure):
+    """f110_host_block: where f110_step_host writes (page-locked memory of f110_host_alloc)"""
+    _fields_ = [("state", _dp), ("collisions", _dp), ("collision_idx", _dp), ("agent_poses", _dp),
+                ("lap_times", _dp), ("lap_counts", _dp), ("toggles", _dp), ("current_time", _dp),
+                ("in_collision", _i32p), ("near_starts", _u8p), ("checkpoint_done", _u8p), ("done", _u8p),
+                ("scans", _dp)]
+
+
+STEP_AUTO_RESET, STEP_NO_SYNC, STEP_ACTIONS_MAPPED, STEP_SPIN_WAIT = 1, 2, 4, 8
+
+
 class DeviceViews(C.Structure):
     _fields_ = [("scans", C.c_void_p), ("state", C.c_void_p), ("agent_poses", C.c_void_p),
                 ("collisions", C.c_void_p), ("collision_idx", C.c_void_p),
@@ -107,6 +118,8 @@ PROTOTYPES = {
     "f110_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "f110_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_episode_device_views": (C.c_int, [C.c_void_p, C.POINTER(EpisodeViews)]),
+    "f110_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(HostBlock), C.c_int32]),
+    "f110_step_host_stats": (C.c_int, [C.c_void_p, _dp]),
     "f110_step": (C.c_int, [C.c_void_p, _dp]),
     "f110_step_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_get_obs": (C.c_int, [C.c_void_p, C.POINTER(ObsHost)]),

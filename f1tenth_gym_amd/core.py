@@ -6,6 +6,7 @@ The reference-compatible façades (Simulator, ScanSimulator2D, F110Env) are buil
 """
 import ctypes as C
 import os
+import types
 import weakref
 
 import numpy as np
@@ -485,6 +486,68 @@ class BatchSim(object):
         buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)   # every NumPy view keeps `buf` alive through .base
         weakref.finalize(buf, _ffi.lib().f110_host_free, None, p.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    # ------------------------------------------------------------------ one call per env.step()
+    HOST_FIELDS = {   # name -> (dtype, shape as a function of (N, E, B))
+        "state": (np.float64, lambda N, E, B: (7, N)), "collisions": (np.float64, lambda N, E, B: (N,)),
+        "collision_idx": (np.float64, lambda N, E, B: (N,)), "agent_poses": (np.float64, lambda N, E, B: (3, N)),
+        "lap_times": (np.float64, lambda N, E, B: (N,)), "lap_counts": (np.float64, lambda N, E, B: (N,)),
+        "toggles": (np.float64, lambda N, E, B: (N,)), "current_time": (np.float64, lambda N, E, B: (E,)),
+        "in_collision": (np.int32, lambda N, E, B: (N,)), "near_starts": (np.uint8, lambda N, E, B: (N,)),
+        "checkpoint_done": (np.uint8, lambda N, E, B: (N,)), "done": (np.uint8, lambda N, E, B: (E,)),
+        "scans": (np.float64, lambda N, E, B: (N, B))}
+
+    def host_block(self, fields):
+        """page-locked memory for f110_step_host: returns an object with .actions ([N][2], written by the
+        caller), one NumPy view per requested field (attribute .views, a dict) and the ctypes struct.
+        The views are OVERWRITTEN by every step_host(): copy what you keep."""
+        fields = tuple(fields)
+        for f in fields:
+            if f not in self.HOST_FIELDS:
+                raise KeyError(f)
+        N, E, B = self.N, self.E, self.B
+        offs, total = {}, 16 * N     # the actions lead the block
+        for f in fields:
+            dt, shp = self.HOST_FIELDS[f]
+            total = (total + 255) // 256 * 256
+            offs[f] = total
+            total += int(np.prod(shp(N, E, B))) * np.dtype(dt).itemsize
+        raw = self.pinned_empty((total,), np.uint8)
+        hb = types.SimpleNamespace(raw=raw, fields=fields, views={}, struct=_ffi.HostBlock())
+        hb.actions = raw[:16 * N].view(np.float64).reshape(N, 2)
+        hb.actions[...] = 0.0
+        for f in fields:
+            dt, shp = self.HOST_FIELDS[f]
+            shape = shp(N, E, B)
+            nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+            v = raw[offs[f]:offs[f] + nb].view(dt).reshape(shape)
+            hb.views[f] = v
+            setattr(hb.struct, f, v.ctypes.data_as(dict(_ffi.HostBlock._fields_)[f]))
+        hb.struct_ref = C.byref(hb.struct)
+        hb.actions_ptr = hb.actions.ctypes.data
+        return hb
+
+    def step_host_stats(self):
+        """(calls, mean host us enqueuing, mean host us waiting) of step_host since the last read"""
+        o = np.zeros(3)
+        check(_ffi.lib().f110_step_host_stats(self._h, dptr(o)), self._h)
+        n = max(o[0], 1.0)
+        return int(o[0]), o[1] / n, o[2] / n
+
+    def step_host(self, hb, actions=None, auto_reset=False, sync=True, mapped_actions=True, spin=False):
+        """f110_step_host: `actions` (None: hb.actions as the caller filled it in place) up, the step, the
+        episode logic if episode_init was called, hb's fields down — one ABI call."""
+        flags = (_ffi.STEP_AUTO_RESET if auto_reset else 0) | (0 if sync else _ffi.STEP_NO_SYNC) | (_ffi.STEP_SPIN_WAIT if spin else 0)
+        if actions is None or actions is hb.actions:
+            ptr = hb.actions_ptr
+            if mapped_actions:
+                flags |= _ffi.STEP_ACTIONS_MAPPED
+        else:
+            a = as_f64(actions, (self.N, 2))
+            ptr = a.ctypes.data
+        rc = _ffi.lib().f110_step_host(self._h, ptr, hb.struct_ref, flags)
+        if rc:
+            check(rc, self._h)
 
     def episode_step_host(self, actions_pinned, packed_pinned, auto_reset=False):
         """actions up, step, _check_done, the packed scalar observation down (one copy), optional re-seat;

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -165,6 +166,16 @@ struct f110_sim {
     bool has_episode = false;
     double *d_rot_stage = nullptr;
     void *d_packed = nullptr;   // f110_episode_step_host's packed block
+    // f110_step_host: the caller's block as last validated, and its device-side pointers
+    bool hb_valid = false;
+    f110_host_block hb_host{};
+    HostBlock hb_dev{};
+    const double *hb_actions_host = nullptr, *hb_actions_dev = nullptr;
+    unsigned long long *hb_seq_host = nullptr;   // page-locked completion word (F110_STEP_SPIN_WAIT)
+    unsigned int *hb_blocks_done = nullptr;
+    unsigned long long hb_seq = 0;
+    double hs_enqueue_us = 0, hs_wait_us = 0;    // f110_step_host_stats
+    long long hs_calls = 0;
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool profiling = false;
@@ -767,6 +778,8 @@ void f110_destroy(f110_sim *h)
         for (void *p : eptrs)
             if (p) (void)hipFree(p);
     }
+    if (h->hb_seq_host) (void)hipHostFree(h->hb_seq_host);
+    if (h->hb_blocks_done) (void)hipFree(h->hb_blocks_done);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     if (h->ev_integrated) (void)hipEventDestroy(h->ev_integrated);
     if (h->ev_collided) (void)hipEventDestroy(h->ev_collided);
@@ -1687,6 +1700,127 @@ int f110_episode_step_host(f110_sim *h, const double *h_actions, int32_t auto_re
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+// One entry per env.step() of a host-driven loop (f110.h).  Every pointer of `out` and — with
+// F110_STEP_ACTIONS_MAPPED — h_actions must be page-locked memory of f110_host_alloc: the kernels read / write
+// it in place.  The (struct, actions) pair is validated once (hipHostGetDevicePointer) and remembered.
+static int map_host_ptr(f110_sim *h, const void *host, void **dev, const char *what)
+{
+    *dev = nullptr;
+    if (!host) return F110_OK;
+    if (hipHostGetDevicePointer(dev, const_cast<void *>(host), 0) != hipSuccess || !*dev) {
+        (void)hipGetLastError();
+        return fail(h, F110_ERR_INVALID, "f110_step_host: %s is not page-locked memory of f110_host_alloc", what);
+    }
+    return F110_OK;
+}
+
+int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *out, int32_t flags)
+{
+    if (!h || !h_actions || !out) return fail(h, F110_ERR_INVALID, "null argument");
+    if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    const bool episode = h->has_episode;
+    if (!episode && (out->lap_times || out->lap_counts || out->toggles || out->current_time || out->near_starts ||
+                     out->checkpoint_done || out->done || (flags & F110_STEP_AUTO_RESET)))
+        return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
+    ENTER(h);
+    const size_t N = (size_t)h->N, E = (size_t)h->cfg.num_envs;
+    const bool mapped_actions = (flags & F110_STEP_ACTIONS_MAPPED) != 0;
+    if (!h->hb_valid || std::memcmp(&h->hb_host, out, sizeof *out) != 0 || h->hb_actions_host != (mapped_actions ? h_actions : nullptr)) {
+        HostBlock d{};
+        void *p = nullptr;
+#define MAP_FIELD(dst, src, name)                     \
+    do {                                              \
+        TRY(map_host_ptr(h, out->src, &p, name));     \
+        d.dst = reinterpret_cast<decltype(d.dst)>(p); \
+    } while (0)
+        MAP_FIELD(state, state, "state");
+        MAP_FIELD(collisions, collisions, "collisions");
+        MAP_FIELD(collision_idx, collision_idx, "collision_idx");
+        MAP_FIELD(agent_poses, agent_poses, "agent_poses");
+        MAP_FIELD(lap_time, lap_times, "lap_times");
+        MAP_FIELD(lap_count, lap_counts, "lap_counts");
+        MAP_FIELD(toggle, toggles, "toggles");
+        MAP_FIELD(current_time, current_time, "current_time");
+        MAP_FIELD(in_collision, in_collision, "in_collision");
+        MAP_FIELD(near_start, near_starts, "near_starts");
+        MAP_FIELD(checkpoint, checkpoint_done, "checkpoint_done");
+        MAP_FIELD(done, done, "done");
+#undef MAP_FIELD
+        TRY(map_host_ptr(h, mapped_actions ? h_actions : nullptr, &p, "h_actions"));
+        h->hb_actions_dev = reinterpret_cast<const double *>(p);
+        h->hb_actions_host = mapped_actions ? h_actions : nullptr;
+        h->hb_dev = d;
+        h->hb_host = *out;
+        h->hb_valid = true;
+    }
+    const auto t_in = std::chrono::steady_clock::now();
+    const bool spin = (flags & F110_STEP_SPIN_WAIT) && !(flags & F110_STEP_NO_SYNC) && !out->scans;
+    if (spin && !h->hb_seq_host) {
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->hb_seq_host), 64, hipHostMallocDefault));
+        *h->hb_seq_host = 0;
+        TRY(dmalloc(h, &h->hb_blocks_done, 1));
+        HIPCHK(h, hipMemsetAsync(h->hb_blocks_done, 0, sizeof(unsigned int), h->stream));
+    }
+    const double *d_act = h->d_actions;
+    if (mapped_actions)
+        d_act = h->hb_actions_dev;   // k_integrate reads the [N][2] block over PCIe, once, coalesced
+    else
+        HIPCHK(h, hipMemcpyAsync(h->d_actions, h_actions, sizeof(double) * 2 * N, hipMemcpyHostToDevice, h->stream));
+    TRY(f110_step_device(h, d_act));
+    ENTER(h);
+    const int A = h->cfg.num_agents;
+    const int epb = A >= 256 ? 1 : 256 / A;
+    HostBlock hbk = h->hb_dev;
+    if (spin) {
+        void *p = nullptr;
+        TRY(map_host_ptr(h, h->hb_seq_host, &p, "completion word"));
+        hbk.seq_host = reinterpret_cast<unsigned long long *>(p);
+        hbk.blocks_done = h->hb_blocks_done;
+        hbk.seq = ++h->hb_seq;
+    }
+    hipLaunchKernelGGL(k_host_block, dim3((unsigned)((E + epb - 1) / epb)), dim3(256), 0, h->stream, h->dev, h->ep, hbk, (int)E, epb,
+                       episode ? 1 : 0, (flags & F110_STEP_AUTO_RESET) ? 1 : 0);
+    // the scans are contiguous in HBM already: a DMA copy, behind the kernel (the re-seat leaves scans alone)
+    if (out->scans) HIPCHK(h, hipMemcpyAsync(out->scans, h->dev.scans, sizeof(double) * N * (size_t)h->cfg.num_beams, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipGetLastError());
+    const auto t_enq = std::chrono::steady_clock::now();
+    if (spin) {
+        // poll the completion word the last workgroup stores (no runtime call on the way out); a kernel that
+        // never signals (a device fault) is caught by the runtime after the spin budget
+        const unsigned long long want = h->hb_seq;
+        const volatile unsigned long long *w = h->hb_seq_host;
+        bool seen = false;
+        for (long it = 0; it < 2000000000L; ++it) {
+            if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == want) {
+                seen = true;
+                break;
+            }
+            __builtin_ia32_pause();
+            if ((it & 0xfffff) == 0xfffff &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq).count() > 5.0) break;
+        }
+        if (!seen) HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else if (!(flags & F110_STEP_NO_SYNC)) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    const auto t_out = std::chrono::steady_clock::now();
+    h->hs_enqueue_us += std::chrono::duration<double, std::micro>(t_enq - t_in).count();
+    h->hs_wait_us += std::chrono::duration<double, std::micro>(t_out - t_enq).count();
+    h->hs_calls += 1;
+    return F110_OK;
+}
+
+int f110_step_host_stats(f110_sim *h, double *out3)
+{
+    if (!h || !out3) return fail(h, F110_ERR_INVALID, "null argument");
+    out3[0] = (double)h->hs_calls;
+    out3[1] = h->hs_enqueue_us;
+    out3[2] = h->hs_wait_us;
+    h->hs_calls = 0;
+    h->hs_enqueue_us = h->hs_wait_us = 0;
     return F110_OK;
 }
 

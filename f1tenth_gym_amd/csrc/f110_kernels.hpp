@@ -2088,6 +2088,158 @@ __global__ void __launch_bounds__(256) k_pack_episode(AgentArrays a, EpisodeArra
     }
 }
 
+// f110_step_host: what a host-driven loop reads after a step, written by ONE kernel straight into the caller's
+// page-locked block (the pointers are device-visible host memory: the stores cross PCIe as posted writes, no
+// staging buffer and no copy command behind the kernel).  With the episode logic on (f110_episode_init) the
+// same kernel is F110Env._check_done (k_episode's arithmetic, f110_env.py:204-246) and, with auto_reset, the
+// in-place re-seat of finished envs (k_episode_reset_done) AFTER their terminal observation has been written.
+// A workgroup owns whole envs (envs_per_block of them): phase 1 per agent (toggles + the agent's columns),
+// phase 2 per env (done, current_time), phase 3 per agent (re-seat).  Any pointer may be nullptr.
+struct HostBlock {
+    double *state;          // [7][N]
+    double *collisions;     // [N]
+    double *collision_idx;  // [N]
+    double *agent_poses;    // [3][N]
+    double *lap_time, *lap_count, *toggle;  // [N]
+    double *current_time;   // [E]
+    int32_t *in_collision;  // [N]
+    uint8_t *near_start, *checkpoint;  // [N]
+    uint8_t *done;          // [E]
+    // completion word (F110_STEP_SPIN_WAIT): the workgroup that finishes last stores `seq` here, after every
+    // workgroup's stores have been fenced at system scope — the host polls it instead of entering the runtime
+    unsigned long long *seq_host;   // page-locked
+    unsigned int *blocks_done;      // device counter, returns to 0
+    unsigned long long seq;
+};
+
+// last statement of a workgroup of k_host_block: publish the block's host stores, count, and let the last one signal
+__device__ __forceinline__ void host_block_signal(const HostBlock &hb)
+{
+    if (!hb.seq_host) return;
+    __syncthreads();               // every lane's stores are issued
+    if (threadIdx.x == 0) {
+        __threadfence_system();    // ... and visible system-wide before the count
+        const unsigned int prev = __hip_atomic_fetch_add(hb.blocks_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(hb.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(hb.seq_host, hb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays ep, HostBlock hb, int num_envs, int envs_per_block,
+                                                    int episode, int auto_reset)
+{
+    __shared__ int s_running[256];    // per local env: agents with fewer than 4 toggles
+    __shared__ uint8_t s_done[256];
+    const int A = a.agents_per_env, tid = threadIdx.x;
+    const size_t N = (size_t)a.n_agents_total;
+    const int e0 = blockIdx.x * envs_per_block;
+    const int ne = min(envs_per_block, num_envs - e0);   // >= 1: the grid is ceil(num_envs / envs_per_block)
+    if (episode) {
+        for (int le = tid; le < ne; le += 256) s_running[le] = 0;
+        __syncthreads();
+    }
+    const int items = ne * A;
+    for (int idx = tid; idx < items; idx += 256) {
+        const int le = idx / A;
+        const size_t i = (size_t)e0 * A + idx;
+        const double x = a.state[i], y = a.state[N + i];
+        if (hb.state) {
+            hb.state[i] = x;
+            hb.state[N + i] = y;
+#pragma unroll
+            for (int c = 2; c < 7; ++c) hb.state[c * N + i] = a.state[c * N + i];
+        }
+        if (hb.collisions) hb.collisions[i] = a.collisions[i];
+        if (hb.collision_idx) hb.collision_idx[i] = a.collision_idx[i];
+        if (hb.in_collision) hb.in_collision[i] = a.in_collision[i];
+        if (hb.agent_poses) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) hb.agent_poses[c * N + i] = a.snap_pose[c * N + i];
+        }
+        if (episode) {
+            const int e = e0 + le;
+            const double ct = ep.current_time[e] + ep.timestep;  // f110_env.py:295 (written back in phase 2)
+            const double r00 = ep.rot[4 * e], r01 = ep.rot[4 * e + 1], r10 = ep.rot[4 * e + 2], r11 = ep.rot[4 * e + 3];
+            const double left_t = 2, right_t = 2;
+            const double px = x - ep.start_poses[3 * i];
+            const double py = y - ep.start_poses[3 * i + 1];
+            const double dx = r00 * px + r01 * py;  // np.dot(start_rot, [px; py]) :223
+            double ty = r10 * px + r11 * py;
+            if (ty > left_t)
+                ty -= left_t;
+            else if (ty < -right_t)
+                ty = -right_t - ty;
+            else
+                ty = 0;
+            const double dist2 = dx * dx + ty * ty;
+            const bool closes = dist2 <= 0.1;
+            bool near = ep.near_start[i] != 0;
+            double tog = ep.toggle[i];
+            if (closes && !near) {
+                near = true;
+                tog += 1;
+            } else if (!closes && near) {
+                near = false;
+                tog += 1;
+            }
+            const double laps = floor(tog / 2);  // toggle_list // 2
+            ep.near_start[i] = near ? 1 : 0;
+            ep.toggle[i] = tog;
+            ep.lap_count[i] = laps;
+            double lt = ep.lap_time[i];
+            if (tog < 4) {
+                lt = ct;
+                ep.lap_time[i] = ct;
+                atomicAdd(&s_running[le], 1);
+            }
+            ep.checkpoint[i] = tog >= 4 ? 1 : 0;
+            if (hb.lap_time) hb.lap_time[i] = lt;
+            if (hb.lap_count) hb.lap_count[i] = laps;
+            if (hb.toggle) hb.toggle[i] = tog;
+            if (hb.near_start) hb.near_start[i] = near ? 1 : 0;
+            if (hb.checkpoint) hb.checkpoint[i] = tog >= 4 ? 1 : 0;
+        }
+    }
+    if (!episode) {
+        host_block_signal(hb);
+        return;
+    }
+    __syncthreads();
+    for (int le = tid; le < ne; le += 256) {
+        const int e = e0 + le;
+        const bool done = a.collisions[(size_t)e * A + ep.ego_idx] != 0.0 || s_running[le] == 0;  // :244
+        const double ct = ep.current_time[e] + ep.timestep;
+        if (hb.current_time) hb.current_time[e] = ct;
+        if (hb.done) hb.done[e] = done ? 1 : 0;
+        s_done[le] = done ? 1 : 0;
+        const bool reseat = auto_reset && done;
+        ep.done[e] = (done && !reseat) ? 1 : 0;
+        ep.current_time[e] = reseat ? 0. : ct;
+    }
+    host_block_signal(hb);   // the host block is complete here; the re-seat below touches device memory only
+    if (!auto_reset) return;
+    __syncthreads();         // s_done
+    for (int idx = tid; idx < items; idx += 256) {
+        if (!s_done[idx / A]) continue;
+        const size_t i = (size_t)e0 * A + idx;   // F110Env.reset :319-334 without its zero-action step
+#pragma unroll
+        for (int c = 0; c < 7; ++c) a.state[c * N + i] = 0.;
+        a.state[i] = ep.start_poses[3 * i];
+        a.state[N + i] = ep.start_poses[3 * i + 1];
+        a.state[4 * N + i] = ep.start_poses[3 * i + 2];
+        a.steer_buf[i] = 0.;
+        a.steer_buf[N + i] = 0.;
+        a.buf_cnt[i] = 0;
+        a.in_collision[i] = 0;
+        a.step_count[i] = 0;
+        ep.near_start[i] = 1;
+        ep.toggle[i] = 0.;
+    }
+}
+
 // The scalar part of Simulator.step's observation (base_classes.py:594-610), packed for the RCCL
 // observation gather: [7][N] = poses_x, poses_y, poses_theta, linear_vels_x, linear_vels_y (always 0.,
 // :603), ang_vels_z, collisions.  Next to the scans it is what a consumer on another GPU needs.

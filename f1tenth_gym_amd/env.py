@@ -179,13 +179,18 @@ class F110VecEnv(object):
     cleared for the re-seated envs.
 
     device_logic=True runs the lap / done bookkeeping (F110Env._check_done) and the auto-reset on
-    the GPU (f110_episode_*): one call per step (f110_episode_step_host) uploads the actions from a
-    pinned buffer and brings `done`, the lap arrays and the scalar observation fields back in ONE
-    device-to-host copy into pinned memory.  The arrays step() returns in that mode are VIEWS of
-    that pinned block, overwritten by the next step(): copy what you keep, or pass copy_obs=True
-    (the block itself stays valid as long as any array views it, also after close()).
-    obs_fields selects the fields put into `obs` ('scans', 8.6 KB per agent, is a separate
-    read-back); everything stays available in HBM through `device_views()`.
+    the GPU: a step is ONE ABI call (f110_step_host) — the step's kernels read the actions in place
+    from a page-locked buffer (`mapped_actions`; False: a staging copy first) and one kernel writes
+    `done`, the lap arrays and the requested observation columns straight into page-locked host
+    memory (scans: one DMA copy).  The arrays step() returns in that mode are VIEWS of that block,
+    the same objects every step, overwritten by the next step(): copy what you keep, or pass
+    copy_obs=True (the block stays valid as long as any array views it, also after close()).
+    obs_fields selects the fields put into `obs` ('scans' is 8.6 KB per agent); episode_fields
+    the episode columns brought back next to `done` (default: lap_times, lap_counts in obs and
+    toggle_list, near_starts, checkpoint_done in info; () for the leanest loop); everything stays
+    available in HBM through `device_views()`.  `env.action_buffer` ([E][A][2], page-locked) can be
+    filled in place and step(None) called: no copy of the actions at all.  step_async() /
+    step_wait() split the call the way gym.vector.VectorEnv does.
 
     Domain randomisation over tracks: `extra_maps=[(yaml_path, ext), ...]` registers further maps
     (slots 1, 2, ...; `map` is slot 0) and `env_map=[slot per env]` assigns them; `set_env_maps()`
@@ -195,7 +200,11 @@ class F110VecEnv(object):
     # every key of the reference's observation (base_classes.py:594-610, docs/api/obv.rst:6-14)
     _ALL = ("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "linear_vels_y", "ang_vels_z", "collisions")
 
-    def __init__(self, num_envs, auto_reset=False, device_logic=False, obs_fields=None, copy_obs=False, **kwargs):
+    # what the device episode logic can bring back next to `done` (info keys + the two lap arrays of obs)
+    _EPISODE = ("lap_times", "lap_counts", "toggle_list", "near_starts", "checkpoint_done")
+
+    def __init__(self, num_envs, auto_reset=False, device_logic=False, obs_fields=None, copy_obs=False,
+                 episode_fields=None, mapped_actions=True, spin_wait=False, **kwargs):
         self.num_envs = int(num_envs)
         self.seed = kwargs.get('seed', 12345)
         self.map_name, self.map_path = _resolve_map_path(kwargs)
@@ -227,12 +236,48 @@ class F110VecEnv(object):
         self._start_poses = None
         self._d_actions = None
         self.copy_obs = bool(copy_obs)
+        self.episode_fields = tuple(self._EPISODE if episode_fields is None else episode_fields)
+        self.mapped_actions = bool(mapped_actions)
+        self.spin_wait = bool(spin_wait)
         if self.device_logic:
             b = self.sim.batch
             b.episode_init(self.ego_idx)
             self._d_actions = b.device_array((self.num_envs * self.num_agents, 2))
-            self._h_actions = b.pinned_empty((self.num_envs * self.num_agents, 2))
-            self._h_packed = b.pinned_empty((b.packed_bytes(),), np.uint8)
+            self._build_host_block()
+
+    def _build_host_block(self):
+        """the page-locked block f110_step_host fills, and the (obs, reward, done, info) tuple of views into it
+        that step() hands out — built once: a step is one ABI call, no per-step allocation"""
+        E, A, b = self.num_envs, self.num_agents, self.sim.batch
+        want = ["done"]
+        st_fields = {"poses_x": 0, "poses_y": 1, "poses_theta": 4, "linear_vels_x": 3, "ang_vels_z": 5}
+        if any(f in st_fields for f in self.obs_fields):
+            want.append("state")
+        want += [f for f in ("collisions", "scans") if f in self.obs_fields]
+        ep_names = {"lap_times": "lap_times", "lap_counts": "lap_counts", "toggle_list": "toggles",
+                    "near_starts": "near_starts", "checkpoint_done": "checkpoint_done"}
+        for f in self.episode_fields:
+            want.append(ep_names[f])      # KeyError: not an episode field
+        hb = self._hb = b.host_block(want)
+        v = hb.views
+        self.action_buffer = hb.actions.reshape(E, A, 2)   # write actions here and call step(None): no copy at all
+        obs = {'ego_idx': self.ego_idx}
+        for f in self.obs_fields:
+            if f in st_fields:
+                obs[f] = v["state"][st_fields[f]].reshape(E, A)
+            elif f == "linear_vels_y":
+                obs[f] = np.zeros((E, A))      # base_classes.py:603: always 0. in the reference
+            elif f == "scans":
+                obs[f] = v["scans"].reshape(E, A, -1)
+            else:
+                obs[f] = v[f].reshape(E, A)
+        info = {}
+        for f in self.episode_fields:
+            arr = v[ep_names[f]].reshape(E, A)
+            if f in ("near_starts", "checkpoint_done"):
+                arr = arr.view(np.bool_)
+            (obs if f in ("lap_times", "lap_counts") else info)[f] = arr
+        self._ret_views = (obs, self.timestep, v["done"].view(np.bool_), info)
 
     def update_params_batch(self, params):
         """a vehicle parameter set per agent of every env ([E*A] dicts or [E*A][18] array; None: back
@@ -269,31 +314,36 @@ class F110VecEnv(object):
             return self._last
         return self.step(np.zeros((self.num_envs, self.num_agents, 2)))
 
-    def _step_device(self, actions):
-        E, A = self.num_envs, self.num_agents
-        b = self.sim.batch
+    def _step_device(self, actions, sync=True):
+        b, hb = self.sim.batch, self._hb
         if self.sim._noise is not None:
             self.sim._noise.ensure(b, self.sim._steps_since_full_reset + 1)
-        self._h_actions[...] = np.asarray(actions, dtype=np.float64).reshape(E * A, 2)
-        p = b.episode_step_host(self._h_actions, self._h_packed, auto_reset=self.auto_reset)
+        if actions is not None and actions is not self.action_buffer:
+            hb.actions[...] = np.asarray(actions, dtype=np.float64).reshape(hb.actions.shape)
+        b.step_host(hb, None, auto_reset=self.auto_reset, sync=sync, mapped_actions=self.mapped_actions, spin=self.spin_wait)
         self.sim._steps_since_full_reset += 1
+        if not sync:
+            return None
+        return self._collect()
+
+    def _collect(self):
+        obs, r, done, info = self._ret_views
         if self.copy_obs:
-            p = {k: v.copy() for k, v in p.items()}
-        obs = {'ego_idx': self.ego_idx}
-        for f in self.obs_fields:
-            if f == "scans":
-                obs[f] = b.get("scans")["scans"].reshape(E, A, -1)
-            elif f == "linear_vels_y":
-                obs[f] = np.zeros((E, A))      # base_classes.py:603: always 0. in the reference
-            else:
-                obs[f] = p[f].reshape(E, A)
-        obs['lap_times'] = p["lap_times"].reshape(E, A)
-        obs['lap_counts'] = p["lap_counts"].reshape(E, A)
-        done = p["done"].astype(bool)
-        info = {'checkpoint_done': p["checkpoint_done"].reshape(E, A).astype(bool),
-                'toggle_list': p["toggles"].reshape(E, A), 'near_starts': p["near_starts"].reshape(E, A).astype(bool)}
-        self._last = (obs, self.timestep, done, info)
+            obs = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in obs.items()}
+            done, info = done.copy(), {k: v.copy() for k, v in info.items()}
+        self._last = (obs, r, done, info)
         return self._last
+
+    # gym.vector.VectorEnv's split: step_async() enqueues the whole step and returns at once, step_wait()
+    # blocks until the observation block is complete (the host may do other work in between)
+    def step_async(self, actions):
+        if not self.device_logic:
+            raise ValueError("step_async needs device_logic=True")
+        self._step_device(actions, sync=False)
+
+    def step_wait(self):
+        self.sim.batch.sync()
+        return self._collect()
 
     def step(self, actions):
         if self.device_logic:

@@ -117,6 +117,7 @@ class Simulator(object):
             else:
                 self._noise = ScanNoise(seed, num_beams, scan_noise_std)
         self._steps_since_full_reset = 0
+        self._hb = None
 
     @property
     def batch(self):
@@ -161,9 +162,18 @@ class Simulator(object):
         actions = np.asarray(control_inputs, dtype=np.float64).reshape(E * A, 2)
         if self._noise is not None:
             self._noise.ensure(self._b, self._steps_since_full_reset + 1)
-        self._b.step(actions)
+        # one ABI call per step (f110_step_host): actions up, the step, the observation written into a
+        # page-locked block; the reference hands out fresh arrays every step, so they are copied out
+        hb = self._hb
+        if hb is None:
+            hb = self._hb = self._b.host_block(("scans", "state", "agent_poses", "collisions", "collision_idx", "in_collision"))
+        hb.actions[...] = actions
+        self._b.step_host(hb)
         self._steps_since_full_reset += 1
-        o = self._b.get("scans", "state", "agent_poses", "collisions", "collision_idx", "in_collision")
+        v = hb.views
+        o = {"scans": v["scans"].copy(), "state": v["state"].T.copy(), "agent_poses": v["agent_poses"].T.copy(),
+             "collisions": v["collisions"].copy(), "collision_idx": v["collision_idx"].copy(),
+             "in_collision": v["in_collision"].copy()}
         self._state = o["state"]
         self._in_collision = o["in_collision"]
         st = o["state"]

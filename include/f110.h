@@ -230,6 +230,41 @@ int f110_host_alloc(f110_sim *h, size_t bytes, void **h_out);   /* page-locked h
 int f110_host_free(f110_sim *h, void *h_ptr);  /* h may be NULL once the handle that allocated it is destroyed */
 int f110_episode_device_views(f110_sim *h, f110_episode_views *out);
 
+/* env.step() of a host-driven loop as ONE call (replaces, per step, F110Env.step -> Simulator.step's agent
+ * loops + observation dict base_classes.py:553-612 and, once f110_episode_init was called, _check_done
+ * f110_env.py:204-246 and the re-seat of reset() :319-334): actions up, the step, the episode logic, and the
+ * requested observation columns written by one kernel straight into the caller's PAGE-LOCKED memory
+ * (f110_host_alloc — required: the kernel stores into it in place; anything else is refused with
+ * F110_ERR_INVALID), scans by one DMA copy behind it.  Any pointer may be NULL = not wanted.  The episode
+ * columns and F110_STEP_AUTO_RESET need f110_episode_init (else F110_ERR_STATE).  The block holds the
+ * observation of the step just taken; with F110_STEP_AUTO_RESET finished envs (done != 0) are re-seated
+ * at their start poses AFTER it was written, and the device-side done flag is cleared. */
+typedef struct f110_host_block {
+    double *state;            /* [7][N] columns x, y, steer, v, yaw, yaw_rate, slip (poses_x = row 0, ...) */
+    double *collisions;       /* [N] */
+    double *collision_idx;    /* [N] */
+    double *agent_poses;      /* [3][N] Simulator.agent_poses (:574 snapshot) */
+    double *lap_times;        /* [N] */
+    double *lap_counts;       /* [N] */
+    double *toggles;          /* [N] */
+    double *current_time;     /* [E] */
+    int32_t *in_collision;    /* [N] */
+    uint8_t *near_starts;     /* [N] */
+    uint8_t *checkpoint_done; /* [N] */
+    uint8_t *done;            /* [E] */
+    double *scans;            /* [N][B] (any host memory; page-locked for a full-rate copy) */
+} f110_host_block;
+#define F110_STEP_AUTO_RESET 1      /* re-seat finished envs inside the call */
+#define F110_STEP_NO_SYNC 2         /* return once everything is enqueued: f110_sync(h) completes the block
+                                       (gym.vector's step_async / step_wait split) */
+#define F110_STEP_ACTIONS_MAPPED 4  /* h_actions is f110_host_alloc memory: read in place, no staging copy */
+#define F110_STEP_SPIN_WAIT 8       /* wait by polling a page-locked completion word the last workgroup stores,
+                                       instead of a runtime synchronise (ignored with scans / NO_SYNC) */
+int f110_step_host(f110_sim *h, const double *h_actions /* [N][2] */, const f110_host_block *out, int32_t flags);
+/* measurement aid: {calls, host microseconds spent enqueuing, host microseconds spent waiting} of the
+ * f110_step_host calls since the last read (cleared by the read) */
+int f110_step_host_stats(f110_sim *h, double *out3);
+
 /* Simulator.step base_classes.py:553-612.  actions [N][2] = (steer, speed).
  * Asynchronous on the handle's stream; outputs are read with f110_get_* (which sync). */
 int f110_step(f110_sim *h, const double *h_actions);

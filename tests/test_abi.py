@@ -38,6 +38,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_ffi.Config) == 12 * 4 + 6 * 8 + 18 * 8
     assert _ffi.Config.fov.offset == 48 and _ffi.Config.params.offset == 96
     assert C.sizeof(_ffi.ObsHost) == 12 * 8 and C.sizeof(_ffi.DeviceViews) == 8 * 8
+    assert C.sizeof(_ffi.HostBlock) == 13 * 8 and _ffi.HostBlock.scans.offset == 12 * 8 and _ffi.HostBlock.in_collision.offset == 8 * 8
 
 
 def test_no_gpu_fails_loudly():
