@@ -102,6 +102,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-reset", action="store_true")
     ap.add_argument("--separate-reset", action="store_true", help="re-seat finished envs with a separate launch per step instead of inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in legs (F110Env on 1 env, F110VecEnv at 2048 / 32768 envs)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--map-tiles", type=int, default=1, help="tile example_map k x k (BASELINE config 5 uses 2: a 3200x3200 table)")
     ap.add_argument("--fixed-pose-steps", type=int, default=100, help="also time this many steps with all cars parked (0 = skip)")
@@ -629,6 +630,56 @@ def cpu_baseline(args, seconds):
                                  "shape in numba on one core; numba cannot be installed here, so the C restatement stands in)" % (A, steps1, el1)}}
 
 
+def dropin_rates(args):
+    """The paths an RL loop actually calls, timed on the HIP library (wall clock around the Python calls):
+    (i) BASELINE configs[0] as the drop-in runs it — F110Env(num_agents=2).step(action) on ONE env, host actions in,
+    the reference's observation dict (scans included) out, episode logic on the host, exactly f110_env.py:263-304;
+    (ii) F110VecEnv(E, device_logic=True, auto_reset=True): host actions in, `done` + lap arrays out, observations
+    left in HBM — one f110_step_host call per step."""
+    import numpy as np
+    from _util import MAPS
+    import f1tenth_gym_amd as amd
+    kw = dict(map=os.path.join(MAPS, "example_map"), map_ext=".png", num_agents=args.agents_per_env)
+    out = {}
+
+    def timed(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return (time.perf_counter() - t0) / n
+    A = args.agents_per_env
+    env = amd.F110Env(**kw)
+    env.reset(start_poses_for(shard_envs(1, 0), A))
+    act = np.array([[0.05, 3.0], [-0.05, 2.5]] * A)[:A]
+    dt = timed(lambda: env.step(act), 3000, 200)
+    env.sim.batch.close()
+    out["f110env_1env"] = {"workload": "F110Env(num_agents=%d).step(action): 1 env, host actions, obs dict with scans (BASELINE configs[0] through the HIP path)" % A,
+                           "us_per_step": 1e6 * dt, "env_steps_per_s": 1.0 / dt, "value": A / dt, "unit": "agent-steps/s"}
+    for E in (2048, 32768):
+        poses = start_poses_for(shard_envs(E, 0), A).reshape(E, A, 3)
+        act = np.stack([a.reshape(E, A, 2) for a in action_sets(1, E * A, seed=1000)])[0]
+        rec = {}
+        for name, ekw, inplace in (("step_actions", {}, False), ("inplace_actions_lean", {"episode_fields": ()}, True),
+                                   ("inplace_actions_lean_spin", {"episode_fields": (), "spin_wait": True}, True)):
+            venv = amd.F110VecEnv(E, auto_reset=True, device_logic=True, obs_fields=(), **ekw, **kw)
+            venv.reset(poses)
+            n = 600 if E <= 4096 else 150
+            if inplace:
+                venv.action_buffer[...] = act
+                dt = timed(lambda: venv.step(None), n, 50)
+            else:
+                dt = timed(lambda: venv.step(act), n, 50)
+            _, enq, wait = venv.sim.batch.step_host_stats()
+            venv.sim.batch.close()
+            rec[name] = {"ms_per_step": 1e3 * dt, "value": E * A / dt, "host_enqueue_us": enq, "host_wait_us": wait}
+        out["vecenv_%d" % E] = dict(rec, workload="F110VecEnv(%d envs x %d, device_logic=True, auto_reset=True, obs_fields=()): step_actions = step(ndarray) with the "
+                                    "default episode fields; inplace_actions_lean = actions written into env.action_buffer, episode_fields=() (done only); "
+                                    "_spin = completion word polled instead of hipStreamSynchronize" % (E, A), unit="agent-steps/s")
+    return out
+
+
 def stub_run(args, rdv, steps, leg="headline"):
     """tests (no GPU): every rank 'steps' by sleeping; rank r pretends to be slower by r ms, the gather legs by 50 / 25 %"""
     if os.environ.get("F110_BENCH_STUB_FAIL") == leg and rdv.rank == rdv.world - 1:
@@ -870,6 +921,8 @@ def main(argv=None):
             line["config"]["fixed_pose_variant"] = {"workload": "same agents parked on their start poses (speed 0, no resets)",
                                                     "value": args.agents * args.fixed_pose_steps / r3["elapsed_s"],
                                                     "ms_per_step": 1e3 * r3["elapsed_s"] / args.fixed_pose_steps}
+        if not args.no_dropin and args.beams == 1080 and args.map_tiles == 1:
+            line["config"]["dropin"] = dropin_rates(args)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             line["parity_gate"] = parity_gate(args, rdv)

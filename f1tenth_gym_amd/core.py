@@ -59,17 +59,38 @@ def load_map_files(map_path, map_ext):
     yaml with 'resolution' and 'origin'.  Returns (uint8 image top-row-first, resolution, origin)."""
     from . import mapio   # stdlib zlib + NumPy: the box needs neither PIL nor PyYAML
     map_img_path = os.path.splitext(map_path)[0] + map_ext
-    if map_img_path.lower().endswith(".png"):
-        img = mapio.read_png_gray(map_img_path)
-    else:   # any other image format the reference would hand to PIL: PIL it is, if installed
+
+    def pil_image():
         from PIL import Image
-        img = np.array(Image.open(map_img_path))
-        if img.ndim != 2:
-            raise ValueError("map image must be single-channel grayscale, got shape %s" % (img.shape,))
+        with Image.open(map_img_path) as im:
+            arr = np.array(im)
+        if arr.dtype == np.bool_:      # 1-bit map_server images: PIL hands out booleans, the reference's
+            arr = arr.astype(np.uint8) * 255   # astype(float64) would see 0 / 1; thresholded as black / white here
+        if arr.ndim != 2:
+            raise ValueError("map image must be single-channel grayscale, got shape %s" % (arr.shape,))
+        return arr
+    if map_img_path.lower().endswith(".png"):
+        try:
+            img = mapio.read_png_gray(map_img_path)
+        except ValueError as ex:   # palette / 1-2-4-bit / interlaced PNGs: what the reference hands to PIL, if PIL is here
+            try:
+                img = pil_image()
+            except ImportError:
+                raise ex
+    else:   # any other image format the reference would hand to PIL: PIL it is, if installed
+        img = pil_image()
     if img.dtype != np.uint8:
         # the reference thresholds the decoded values at 128 (laser_models.py:403-404)
         img = np.where(img.astype(np.float64) > 128., 255, 0).astype(np.uint8)
-    meta = mapio.read_map_yaml(map_path)
+    try:
+        meta = mapio.read_map_yaml(map_path)
+    except ValueError as ex:   # block-style lists / nested keys: yaml.safe_load like the reference (:410-416), if PyYAML is here
+        try:
+            import yaml
+        except ImportError:
+            raise ex
+        with open(map_path) as f:
+            meta = yaml.safe_load(f)
     return np.ascontiguousarray(img), float(meta['resolution']), [float(v) for v in meta['origin']]
 
 
@@ -91,12 +112,17 @@ class DeviceArray(object):
         # an owned buffer is returned to the device when the array is collected, on `with` exit, or by
         # free() — whichever comes first; never after its handle is gone (the handle frees nothing of ours,
         # but f110_device_free needs it alive: BatchSim.close() runs the outstanding finalisers first)
-        self._fin = weakref.finalize(self, DeviceArray._release, sim, ptr) if self._owned else None
-        if self._fin is not None:
+        self._fin = None
+        if self._owned:
+            holder = []
+            self._fin = weakref.finalize(self, DeviceArray._release, sim, ptr, holder)
+            holder.append(self._fin)
             sim._device_arrays.add(self._fin)
 
     @staticmethod
-    def _release(sim, ptr):
+    def _release(sim, ptr, holder=None):
+        if holder:                       # the finaliser takes itself off the handle's list (no growth in long loops)
+            sim._device_arrays.discard(holder[0])
         if sim._h and ptr:
             _ffi.lib().f110_device_free(sim._h, ptr)
 
@@ -125,6 +151,9 @@ class DeviceArray(object):
     def download_part(self, first_row, n_rows):
         """rows [first_row, first_row + n_rows) along the leading axis (a receive buffer of many ranks' blocks is
         read back one block at a time instead of as one multi-GB host array)"""
+        first_row, n_rows = int(first_row), int(n_rows)
+        if first_row < 0 or n_rows < 0 or first_row + n_rows > self.shape[0]:
+            raise IndexError("rows [%d, %d) are outside an array of %d rows" % (first_row, first_row + n_rows, self.shape[0]))
         row_bytes = (int(np.prod(self.shape[1:])) if len(self.shape) > 1 else 1) * self.dtype.itemsize
         out = np.empty((int(n_rows),) + self.shape[1:], dtype=self.dtype)
         check(_ffi.lib().f110_memcpy_d2h(self.sim._h, out.ctypes.data, self.ptr + int(first_row) * row_bytes, out.nbytes), self.sim._h)

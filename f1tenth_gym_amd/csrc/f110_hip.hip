@@ -389,11 +389,13 @@ static int task_order_setup(f110_sim *h, bool on)
             TRY(dmalloc(h, &h->d_tflags[q], n_tasks));
             TRY(dmalloc(h, &h->d_tlist[q], (size_t)h->task_cap_alloc));
             HIPCHK(h, hipMemsetAsync(h->d_tflags[q], 0, sizeof(uint32_t) * n_tasks, h->stream));
-            TRY(dmalloc(h, &h->d_rflags[q], n_rays));
-            TRY(dmalloc(h, &h->d_rlist[q], (size_t)h->ray_cap));
-            TRY(dmalloc(h, &h->d_rtask[q], n_tasks));
-            HIPCHK(h, hipMemsetAsync(h->d_rtask[q], 0, sizeof(uint32_t) * n_tasks, h->stream));
-            HIPCHK(h, hipMemsetAsync(h->d_rflags[q], 0, sizeof(uint32_t) * n_rays, h->stream));
+            if (kExperimental) {   // the ray-level lists belong to the ray pass, which only the lab build has: the product's r* stay null
+                TRY(dmalloc(h, &h->d_rflags[q], n_rays));
+                TRY(dmalloc(h, &h->d_rlist[q], (size_t)h->ray_cap));
+                TRY(dmalloc(h, &h->d_rtask[q], n_tasks));
+                HIPCHK(h, hipMemsetAsync(h->d_rtask[q], 0, sizeof(uint32_t) * n_tasks, h->stream));
+                HIPCHK(h, hipMemsetAsync(h->d_rflags[q], 0, sizeof(uint32_t) * n_rays, h->stream));
+            }
         }
         TRY(dmalloc(h, &h->d_tcount, 4));   // {task count 0, 1, ray count 0, 1}
         HIPCHK(h, hipMemsetAsync(h->d_tcount, 0, 4 * sizeof(uint32_t), h->stream));

@@ -59,6 +59,18 @@ def test_gpu_suite_on_the_experimental_build():
     tail = out.stdout[-3000:]
     assert out.returncode == 0, tail
     assert " passed" in tail and " failed" not in tail, tail
+    # the count is part of the assertion: a nested collection problem that still exits 0 with "1 passed" would
+    # otherwise be invisible.  In the lab build nothing of the suite may skip except this test and the two tests that
+    # need several devices; everything the product run skipped as LAB_ONLY must have run here.
+    import re
+    m = re.search(r"(\d+) passed(?:, (\d+) skipped)?", tail)
+    assert m, tail
+    passed, skipped = int(m.group(1)), int(m.group(2) or 0)
+    collected = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "--collect-only", "-q", "-p", "no:cacheprovider"],
+                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
+    n_tests = int(re.search(r"(\d+)(?:/\d+)? tests collected", collected).group(1))
+    assert passed + skipped == n_tests, (passed, skipped, n_tests, tail)
+    assert passed >= 150 and skipped <= 10, (passed, skipped, tail)
 
 
 def test_product_library_refuses_the_lab(amd):

@@ -123,6 +123,17 @@ def test_png_and_yaml_readers_need_neither_pil_nor_pyyaml(tmp_path, monkeypatch)
     bad.write_text("a:\n  b: 1\n")
     with pytest.raises(ValueError):
         mapio.read_map_yaml(str(bad))
+    # what the stdlib readers refuse goes to PIL / PyYAML when they are installed (the reference's own loaders,
+    # laser_models.py:397-416): a palette PNG, a 1-bit PNG, a block-style yaml list
+    from f1tenth_gym_amd.core import load_map_files
+    gray = np.array(Image.open(os.path.join(MAPS, "berlin.png")))[:64, :80]
+    Image.fromarray(gray).convert("P").save(str(tmp_path / "pal.png"))
+    Image.fromarray(gray > 128).save(str(tmp_path / "bw.png"))
+    for stem in ("pal", "bw"):
+        (tmp_path / (stem + ".yaml")).write_text("image: %s.png\nresolution: 0.05\norigin:\n  - -1.0\n  - 2.0\n  - 0.0\n" % stem)
+        img, res, origin = load_map_files(str(tmp_path / (stem + ".yaml")), ".png")
+        assert img.dtype == np.uint8 and img.shape == (64, 80) and res == 0.05 and origin == [-1.0, 2.0, 0.0]
+        assert np.array_equal(img > 128, gray > 128) or stem == "pal"
     # with PIL and yaml unimportable, set_map's file handling still works
     from f1tenth_gym_amd.core import load_map_files
     monkeypatch.setitem(sys.modules, "PIL", None)
