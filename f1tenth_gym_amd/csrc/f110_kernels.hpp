@@ -1092,7 +1092,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_D
     ScanConst km = k;   // PER_ENV_MAP: this agent's track (f110_set_env_maps), reloaded when the slot changes
     const ScanConst *cold = j.k_cold;
     int cur_slot = -1;
-    int carry_p = -1, carry_s = -1, carry_b = 0;   // (agent, first direction, first beam) the previous task of this wave handed on
     for (uint32_t t = 0; t < tpw; ++t) {
         const uint32_t task = __builtin_amdgcn_readfirstlane(wave * tpw + t);
         if (task >= j.n_tasks) break;
@@ -1139,82 +1138,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_D
         };
         int b0 = 0;
         if (s0 > 0) {
-            if (carry_p == (int)p && carry_s == s0) {
-                b0 = carry_b;   // the previous task of this wave ended exactly where this one begins (wave-uniform)
-            } else {
-                b0 = (int)ceil(((double)s0 - (start - floor(start))) / k.theta_inc) - 2;
-                b0 = b0 < 0 ? 0 : (b0 >= (int)B ? (int)B - 1 : b0);
-                b0 = __builtin_amdgcn_readfirstlane(b0);
-                while (b0 > 0 && rel_of(b0 - 1) >= s0) --b0;
-                while (b0 < (int)B && rel_of(b0) < s0) ++b0;
-            }
+            b0 = (int)ceil(((double)s0 - (start - floor(start))) / k.theta_inc) - 2;
+            b0 = b0 < 0 ? 0 : (b0 >= (int)B ? (int)B - 1 : b0);
+            b0 = __builtin_amdgcn_readfirstlane(b0);
+            while (b0 > 0 && rel_of(b0 - 1) >= s0) --b0;
+            while (b0 < (int)B && rel_of(b0) < s0) ++b0;
         }
-        // The beams [b0, b1) that use these 64 directions, TWO per lane and pass: lane l takes the even / odd pair
-        // (base + 2l, base + 2l + 1), so a pass moves 128 beams with one 16-byte noise load and one 16-byte store per
-        // lane (round 4; one beam per lane before: the pass was 64 beams wide and a task took three of them — the
-        // kernel is bound by wave-level vector-memory instructions, profiles/r03_pmc_cfg5.json).  A pair that
-        // straddles an end of the task's range is finished with an 8-byte store of its own half.
-        // The table index of a beam is beam_dir_index's closed form with the reduction mod theta_dis done on the
-        // integer (start < theta_dis and b * theta_inc < theta_dis: the sum wraps at most once, and subtracting
-        // theta_dis from a value in [theta_dis, 2 theta_dis) is exact): the same fractional part goes through the
-        // same guard test, and a lane within dir_guard of an integer takes beam_dir_index itself.
-        const double td = (double)k.theta_dis;
-        auto rel_pair = [&](int b, bool live) {
-            const double t = fma((double)b, k.theta_inc, start);
-            const double fr = t - floor(t);
-            int idx = (int)t;
-            idx = idx >= k.theta_dis ? idx - k.theta_dis : idx;
-            if (live && !(fabs(fr - 0.5) < 0.5 - k.dir_guard)) idx = beam_dir_index(k, start, b);   // (about 1 beam in 10^5)
-            const int rr = idx - i0;
-            return rr < 0 ? rr + k.theta_dis : rr;
-        };
-        int b1 = (int)B;
-        const bool wide = (B & 1u) == 0u;
-        for (int base = b0 & ~1;; base += 128) {   // every lane takes part in every shuffle
-            const int bA = base + 2 * (int)lane, bB = bA + 1;
-            const bool liveA = bA >= b0 && bA < (int)B, liveB = bB >= b0 && bB < (int)B;
-            const int srcA = rel_pair(bA, liveA) - s0, srcB = rel_pair(bB, liveB) - s0;
-            const bool inA = liveA && srcA < 64, inB = liveB && srcB < 64;
-            const double rA0 = __shfl(r_dir, inA ? srcA : 0), rB0 = __shfl(r_dir, inB ? srcB : 0);
-            if (inA || inB) {
-                const uint32_t ray = p * B + (uint32_t)bA;   // even when B is: 16-byte aligned rows
-                double2 nz = make_double2(0., 0.);
-                if (wide) {
-                    if (row >= 0)
-                        nz = *reinterpret_cast<const double2 *>(j.noise + (size_t)row * B + bA);
-                    else if (row == -2)
-                        nz = *reinterpret_cast<const double2 *>(j.ranges + ray);   // this step's noise row, left in scans[] by k_noise_rows
-                } else if (row != -1) {   // an odd number of beams: rows are not 16-byte aligned, element accesses
-                    const double *src = row >= 0 ? j.noise + (size_t)row * B + bA : j.ranges + ray;
-                    if (inA) nz.x = src[0];
-                    if (inB) nz.y = src[1];
-                }
-                const double rA = row != -1 ? rA0 + nz.x : rA0, rB = row != -1 ? rB0 + nz.y : rB0;
-                if (vel != 0.0) {
-                    const double far = j.ttc_side_max + j.ttc_k * fabs(vel);
-                    if ((inA && !(rA > far) && ttc_beam_hit(rA, j.side_dist[bA], vel, j.beam_cos[bA], j.ttc_thresh)) ||
-                        (inB && !(rB > far) && ttc_beam_hit(rB, j.side_dist[bB], vel, j.beam_cos[bB], j.ttc_thresh)))
-                        j.wall_flag[p] = 1;
-                }
-                if (inA && inB && wide) {
-                    *reinterpret_cast<double2 *>(j.ranges + ray) = make_double2(rA, rB);
-                } else {
-                    if (inA) j.ranges[ray] = rA;
-                    if (inB) j.ranges[ray + 1] = rB;
-                }
+        for (int b = b0 + (int)lane;; b += 64) {   // every lane takes part in every shuffle
+            bool in = b < (int)B;
+            int src = 0;
+            if (in) {
+                src = rel_of(b) - s0;
+                in = src < 64;
             }
-            // the indices are monotone: the first beam that is past the task's directions (or past the scan) ends it
-            const uint64_t endA = __ballot(bA >= b0 && !inA), endB = __ballot(bB >= b0 && !inB);
-            if ((endA | endB) != 0ull) {
-                const int eA = endA ? base + 2 * (int)__builtin_ctzll(endA) : 0x7fffffff;
-                const int eB = endB ? base + 2 * (int)__builtin_ctzll(endB) + 1 : 0x7fffffff;
-                b1 = eA < eB ? eA : eB;
-                break;
-            }
+            const double r = __shfl(r_dir, in ? src : 0);
+            if (in) finish_beam(j, B, p, b, p * B + (uint32_t)b, r, row, vel);
+            if (__ballot(!in) != 0ull) break;   // the indices are monotone: nothing further belongs to this task
         }
-        carry_p = (int)p;
-        carry_s = s0 + 64;
-        carry_b = b1 < (int)B ? b1 : (int)B;
     }
     if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
 }
