@@ -582,10 +582,11 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         G = std::min(std::min(G, 16), cfg->num_envs);
         h->groups = G;
         h->use_graph = cfg->step_graph != 0;
-        // pair tests + opponent windows inside the finalize kernel: A = 2 (k_finalize_pair_roles) and every A whose
-        // ordered pairs of one env fit a workgroup's record table (k_finalize_multi: A <= 16); above that the
-        // round-1 form (k_collide on the side stream + k_finalize)
-        h->collide_mode = (cfg->num_agents >= 2 && cfg->num_agents * (cfg->num_agents - 1) <= kMaxRecBig) ? 3 : 0;
+        // pair tests + opponent windows inside the finalize kernel: A = 2 (k_finalize_pair_roles) and every A up to
+        // kMaxAgentsMulti = 256 (k_finalize_multi up to 16, k_finalize_multi_tiled above: an env's ordered pairs in tiles of a
+        // workgroup's record table); above
+        // that — no use case known — the round-1 form (k_collide on the side stream + k_finalize)
+        h->collide_mode = (cfg->num_agents >= 2 && cfg->num_agents <= kMaxAgentsMulti) ? 3 : 0;
         for (int g = 0; g < G && G > 1; ++g) {
             hipStream_t gs = nullptr;
             hipEvent_t ge = nullptr;
@@ -1911,7 +1912,8 @@ static int noise_cache_extend(f110_sim *h, int upto)
 //   A = 1                      k_integrate -> scan -> k_finalize_solo
 //   A = 2                      k_integrate -> scan -> k_finalize_pair_roles    (pair test + window inside the last kernel)
 //   A = 3 .. 16                k_integrate -> scan -> k_finalize_multi         (the same for every ordered pair of an env)
-//   A > 16                     k_integrate -> { scan || k_collide on the side stream } -> k_finalize
+//   A = 17 .. 256              k_integrate -> scan -> k_finalize_multi_tiled   (the env's ordered pairs in tiles of 256 records)
+//   A > 256                    k_integrate -> { scan || k_collide on the side stream } -> k_finalize
 // and the scan kernel by table / beam count: k_scan_rays_agent (PADDED table; longest-first order for small
 // batches), k_scan_dirs_agent (more beams than table directions), k_scan_rays (row-major table, few beams).
 // The experimental build adds collide_mode 1 (pair tests fused into k_integrate) / 2 (k_collide in line), the
@@ -1974,7 +1976,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     // balances that inside the workgroup: 65 536 parked cars 0.624 -> 0.579 ms, crashed cars piling up 0.899 -> 0.852.)
     const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0 &&
                                   (kFinalizeFlatDefault || h->dev.reseat_poses != nullptr || N < 8192 || (kExperimental && h->exp.pair_always));
-    const bool multi_in_finalize = multi && collide_mode == 3 && A > 2 && A * (A - 1) <= kMaxRecBig && (begin % A) == 0 && (count % A) == 0;
+    const bool multi_in_finalize = multi && collide_mode == 3 && A > 2 && A <= kMaxAgentsMulti && (begin % A) == 0 && (count % A) == 0;
     const bool no_collide_launch = fused_integrate || pair_in_finalize || multi_in_finalize;
     const bool side_collide = multi && !no_collide_launch && !(kExperimental && collide_mode == 2);
     // k_collide only feeds k_finalize, k_scan_rays only needs k_integrate: run the two side by
@@ -2208,8 +2210,10 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             if (A * (A - 1) <= kMaxRec) {
                 const int G = kMaxRec / (A * (A - 1));
                 hipLaunchKernelGGL(k_finalize_multi<kMaxRec>, dim3((envs + G - 1) / G), dim3(256), 0, st, dev, B, G);
-            } else {
+            } else if (A * (A - 1) <= kMaxRecBig) {
                 hipLaunchKernelGGL(k_finalize_multi<kMaxRecBig>, dim3(envs), dim3(256), 0, st, dev, B, 1);
+            } else {   // more than 16 agents: one env per workgroup, its A (A - 1) records in tiles of 256
+                hipLaunchKernelGGL(k_finalize_multi_tiled<kMaxRecBig>, dim3(envs), dim3(256), multi_lds_bytes(A, kMaxRecBig), st, dev, B, 1);
             }
         }
         else if (lanes == 8)

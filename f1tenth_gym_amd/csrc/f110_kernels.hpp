@@ -1926,6 +1926,226 @@ __global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B
     }
 }
 
+// ---- K3t: envs of MORE than sixteen agents (round 4) — k_finalize_multi with the env's ordered pairs in TILES -------
+// k_finalize_multi for any number of agents per env (17 ... 256; it also runs 3 ... 16, where k_finalize_multi's role-parallel
+// form is faster: A = 8 75.7 against 79.3 M agent-steps/s, 16: equal): a workgroup holds G whole envs of A agents.  What k_collide + k_finalize did with one lane per agent (a serial loop over the A - 1 opponents: box, GJK, two
+// beam windows, 80 bytes of windows and boxes through HBM per ordered pair, a side stream with an event fork / join
+// around the scan) is one kernel behind the scan:
+//   agents    once per agent, into LDS: the live pose and the heading the ray cast uses (0 after a wall hit, :246-249),
+//             head = atan2(sin, cos) of it (get_blocked_view_indices :296-297), and cos / sin of the agent's :574
+//             snapshot heading (what every box drawn around it needs) — per AGENT, not per ordered pair (round 4: the
+//             record threads of round 3 recomputed them 4 (A - 1) times);
+//   pairs     every UNORDERED pair (p < q) of an env: collision_multiple's GJK in the reference's (lower, higher)
+//             argument order behind a conservative reject (centres further apart than the boxes' diagonal: the
+//             prune north_star asks for; SURVEY a15: flag-preserving) — the largest colliding partner per agent by
+//             atomicMax (collision_multiple's last writer, :199-210);
+//   records   every ORDERED pair (agent i, opponent o), in tiles of at most MAXREC: first the disc cull (beams whose
+//             ray can touch the disc around o's box), then — only for records the cull leaves a window — the four
+//             corners of o's box (drawn with i's length / width, RaceCar.ray_cast_agents :223) -> beam indices, four
+//             threads per record;
+//   windows   a tile's beam windows flattened into one item list over the 256 threads.  An item whose map range is
+//             already shorter than the distance to the nearest point of o's disc is finished (every edge distance is
+//             at least that far: the minimum keeps the map range).  Two opponents of one agent may cover the same
+//             beam; the reference takes them one after the other, each keeping the smaller range (:206-227), i.e. the
+//             minimum — ranges are non-negative doubles, whose bit patterns order like unsigned integers, so the items
+//             settle it with atomicMin on the pattern: no rounds, no order, the same value — also across tiles.
+//   flags     Simulator's collision OR (:588-589), check_ttc's side effects, step count, re-seat: one thread per agent.
+// Same functions on the same operands as collide_agent / k_finalize: bit-identical (test_finalize_multi_*,
+// tests/golden/sim_rollout_multi.npz = the reference itself at A = 3, 4, 8).
+constexpr int kMaxAgentsMulti = 256;   // agents per env this kernel takes (its per-agent LDS table)
+struct MultiAgentLds {   // one per agent of the workgroup
+    double ex, ey, eth, head;      // live position, ray-cast heading, atan2(sin(eth), cos(eth))
+    double ox, oy, co, so;         // :574 snapshot position, cos / sin of the snapshot heading
+};
+// dynamic LDS of k_finalize_multi for `agents` agents per workgroup (host and device agree through this one function):
+// the agent table, a tile's boxes / near distances, a tile's int tables, the scan offsets, the partners
+__host__ __device__ inline size_t multi_lds_bytes(int agents, int maxrec)
+{
+    return sizeof(MultiAgentLds) * (size_t)agents + (size_t)maxrec * 9 * sizeof(double) + sizeof(int) * ((size_t)maxrec * 8 + (size_t)maxrec + 1 + 4 + (size_t)agents) + 16;
+}
+
+template <int MAXREC>
+__global__ void __launch_bounds__(256) k_finalize_multi_tiled(AgentArrays a, int32_t B, int G)
+{
+    static_assert(MAXREC == 64 || MAXREC == 256, "record tile sizes");
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    const int t = (int)threadIdx.x;
+    const int A = a.agents_per_env, N = a.n_agents_total;
+    const int per_env = A * (A - 1), pairs_env = per_env / 2;
+    const int first = a.agent_begin + (int)blockIdx.x * G * A, end = a.agent_begin + a.agent_count;
+    int envs = (end - first) / A;
+    envs = envs < G ? envs : G;                 // (whole envs only: ranges are env-aligned)
+    const int R = envs * per_env, P = envs * pairs_env, AGN = envs * A;
+    // LDS carve-up (dynamic: sized by the launch for G * A agents, multi_lds_bytes)
+    MultiAgentLds *s_ag = reinterpret_cast<MultiAgentLds *>(s_raw);
+    double (*s_box)[8] = reinterpret_cast<double (*)[8]>(s_ag + G * A);   // a record's opponent box
+    double *s_near = reinterpret_cast<double *>(s_box + MAXREC);          // a map range below this cannot be lowered by the record
+    int (*s_idx)[4] = reinterpret_cast<int (*)[4]>(s_near + MAXREC);
+    int *s_cl = reinterpret_cast<int *>(s_idx + MAXREC), *s_ch = s_cl + MAXREC, *s_lo = s_ch + MAXREC, *s_agent = s_lo + MAXREC;
+    int *s_off = s_agent + MAXREC;      // [MAXREC + 1]
+    int *s_wsum = s_off + MAXREC + 1;   // [4]
+    int *s_partner = s_wsum + 4;        // [G * A] largest colliding partner (slot index) or -1
+
+    // ---- agents: everything that is per agent, once
+    for (int ag = t; ag < AGN; ag += 256) {
+        const int i = first + ag;
+        MultiAgentLds m;
+        m.ex = a.state[i];
+        m.ey = a.state[(size_t)N + i];
+        const double th_live = a.state[4 * (size_t)N + i];   // == the :574 snapshot heading: nothing has zeroed it yet
+        m.eth = a.in_collision[i] ? 0.0 : th_live;
+        double ce_, se_;
+        cos_sin(m.eth, ce_, se_);
+        m.head = atan2(se_, ce_);
+        m.ox = a.snap_pose[i];
+        m.oy = a.snap_pose[(size_t)N + i];
+        cos_sin(a.snap_pose[2 * (size_t)N + i], m.co, m.so);
+        s_ag[ag] = m;
+        s_partner[ag] = -1;
+    }
+    __syncthreads();
+
+    // ---- pairs: collision_multiple's pair (p < q) of the env, boxes with the Simulator's length / width (:549)
+    {
+        const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+        for (int pr = t; pr < P; pr += 256) {
+            const int e = pr / pairs_env;
+            int w = pr - e * pairs_env, p = 0;
+            while (w >= A - 1 - p) { w -= A - 1 - p; ++p; }   // row p of the upper triangle holds A - 1 - p pairs
+            const int q = p + 1 + w;
+            const MultiAgentLds &mp = s_ag[e * A + p], &mq = s_ag[e * A + q];
+            const double cdx = mq.ox - mp.ox, cdy = mq.oy - mp.oy;
+            if (cdx * cdx + cdy * cdy <= reach * reach) {
+                double lower[8], higher[8];
+                box_vertices_cs(mp.ox, mp.oy, mp.co, mp.so, a.box_length, a.box_width, lower);
+                box_vertices_cs(mq.ox, mq.oy, mq.co, mq.so, a.box_length, a.box_width, higher);
+                if (gjk_overlap(lower, higher)) {
+                    atomicMax(&s_partner[e * A + p], q);
+                    atomicMax(&s_partner[e * A + q], p);
+                }
+            }
+        }
+    }
+
+    // ---- records, tile by tile
+    for (int tile = 0; tile < R; tile += MAXREC) {
+        const int RT = (R - tile) < MAXREC ? (R - tile) : MAXREC;   // records of this tile
+        // the disc cull of record `rec` (and who it is)
+        for (int rec = t; rec < RT; rec += 256) {
+            const int gr = tile + rec;
+            const int e = gr / per_env, w = gr - e * per_env, me = w / (A - 1), k = w - me * (A - 1), oj = k < me ? k : k + 1;
+            const int ia = e * A + me;
+            const MultiAgentLds &mm = s_ag[ia], &mo = s_ag[e * A + oj];
+            const size_t prow = (size_t)(a.params_per_agent ? first + ia : me) * NPARAMS;
+            const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
+            const double dx = mo.ox - mm.ex, dy = mo.oy - mm.ey;
+            const double norm = sqrt(dx * dx + dy * dy);
+            const double dir = atan2(dy, dx);
+            const double rad = 0.5 * sqrt(blen * blen + bwid * bwid);
+            int cl, ch;
+            disc_beam_range_from(norm, mm.eth, dir, mm.head, rad, a.scan_angles, B, a.angle_inc, cl, ch);
+            s_cl[rec] = cl;
+            s_ch[rec] = ch;
+            s_agent[rec] = ia;
+            s_near[rec] = norm - rad * 1.000001 - 1e-9;   // no point of the box is nearer than this
+            if (cl <= ch) box_vertices_cs(mo.ox, mo.oy, mo.co, mo.so, blen, bwid, s_box[rec]);
+        }
+        __syncthreads();
+        // corner `sub` of record `rec`'s opponent box -> beam index (records with an empty cull are skipped)
+        for (int q = t; q < 4 * RT; q += 256) {
+            const int rec = q >> 2, sub = q & 3;
+            if (s_cl[rec] > s_ch[rec]) continue;
+            const MultiAgentLds &mm = s_ag[s_agent[rec]];
+            const double px = s_box[rec][2 * sub], py = s_box[rec][2 * sub + 1];
+            const double dx = px - mm.ex, dy = py - mm.ey;
+            const double norm = sqrt(dx * dx + dy * dy);
+            const double dir = atan2(dy / norm, dx / norm);
+            s_idx[rec][sub] = vertex_beam_from_angles(mm.head, dir, a.scan_angles, B, a.angle_inc);
+        }
+        __syncthreads();
+        if (t < MAXREC) {   // every record's window = corner hull clipped by the disc cull
+            const int rec = t;
+            int lo = 0, cnt = 0;
+            if (rec < RT && s_cl[rec] <= s_ch[rec]) {
+                const int i0 = s_idx[rec][0], i1 = s_idx[rec][1], i2 = s_idx[rec][2], i3 = s_idx[rec][3];
+                int ref_lo = i0 < i1 ? i0 : i1, t2 = i2 < i3 ? i2 : i3;
+                ref_lo = ref_lo < t2 ? ref_lo : t2;
+                int ref_hi = i0 > i1 ? i0 : i1;
+                t2 = i2 > i3 ? i2 : i3;
+                ref_hi = ref_hi > t2 ? ref_hi : t2;
+                const int cl = s_cl[rec], ch = s_ch[rec];
+                lo = ref_lo > cl ? ref_lo : cl;
+                const int hi = ref_hi < ch ? ref_hi : ch;
+                cnt = hi >= lo ? hi - lo + 1 : 0;
+            }
+            s_lo[rec] = lo;
+            int c = cnt;   // inclusive scan over the wave's 64 records
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(c, d);
+                if ((rec & 63) >= d) c += up;
+            }
+            s_off[rec + 1] = c;
+            if (rec == 0) s_off[0] = 0;
+            if (MAXREC > 64 && (rec & 63) == 63) s_wsum[rec >> 6] = c;
+        }
+        __syncthreads();
+        if (MAXREC > 64) {   // the later waves' records start behind the earlier waves' totals
+            if (t >= 64 && t < MAXREC) {
+                int base = 0;
+                for (int w = 0; w < (t >> 6); ++w) base += s_wsum[w];
+                s_off[t + 1] += base;
+            }
+            __syncthreads();
+        }
+        const int total = s_off[MAXREC];
+        for (int item = t; item < total; item += 256) {
+            int rec = 0;   // the largest rec with s_off[rec] <= item (its window is not empty: item < s_off[rec + 1])
+#pragma unroll
+            for (int st = MAXREC / 2; st; st >>= 1)
+                if (s_off[rec + st] <= item) rec += st;
+            const int b = s_lo[rec] + (item - s_off[rec]);
+            const int ia = s_agent[rec];
+            double *sc = a.scans + (size_t)(first + ia) * B;
+            const double r0 = sc[b];   // (possibly already lowered by another opponent's item: the minimum does not care)
+            if (r0 < s_near[rec]) continue;   // the wall is nearer than any point of this opponent
+            const MultiAgentLds &mm = s_ag[ia];
+            double bv[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bv[c] = s_box[rec][c];
+            const double bt = mm.eth + a.scan_angles[b];
+            double v3x, v3y;
+            sincos(bt + kPi / 2., &v3y, &v3x);
+            const double r = box_range(mm.ex, mm.ey, v3x, v3y, bv, r0);
+            if (r < r0) atomicMin(reinterpret_cast<unsigned long long *>(sc + b), (unsigned long long)__double_as_longlong(r));
+        }
+        __syncthreads();   // the next tile overwrites the record tables
+    }
+
+    // ---- flags, check_ttc's side effects, step count, re-seat
+    __syncthreads();
+    for (int ag = t; ag < AGN; ag += 256) {
+        const int i = first + ag;
+        const int partner = s_partner[ag];
+        const int wall = a.in_collision[i];
+        if (wall) {
+            a.state[3 * (size_t)N + i] = 0.;
+            a.state[4 * (size_t)N + i] = 0.;
+            a.state[5 * (size_t)N + i] = 0.;
+            a.state[6 * (size_t)N + i] = 0.;
+        }
+        a.collisions[i] = (partner >= 0 || wall) ? 1.0 : 0.0;
+        a.collision_idx[i] = (double)partner;
+        a.step_count[i] += 1;
+    }
+    if (a.reseat_poses) {
+        for (int ag = t; ag < AGN; ag += 256) {
+            const int e = ag / A, i = first + ag, ego_t = e * A + a.reseat_ego, ego = first + ego_t;
+            if (s_partner[ego_t] >= 0 || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
+        }
+    }
+}
+
 // single-agent envs: no opponents, one lane per agent is enough
 __global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
 {

@@ -274,6 +274,60 @@ def test_raycast_and_get_range(hh):
     assert rel_err(out[fin], ref[fin]) < 1e-9
 
 
+def test_get_range_division_free_decisions_equal_the_reference_expression(hh):
+    """edge_range decides hit / miss on the numerators and divides only for an edge that is hit (round 4); it must
+    return exactly what get_range's own expression returns (laser_models.py:249-280: d1 = n1 / denom, d2 = n2 / denom,
+    hit <=> d1 >= 0 and 0 <= d2 <= 1) — random boxes, rays through corners (d2 at 0 / 1 to the last bit), rays parallel
+    to an edge, the lidar on an edge's line, tiny and huge operands"""
+    import math
+    rng = np.random.default_rng(77)
+
+    def ref(row):
+        ox, oy, _, bt, vax, vay, vbx, vby = row
+        v3x, v3y = math.cos(bt + math.pi / 2.), math.sin(bt + math.pi / 2.)
+        v1x, v1y = ox - vax, oy - vay
+        v2x, v2y = vbx - vax, vby - vay
+        denom = v2x * v3x + v2y * v3y
+        if abs(denom) > 0.0:
+            n1 = v2x * v1y - v2y * v1x
+            n2 = v1x * v3x + v1y * v3y
+            with np.errstate(all="ignore"):
+                d1 = float(np.float64(n1) / np.float64(denom)); d2 = float(np.float64(n2) / np.float64(denom))
+            return d1 if (d1 >= 0.0 and d2 >= 0.0 and d2 <= 1.0) else math.inf
+        return None   # collinear branch: not what this test is about
+
+    rows = []
+    for k in range(30000):
+        o = rng.uniform(-3, 3, 2); bt = rng.uniform(-4, 4)
+        va = rng.uniform(-3, 3, 2); vb = va + rng.uniform(-0.7, 0.7, 2)
+        kind = k % 6
+        if kind == 1:      # the ray aimed exactly at an end point (d2 == 0 or 1 up to rounding)
+            tgt = va if k % 12 == 1 else vb
+            bt = math.atan2(tgt[1] - o[1], tgt[0] - o[0])
+        elif kind == 2:    # ... and one ulp-ish beside it
+            tgt = vb
+            bt = math.atan2(tgt[1] - o[1], tgt[0] - o[0]) + rng.choice([-1, 1]) * rng.choice([1e-16, 3e-16, 1e-15, 1e-13, 1e-12, 1e-11])
+        elif kind == 3:    # nearly parallel to the edge
+            bt = math.atan2(vb[1] - va[1], vb[0] - va[0]) + rng.choice([-1, 1]) * rng.choice([0.0, 1e-17, 1e-15, 1e-12, 1e-9])
+        elif kind == 4:    # the lidar on the edge's line / on a vertex
+            tt = rng.uniform(-1, 2)
+            o = va + tt * (vb - va) if k % 3 else va.copy()
+        elif kind == 5:    # scaled operands: tiny, huge
+            sc = 10.0 ** rng.choice([-160, -120, -60, 60, 120, 160])
+            o, va, vb = o * sc, va * sc, vb * sc
+        rows.append([o[0], o[1], 0.0, bt, va[0], va[1], vb[0], vb[1]])
+    n_hit = n_band = 0
+    for row in rows:
+        want = ref(row)
+        if want is None:
+            continue
+        r_, rp = d(np.array(row))
+        got = hh.hh_get_range(rp)
+        assert (got == want) or (math.isnan(got) and math.isnan(want)), (row, got, want)
+        n_hit += int(math.isfinite(want))
+    assert n_hit > 3000
+
+
 def test_disc_cull_is_result_preserving(hh):
     """the product only evaluates window beams whose ray can touch the opponent's circumscribed
     disc; the oracle evaluates the whole [min_ind, max_ind] window like the reference.  Results

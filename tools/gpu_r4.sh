@@ -33,6 +33,13 @@ rates)
 cfg5)
   for i in 1 2; do timeout 300 python bench.py $C5 > $OUT/rate_cfg5.log 2>&1; line $OUT/rate_cfg5.log "configs[4]"; done | tee $OUT/rates_cfg5.txt
   ;;
+manyagents)
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  bench.py --only-headline --agents 65520|65536 --agents-per-env A --steps 200 --warmup 20"
+  for a in 1 2 3 4 6 8 12 16 24 32; do
+    n=$(( 65536 / a * a ))
+    timeout 200 python bench.py --only-headline --agents $n --agents-per-env $a --steps 200 --warmup 20 > $OUT/many_$a.log 2>&1; line $OUT/many_$a.log "A=$a product"
+  done; } | tee $OUT/many_agents.txt
+  ;;
 dropin)
   timeout 500 python tools/debug/dropin_rate.py 2048,32768 > $OUT/dropin_rate.txt 2>&1; cat $OUT/dropin_rate.txt
   ;;
