@@ -586,45 +586,77 @@ def parity_gate(args, rdv):
 
 
 def cpu_baseline(args, seconds):
-    """the CPU oracle (C port of the reference) on a bounded sample of the same workload:
-    (i) OpenMP over envs on all host cores (the "best CPU" comparator), (ii) cpu_1t: the reference's
-    own shape — 1 env x 2 agents, one thread (BASELINE configs[0], SURVEY 8d "Config 1")."""
+    """the CPU oracle (C port of the reference) on a bounded sample of the same workload, in the CPU's best shape:
+    compiled for this machine (-O3 -march=native, the strict float64 flags kept: oracle/orc.py native_lib), every env
+    walked through all its steps by one thread with the re-seats inside the C loop (orc_sim_rollout: no barrier per
+    step, no Python between steps), OpenMP dynamic over envs on every CPU this rank may run on.  Beside it: the same
+    code on ONE thread with the same envs (-> the 1 -> N scaling factor), and cpu_1t: the reference's own shape —
+    1 env x 2 agents, one thread (BASELINE configs[0], SURVEY 8d "Config 1")."""
     import numpy as np
     from _util import oracle_map_dt
     from oracle import orc
     A = args.agents_per_env
     dt, res, origin = oracle_map_dt("example_map")
     no_noise = args.no_noise or args.noise == "off"
+    per_set = 20
 
-    def leg(E, threads, budget, T_est=400):
-        ref = orc.SimOracle(E, A, num_beams=args.beams)
+    def leg(E, threads, budget, native=True, max_steps=400):
+        ref = orc.SimOracle(E, A, num_beams=args.beams, native=native)
         ref.set_map_dt(dt, res, origin)
         if not no_noise:
-            ref.set_noise(np.random.default_rng(NOISE_SEED).normal(0., 0.01, size=(T_est + 2, args.beams)))
+            ref.set_noise(np.random.default_rng(NOISE_SEED).normal(0., 0.01, size=(max_steps + 2, args.beams)))
         poses = start_poses_for(shard_envs(E, 0), A)
         ref.reset(poses)
-        sets = action_sets((T_est + 19) // 20, E * A, seed=1000)
-        t0 = time.perf_counter(); ref.step(sets[0], threads); one = time.perf_counter() - t0   # calibrate
-        steps = int(max(3, min(T_est - 1, budget / max(one, 1e-6))))
+        sets = np.stack(action_sets((max_steps + per_set - 1) // per_set, E * A, seed=1000))
+        ref.rollout(sets, 2, per_set, poses, not args.no_reset, threads)    # first touch of the arrays, thread pool
+        ref.reset(poses)
         look0 = ref.lookups
+        steps = n_reset = 0
         t0 = time.perf_counter()
-        for t in range(1, 1 + steps):
-            ref.step(sets[t // 20], threads)
-            if not args.no_reset:
-                mask = (ref.collisions.reshape(E, A)[:, 0] != 0).astype(np.uint8)
-                if mask.any():
-                    ref.reset(poses, mask)
+        while steps < max_steps - per_set:          # whole action sets until the budget is spent
+            k = steps // per_set
+            n_reset += ref.rollout(sets[k:k + 1], per_set, per_set, poses, not args.no_reset, threads)
+            steps += per_set
+            if time.perf_counter() - t0 >= budget:
+                break
         el = time.perf_counter() - t0
-        return E * A * steps / el, steps, el, (ref.lookups - look0) / float(steps * E * A * args.beams)
+        return E * A * steps / el, steps, el, (ref.lookups - look0) / float(steps * E * A * args.beams), n_reset
 
-    threads = max(1, min(os.cpu_count() or 1, 64))
-    E = max(64, 32 * threads)
-    v, steps, el, lbar = leg(E, threads, seconds)
-    v1, steps1, el1, _ = leg(1, 1, min(seconds, 5.0), T_est=20000)
-    return {"value": v, "unit": "agent-steps/s", "cores": threads, "kind": "port",
-            "sample": "%d envs x %d agents x %d steps of the bench workload (oracle/f110_oracle.c, gcc -O2 "
-                      "-ffp-contract=off, OpenMP over envs), %.1f s" % (E, A, steps, el),
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    threads = max(1, len(cpus))
+    phys = None
+    try:   # physical cores among the CPUs this rank may use (SMT siblings share one)
+        seen = set()
+        for c in cpus:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                seen.add(f.read().strip())
+        phys = len(seen)
+    except OSError:
+        pass
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), None)
+    except OSError:
+        pass
+    E = max(256, 16 * threads)
+    # two builds of the same source: for this machine (-O3 -march=native) and the portable checker library (-O2); the
+    # faster one is the baseline (on AVX-512 Xeons the -O2 build has been the faster one)
+    half = max(2.0, seconds / 2.0)
+    legs = {"native": leg(E, threads, half, native=True), "portable": leg(E, threads, half, native=False)}
+    best = max(legs, key=lambda k: legs[k][0])
+    v, steps, el, lbar, n_reset = legs[best]
+    flags = " ".join(orc.NATIVE_CFLAGS[:2]) if best == "native" else "-O2"
+    vs, steps_s, el_s, _, _ = leg(E, 1, min(seconds, 6.0), native=(best == "native"), max_steps=60)   # the same envs, same build, one thread
+    v1, steps1, el1, _, _ = leg(1, 1, min(seconds, 5.0), native=(best == "native"), max_steps=20000)
+    return {"value": v, "unit": "agent-steps/s", "cores": threads, "physical_cores": phys, "cpu_model": model, "kind": "port",
+            "sample": "%d envs x %d agents x %d steps of the bench workload, %d re-seats (oracle/f110_oracle.c orc_sim_rollout, gcc %s "
+                      "-ffp-contract=off -fno-builtin, OpenMP dynamic over envs, every env through all its steps on one thread), %.1f s"
+                      % (E, A, steps, n_reset, flags, el),
             "lookups_per_ray_on_sample": lbar,
+            "builds": {k: {"value": r[0], "steps": r[1], "seconds": r[2]} for k, r in legs.items()}, "build_used": best,
+            "scaling_1_to_n": {"threads": threads, "one_thread_value": vs, "factor": v / vs,
+                               "sample_one_thread": "%d steps of the same %d envs, %.1f s" % (steps_s, E, el_s)},
             "cpu_1t": {"value": v1, "unit": "agent-steps/s", "cores": 1, "kind": "port",
                        "sample": "BASELINE configs[0] shape: 1 env x %d agents, %d steps, one thread, %.1f s (the reference runs this "
                                  "shape in numba on one core; numba cannot be installed here, so the C restatement stands in)" % (A, steps1, el1)}}

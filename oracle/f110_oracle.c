@@ -899,6 +899,51 @@ void orc_sim_step(orc_sim *s, const double *actions, int n_threads)
     s->lookups += total;
 }
 
+/* The CPU baseline's best shape (bench.py cpu_baseline): envs never interact, so every env is walked through ALL
+ * `steps` steps by one thread — no barrier per step, the env's state stays in that core's cache — with the in-place
+ * re-seat of an env whose ego (slot 0) collided done right here (what bench.py's Python loop did between steps:
+ * orc_sim_reset with a mask).  actions = [n_sets][N][2], set t / steps_per_set is applied at step t (the bench's
+ * pre-drawn action sets).  Identical, env by env, to `steps` calls of orc_sim_step + masked resets
+ * (tests/test_oracle_golden.py).  Returns the number of re-seats. */
+int64_t orc_sim_rollout(orc_sim *s, const double *actions, int n_sets, int steps_per_set, int steps,
+                        const double *start_poses, int reseat_on_ego_collision, int n_threads)
+{
+    int e;
+    int64_t total = 0, reseats = 0;
+    const size_t set_stride = (size_t)2 * s->E * s->A;
+    if (n_threads < 1) n_threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(n_threads) schedule(dynamic, 1) reduction(+ : total, reseats)
+#endif
+    for (e = 0; e < s->E; e++) {
+        int t, a;
+        int64_t lk = 0;
+        for (t = 0; t < steps; t++) {
+            int set = t / steps_per_set;
+            if (set >= n_sets) set = n_sets - 1;
+            orc_sim_step_env(s, e, actions + set_stride * set, &lk);
+            if (reseat_on_ego_collision && s->collisions[e * s->A] != 0.) {
+                for (a = 0; a < s->A; a++) { /* orc_sim_reset for this env */
+                    int i = e * s->A + a;
+                    double *st = s->state + 7 * (size_t)i;
+                    memset(st, 0, 7 * sizeof(double));
+                    st[0] = start_poses[3 * i];
+                    st[1] = start_poses[3 * i + 1];
+                    st[4] = start_poses[3 * i + 2];
+                    s->steer_buf[2 * i] = s->steer_buf[2 * i + 1] = 0.;
+                    s->buf_count[i] = 0;
+                    s->in_collision[i] = 0;
+                    s->step_count[i] = 0;
+                }
+                reseats += 1;
+            }
+        }
+        total += lk;
+    }
+    s->lookups += total;
+    return reseats;
+}
+
 double *orc_sim_state(orc_sim *s) { return s->state; }
 double *orc_sim_scans(orc_sim *s) { return s->scans; }
 double *orc_sim_collisions(orc_sim *s) { return s->collisions; }

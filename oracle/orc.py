@@ -45,66 +45,91 @@ def build(force=False):
     return _LIB_PATH
 
 
+def _bind(L):
+    """restype / argtypes of everything oracle/f110_oracle.h declares"""
+    L.orc_accl_constraints.restype = C.c_double
+    L.orc_accl_constraints.argtypes = [C.c_double] * 6
+    L.orc_steering_constraint.restype = C.c_double
+    L.orc_steering_constraint.argtypes = [C.c_double] * 6
+    L.orc_vehicle_dynamics_ks.argtypes = [_dp, _dp, _dp, _dp]
+    L.orc_vehicle_dynamics_st.argtypes = [_dp, _dp, _dp, _dp]
+    L.orc_pid.argtypes = [C.c_double] * 8 + [_dp, _dp]
+    L.orc_update_pose.argtypes = [_dp, _dp, _ip, C.c_double, C.c_double, _dp, C.c_double,
+                                  C.c_int, C.c_double, _dp]
+    L.orc_xy_2_rc.argtypes = [C.POINTER(ScanCfg), C.c_double, C.c_double, _ip, _ip]
+    L.orc_trace_ray.restype = C.c_double
+    L.orc_trace_ray.argtypes = [C.POINTER(ScanCfg), C.c_double, C.c_double, C.c_double, _ip, _i64p]
+    L.orc_get_scan.argtypes = [C.POINTER(ScanCfg), _dp, _dp, _ip, _i64p]
+    L.orc_beam_dir_indices.argtypes = [C.POINTER(ScanCfg), C.c_double, _ip]
+    L.orc_check_ttc.restype = C.c_int
+    L.orc_check_ttc.argtypes = [_dp, C.c_int, C.c_double, _dp, _dp, C.c_double]
+    L.orc_get_range.restype = C.c_double
+    L.orc_get_range.argtypes = [_dp, C.c_double, _dp, _dp]
+    L.orc_get_blocked_view_indices.argtypes = [_dp, _dp, _dp, C.c_int, _ip, _ip]
+    L.orc_ray_cast.argtypes = [_dp, _dp, _dp, C.c_int, _dp]
+    L.orc_build_beam_tables.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, _dp, _dp, _dp]
+    L.orc_edt_sq.argtypes = [_u8p, C.c_int, C.c_int, _u32p]
+    L.orc_map_dt_from_image.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, _dp]
+    L.orc_get_vertices.argtypes = [_dp, C.c_double, C.c_double, _dp]
+    L.orc_collision.restype = C.c_int
+    L.orc_collision.argtypes = [_dp, _dp]
+    L.orc_collision_multiple.argtypes = [_dp, C.c_int, _dp, _dp]
+    L.orc_sim_create.restype = C.c_void_p
+    L.orc_sim_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                 C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, _dp]
+    L.orc_sim_destroy.argtypes = [C.c_void_p]
+    L.orc_sim_set_tables.argtypes = [C.c_void_p, _dp, _dp]
+    L.orc_sim_set_map_dt.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int] + [C.c_double] * 5
+    L.orc_sim_set_params.restype = C.c_int
+    L.orc_sim_set_params.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.orc_sim_set_noise.argtypes = [C.c_void_p, _dp, C.c_int]
+    L.orc_sim_reset.argtypes = [C.c_void_p, _dp, _u8p]
+    L.orc_sim_step.argtypes = [C.c_void_p, _dp, C.c_int]
+    for name, ty in [("state", _dp), ("scans", _dp), ("collisions", _dp),
+                     ("collision_idx", _dp), ("agent_poses", _dp), ("in_collision", _i32p),
+                     ("step_count", _i32p), ("hit_rc", _i32p)]:
+        fn = getattr(L, "orc_sim_" + name)
+        fn.restype = ty
+        fn.argtypes = [C.c_void_p]
+    L.orc_sim_lookups.restype = C.c_int64
+    L.orc_sim_lookups.argtypes = [C.c_void_p]
+    L.orc_nearest_on_trajectory.restype = C.c_int
+    L.orc_nearest_on_trajectory.argtypes = [_dp, C.c_int, C.c_double, C.c_double, _dp, _dp]
+    L.orc_first_point_on_circle.restype = C.c_int
+    L.orc_first_point_on_circle.argtypes = [_dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.orc_pure_pursuit_plan.restype = None
+    L.orc_pure_pursuit_plan.argtypes = [_dp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_double, _dp]
+    L.orc_sim_rollout.restype = C.c_int64
+    L.orc_sim_rollout.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int]
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
-        L.orc_accl_constraints.restype = C.c_double
-        L.orc_accl_constraints.argtypes = [C.c_double] * 6
-        L.orc_steering_constraint.restype = C.c_double
-        L.orc_steering_constraint.argtypes = [C.c_double] * 6
-        L.orc_vehicle_dynamics_ks.argtypes = [_dp, _dp, _dp, _dp]
-        L.orc_vehicle_dynamics_st.argtypes = [_dp, _dp, _dp, _dp]
-        L.orc_pid.argtypes = [C.c_double] * 8 + [_dp, _dp]
-        L.orc_update_pose.argtypes = [_dp, _dp, _ip, C.c_double, C.c_double, _dp, C.c_double,
-                                      C.c_int, C.c_double, _dp]
-        L.orc_xy_2_rc.argtypes = [C.POINTER(ScanCfg), C.c_double, C.c_double, _ip, _ip]
-        L.orc_trace_ray.restype = C.c_double
-        L.orc_trace_ray.argtypes = [C.POINTER(ScanCfg), C.c_double, C.c_double, C.c_double, _ip, _i64p]
-        L.orc_get_scan.argtypes = [C.POINTER(ScanCfg), _dp, _dp, _ip, _i64p]
-        L.orc_beam_dir_indices.argtypes = [C.POINTER(ScanCfg), C.c_double, _ip]
-        L.orc_check_ttc.restype = C.c_int
-        L.orc_check_ttc.argtypes = [_dp, C.c_int, C.c_double, _dp, _dp, C.c_double]
-        L.orc_get_range.restype = C.c_double
-        L.orc_get_range.argtypes = [_dp, C.c_double, _dp, _dp]
-        L.orc_get_blocked_view_indices.argtypes = [_dp, _dp, _dp, C.c_int, _ip, _ip]
-        L.orc_ray_cast.argtypes = [_dp, _dp, _dp, C.c_int, _dp]
-        L.orc_build_beam_tables.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double,
-                                            C.c_double, _dp, _dp, _dp]
-        L.orc_edt_sq.argtypes = [_u8p, C.c_int, C.c_int, _u32p]
-        L.orc_map_dt_from_image.argtypes = [_u8p, C.c_int, C.c_int, C.c_double, _dp]
-        L.orc_get_vertices.argtypes = [_dp, C.c_double, C.c_double, _dp]
-        L.orc_collision.restype = C.c_int
-        L.orc_collision.argtypes = [_dp, _dp]
-        L.orc_collision_multiple.argtypes = [_dp, C.c_int, _dp, _dp]
-        L.orc_sim_create.restype = C.c_void_p
-        L.orc_sim_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
-                                     C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, _dp]
-        L.orc_sim_destroy.argtypes = [C.c_void_p]
-        L.orc_sim_set_tables.argtypes = [C.c_void_p, _dp, _dp]
-        L.orc_sim_set_map_dt.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int] + [C.c_double] * 5
-        L.orc_sim_set_params.restype = C.c_int
-        L.orc_sim_set_params.argtypes = [C.c_void_p, C.c_int, _dp]
-        L.orc_sim_set_noise.argtypes = [C.c_void_p, _dp, C.c_int]
-        L.orc_sim_reset.argtypes = [C.c_void_p, _dp, _u8p]
-        L.orc_sim_step.argtypes = [C.c_void_p, _dp, C.c_int]
-        for name, ty in [("state", _dp), ("scans", _dp), ("collisions", _dp),
-                         ("collision_idx", _dp), ("agent_poses", _dp), ("in_collision", _i32p),
-                         ("step_count", _i32p), ("hit_rc", _i32p)]:
-            fn = getattr(L, "orc_sim_" + name)
-            fn.restype = ty
-            fn.argtypes = [C.c_void_p]
-        L.orc_sim_lookups.restype = C.c_int64
-        L.orc_sim_lookups.argtypes = [C.c_void_p]
-        L.orc_nearest_on_trajectory.restype = C.c_int
-        L.orc_nearest_on_trajectory.argtypes = [_dp, C.c_int, C.c_double, C.c_double, _dp, _dp]
-        L.orc_first_point_on_circle.restype = C.c_int
-        L.orc_first_point_on_circle.argtypes = [_dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
-        L.orc_pure_pursuit_plan.restype = None
-        L.orc_pure_pursuit_plan.argtypes = [_dp, C.c_int, _dp, C.c_double, C.c_double, C.c_double, C.c_double, _dp]
-        _lib = L
+        _lib = _bind(C.CDLL(_LIB_PATH))
     return _lib
+
+
+_NATIVE_DIR = os.path.join(_HERE, "_native")
+_native = None
+NATIVE_CFLAGS = ["-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-fno-builtin", "-fopenmp", "-D_GNU_SOURCE"]
+
+
+def native_lib():
+    """bench.py's cpu_baseline only: the same source compiled FOR THE MACHINE IT RUNS ON (-O3 -march=native; the strict
+    float64 flags of the Makefile stay), built where it is used — the checker library above is built once, portably,
+    and travels to the GPU box."""
+    global _native
+    if _native is None:
+        os.makedirs(_NATIVE_DIR, exist_ok=True)
+        out = os.path.join(_NATIVE_DIR, "libf110_oracle_native.so")
+        subprocess.check_call([os.environ.get("CC", "gcc")] + NATIVE_CFLAGS + ["-shared", "-o", out, os.path.join(_HERE, "f110_oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _native = _bind(C.CDLL(out))
+    return _native
 
 
 def _d(a):
@@ -267,54 +292,63 @@ class SimOracle(object):
 
     def __init__(self, num_envs, num_agents, params=None, num_beams=1080, fov=4.7, eps=1e-4,
                  theta_dis=2000, max_range=30.0, time_step=0.01, integrator=1, lidar_dist=0.0,
-                 ttc_thresh=0.005):
+                 ttc_thresh=0.005, native=False):
         self.E, self.A, self.N, self.B = num_envs, num_agents, num_envs * num_agents, num_beams
+        self._L = native_lib() if native else lib()
         pv, pp = _d(params_vec(params))
-        self._h = lib().orc_sim_create(num_envs, num_agents, num_beams, fov, eps, theta_dis,
+        self._h = self._L.orc_sim_create(num_envs, num_agents, num_beams, fov, eps, theta_dis,
                                        max_range, time_step, integrator, lidar_dist, ttc_thresh, pp)
         theta_arr = np.linspace(0.0, 2 * np.pi, num=theta_dis)
         s, sp = _d(np.sin(theta_arr)); c, cp = _d(np.cos(theta_arr))
-        lib().orc_sim_set_tables(self._h, sp, cp)
+        self._L.orc_sim_set_tables(self._h, sp, cp)
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_sim_destroy(self._h)
+            self._L.orc_sim_destroy(self._h)
             self._h = None
 
     def set_map_dt(self, dt, resolution, origin):
         dt, p = _d(dt)
-        lib().orc_sim_set_map_dt(self._h, p, dt.shape[0], dt.shape[1], float(resolution),
+        self._L.orc_sim_set_map_dt(self._h, p, dt.shape[0], dt.shape[1], float(resolution),
                                  float(origin[0]), float(origin[1]), float(np.cos(origin[2])),
                                  float(np.sin(origin[2])))
 
     def set_params(self, params, agent_idx=-1):
         pv, pp = _d(params_vec(params))
-        if lib().orc_sim_set_params(self._h, agent_idx, pp) != 0:
+        if self._L.orc_sim_set_params(self._h, agent_idx, pp) != 0:
             raise IndexError('Index given is out of bounds for list of agents.')
 
     def set_noise(self, noise):
         if noise is None:
-            lib().orc_sim_set_noise(self._h, None, 0)
+            self._L.orc_sim_set_noise(self._h, None, 0)
         else:
             noise, p = _d(noise)
-            lib().orc_sim_set_noise(self._h, p, noise.shape[0])
+            self._L.orc_sim_set_noise(self._h, p, noise.shape[0])
 
     def reset(self, poses, env_mask=None):
         poses, p = _d(poses)
         assert poses.shape == (self.N, 3)
         if env_mask is None:
-            lib().orc_sim_reset(self._h, p, None)
+            self._L.orc_sim_reset(self._h, p, None)
         else:
             m = np.ascontiguousarray(env_mask, dtype=np.uint8)
-            lib().orc_sim_reset(self._h, p, m.ctypes.data_as(_u8p))
+            self._L.orc_sim_reset(self._h, p, m.ctypes.data_as(_u8p))
 
     def step(self, actions, n_threads=1):
         actions, p = _d(actions)
         assert actions.shape == (self.N, 2)
-        lib().orc_sim_step(self._h, p, int(n_threads))
+        self._L.orc_sim_step(self._h, p, int(n_threads))
+
+    def rollout(self, action_sets, steps, steps_per_set, start_poses, reseat=True, n_threads=1):
+        """every env through `steps` steps on its own (orc_sim_rollout); action_sets [n_sets][N][2]; -> re-seats"""
+        acts, ap = _d(action_sets)
+        assert acts.ndim == 3 and acts.shape[1:] == (self.N, 2)
+        poses, pp = _d(start_poses)
+        assert poses.shape == (self.N, 3)
+        return int(self._L.orc_sim_rollout(self._h, ap, acts.shape[0], int(steps_per_set), int(steps), pp, 1 if reseat else 0, int(n_threads)))
 
     def _view(self, name, shape, dtype=np.float64):
-        ptr = getattr(lib(), "orc_sim_" + name)(self._h)
+        ptr = getattr(self._L, "orc_sim_" + name)(self._h)
         return np.ctypeslib.as_array(ptr, shape=shape)
 
     @property
@@ -334,7 +368,7 @@ class SimOracle(object):
     @property
     def hit_rc(self): return self._view("hit_rc", (self.N, self.B, 2))
     @property
-    def lookups(self): return lib().orc_sim_lookups(self._h)
+    def lookups(self): return self._L.orc_sim_lookups(self._h)
 
 
 # ---- examples/waypoint_follow.py (pure-pursuit planner) ----
