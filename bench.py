@@ -326,6 +326,7 @@ class Workload(object):
         self.d_count = sim.device_array((1,), dtype=np.int32)
         self.d_all = None       # gather off
         self.d_alls, self.d_scals, self.comm_ready = [], [], False
+        self.g_f32, self.g_root = False, None
         if args.gather:
             self.set_gather(True, args.gather_overlap)
         self.planner = self.d_plan = self.d_zero = None
@@ -341,14 +342,20 @@ class Workload(object):
         # kernel (f110_set_auto_reseat), or as the separate f110_reset_collided_device launch
         self.fused_reset = not self.no_reset and not args.separate_reset
 
-    def set_gather(self, on, overlap=False):
-        """the RCCL observation gather after every step: off / in-stream / overlapped with the next step.
+    def set_gather(self, on, overlap=False, f32=False, root=None):
+        """the RCCL observation gather after every step: off / in-stream / overlapped with the next step; f32: the scans
+        cross the links as float32; root: only that rank receives (f110_comm_gather_obs).
         The communicator is created once (rank 0 makes the id, the control plane broadcasts it)."""
         sim, rdv = self.sim, self.rdv
         if self.d_all is not None:
             sim.sync()
             sim.comm_set_overlap(False)
         self.d_all = None
+        if (f32, root) != (self.g_f32, self.g_root):   # other element type / other receivers: new receive buffers
+            for d in self.d_alls + self.d_scals:
+                d.free()
+            self.d_alls, self.d_scals = [], []
+        self.g_f32, self.g_root = bool(f32), root
         if not on:
             return
         if not self.comm_ready:
@@ -357,9 +364,10 @@ class Workload(object):
             sim.comm_init(rdv.world, rdv.rank, rdv.broadcast_bytes(uid, 128))
             self.comm_ready = True
         want = 2 if overlap else 1
-        while len(self.d_alls) < want:   # receive buffers: scans [ranks][N][B] + scalars [ranks][7][N]
-            self.d_alls.append(sim.device_array((rdv.world, self.N, self.beams)))
-            self.d_scals.append(sim.device_array((rdv.world, 7, self.N)))
+        recv = root is None or root == rdv.rank
+        while len(self.d_alls) < want:   # receive buffers: scans [ranks][N][B] + scalars [ranks][7][N] (a non-root rank: one row, never written)
+            self.d_alls.append(sim.device_array((rdv.world if recv else 1, self.N, self.beams), self.np.float32 if f32 else self.np.float64))
+            self.d_scals.append(sim.device_array((rdv.world if recv else 1, 7, self.N)))
         self.n_recv = want
         self.d_all = self.d_alls[0]
         sim.comm_set_overlap(bool(overlap))
@@ -374,7 +382,10 @@ class Workload(object):
         else:
             sim.step_device(self.d_sets[t // 20])
         if self.d_all is not None and gather:
-            sim.comm_all_gather_obs(self.d_alls[t % self.n_recv], self.d_scals[t % self.n_recv])
+            if self.g_f32 or self.g_root is not None:
+                sim.comm_gather_obs(self.d_alls[t % self.n_recv], self.d_scals[t % self.n_recv], f32=self.g_f32, root=self.g_root)
+            else:
+                sim.comm_all_gather_obs(self.d_alls[t % self.n_recv], self.d_scals[t % self.n_recv])
         if not self.no_reset and not self.fused_reset:
             sim.reset_collided_device(self.d_start, 0, self.d_count)
 
@@ -435,11 +446,14 @@ class Workload(object):
         np, sim, rdv = self.np, self.sim, self.rdv
         o = sim.get("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions")
         scal = np.stack([o["poses_x"], o["poses_y"], o["poses_theta"], o["linear_vels_x"], np.zeros(self.N), o["ang_vels_z"], o["collisions"]])
-        theirs = rdv.gather_bytes(self.digest(o["scans"]) + self.digest(scal))
+        mine = o["scans"].astype(np.float32).astype(np.float64) if self.g_f32 else o["scans"]   # (digests are over 64-bit words)
+        theirs = rdv.gather_bytes(self.digest(mine) + self.digest(scal))
         ok = True
-        for r in range(rdv.world):   # one rank's block at a time: the receive buffer is world x 570 MB
-            got = self.digest(self.d_alls[slot].download_part(r, 1)) + self.digest(self.d_scals[slot].download_part(r, 1))
-            ok = ok and got == theirs[r]
+        if self.g_root is None or self.g_root == rdv.rank:
+            for r in range(rdv.world):   # one rank's block at a time: the receive buffer is world x 570 MB
+                blk = self.d_alls[slot].download_part(r, 1)
+                got = self.digest(blk.astype(np.float64) if self.g_f32 else blk) + self.digest(self.d_scals[slot].download_part(r, 1))
+                ok = ok and got == theirs[r]
         return bool(ok)
 
     def close(self):
@@ -718,7 +732,7 @@ def stub_run(args, rdv, steps, leg="headline"):
         raise RuntimeError("stub: the %s leg fails on rank %d" % (leg, rdv.rank))   # tests: a leg that dies on one rank
     rdv.barrier()
     t0 = time.perf_counter()
-    time.sleep(0.001 * steps * {"headline": 1.0, "gather": 1.5, "gather_overlap": 1.25}[leg] + 0.001 * rdv.rank)
+    time.sleep(0.001 * steps * {"headline": 1.0, "gather": 1.5, "gather_overlap": 1.25}.get(leg, 1.2) + 0.001 * rdv.rank)
     mine = time.perf_counter() - t0
     rdv.barrier()
     return {"elapsed_s": time.perf_counter() - t0, "rank_s": mine, "n_reset": rdv.rank + 1, "steps": steps, "warmup": args.warmup,
@@ -835,7 +849,8 @@ def main(argv=None):
                       "per_rank_ms_per_step_max": head["per_rank_ms_per_step_max"], "per_gpu_value": value / n_gpus,
                       "rccl_ranks": rccl_ranks, "numa": numa_all,
                       "legs": "headline = no collective on the step path" + ("; gather = f110_comm_all_gather_obs after every step on the step's stream; "
-                              "gather_overlap = the same on a stream of its own beside the next step (double-buffered observation)" if gather_legs else "")},
+                              "gather_overlap = the same on a stream of its own beside the next step (double-buffered observation); gather_f32 = the scans "
+                              "cross the links as float32 (f110_comm_gather_obs); gather_root = only rank 0 receives (grouped ncclSend / ncclRecv)" if gather_legs else "")},
     }
     if args.gather:
         line["config"]["gather_ok"] = head["gather_ok"]
@@ -874,15 +889,20 @@ def main(argv=None):
 
         def gather_pair(work, agents_per_rank, out):
             """the same steps with the observation gather in the step's stream, then overlapped; -> rccl_ranks"""
-            for name, overlap in (("gather", False), ("gather_overlap", True)):
+            for name, overlap, f32, root in (("gather", False, False, None), ("gather_overlap", True, False, None),
+                                             ("gather_f32", False, True, None), ("gather_f32_overlap", True, True, None),
+                                             ("gather_root", False, False, 0), ("gather_root_f32_overlap", True, True, 0)):
                 if args.stub:
                     res = stub_run(args, rdv, args.steps, name)
                 else:
-                    res, e = guarded(lambda: (work.set_gather(True, overlap), work.run(args.steps, args.warmup, "timed"))[1], args.gather_timeout)
+                    res, e = guarded(lambda: (work.set_gather(True, overlap, f32, root), work.run(args.steps, args.warmup, "timed"))[1], args.gather_timeout)
                     if e:
                         raise RuntimeError("%s leg: %s" % (name, e))
                 rec = leg_record(rdv, agents_per_rank * n_gpus, res)
-                out[name] = dict(rec, per_gpu_value=rec["value"] / n_gpus, bytes_gathered_per_rank_per_step=8 * agents_per_rank * (args.beams + 7) * n_gpus)
+                esz = 4 if f32 else 8
+                out[name] = dict(rec, per_gpu_value=rec["value"] / n_gpus,
+                                 bytes_received_per_step={"root" if root is not None else "every_rank": agents_per_rank * (esz * args.beams + 56) * n_gpus},
+                                 bytes_sent_per_rank_per_step=agents_per_rank * (esz * args.beams + 56))
             if args.stub:
                 return None
             n = work.sim.comm_info()[0]

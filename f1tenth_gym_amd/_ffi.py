@@ -66,6 +66,7 @@ class HostBlock(C.Structure):
                 ("scans", _dp)]
 
 
+GATHER_F64, GATHER_F32 = 0, 1
 STEP_AUTO_RESET, STEP_NO_SYNC, STEP_ACTIONS_MAPPED, STEP_SPIN_WAIT = 1, 2, 4, 8
 
 
@@ -134,6 +135,7 @@ PROTOTYPES = {
     "f110_comm_init": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "f110_comm_all_gather_scans": (C.c_int, [C.c_void_p, C.c_void_p]),
     "f110_comm_all_gather_obs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "f110_comm_gather_obs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "f110_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "f110_comm_set_overlap": (C.c_int, [C.c_void_p, C.c_int32]),
     "f110_comm_destroy": (C.c_int, [C.c_void_p]),

@@ -470,6 +470,14 @@ class BatchSim(object):
         b = d_recv_scalars.ptr if isinstance(d_recv_scalars, DeviceArray) else int(d_recv_scalars)
         check(_ffi.lib().f110_comm_all_gather_obs(self._h, a, b), self._h)
 
+    def comm_gather_obs(self, d_recv_scans, d_recv_scalars, f32=False, root=None):
+        """f110_comm_gather_obs: the observation gather with float32 transport of the scans (d_recv_scans then holds
+        float32 [ranks][N][B]) and / or to ONE receiving rank (root; None: every rank, the all-gather)"""
+        def ptr(x):
+            return None if x is None else (x.ptr if isinstance(x, DeviceArray) else int(x))
+        check(_ffi.lib().f110_comm_gather_obs(self._h, ptr(d_recv_scans), ptr(d_recv_scalars), _ffi.GATHER_F32 if f32 else _ffi.GATHER_F64,
+                                              -1 if root is None else int(root)), self._h)
+
     def comm_info(self):
         """(n_ranks, rank) as RCCL reports them"""
         n, r = C.c_int32(0), C.c_int32(-1)

@@ -158,6 +158,9 @@ struct f110_sim {
     bool comm_overlap = false, comm_swap_next = false, comm_inflight = false;
     double *scan_bufs[2] = {nullptr, nullptr};
     double *obs_scal[2] = {nullptr, nullptr};   // [7][N] scalar observation block(s) of the observation gather
+    float *scan_f32[2] = {nullptr, nullptr};    // [N][B] float32 copies of the scans (F110_GATHER_F32 transport)
+    int comm_rank = -1;
+    bool comm_send_scalars = false;
     int scans_cur = 0;
     bool gather_pending[2] = {false, false};
     hipStream_t comm_stream = nullptr;
@@ -751,6 +754,8 @@ void f110_destroy(f110_sim *h)
         if (h->scan_bufs[1]) (void)hipFree(h->scan_bufs[1]);
     }
     for (double *p : h->obs_scal)
+        if (p) (void)hipFree(p);
+    for (float *p : h->scan_f32)
         if (p) (void)hipFree(p);
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (hipStream_t gs : h->gstreams) (void)hipStreamDestroy(gs);
@@ -1389,6 +1394,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;   // optional: gather to a root
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
@@ -1417,6 +1424,8 @@ RcclApi *rccl_api()
             api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.lib, "ncclGroupEnd"));
             api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
             api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.lib, "ncclCommUserRank"));
+            api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(api.lib, "ncclSend"));
+            api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(api.lib, "ncclRecv"));
         }
     }
     const bool ok = api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy && api.GetErrorString &&
@@ -1454,6 +1463,7 @@ int f110_comm_init(f110_sim *h, int32_t n_ranks, int32_t rank, const void *id128
         return fail(h, F110_ERR_HIP, "ncclCommInitRank failed: %s", r->GetErrorString(rc));
     }
     h->comm_ranks = n_ranks;
+    h->comm_rank = rank;
     return F110_OK;
 }
 
@@ -1492,28 +1502,58 @@ int f110_comm_set_overlap(f110_sim *h, int32_t enable)
 
 // scans (+ the [7][N] scalar block when d_recv_scal != nullptr) of every rank to every rank.  The two
 // ncclAllGather calls are one group (ncclGroupStart / End): RCCL fuses them into one launch per rank.
-static int comm_gather(f110_sim *h, void *d_recv_scans, void *d_recv_scal)
+// transport F110_GATHER_F32: the scans cross the links as float32 (a conversion kernel in front of the collective; the
+// receive buffer then holds floats) — half the bytes of the one leg that is link-bound.  root >= 0: only
+// that rank receives (grouped ncclSend / ncclRecv: every peer's block rides its one direct xGMI link to the root; the
+// other ranks receive nothing, 1 / n_ranks of the all-gather's receive volume per rank).
+static int comm_gather(f110_sim *h, void *d_recv_scans, void *d_recv_scal, int transport = F110_GATHER_F64, int root = -1)
 {
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h->comm) return fail(h, F110_ERR_STATE, "f110_comm_init has not been called");
     RcclApi *r = rccl_api();
+    if (root >= h->comm_ranks) return fail(h, F110_ERR_INVALID, "f110_comm_gather_obs: root %d of %d ranks", root, h->comm_ranks);
+    if (root >= 0 && (!r->Send || !r->Recv)) return fail(h, F110_ERR_STATE, "this RCCL has no ncclSend / ncclRecv: gather to a root is not available");
+    const bool f32 = transport == F110_GATHER_F32;
+    const bool i_receive = root < 0 || root == h->comm_rank;
+    if (i_receive && !d_recv_scans) return fail(h, F110_ERR_INVALID, "null receive buffer on a receiving rank");
     const size_t N = (size_t)h->N, count = N * h->cfg.num_beams, scount = N * kObsScalars;
     const int cur = h->comm_overlap ? h->scans_cur : 0;
-    if (d_recv_scal && !h->obs_scal[cur]) {
+    const bool scal = d_recv_scal != nullptr || (root >= 0 && !i_receive && h->comm_send_scalars);
+    if (scal && !h->obs_scal[cur]) {
         TRY(dmalloc(h, &h->obs_scal[cur], scount));   // (k_pack_obs writes every element before the gather reads it)
     }
+    if (f32 && !h->scan_f32[cur]) TRY(dmalloc(h, &h->scan_f32[cur], count));
     auto gather_on = [&](hipStream_t st, const double *scans) -> int {
+        const void *send = scans;
+        const ncclDataType_t ty = f32 ? ncclFloat32 : ncclFloat64;
+        const size_t esz = f32 ? sizeof(float) : sizeof(double);
+        if (f32) {
+            hipLaunchKernelGGL(k_scans_to_f32, grid1d(count, 256), dim3(256), 0, st, scans, h->scan_f32[cur], count);
+            send = h->scan_f32[cur];
+        }
         ncclResult_t rc = r->GroupStart();
-        if (rc == ncclSuccess) rc = r->AllGather(scans, d_recv_scans, count, ncclFloat64, h->comm, st);
-        if (rc == ncclSuccess && d_recv_scal) rc = r->AllGather(h->obs_scal[cur], d_recv_scal, scount, ncclFloat64, h->comm, st);
+        if (root < 0) {
+            if (rc == ncclSuccess) rc = r->AllGather(send, d_recv_scans, count, ty, h->comm, st);
+            if (rc == ncclSuccess && d_recv_scal) rc = r->AllGather(h->obs_scal[cur], d_recv_scal, scount, ncclFloat64, h->comm, st);
+        } else {
+            if (rc == ncclSuccess) rc = r->Send(send, count, ty, root, h->comm, st);
+            if (rc == ncclSuccess && scal) rc = r->Send(h->obs_scal[cur], scount, ncclFloat64, root, h->comm, st);
+            if (i_receive) {
+                for (int p = 0; p < h->comm_ranks && rc == ncclSuccess; ++p) {
+                    rc = r->Recv(static_cast<char *>(d_recv_scans) + (size_t)p * count * esz, count, ty, p, h->comm, st);
+                    if (rc == ncclSuccess && d_recv_scal)
+                        rc = r->Recv(static_cast<double *>(d_recv_scal) + (size_t)p * scount, scount, ncclFloat64, p, h->comm, st);
+                }
+            }
+        }
         const ncclResult_t re = r->GroupEnd();
         if (rc == ncclSuccess) rc = re;
-        if (rc != ncclSuccess) return fail(h, F110_ERR_HIP, "ncclAllGather failed: %s", r->GetErrorString(rc));
+        if (rc != ncclSuccess) return fail(h, F110_ERR_HIP, "RCCL gather failed: %s", r->GetErrorString(rc));
         return F110_OK;
     };
     if (!h->comm_overlap) {
         ENTER(h);
-        if (d_recv_scal) hipLaunchKernelGGL(k_pack_obs, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->obs_scal[0]);
+        if (scal) hipLaunchKernelGGL(k_pack_obs, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->obs_scal[0]);
         return gather_on(h->stream, h->dev.scans);
     }
     // overlapped: the gather waits for the step that produced this buffer and runs beside the next one,
@@ -1528,7 +1568,7 @@ static int comm_gather(f110_sim *h, void *d_recv_scans, void *d_recv_scal)
     // the scalar block is packed on the main stream, behind the step and before anything (a re-seat, the
     // next step) can change the state it reads; obs_scal[cur] was last read by the gather of two steps ago,
     // which the step that just ran has waited for
-    if (d_recv_scal) hipLaunchKernelGGL(k_pack_obs, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->obs_scal[cur]);
+    if (scal) hipLaunchKernelGGL(k_pack_obs, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->obs_scal[cur]);
     HIPCHK(h, hipEventRecord(h->ev_step_done, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step_done, 0));
     TRY(gather_on(h->comm_stream, h->scan_bufs[cur]));
@@ -1549,6 +1589,16 @@ int f110_comm_all_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scala
 {
     if (!h || !d_recv_scans || !d_recv_scalars) return fail(h, F110_ERR_INVALID, "null argument");
     return comm_gather(h, d_recv_scans, d_recv_scalars);
+}
+
+int f110_comm_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scalars, int32_t transport, int32_t root)
+{
+    if (!h) return fail(h, F110_ERR_INVALID, "null handle");
+    if (transport != F110_GATHER_F64 && transport != F110_GATHER_F32) return fail(h, F110_ERR_INVALID, "f110_comm_gather_obs: unknown transport %d", transport);
+    // a rank that is not the root sends its scalar block exactly when the root asked for one: the ranks agree on that
+    // through this flag's convention — a sender passes a non-null d_recv_scalars (never written) to say "with scalars"
+    h->comm_send_scalars = d_recv_scalars != nullptr;
+    return comm_gather(h, d_recv_scans, d_recv_scalars, transport, root);
 }
 
 int f110_comm_info(f110_sim *h, int32_t *n_ranks, int32_t *rank)

@@ -2478,6 +2478,13 @@ __global__ void __launch_bounds__(256) k_pack_obs(AgentArrays a, double *__restr
     cols[6 * N + i] = a.collisions[i];
 }
 
+// float32 transport of the observation gather (f110_comm_gather_obs, F110_GATHER_F32): round-to-nearest of every range
+__global__ void __launch_bounds__(256) k_scans_to_f32(const double *__restrict__ src, float *__restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
 // re-seat every env whose done flag is set (F110Env.reset :319-334 without its zero-action step)
 __global__ void __launch_bounds__(256) k_episode_reset_done(AgentArrays a, EpisodeArrays ep, int32_t *__restrict__ n_reset)
 {

@@ -329,6 +329,16 @@ int f110_comm_all_gather_scans(f110_sim *h, void *d_recv);
  * double-buffered with the scans). */
 #define F110_OBS_SCALARS 7
 int f110_comm_all_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scalars);
+/* The same gather with the two knobs SURVEY 8e prices: transport F110_GATHER_F32 sends the scans as float32 (a
+ * conversion kernel in front of the collective; d_recv_scans then holds n_ranks*N*B FLOATS; the scalars stay
+ * float64) — 142 MB instead of 283 MB per rank and step at 32 768 agents; root >= 0 gathers to that rank only
+ * (grouped ncclSend / ncclRecv: every peer's block rides its one direct link to the root, the other ranks
+ * receive nothing; their d_recv_scans may be NULL, and they pass a non-NULL d_recv_scalars — never written —
+ * exactly when the root wants the scalar blocks), root = -1 is the all-gather above.  Honours
+ * f110_comm_set_overlap. */
+#define F110_GATHER_F64 0
+#define F110_GATHER_F32 1
+int f110_comm_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scalars, int32_t transport, int32_t root);
 /* size and rank of the communicator as RCCL itself reports them (ncclCommCount / ncclCommUserRank) */
 int f110_comm_info(f110_sim *h, int32_t *n_ranks, int32_t *rank);
 /* enable = 1: the gather OVERLAPS the following step.  The scans are double-buffered (a second

@@ -105,7 +105,12 @@ def test_bench_main_as_two_launched_ranks_with_stub_step():
     for leg in ("gather", "gather_overlap"):
         assert mg[leg]["gather_ok"] is True and len(mg[leg]["per_rank_ms_per_step"]) == 2
         assert mg[leg]["value"] < line["value"]                # the stub's gather legs are slower by 50 / 25 %
-        assert mg[leg]["bytes_gathered_per_rank_per_step"] == 8 * 1000 * (1080 + 7) * 2
+        assert mg[leg]["bytes_received_per_step"] == {"every_rank": 8 * 1000 * (1080 + 7) * 2}
+        assert mg[leg]["bytes_sent_per_rank_per_step"] == 8 * 1000 * (1080 + 7)
+    # round 4: float32 transport and gather-to-root as legs of their own (SURVEY 8e's 142 MB / one receiver)
+    assert mg["gather_f32"]["bytes_sent_per_rank_per_step"] == 1000 * (4 * 1080 + 56)
+    assert mg["gather_root"]["bytes_received_per_step"] == {"root": 8 * 1000 * (1080 + 7) * 2}
+    assert set(mg) >= {"gather_f32_overlap", "gather_root_f32_overlap"}
     assert mg["gather_overlap"]["value"] > mg["gather"]["value"]
     assert mg["rccl_ranks"] is None                          # no communicator in the stub
     assert len(mg["numa"]) == 2
@@ -133,7 +138,7 @@ def test_configs3_to_the_letter_legs():
     assert "131072 per GPU" in c3["workload"]
     for leg in ("no_gather", "gather", "gather_overlap"):
         assert c3[leg]["value"] > 0 and len(c3[leg]["per_rank_ms_per_step"]) == 2
-    assert c3["gather"]["bytes_gathered_per_rank_per_step"] == 8 * 131072 * 1087 * 2
+    assert c3["gather"]["bytes_received_per_step"] == {"every_rank": 8 * 131072 * 1087 * 2}
     assert c3["no_gather"]["value"] > c3["gather_overlap"]["value"] > c3["gather"]["value"]
 
 
