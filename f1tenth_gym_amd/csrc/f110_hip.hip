@@ -50,6 +50,7 @@ struct ExpSwitches {
     int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
     int scan_env_counter = 0;  // 1: the scan kernel also counts finished tasks per env (fusion feasibility A/B)
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
+    int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
     uint64_t scan_trace = 0;   // device address of a caller-owned [waves][8] uint64 buffer: clock stamps, hardware id, samples of every scan wave (0 = off)
 };
 
@@ -466,6 +467,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "scan_occupancy") h->exp.scan_occupancy = value;
     else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
     else if (k == "integrate_duo") h->exp.integrate_duo = value;
+    else if (k == "integrate_fan") h->exp.integrate_fan = value;
     else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
     else if (k == "scan_trace_lo") h->exp.scan_trace = (h->exp.scan_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "collide_mode") {
@@ -2012,10 +2014,15 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
 #endif
     if (!fused_integrate) {
         bool duo = true;   // the integration in two waves per 64 agents (k_integrate_duo)
+        // RK4: thirteen waves per 64 agents (k_integrate_fan) up to kFanMaxAgents agents — the kernel is a latency
+        // chain there; big batches are throughput-bound and keep the two-wave form
+        bool fan = h->dev.integrator == F110_INTEGRATOR_RK4 && count <= kFanMaxAgents;
 #ifdef F110_EXPERIMENTAL
         if (h->exp.integrate_duo >= 0) duo = h->exp.integrate_duo != 0;
+        if (h->exp.integrate_fan >= 0) fan = h->exp.integrate_fan != 0 && h->dev.integrator == F110_INTEGRATOR_RK4;
 #endif
-        if (duo) hipLaunchKernelGGL(k_integrate_duo, grid1d(count, 64), dim3(128), 0, st, dev, h->k, d_actions);
+        if (fan) hipLaunchKernelGGL(k_integrate_fan, grid1d(count, 64), dim3(64 * kFanWaves), 0, st, dev, h->k, d_actions);
+        else if (duo) hipLaunchKernelGGL(k_integrate_duo, grid1d(count, 64), dim3(128), 0, st, dev, h->k, d_actions);
 #ifdef F110_EXPERIMENTAL
         else hipLaunchKernelGGL(k_integrate<0>, grid1d(count, 256), dim3(256), 0, st, dev, h->k, d_actions);
 #endif

@@ -321,6 +321,100 @@ __global__ void __launch_bounds__(128) k_integrate_duo(AgentArrays a, ScanConst 
     integrate_store(a, k, i, N, st, b0, b1, cnt, sp);
 }
 
+// ---- K1 fanned out over thirteen waves (round 4; RK4) -------------------------------------------------------------
+// k_integrate_duo still runs one ~1900-instruction chain per wave; at 4096 agents that chain IS the kernel's 9.4 us
+// (one wave per SIMD: ~10 cycles per dependent instruction).  The step's dataflow is much shallower (f110_math.hpp,
+// "the RK4 step taken apart"): a workgroup of 13 waves serves 64 agents —
+//   wave 0        the main chain: loads, delay buffer, fan_main (a handful of multiply-adds per stage), combine, store;
+//   waves 1-4     stage s's low-speed branch (tan / cos of the steering angle -> f4, f5), lanes that take it;
+//   waves 5-8     stage s's single-track coefficients (the three divisions by the velocity), lanes that take it;
+//   waves 9-12    stage s's position derivatives (cos / sin of the heading) once the main chain has the headings —
+// three workgroup barriers in all.  Same operations on the same operands as k_integrate<0>: bit-identical
+// (tests/test_host_math.py test_fan_integration_*, test_integrate_fan_is_invisible).
+constexpr int kFanWaves = 13;
+constexpr int kFanMaxAgents = 24576;   // measured (profiles/r04_fan_sweep.txt): pays up to 16 384 agents (-1 us per step), loses from 32 768
+__global__ void __launch_bounds__(64 * kFanWaves) k_integrate_fan(AgentArrays a, ScanConst k, const double *__restrict__ actions)
+{
+    __shared__ double s_l4[4][64], s_l5[4][64], s_k[4][6][64], s_ang[4][64], s_vel[4][64], s_f0[4][64], s_f1[4][64];
+    const int lane = (int)(threadIdx.x & 63u);
+    const int role = (int)(threadIdx.x >> 6);
+    const int N = a.n_agents_total;
+    const int i_raw = a.agent_begin + (int)(blockIdx.x * 64u) + lane;
+    const bool live = i_raw < a.agent_begin + a.agent_count;
+    const int i = live ? i_raw : a.agent_begin;   // (lanes past the end shadow the first agent: every lane meets every barrier)
+    const VehicleParams vp = load_params(a.params + (size_t)(a.params_per_agent ? i : i % a.agents_per_env) * NPARAMS);
+    const double2 act = reinterpret_cast<const double2 *>(actions)[i];
+    const double steer0 = a.state[(size_t)2 * N + i], vel0 = a.state[(size_t)3 * N + i];
+    const double buf1_in = a.steer_buf[(size_t)N + i];
+    const int cnt_in = a.buf_cnt[i];
+    double accl, sv;
+    fan_inputs(steer0, vel0, buf1_in, cnt_in, act.y, vp, accl, sv);
+    double st[7];
+    double b0 = 0., b1 = 0.;
+    int cnt = 0;
+    if (role == 0) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) st[c] = a.state[(size_t)c * N + i];
+        b0 = a.steer_buf[i];
+        b1 = buf1_in;
+        cnt = cnt_in;
+        if (cnt < 2) cnt += 1;   // :271-278 two-step steering delay
+        b1 = b0;
+        b0 = act.x;
+    } else if (role <= 4) {
+        const int s = role - 1;
+        const FanWalk w = fan_walk(steer0, vel0, accl, sv, vp, a.time_step, s);
+        if (w.low) {
+            double f4, f5;
+            fan_low(w, vp, f4, f5);
+            s_l4[s][lane] = f4;
+            s_l5[s][lane] = f5;
+        }
+    } else if (role <= 8) {
+        const int s = role - 5;
+        const FanWalk w = fan_walk(steer0, vel0, accl, sv, vp, a.time_step, s);
+        if (!w.low) {
+            double kk[6];
+            fan_dyn(w, vp, kk);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s_k[s][c][lane] = kk[c];
+        }
+    }
+    __syncthreads();
+    const double x0 = st[0], y0 = st[1];
+    if (role == 0) {
+        fan_main(st, accl, sv, vp, a.time_step,
+                 [&](int s, double &f4, double &f5) {
+                     f4 = s_l4[s][lane];
+                     f5 = s_l5[s][lane];
+                 },
+                 [&](int s, double *kk) {
+#pragma unroll
+                     for (int c = 0; c < 6; ++c) kk[c] = s_k[s][c][lane];
+                 },
+                 [&](int s, double ang, double v) {
+                     s_ang[s][lane] = ang;
+                     s_vel[s][lane] = v;
+                 });
+    }
+    __syncthreads();
+    if (role >= 9) {
+        const int s = role - 9;
+        double f0, f1;
+        fan_pos(s_ang[s][lane], s_vel[s][lane], f0, f1);
+        s_f0[s][lane] = f0;
+        s_f1[s][lane] = f1;
+    }
+    __syncthreads();
+    if (role != 0) return;
+    st[0] = fan_combine(x0, a.time_step, s_f0[0][lane], s_f0[1][lane], s_f0[2][lane], s_f0[3][lane]);
+    st[1] = fan_combine(y0, a.time_step, s_f1[0][lane], s_f1[1][lane], s_f1[2][lane], s_f1[3][lane]);
+    double sp[3];
+    fan_finish(st, a.lidar_dist, sp);
+    if (!live) return;
+    integrate_store(a, k, i, N, st, b0, b1, cnt, sp);
+}
+
 // ---- K1b: pairwise body collisions inside each env (separate launch, side stream) ------------
 __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
 {

@@ -260,6 +260,150 @@ F110_HD void low_speed_trig_ahead(double steer0, double vel0, double buf1, int b
     }
 }
 
+// ---- the RK4 step taken apart by what depends on what (k_integrate_fan, round 4) --------------------------------
+// advance_vehicle_with is one dependent chain of ~1900 instructions per agent: four stages, each a cos / sin of the
+// heading, the low-speed branch's tan / cos of the steering angle or the single-track branch's three divisions by the
+// velocity, and the stage update.  Its dataflow is much shallower than that:
+//   * (steer, velocity) walk through the stages on their own (their derivatives are the constrained inputs);
+//   * the low-speed branch's f4, f5 and the single-track branch's coefficients of (yaw rate, slip) in f5, f6 depend on
+//     that walk only;
+//   * given those, (yaw, yaw rate, slip) advance by a handful of multiply-adds per stage;
+//   * the position derivatives — velocity x (cos, sin)(heading) — feed nothing but the position itself.
+// So: one wave per (role, stage) computes the expensive piece it owns (fan_low, fan_dyn, fan_pos), the main wave
+// chains the cheap recurrence (fan_main) and combines.  Every operation of advance_vehicle_with is executed once, on
+// the same operands, in the same order within each expression: bit-identical (tests/test_host_math.py).
+struct FanWalk {   // (steer, velocity) and their constrained rates at one stage
+    double x2, x3, u0, u1;
+    bool low;
+};
+// the pid of :282 — (accl, sv) — from what every role reads of the agent: raw state, delay buffer, speed command
+F110_HD void fan_inputs(double steer0, double vel0, double buf1, int buf_cnt, double speed_cmd, const VehicleParams &p, double &accl, double &sv)
+{
+    const double steer = (buf_cnt < 2) ? 0. : buf1;   // :271-278 (the command that leaves the delay buffer this step)
+    speed_steer_controller(speed_cmd, steer, vel0, steer0, p, accl, sv);
+}
+// the walk up to `stage` (0..3): same operations as low_speed_trig_ahead / advance_vehicle_with's loop for x[2], x[3]
+F110_HD FanWalk fan_walk(double steer0, double vel0, double accl, double sv, const VehicleParams &p, double dt, int stage)
+{
+    FanWalk w;
+    w.x2 = steer0;
+    w.x3 = vel0;
+    for (int sidx = 0;; ++sidx) {
+        w.low = fabs(w.x3) < 0.5;
+        w.u0 = clamp_steer_rate(w.x2, sv, p);
+        w.u1 = clamp_accel(w.x3, accl, p);
+        if (sidx == stage) return w;
+        const double f2 = w.low ? clamp_steer_rate(w.x2, w.u0, p) : w.u0;
+        const double f3 = w.low ? clamp_accel(w.x3, w.u1, p) : w.u1;
+        const double h2 = (sidx < 2) ? f2 / 2 : f2, h3 = (sidx < 2) ? f3 / 2 : f3;
+        w.x2 = steer0 + dt * h2;
+        w.x3 = vel0 + dt * h3;
+    }
+}
+// low-speed branch (:152-160): f[4], f[5] of rhs_single_track_with
+F110_HD void fan_low(const FanWalk &w, const VehicleParams &p, double &f4, double &f5)
+{
+    const double lwb = p.v[P_LF] + p.v[P_LR];
+    const double tn = tan(w.x2), cd = cos(w.x2);
+    f4 = w.x3 / lwb * tn;
+    f5 = w.u1 / lwb * tn + w.x3 / (lwb * (cd * cd)) * w.u0;
+}
+// single-track branch (:164-174): f5 = (k[0] * yaw_rate + k[1] * slip) + k[2], f6 = (k[3] * yaw_rate - k[4] * slip) + k[5]
+F110_HD void fan_dyn(const FanWalk &w, const VehicleParams &p, double *k)
+{
+    const double g = 9.81;
+    const double mu = p.v[P_MU], csf = p.v[P_CSF], csr = p.v[P_CSR], lf = p.v[P_LF], lr = p.v[P_LR];
+    const double h = p.v[P_H], m = p.v[P_M], iz = p.v[P_I];
+    const double rear = g * lr - w.u1 * h;
+    const double front = g * lf + w.u1 * h;
+    const double wb = lr + lf;
+    k[0] = -mu * m / (w.x3 * iz * wb) * ((lf * lf) * csf * rear + (lr * lr) * csr * front);
+    k[1] = mu * m / (iz * wb) * (lr * csr * front - lf * csf * rear);
+    k[2] = mu * m / (iz * wb) * lf * csf * rear * w.x2;
+    k[3] = mu / ((w.x3 * w.x3) * wb) * (csr * front * lr - csf * rear * lf) - 1;
+    k[4] = mu / (w.x3 * wb) * (csr * front + csf * rear);
+    k[5] = mu / (w.x3 * wb) * (csf * rear) * w.x2;
+}
+// position derivatives of one stage: velocity x (cos, sin)(angle), angle = heading (low speed) or heading + slip
+F110_HD void fan_pos(double angle, double vel, double &f0, double &f1)
+{
+    double ca, sa;
+    cos_sin(angle, ca, sa);
+    f0 = vel * ca;
+    f1 = vel * sa;
+}
+// The main chain.  take_low(stage, f4, f5) / take_dyn(stage, k6) fetch what fan_low / fan_dyn produced for the stages that
+// took that branch; emit_angle(stage, angle, vel) hands the stage's position-derivative operands on.  st[2..6] are
+// advanced to the end of the step here (st[0], st[1] by fan_combine_position); returns nothing else.
+template <class TakeLow, class TakeDyn, class EmitAngle>
+F110_HD void fan_main(double *st, double accl, double sv, const VehicleParams &p, double dt, const TakeLow &take_low, const TakeDyn &take_dyn,
+                      const EmitAngle &emit_angle)
+{
+    double acc[5], tmp[5], kk[5];   // components 2..6
+#pragma unroll
+    for (int i = 0; i < 5; ++i) tmp[i] = st[2 + i];
+#pragma unroll 1
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        const double x2 = tmp[0], x3 = tmp[1], x4 = tmp[2], x5 = tmp[3], x6 = tmp[4];
+        const double u0 = clamp_steer_rate(x2, sv, p);
+        const double u1 = clamp_accel(x3, accl, p);
+        const bool low = fabs(x3) < 0.5;
+        emit_angle(sidx, low ? x4 : x6 + x4, x3);
+        if (low) {
+            kk[0] = clamp_steer_rate(x2, u0, p);
+            kk[1] = clamp_accel(x3, u1, p);
+            take_low(sidx, kk[2], kk[3]);
+            kk[4] = 0.;
+        } else {
+            double k[6];
+            take_dyn(sidx, k);
+            kk[0] = u0;
+            kk[1] = u1;
+            kk[2] = x5;
+            kk[3] = (k[0] * x5 + k[1] * x6) + k[2];
+            kk[4] = (k[3] * x5 - k[4] * x6) + k[5];
+        }
+        const double wgt = (sidx == 1 || sidx == 2) ? 2.0 : 1.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            acc[i] = (sidx == 0) ? kk[i] : acc[i] + wgt * kk[i];
+            const double h = (sidx < 2) ? kk[i] / 2 : kk[i];
+            tmp[i] = st[2 + i] + dt * h;
+        }
+    }
+    const double w = dt * (1. / 6.);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st[2 + i] = st[2 + i] + w * acc[i];
+}
+// x, y: the four stages' derivatives combined as advance_vehicle_with combines them
+F110_HD double fan_combine(double x, double dt, double k1, double k2, double k3, double k4)
+{
+    double acc = k1;
+    acc = acc + 2.0 * k2;
+    acc = acc + 2.0 * k3;
+    acc = acc + 1.0 * k4;
+    return x + (dt * (1. / 6.)) * acc;
+}
+// what follows the integration in advance_vehicle_with: yaw wrap :400-404 and the lidar pose :407-409
+F110_HD void fan_finish(double *st, double lidar_dist, double *scan_pose)
+{
+    if (st[4] > kTwoPi)
+        st[4] = st[4] - kTwoPi;
+    else if (st[4] < 0)
+        st[4] = st[4] + kTwoPi;
+    const bool on_axle = lidar_dist == 0.0 && fabs(st[4]) < 1e300 && !(st[0] == 0.0 && signbit(st[0])) && !(st[1] == 0.0 && signbit(st[1]));
+    if (on_axle) {
+        scan_pose[0] = st[0];
+        scan_pose[1] = st[1];
+    } else {
+        double ch, sh;
+        cos_sin(st[4], ch, sh);
+        scan_pose[0] = st[0] + lidar_dist * ch;
+        scan_pose[1] = st[1] + lidar_dist * sh;
+    }
+    scan_pose[2] = st[4];
+}
+
 // ------------------------------------------------------------------ laser_models.py
 enum { LAYOUT_ROWMAJOR = 0, LAYOUT_TILED = 1, LAYOUT_CODE8 = 2, LAYOUT_PADDED = 3 };
 constexpr int kLutEntries = 255;   // codes 0..254 index the LUT, 255 = escape to the float64 table

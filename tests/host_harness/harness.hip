@@ -82,6 +82,39 @@ void hh_advance_duo(double *st, double *buf, int *cnt, double steer, double spee
     for (int s = 0; s < 4; ++s) which[s] = tab.produced[s] * 2 + tab.consumed[s];
 }
 
+// k_integrate_fan's decomposition on the host: every role's piece is computed by its own function from the RAW inputs
+// (as the role's wave would), the main chain takes them from tables.  which[s]: 1 = stage s took the low-speed branch,
+// 2 = the single-track branch (the table entry of the other kind is poisoned).
+void hh_advance_fan(double *st, double *buf, int *cnt, double steer, double speed, const double *p, double dt, double lidar_dist,
+                    double *scan_pose, int *which)
+{
+    VehicleParams vp;
+    for (int i = 0; i < NPARAMS; ++i) vp.v[i] = p[i];
+    double accl, sv;
+    fan_inputs(st[2], st[3], buf[1], *cnt, speed, vp, accl, sv);
+    double L4[4], L5[4], K[4][6], ang[4], vel[4], F0[4], F1[4];
+    for (int s = 0; s < 4; ++s) {   // the LOW / DYN roles, one "wave" per stage, each walking from the raw state
+        const FanWalk w = fan_walk(st[2], st[3], accl, sv, vp, dt, s);
+        L4[s] = L5[s] = -12345.0;
+        for (int c = 0; c < 6; ++c) K[s][c] = -54321.0;
+        if (w.low) fan_low(w, vp, L4[s], L5[s]);
+        else fan_dyn(w, vp, K[s]);
+        which[s] = w.low ? 1 : 2;
+    }
+    // :271-278 the delay buffer (the main wave's bookkeeping)
+    if (*cnt < 2) *cnt += 1;
+    buf[1] = buf[0];
+    buf[0] = steer;
+    const double x0 = st[0], y0 = st[1];
+    fan_main(st, accl, sv, vp, dt, [&](int s, double &f4, double &f5) { f4 = L4[s]; f5 = L5[s]; },
+             [&](int s, double *k) { for (int c = 0; c < 6; ++c) k[c] = K[s][c]; },
+             [&](int s, double a, double v) { ang[s] = a; vel[s] = v; });
+    for (int s = 0; s < 4; ++s) fan_pos(ang[s], vel[s], F0[s], F1[s]);   // the POS roles
+    st[0] = fan_combine(x0, dt, F0[0], F0[1], F0[2], F0[3]);
+    st[1] = fan_combine(y0, dt, F1[0], F1[1], F1[2], F1[3]);
+    fan_finish(st, lidar_dist, scan_pose);
+}
+
 // guard-band re-marches of the PADDED layout since the last call to hh_padded_stats
 static long long g_pad_fast = 0, g_pad_guard = 0, g_pad_far = 0;
 void hh_padded_stats(long long *out)

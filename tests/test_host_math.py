@@ -119,6 +119,48 @@ def test_two_wave_integration_is_the_one_wave_integration(hh, integ):
     assert n_low > 500 and n_high > 500 and (n_cross > 20 or integ == 2), (n_low, n_high, n_cross)
 
 
+def test_fan_integration_is_the_one_wave_integration(hh):
+    """k_integrate_fan's decomposition, on the host (round 4): per stage one role computes the low-speed branch's f4 / f5
+    (fan_low) or the single-track branch's coefficients (fan_dyn) from the RAW state, the main chain (fan_main) advances
+    steer / velocity / yaw / yaw rate / slip taking them from tables, and the position derivatives come from fan_pos
+    afterwards.  Bit-identical to advance_vehicle (RK4) on both sides of |v| = 0.5, crossing it inside a step, every
+    delay-buffer fill, steering at its limits, lidar on and off the axle, yaw wrap both ways"""
+    g = gold("update_pose")
+    p, pp = d(g["params"])
+    rng = np.random.default_rng(404)
+    n_low = n_high = n_cross = 0
+    for i in range(8000):
+        st0 = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-0.45, 0.45), 0.0, rng.uniform(-7, 7), rng.uniform(-2, 2), rng.uniform(-0.3, 0.3)])
+        kind = i % 4
+        st0[3] = (rng.uniform(-0.6, 0.6), rng.uniform(0.4, 0.6) * rng.choice([-1, 1]), rng.uniform(-6, 12), 0.0)[kind]
+        if i % 7 == 0:
+            st0[2] = rng.choice([-0.4189, 0.4189])
+        if i % 11 == 0:
+            st0[4] = rng.choice([-1e-3, 2 * np.pi + 1e-3, 0.0, 2 * np.pi])     # around the yaw wrap
+        if i % 13 == 0:
+            st0[0] = -0.0                                                          # the on-axle shortcut's exception
+        c0 = int(rng.integers(0, 3))
+        buf0 = np.concatenate([rng.uniform(-0.4, 0.4, c0), np.zeros(2 - c0)])
+        steer, speed = rng.uniform(-0.5, 0.5), rng.uniform(-3, 15)
+        ld = 0.275 if i % 5 == 0 else 0.0
+        outs = []
+        for fn in ("hh_advance", "hh_advance_fan"):
+            st = st0.copy(); buf = buf0.copy(); cnt = C.c_int(c0); sp = np.empty(3); which = np.zeros(4, dtype=np.intc)
+            if fn == "hh_advance":
+                hh.hh_advance(st.ctypes.data_as(_dp), buf.ctypes.data_as(_dp), C.byref(cnt), C.c_double(steer), C.c_double(speed), pp, C.c_double(0.01), 1,
+                              C.c_double(ld), sp.ctypes.data_as(_dp))
+            else:
+                hh.hh_advance_fan(st.ctypes.data_as(_dp), buf.ctypes.data_as(_dp), C.byref(cnt), C.c_double(steer), C.c_double(speed), pp, C.c_double(0.01),
+                                  C.c_double(ld), sp.ctypes.data_as(_dp), which.ctypes.data_as(_ip))
+            outs.append((st, buf, cnt.value, sp, which))
+        (s1, b1, c1, p1, _), (s2, b2, c2, p2, which) = outs
+        same = lambda a, b: np.array_equal(a.view(np.uint64), b.view(np.uint64))     # bit patterns (incl. the sign of zero)
+        assert same(s1, s2) and same(b1, b2) and c1 == c2 and same(p1, p2), (i, st0, s1, s2)
+        low = [w == 1 for w in which]
+        n_low += all(low); n_high += not any(low); n_cross += any(low) and not all(low)
+    assert n_low > 500 and n_high > 500 and n_cross > 20, (n_low, n_high, n_cross)
+
+
 def _hh_scan(hh, layout, dt, res, origin, sines, cosines, B, fov, pose, theta_dis=2000):
     dt_, dtp = d(dt); s_, sp = d(sines); c_, cp = d(cosines); pose_, pp = d(pose)
     ranges = np.empty(B); hits = np.empty((B, 2), dtype=np.intc); idx = np.empty(B, dtype=np.intc)

@@ -40,6 +40,13 @@ manyagents)
     timeout 200 python bench.py --only-headline --agents $n --agents-per-env $a --steps 200 --warmup 20 > $OUT/many_$a.log 2>&1; line $OUT/many_$a.log "A=$a product"
   done; } | tee $OUT/many_agents.txt
   ;;
+fan)
+  X="env F110_LIB_VARIANT=experimental"
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  experimental build, bench.py $H --agents n, F110_EXP=integrate_fan=f"
+  for n in 1024 2048 4096 8192 16384 32768 65536 131072; do for f in 0 1; do
+    F110_EXP=integrate_fan=$f timeout 200 $X python bench.py $H --agents $n > $OUT/fan_n${n}_f$f.log 2>&1; line $OUT/fan_n${n}_f$f.log "agents $n integrate_fan $f"
+  done; done; } | tee $OUT/fan_sweep.txt
+  ;;
 dropin)
   timeout 500 python tools/debug/dropin_rate.py 2048,32768 > $OUT/dropin_rate.txt 2>&1; cat $OUT/dropin_rate.txt
   ;;
@@ -59,6 +66,29 @@ prof)
   timeout 300 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_vec -o stats -- python $R/tools/debug/vecenv_loop.py 2048 1000 > $OUT/prof_vec.log 2>&1
   python $R/tools/summarize_prof.py stats $OUT/prof_vec $OUT/kernel_stats_vecenv2048.txt 1000; rm -rf $OUT/prof_vec
   cd "$R"; head -14 $OUT/kernel_stats.txt; tail -8 $OUT/kernel_stats_4096.txt; tail -8 $OUT/kernel_stats_vecenv2048.txt
+  ;;
+pmc)
+  cd /tmp
+  i=0
+  for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_TA_BUSY GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays|k_finalize|k_integrate|k_collide" -T -f csv -d $OUT/pmc_$i -o p -- python $R/bench.py $H > $OUT/pmc_$i.log 2>&1
+    python $R/tools/summarize_prof.py pmc $OUT/pmc_$i $OUT/pmc_pass$i.json - 300   # the 300 timed steps only (steady regime: after pre-roll + warm-up)
+    rm -rf $OUT/pmc_$i
+  done
+  # HBM traffic of the scan kernel for the two other bench legs (FETCH_SIZE, WRITE_SIZE)
+  for cfg in "4096:--agents 4096" "cfg5:--agents 65536 --beams 4096 --map-tiles 2 --steps 100 --warmup 20 --preroll 100"; do
+    tagc=${cfg%%:*}; argsc=${cfg#*:}; n=300; [ "$tagc" = cfg5 ] && n=100
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout 300 rocprofv3 --pmc $c --kernel-include-regex "k_scan_rays|k_scan_dirs" -T -f csv -d $OUT/tr_$c -o p -- python $R/bench.py --only-headline $argsc > $OUT/tr_${tagc}_$c.log 2>&1
+      python $R/tools/summarize_prof.py pmc $OUT/tr_$c $OUT/traffic_${tagc}_$c.json - $n
+      rm -rf $OUT/tr_$c
+    done
+    timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --kernel-include-regex "k_scan_rays|k_scan_dirs" -T -f csv -d $OUT/tr_vm -o p -- python $R/bench.py --only-headline $argsc > $OUT/tr_${tagc}_vm.log 2>&1
+    python $R/tools/summarize_prof.py pmc $OUT/tr_vm $OUT/traffic_${tagc}_VMEM.json - $n
+    rm -rf $OUT/tr_vm
+  done
+  cd "$R"; ls $OUT/pmc_pass*.json $OUT/traffic_*.json 2>/dev/null | wc -l
   ;;
 pmccfg5)
   cd /tmp
