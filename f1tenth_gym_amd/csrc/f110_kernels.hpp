@@ -86,6 +86,8 @@ struct AgentArrays {
     int32_t noise_rows, integrator;
     double time_step, lidar_dist, ttc_thresh, angle_inc;
     double box_length, box_width;  // Simulator.params used by check_collision (:549)
+    const struct FusedHost *fused_host;   // f110_step_host, A = 2: the finalize kernel ends with the episode logic + host block (or nullptr)
+    unsigned long long fused_seq;         // ... and signals this sequence number (F110_STEP_SPIN_WAIT), 0 = no signal
 };
 
 __device__ __forceinline__ VehicleParams load_params(const double *p)
@@ -95,6 +97,68 @@ __device__ __forceinline__ VehicleParams load_params(const double *p)
     for (int i = 0; i < NPARAMS; ++i) vp.v[i] = p[i];
     return vp;
 }
+
+// ---- episode logic + host block (f110_episode_*, f110_step_host): the structs live here because the A = 2 finalize
+// kernel can carry both as its epilogue (FusedHost) ------------------------------------------------------------------
+// F110Env._check_done (f110_env.py:204-246): start/finish-zone toggles, lap counts and times, done
+// = ego collided or every agent has 4 toggles.
+struct EpisodeArrays {
+    int32_t ego_idx, pad;
+    double timestep;
+    double *start_poses;   // [N][3]
+    double *rot;           // [E][4] start_rot row-major (f110_env.py:331), computed by the host
+    double *current_time;  // [E]
+    uint8_t *near_start;   // [N]
+    double *toggle;        // [N]
+    double *lap_count;     // [N]
+    double *lap_time;      // [N]
+    uint8_t *done;         // [E]
+    uint8_t *checkpoint;   // [N] toggle >= 4
+};
+
+// f110_step_host: what a host-driven loop reads after a step (see k_host_block).  Any pointer may be nullptr.
+struct HostBlock {
+    double *state;          // [7][N]
+    double *collisions;     // [N]
+    double *collision_idx;  // [N]
+    double *agent_poses;    // [3][N]
+    double *lap_time, *lap_count, *toggle;  // [N]
+    double *current_time;   // [E]
+    int32_t *in_collision;  // [N]
+    uint8_t *near_start, *checkpoint;  // [N]
+    uint8_t *done;          // [E]
+    // completion word (F110_STEP_SPIN_WAIT): the workgroup that finishes last stores `seq` here, after every
+    // workgroup's stores have been fenced at system scope — the host polls it instead of entering the runtime
+    unsigned long long *seq_host;   // page-locked
+    unsigned int *blocks_done;      // device counter, returns to 0
+    unsigned long long seq;
+};
+
+// last statement of a workgroup of k_host_block: publish the block's host stores, count, and let the last one signal
+__device__ __forceinline__ void host_block_signal(const HostBlock &hb)
+{
+    if (!hb.seq_host) return;
+    __syncthreads();               // every lane's stores are issued
+    if (threadIdx.x == 0) {
+        __threadfence_system();    // ... and visible system-wide before the count
+        const unsigned int prev = __hip_atomic_fetch_add(hb.blocks_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == gridDim.x - 1) {
+            __hip_atomic_store(hb.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(hb.seq_host, hb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+
+// f110_step_host with the pair kernel: episode logic + host block as k_finalize_pair_roles' epilogue (one launch and one
+// drain less per step than k_host_block behind it).  Lives in device memory (the handle rewrites it when the caller's
+// block changes); the completion word's sequence number travels by value in AgentArrays (it changes every step).
+struct FusedHost {
+    EpisodeArrays ep;
+    HostBlock hb;
+    int32_t episode, auto_reset;
+};
 
 // ---- K1b body: pairwise body collisions inside each env + opponent beam windows ---------------
 // collision_multiple visits pairs (i<j) ascending and overwrites collision_idx, so an agent's
@@ -1674,6 +1738,114 @@ __global__ void __launch_bounds__(256) k_finalize_pair_flat(AgentArrays a, int32
     }
 }
 
+// ---- f110_step_host's work as the pair kernel's epilogue (round 4) -----------------------------------------------
+// What k_host_block does in a launch of its own, done by the agent threads of k_finalize_pair_roles (lanes t < AG of
+// wave 0; the two agents of an env are lanes t, t ^ 1) once the kernel's own work is finished: the agent's columns into
+// the caller's page-locked block, F110Env._check_done for the env, the in-place re-seat.  Same arithmetic as
+// k_host_block / k_episode (tests: the VecEnv forms agree, the reference's 2-agent episodes).
+__device__ __forceinline__ void pair_host_epilogue(const AgentArrays &a, bool agent_thread, int i)
+{
+    const FusedHost *fp = a.fused_host;
+    const EpisodeArrays ep = fp->ep;
+    const HostBlock hb = fp->hb;
+    const int episode = fp->episode, auto_reset = fp->auto_reset;
+    const size_t N = (size_t)a.n_agents_total;
+    double col = 0.;
+    int running = 0;
+    double ct = 0.;
+    if (agent_thread) {
+        const size_t iu = (size_t)i;
+        const double x = a.state[iu], y = a.state[N + iu];
+        if (hb.state) {
+            hb.state[iu] = x;
+            hb.state[N + iu] = y;
+#pragma unroll
+            for (int c = 2; c < 7; ++c) hb.state[c * N + iu] = a.state[c * N + iu];
+        }
+        col = a.collisions[iu];
+        if (hb.collisions) hb.collisions[iu] = col;
+        if (hb.collision_idx) hb.collision_idx[iu] = a.collision_idx[iu];
+        if (hb.in_collision) hb.in_collision[iu] = a.in_collision[iu];
+        if (hb.agent_poses) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) hb.agent_poses[c * N + iu] = a.snap_pose[c * N + iu];
+        }
+        if (episode) {
+            const int e = i >> 1;
+            ct = ep.current_time[e] + ep.timestep;  // f110_env.py:295 (written back by the env's even lane below)
+            const double r00 = ep.rot[4 * e], r01 = ep.rot[4 * e + 1], r10 = ep.rot[4 * e + 2], r11 = ep.rot[4 * e + 3];
+            const double left_t = 2, right_t = 2;
+            const double px = x - ep.start_poses[3 * iu];
+            const double py = y - ep.start_poses[3 * iu + 1];
+            const double dx = r00 * px + r01 * py;  // np.dot(start_rot, [px; py]) :223
+            double ty = r10 * px + r11 * py;
+            if (ty > left_t)
+                ty -= left_t;
+            else if (ty < -right_t)
+                ty = -right_t - ty;
+            else
+                ty = 0;
+            const double dist2 = dx * dx + ty * ty;
+            const bool closes = dist2 <= 0.1;
+            bool near = ep.near_start[iu] != 0;
+            double tog = ep.toggle[iu];
+            if (closes && !near) {
+                near = true;
+                tog += 1;
+            } else if (!closes && near) {
+                near = false;
+                tog += 1;
+            }
+            const double laps = floor(tog / 2);  // toggle_list // 2
+            ep.near_start[iu] = near ? 1 : 0;
+            ep.toggle[iu] = tog;
+            ep.lap_count[iu] = laps;
+            double lt = ep.lap_time[iu];
+            if (tog < 4) {
+                lt = ct;
+                ep.lap_time[iu] = ct;
+                running = 1;
+            }
+            ep.checkpoint[iu] = tog >= 4 ? 1 : 0;
+            if (hb.lap_time) hb.lap_time[iu] = lt;
+            if (hb.lap_count) hb.lap_count[iu] = laps;
+            if (hb.toggle) hb.toggle[iu] = tog;
+            if (hb.near_start) hb.near_start[iu] = near ? 1 : 0;
+            if (hb.checkpoint) hb.checkpoint[iu] = tog >= 4 ? 1 : 0;
+        }
+    }
+    // the env's other agent is the neighbouring lane (every lane of the wave takes part in the shuffles)
+    const double col_o = __shfl_xor(col, 1);
+    const int run_o = __shfl_xor(running, 1);
+    if (episode && agent_thread) {
+        const size_t iu = (size_t)i;
+        const int me = i & 1, e = i >> 1;
+        const double ego_col = (me == ep.ego_idx) ? col : col_o;
+        const bool done = ego_col != 0.0 || (running == 0 && run_o == 0);  // :244
+        const bool reseat = auto_reset && done;
+        if (me == 0) {
+            if (hb.current_time) hb.current_time[e] = ct;
+            if (hb.done) hb.done[e] = done ? 1 : 0;
+            ep.done[e] = (done && !reseat) ? 1 : 0;
+            ep.current_time[e] = reseat ? 0. : ct;
+        }
+        if (reseat) {   // F110Env.reset :319-334 without its zero-action step
+#pragma unroll
+            for (int c = 0; c < 7; ++c) a.state[c * N + iu] = 0.;
+            a.state[iu] = ep.start_poses[3 * iu];
+            a.state[N + iu] = ep.start_poses[3 * iu + 1];
+            a.state[4 * N + iu] = ep.start_poses[3 * iu + 2];
+            a.steer_buf[iu] = 0.;
+            a.steer_buf[N + iu] = 0.;
+            a.buf_cnt[iu] = 0;
+            a.in_collision[iu] = 0;
+            a.step_count[iu] = 0;
+            ep.near_start[iu] = 1;
+            ep.toggle[iu] = 0.;
+        }
+    }
+}
+
 // ---- K3r: k_finalize_pair_flat with the prologue laid out by ROLE instead of by agent (round 3) -----------
 // In k_finalize_pair_flat every wave carries all three pieces of the prologue one after the other (divergent
 // branches: corner -> beam index on lanes 0-3 of an agent's group, disc cull on lane 4, pair test on lane 5), so
@@ -1684,7 +1856,7 @@ __global__ void __launch_bounds__(256) k_finalize_pair_flat(AgentArrays a, int32
 // numbers) in wave 3; each wave runs only its own piece, the pieces run side by side on the CU's four SIMDs,
 // results meet in LDS.  Same functions on the same operands: bit-identical.  The window loop is unchanged.
 template <int AG>
-__global__ void __launch_bounds__(256) k_finalize_pair_roles(AgentArrays a, int32_t B)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_finalize_pair_roles(AgentArrays a, int32_t B)   // (6 waves per SIMD = 80 VGPRs: what the kernel needs without its f110_step_host epilogue)
 {
     static_assert((AG & (AG - 1)) == 0 && AG >= 2 && 4 * AG <= 128, "AG is a power of two, 2..32");
     __shared__ double s_rec[AG][12];   // ex, ey, eth, the opponent's box (8), pad
@@ -1814,6 +1986,15 @@ __global__ void __launch_bounds__(256) k_finalize_pair_roles(AgentArrays a, int3
         sincos(bt + kPi / 2., &v3y, &v3x);
         const double r = box_range(bex, bey, v3x, v3y, bv, r0);
         if (r < r0) sc[b] = r;
+    }
+    if (a.fused_host) {   // f110_step_host (wave-uniform): the host block, the episode logic and its re-seat, right here
+        if (t < 64) pair_host_epilogue(a, agent_thread, first + t);
+        if (a.fused_seq) {
+            HostBlock sig = a.fused_host->hb;
+            sig.seq = a.fused_seq;
+            host_block_signal(sig);
+        }
+        return;
     }
     if (a.reseat_poses && agent_thread) {
         const int i = first + t, ego = (i & ~1) + a.reseat_ego;
@@ -2319,19 +2500,7 @@ __global__ void k_reset_collided(AgentArrays a, const double *__restrict__ start
 // F110Env._check_done (f110_env.py:204-246): start/finish-zone toggles, lap counts and times, done
 // = ego collided or every agent has 4 toggles — one lane per env, so an RL loop that keeps its
 // policy on the GPU never has to read poses back to decide `done`.
-struct EpisodeArrays {
-    int32_t ego_idx, pad;
-    double timestep;
-    double *start_poses;   // [N][3]
-    double *rot;           // [E][4] start_rot row-major (f110_env.py:331), computed by the host
-    double *current_time;  // [E]
-    uint8_t *near_start;   // [N]
-    double *toggle;        // [N]
-    double *lap_count;     // [N]
-    double *lap_time;      // [N]
-    uint8_t *done;         // [E]
-    uint8_t *checkpoint;   // [N] toggle >= 4
-};
+// (struct EpisodeArrays: defined next to AgentArrays, the finalize kernels take it too)
 
 __global__ void __launch_bounds__(256) k_episode(AgentArrays a, EpisodeArrays ep, int num_envs)
 {
@@ -2409,39 +2578,7 @@ __global__ void __launch_bounds__(256) k_pack_episode(AgentArrays a, EpisodeArra
 // in-place re-seat of finished envs (k_episode_reset_done) AFTER their terminal observation has been written.
 // A workgroup owns whole envs (envs_per_block of them): phase 1 per agent (toggles + the agent's columns),
 // phase 2 per env (done, current_time), phase 3 per agent (re-seat).  Any pointer may be nullptr.
-struct HostBlock {
-    double *state;          // [7][N]
-    double *collisions;     // [N]
-    double *collision_idx;  // [N]
-    double *agent_poses;    // [3][N]
-    double *lap_time, *lap_count, *toggle;  // [N]
-    double *current_time;   // [E]
-    int32_t *in_collision;  // [N]
-    uint8_t *near_start, *checkpoint;  // [N]
-    uint8_t *done;          // [E]
-    // completion word (F110_STEP_SPIN_WAIT): the workgroup that finishes last stores `seq` here, after every
-    // workgroup's stores have been fenced at system scope — the host polls it instead of entering the runtime
-    unsigned long long *seq_host;   // page-locked
-    unsigned int *blocks_done;      // device counter, returns to 0
-    unsigned long long seq;
-};
-
-// last statement of a workgroup of k_host_block: publish the block's host stores, count, and let the last one signal
-__device__ __forceinline__ void host_block_signal(const HostBlock &hb)
-{
-    if (!hb.seq_host) return;
-    __syncthreads();               // every lane's stores are issued
-    if (threadIdx.x == 0) {
-        __threadfence_system();    // ... and visible system-wide before the count
-        const unsigned int prev = __hip_atomic_fetch_add(hb.blocks_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev == gridDim.x - 1) {
-            __hip_atomic_store(hb.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            __hip_atomic_store(hb.seq_host, hb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-
+// (struct HostBlock, host_block_signal: defined next to AgentArrays)
 __global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays ep, HostBlock hb, int num_envs, int envs_per_block,
                                                     int episode, int auto_reset)
 {
