@@ -39,7 +39,7 @@ The JSON line carries, besides the contract's fields:
                 separate replay of the same steps) as `kernel_frac`; L-bar counted ON THE DEVICE
                 over exactly the timed steps (a third replay with the counting kernel variant);
                 the compulsory-stream fraction, the PMC-measured HBM fraction, and the binding
-                gather-issue floor (profiles/r02_issue_floor.json)
+                gather-issue floor (profiles/rNN_issue_floor.json of the library's sources)
   steady_state  the same workload over >= 1000 timed steps after >= 100 warm-up steps
   cpu_baseline  the CPU oracle (oracle/, a C port of the reference) on this box's host cores, plus
                 `cpu_1t`: the reference's own shape (1 env x 2 agents, one thread; BASELINE configs[0])
@@ -545,7 +545,7 @@ def roofline_record(args, n_agents, beams, timed, prof, cnt, tiles=1):
             vm = fl["vmem_instr_per_launch"][key]
             floor_ms = vm * fl["gather_cycles_per_wave_instr"] / fl["cus"] / (fl["clock_mhz"] * 1e3)
             rec["issue_floor"] = {"what": "the binding unit: wave-level vector-memory instructions x the cheapest a 64-lane gather can issue "
-                                          "on a gfx950 CU (tools/debug/ta_bench.hip, profiles/r02_ta_bench.txt)",
+                                          "on a gfx950 CU (tools/debug/ta_bench.hip; measured per round: profiles/%s_ta_bench.txt)" % name.split("_")[0],
                                   "vmem_wave_instr_per_launch": vm, "cycles_per_instr": fl["gather_cycles_per_wave_instr"],
                                   "floor_ms": floor_ms, "kernel_ms": k_ms, "frac": floor_ms / k_ms, "csrc": fl.get("csrc"), "window": fl.get("window")}
             # what binds the kernel is the CUs' texture-address / data path issuing L2-resident gathers, not HBM: the

@@ -65,6 +65,39 @@ class _LapLogic(object):
         self.rot_c[m] = np.cos(th)[m]
         self.rot_s[m] = np.sin(th)[m]
 
+    def update_single(self, poses_x, poses_y, collisions, timestep):
+        """update() for ONE env in plain Python floats: the same IEEE operations in the same order, without ~25 NumPy
+        calls on arrays of A elements (the single-env F110Env.step is latency-bound, every microsecond of host time
+        counts).  returns done (bool), checkpoint_done [A]"""
+        ct = float(self.current_time[0]) + timestep
+        self.current_time[0] = ct
+        c, s = float(self.rot_c[0]), float(self.rot_s[0])
+        sx, sy = self.start_xs[0], self.start_ys[0]
+        near, tog = self.near_starts[0], self.toggle_list[0]
+        all4 = True
+        for i in range(self.A):
+            px = float(poses_x[i]) - float(sx[i])
+            py = float(poses_y[i]) - float(sy[i])
+            dx = c * px + (-s) * py
+            ty = s * px + c * py
+            if ty > 2:
+                ty = ty - 2
+            elif ty < -2:
+                ty = -2 - ty
+            else:
+                ty = 0.0
+            closes = dx ** 2 + ty ** 2 <= 0.1
+            if closes != bool(near[i]):
+                near[i] = closes
+                tog[i] += 1
+            t = float(tog[i])
+            self.lap_counts[0, i] = t // 2
+            if t < 4:
+                self.lap_times[0, i] = ct
+                all4 = False
+        done = bool(collisions[self.ego] != 0) or all4
+        return done, tog >= 4
+
     def update(self, poses_x, poses_y, collisions, timestep):
         """returns done[E], checkpoint_done[E][A]"""
         left_t, right_t = 2, 2
@@ -138,9 +171,9 @@ class F110Env(_EnvBase):
         reward = self.timestep
         self.poses_x, self.poses_y, self.poses_theta = obs['poses_x'], obs['poses_y'], obs['poses_theta']
         self.collisions = obs['collisions']
-        done, toggles = self._lap.update(obs['poses_x'], obs['poses_y'], obs['collisions'], self.timestep)
-        info = {'checkpoint_done': toggles[0]}
-        return obs, reward, bool(done[0]), info
+        done, toggles = self._lap.update_single(obs['poses_x'], obs['poses_y'], obs['collisions'], self.timestep)
+        info = {'checkpoint_done': toggles}
+        return obs, reward, done, info
 
     def reset(self, poses):
         poses = np.asarray(poses, dtype=np.float64)

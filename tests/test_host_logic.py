@@ -23,6 +23,27 @@ def test_lap_logic_matches_reference_episode():
     assert bool(tog[0, 0]) and e["toggle"][-1] == 4
 
 
+def test_lap_logic_single_env_scalar_form_equals_the_vectorised_one_and_the_reference():
+    """_LapLogic.update_single (plain floats, what F110Env.step uses) against update() and the reference's 2-agent
+    ego_idx = 1 episodes: toggles, lap counts / times, done, checkpoint flags at every step"""
+    from f1tenth_gym_amd.env import _LapLogic
+    g = gold("env_episode_2agents")
+    for ep in range(3):
+        a, b = _LapLogic(1, 2, 1), _LapLogic(1, 2, 1)
+        start = g["ep%d_start" % ep].reshape(1, 2, 3)
+        a.reset(start); b.reset(start)
+        for k in range(len(g["ep%d_x" % ep])):
+            x, y, col = g["ep%d_x" % ep][k], g["ep%d_y" % ep][k], g["ep%d_col" % ep][k]
+            da, ta = a.update(x, y, col, 0.01)
+            db, tb = b.update_single(list(x), list(y), col, 0.01)
+            assert bool(da[0]) == db == bool(g["ep%d_done" % ep][k]), (ep, k)
+            assert np.array_equal(ta[0], tb) and np.array_equal(tb, g["ep%d_ckpt" % ep][k])
+            for f in ("toggle_list", "near_starts", "lap_counts", "lap_times", "current_time"):
+                assert np.array_equal(getattr(a, f), getattr(b, f)), (ep, k, f)
+            assert np.array_equal(b.toggle_list[0], g["ep%d_toggle" % ep][k]) and np.array_equal(b.lap_counts[0], g["ep%d_lap_count" % ep][k])
+            assert np.max(np.abs(b.lap_times[0] - g["ep%d_lap_time" % ep][k])) < 1e-12
+
+
 def test_lap_logic_vectorised_envs_are_independent():
     from f1tenth_gym_amd.env import _LapLogic
     e = gold("env_episode")

@@ -59,8 +59,8 @@ def main():
         key = "agents=%d,beams=%d,layout=%d" % (agents, beams, layout)
         fl.update({"what": "gather-issue floor of the scan kernel: wave-level vector-memory instructions per launch (rocprofv3 --pmc "
                            "SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR over the bench's timed steps) x the cheapest a 64-lane non-contiguous "
-                           "gather issues on a gfx950 CU (r02_ta_bench.txt: 19.4-19.7 cycles per wave-level u64 load at 1-4 distinct "
-                           "lines; no width, line count or active-lane mask measured is cheaper than ~17.5)",
+                           "gather issues on a gfx950 CU (%s_ta_bench.txt, tools/debug/ta_bench.hip on the same box: 19.0-19.9 cycles per wave-level u64 load at 1-8 distinct "
+                           "lines; no width, line count or active-lane mask measured is cheaper than ~17.4)" % tag,
                    "gather_cycles_per_wave_instr": 19.5, "cus": 256, "clock_mhz": 2400, "round": tag, "csrc": csrc, "window": window})
         fl.setdefault("vmem_instr_per_launch", {})[key] = vm
         fl.setdefault("pmc", {})[key] = {"kernel_cycles": cyc, "TA_TA_BUSY_frac": scan.get("TA_TA_BUSY_sum", 0.0) / 256.0 / cyc,
