@@ -67,7 +67,7 @@ class HostBlock(C.Structure):
 
 
 GATHER_F64, GATHER_F32 = 0, 1
-STEP_AUTO_RESET, STEP_NO_SYNC, STEP_ACTIONS_MAPPED, STEP_SPIN_WAIT, STEP_NO_FUSE = 1, 2, 4, 8, 16
+STEP_AUTO_RESET, STEP_NO_SYNC, STEP_ACTIONS_MAPPED, STEP_SPIN_WAIT, STEP_NO_FUSE, STEP_POLL = 1, 2, 4, 8, 16, 32
 
 
 class DeviceViews(C.Structure):

@@ -571,12 +571,14 @@ class BatchSim(object):
         n = max(o[0], 1.0)
         return int(o[0]), o[1] / n, o[2] / n
 
-    def step_host(self, hb, actions=None, auto_reset=False, sync=True, mapped_actions=True, spin=False, fuse=True):
+    def step_host(self, hb, actions=None, auto_reset=False, sync=True, mapped_actions=True, spin=False, fuse=True, poll=True):
         """f110_step_host: `actions` (None: hb.actions as the caller filled it in place) up, the step, the
         episode logic if episode_init was called, hb's fields down — one ABI call."""
         flags = (_ffi.STEP_AUTO_RESET if auto_reset else 0) | (0 if sync else _ffi.STEP_NO_SYNC) | (_ffi.STEP_SPIN_WAIT if spin else 0)
         if not fuse:
             flags |= _ffi.STEP_NO_FUSE
+        if poll:
+            flags |= _ffi.STEP_POLL
         if actions is None or actions is hb.actions:
             ptr = hb.actions_ptr
             if mapped_actions:

@@ -175,6 +175,7 @@ struct f110_sim {
     f110_host_block hb_host{};
     HostBlock hb_dev{};
     const double *hb_actions_host = nullptr, *hb_actions_dev = nullptr;
+    bool hb_scans_by_kernel = false;             // the validated block's scans are stored by the kernel (small batch, page-locked)
     unsigned long long *hb_seq_host = nullptr;   // page-locked completion word (F110_STEP_SPIN_WAIT)
     unsigned int *hb_blocks_done = nullptr;
     unsigned long long hb_seq = 0;
@@ -1766,6 +1767,8 @@ int f110_episode_step_host(f110_sim *h, const double *h_actions, int32_t auto_re
 // One entry per env.step() of a host-driven loop (f110.h).  Every pointer of `out` and — with
 // F110_STEP_ACTIONS_MAPPED — h_actions must be page-locked memory of f110_host_alloc: the kernels read / write
 // it in place.  The (struct, actions) pair is validated once (hipHostGetDevicePointer) and remembered.
+constexpr size_t kScansByKernelBytes = 8u << 20;   // scans up to this size ride in the host-block kernel instead of a DMA copy
+
 static int map_host_ptr(f110_sim *h, const void *host, void **dev, const char *what)
 {
     *dev = nullptr;
@@ -1809,6 +1812,19 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
         MAP_FIELD(checkpoint, checkpoint_done, "checkpoint_done");
         MAP_FIELD(done, done, "done");
 #undef MAP_FIELD
+        // scans of a small batch: stored by the kernel too (needs page-locked memory; else, and for big batches, the DMA copy)
+        d.scans = nullptr;
+        d.num_beams = h->cfg.num_beams;
+        h->hb_scans_by_kernel = false;
+        if (out->scans && N * (size_t)h->cfg.num_beams * sizeof(double) <= kScansByKernelBytes) {
+            void *ps = nullptr;
+            if (hipHostGetDevicePointer(&ps, out->scans, 0) == hipSuccess && ps) {
+                d.scans = reinterpret_cast<double *>(ps);
+                h->hb_scans_by_kernel = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         TRY(map_host_ptr(h, mapped_actions ? h_actions : nullptr, &p, "h_actions"));
         h->hb_actions_dev = reinterpret_cast<const double *>(p);
         h->hb_actions_host = mapped_actions ? h_actions : nullptr;
@@ -1817,7 +1833,7 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
         h->hb_valid = true;
     }
     const auto t_in = std::chrono::steady_clock::now();
-    const bool spin = (flags & F110_STEP_SPIN_WAIT) && !(flags & F110_STEP_NO_SYNC) && !out->scans;
+    const bool spin = (flags & F110_STEP_SPIN_WAIT) && !(flags & F110_STEP_NO_SYNC) && (!out->scans || (h->hb_valid && h->hb_scans_by_kernel));
     if (spin && !h->hb_seq_host) {
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->hb_seq_host), 64, hipHostMallocDefault));
         *h->hb_seq_host = 0;
@@ -1870,7 +1886,7 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
                            episode ? 1 : 0, (flags & F110_STEP_AUTO_RESET) ? 1 : 0);
     }
     // the scans are contiguous in HBM already: a DMA copy, behind the kernel (the re-seat leaves scans alone)
-    if (out->scans) HIPCHK(h, hipMemcpyAsync(out->scans, h->dev.scans, sizeof(double) * N * (size_t)h->cfg.num_beams, hipMemcpyDeviceToHost, h->stream));
+    if (out->scans && !h->hb_scans_by_kernel) HIPCHK(h, hipMemcpyAsync(out->scans, h->dev.scans, sizeof(double) * N * (size_t)h->cfg.num_beams, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipGetLastError());
     const auto t_enq = std::chrono::steady_clock::now();
     if (spin) {
@@ -1890,7 +1906,15 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
         }
         if (!seen) HIPCHK(h, hipStreamSynchronize(h->stream));
     } else if (!(flags & F110_STEP_NO_SYNC)) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (flags & F110_STEP_POLL) {
+            // hipStreamSynchronize wakes up in coarse quanta once a wait has lasted ~30 us (measured: a 40 us step is
+            // reported after 67 us); polling the stream costs a core for the step's duration and returns within ~1 us
+            hipError_t q;
+            while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) __builtin_ia32_pause();
+            if (q != hipSuccess) return fail(h, F110_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        } else {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
     }
     const auto t_out = std::chrono::steady_clock::now();
     h->hs_enqueue_us += std::chrono::duration<double, std::micro>(t_enq - t_in).count();

@@ -132,7 +132,30 @@ struct HostBlock {
     unsigned long long *seq_host;   // page-locked
     unsigned int *blocks_done;      // device counter, returns to 0
     unsigned long long seq;
+    // small batches: the scans too are stored by the kernel (a DMA copy of 17 KB costs ~36 us of latency on this
+    // runtime, a kernel's stores ~2); nullptr: the caller copies them (big batches: one DMA copy at link rate)
+    double *scans;                  // [N][num_beams] page-locked, or nullptr
+    int32_t num_beams, pad_beams;
 };
+
+// rows [first, first + count) of the device scans into the host block, by every thread of the workgroup
+__device__ __forceinline__ void host_block_copy_scans(const HostBlock &hb, const double *__restrict__ scans, size_t first, size_t count)
+{
+    const size_t B = (size_t)hb.num_beams, n = count * B;
+    const double *__restrict__ src = scans + first * B;
+    double *__restrict__ dst = hb.scans + first * B;
+    // four independent loads in flight per lane, then the four stores (a dependent load -> store per iteration would
+    // walk the rows one memory round trip at a time)
+    size_t q = threadIdx.x;
+    for (; q + 3 * (size_t)blockDim.x < n; q += 4 * (size_t)blockDim.x) {
+        const double v0 = src[q], v1 = src[q + blockDim.x], v2 = src[q + 2 * (size_t)blockDim.x], v3 = src[q + 3 * (size_t)blockDim.x];
+        dst[q] = v0;
+        dst[q + blockDim.x] = v1;
+        dst[q + 2 * (size_t)blockDim.x] = v2;
+        dst[q + 3 * (size_t)blockDim.x] = v3;
+    }
+    for (; q < n; q += blockDim.x) dst[q] = src[q];
+}
 
 // last statement of a workgroup of k_host_block: publish the block's host stores, count, and let the last one signal
 __device__ __forceinline__ void host_block_signal(const HostBlock &hb)
@@ -1988,6 +2011,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
         if (r < r0) sc[b] = r;
     }
     if (a.fused_host) {   // f110_step_host (wave-uniform): the host block, the episode logic and its re-seat, right here
+        if (a.fused_host->hb.scans) {   // small batches: this workgroup's agents' scans, final once every item above is done
+            __syncthreads();
+            const int live_agents = (end - first) < AG ? (end - first) : AG;
+            host_block_copy_scans(a.fused_host->hb, a.scans, (size_t)first, (size_t)(live_agents > 0 ? live_agents : 0));
+        }
         if (t < 64) pair_host_epilogue(a, agent_thread, first + t);
         if (a.fused_seq) {
             HostBlock sig = a.fused_host->hb;
@@ -2654,6 +2682,7 @@ __global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays
             if (hb.checkpoint) hb.checkpoint[i] = tog >= 4 ? 1 : 0;
         }
     }
+    if (hb.scans) host_block_copy_scans(hb, a.scans, (size_t)e0 * A, (size_t)items);
     if (!episode) {
         host_block_signal(hb);
         return;

@@ -237,7 +237,7 @@ class F110VecEnv(object):
     _EPISODE = ("lap_times", "lap_counts", "toggle_list", "near_starts", "checkpoint_done")
 
     def __init__(self, num_envs, auto_reset=False, device_logic=False, obs_fields=None, copy_obs=False,
-                 episode_fields=None, mapped_actions=True, spin_wait=False, fuse_host_block=True, **kwargs):
+                 episode_fields=None, mapped_actions=True, spin_wait=False, fuse_host_block=True, poll_wait=True, **kwargs):
         self.num_envs = int(num_envs)
         self.seed = kwargs.get('seed', 12345)
         self.map_name, self.map_path = _resolve_map_path(kwargs)
@@ -273,6 +273,7 @@ class F110VecEnv(object):
         self.mapped_actions = bool(mapped_actions)
         self.spin_wait = bool(spin_wait)
         self.fuse_host_block = bool(fuse_host_block)
+        self.poll_wait = bool(poll_wait)
         if self.device_logic:
             b = self.sim.batch
             b.episode_init(self.ego_idx)
@@ -354,7 +355,7 @@ class F110VecEnv(object):
             self.sim._noise.ensure(b, self.sim._steps_since_full_reset + 1)
         if actions is not None and actions is not self.action_buffer:
             hb.actions[...] = np.asarray(actions, dtype=np.float64).reshape(hb.actions.shape)
-        b.step_host(hb, None, auto_reset=self.auto_reset, sync=sync, mapped_actions=self.mapped_actions, spin=self.spin_wait, fuse=self.fuse_host_block)
+        b.step_host(hb, None, auto_reset=self.auto_reset, sync=sync, mapped_actions=self.mapped_actions, spin=self.spin_wait, fuse=self.fuse_host_block, poll=self.poll_wait)
         self.sim._steps_since_full_reset += 1
         if not sync:
             return None

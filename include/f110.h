@@ -260,6 +260,8 @@ typedef struct f110_host_block {
 #define F110_STEP_ACTIONS_MAPPED 4  /* h_actions is f110_host_alloc memory: read in place, no staging copy */
 #define F110_STEP_SPIN_WAIT 8       /* wait by polling a page-locked completion word the last workgroup stores,
                                        instead of a runtime synchronise (ignored with scans / NO_SYNC) */
+#define F110_STEP_POLL 32           /* wait by polling hipStreamQuery (a busy core, ~1 us wake-up) instead of
+                                       hipStreamSynchronize (coarse wake-up quanta beyond ~30 us of waiting) */
 #define F110_STEP_NO_FUSE 16        /* A/B: always run the episode logic + host block as a kernel of their own (with 2
                                        agents per env they are otherwise the finalize kernel's epilogue) */
 int f110_step_host(f110_sim *h, const double *h_actions /* [N][2] */, const f110_host_block *out, int32_t flags);

@@ -28,7 +28,27 @@ poses = bench_start_poses(1, 2).reshape(2, 3)
 env.reset(poses)
 act = np.array([[0.05, 3.0], [-0.05, 2.5]])
 dt = timed(lambda: env.step(act), 2000, 100)
-print("F110Env(num_agents=2).step              %8.1f us/step  %9.0f env-steps/s  %9.0f agent-steps/s" % (dt * 1e6, 1 / dt, 2 / dt))
+c, enq, wait = env.sim.batch.step_host_stats()
+print("F110Env(num_agents=2).step              %8.1f us/step  %9.0f env-steps/s  %9.0f agent-steps/s   [host: enqueue %.1f us, wait %.1f us, Python around the call %.1f us]"
+      % (dt * 1e6, 1 / dt, 2 / dt, enq, wait, dt * 1e6 - enq - wait))
+# the same env through the raw one-call-per-step path (no obs dict, no lap logic): what the ABI itself costs
+b = env.sim.batch
+hb = b.host_block(("scans", "state", "collisions"))
+hb.actions[...] = act
+dt2o = timed(lambda: b.step_host(hb, poll=False), 2000, 100)
+c, enq, wait = b.step_host_stats()
+print("  BatchSim.step_host (same env, scans, hipStreamSynchronize)   %8.1f us/step   [host: enqueue %.1f us, wait %.1f us]" % (dt2o * 1e6, enq, wait))
+dt2 = timed(lambda: b.step_host(hb), 2000, 100)
+c, enq, wait = b.step_host_stats()
+print("  BatchSim.step_host (same env, scans+state+collisions)  %8.1f us/step   [host: enqueue %.1f us, wait %.1f us]" % (dt2 * 1e6, enq, wait))
+dt2s = timed(lambda: b.step_host(hb, spin=True), 2000, 100)
+c, enq, wait = b.step_host_stats()
+print("  BatchSim.step_host (same env, scans, completion word polled) %8.1f us/step   [host: enqueue %.1f us, wait %.1f us]" % (dt2s * 1e6, enq, wait))
+hb2 = b.host_block(("state", "collisions"))
+hb2.actions[...] = act
+dt3 = timed(lambda: b.step_host(hb2), 2000, 100)
+c, enq, wait = b.step_host_stats()
+print("  BatchSim.step_host (same env, no scans)                %8.1f us/step   [host: enqueue %.1f us, wait %.1f us]" % (dt3 * 1e6, enq, wait))
 
 sizes = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [2048, 32768]
 for E in sizes:
@@ -57,6 +77,7 @@ for E in sizes:
                                ("VecEnv episode_fields=(), in-place, staged H2D", {"episode_fields": (), "mapped_actions": False}, True),
                                ("VecEnv episode_fields=(), in-place, spin wait", {"episode_fields": (), "spin_wait": True}, True),
                                ("VecEnv default episode fields, step(actions), spin", {"spin_wait": True}, False),
+                               ("VecEnv episode_fields=(), in-place, hipStreamSynchronize", {"episode_fields": (), "poll_wait": False}, True),
                                ("VecEnv obs poses+collisions, default episode", {"obs_fields": ("poses_x", "poses_y", "poses_theta", "collisions")}, False)):
         kw = dict(kw); kw.setdefault("obs_fields", ())
         env = amd.F110VecEnv(E, auto_reset=True, device_logic=True, **kw, **MAP)
