@@ -90,6 +90,31 @@ pmc)
   done
   cd "$R"; ls $OUT/pmc_pass*.json $OUT/traffic_*.json 2>/dev/null | wc -l
   ;;
+pmc4096)
+  cd /tmp
+  i=0
+  for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_BUSY_CYCLES" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_TA_BUSY GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays" -T -f csv -d $OUT/p4k_$i -o p -- python $R/bench.py $H --agents 4096 > $OUT/p4k_$i.log 2>&1
+    python $R/tools/summarize_prof.py pmc $OUT/p4k_$i $OUT/pmc_4096_pass$i.json - 300
+    rm -rf $OUT/p4k_$i
+  done
+  cd "$R"; python - <<'PYEOF'
+import json, glob
+m = {}
+for f in sorted(glob.glob("gpurun_out/pmc_4096_pass*.json")):
+    for k, r in json.load(open(f)).items():
+        m.update(r["mean_per_dispatch"]); meta = r["meta"]; csrc = r.get("csrc")
+cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+tasks = 4096 * 17
+print("k_scan_rays_agent at 4096 agents: kernel cycles %.0f (%.1f us at 2.4 GHz)  VGPR %s SGPR %s" % (cyc, cyc / 2.4e3, meta.get("VGPR_Count"), meta.get("SGPR_Count")))
+print("per task: VALU %.1f  SALU %.1f  VMEM rd %.2f wr %.2f   waves %d" % (m["SQ_INSTS_VALU"] / tasks, m["SQ_INSTS_SALU"] / tasks, m["SQ_INSTS_VMEM_RD"] / tasks, m["SQ_INSTS_VMEM_WR"] / tasks, m["SQ_WAVES"]))
+print("TA busy %.3f  TD busy %.3f  TCP hit %.3f  TCC hit %.3f  wave cycles per wave %.0f" % (m["TA_TA_BUSY_sum"] / 256.0 / cyc, m["TD_TD_BUSY_sum"] / 256.0 / cyc, 1 - m["TCP_TCC_READ_REQ_sum"] / m["TCP_TOTAL_CACHE_ACCESSES_sum"], m["TCC_HIT_sum"] / m["TCC_REQ_sum"], 4 * m["SQ_WAVE_CYCLES"] / m["SQ_WAVES"]))
+m["csrc"] = csrc
+m["what"] = "k_scan_rays_agent, BASELINE configs[1] (4096 agents): PMC means over the 300 timed dispatches (tools/gpu_r4.sh pmc4096)"
+json.dump(m, open("gpurun_out/pmc_4096.json", "w"), indent=1, sort_keys=True)
+PYEOF
+  ;;
 pmccfg5)
   cd /tmp
   i=0
