@@ -637,7 +637,19 @@ def cpu_baseline(args, seconds):
         return E * A * steps / el, steps, el, (ref.lookups - look0) / float(steps * E * A * args.beams), n_reset
 
     cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    threads = max(1, len(cpus))
+    # a container's CPU-time quota (cgroup cpu.max / cfs_quota): more runnable threads than that only get throttled
+    # (measured on the GPU box, quota 16 of 256 CPUs: 154 k agent-steps/s at 16 threads, 104-135 k at 128)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    threads = max(1, len(cpus) if quota is None else min(len(cpus), int(quota + 0.5)))
     phys = None
     try:   # physical cores among the CPUs this rank may use (SMT siblings share one)
         seen = set()
@@ -663,7 +675,8 @@ def cpu_baseline(args, seconds):
     flags = " ".join(orc.NATIVE_CFLAGS[:2]) if best == "native" else "-O2"
     vs, steps_s, el_s, _, _ = leg(E, 1, min(seconds, 6.0), native=(best == "native"), max_steps=60)   # the same envs, same build, one thread
     v1, steps1, el1, _, _ = leg(1, 1, min(seconds, 5.0), native=(best == "native"), max_steps=20000)
-    return {"value": v, "unit": "agent-steps/s", "cores": threads, "physical_cores": phys, "cpu_model": model, "kind": "port",
+    return {"value": v, "unit": "agent-steps/s", "cores": threads, "cpus_in_affinity": len(cpus), "physical_cores_in_affinity": phys,
+            "cgroup_cpu_quota": quota, "cpu_model": model, "kind": "port",
             "sample": "%d envs x %d agents x %d steps of the bench workload, %d re-seats (oracle/f110_oracle.c orc_sim_rollout, gcc %s "
                       "-ffp-contract=off -fno-builtin, OpenMP dynamic over envs, every env through all its steps on one thread), %.1f s"
                       % (E, A, steps, n_reset, flags, el),

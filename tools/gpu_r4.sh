@@ -50,8 +50,19 @@ fan)
 dropin)
   timeout 500 python tools/debug/dropin_rate.py 2048,32768 > $OUT/dropin_rate.txt 2>&1; cat $OUT/dropin_rate.txt
   ;;
+gatherlegs)   # the gather legs at world size 1 (RCCL initialises, every leg's data checked): f64 / f32 / root, in stream / overlapped
+  timeout 600 python bench.py --gather-legs --no-cpu-baseline --no-dropin --secondary 0 --no-config5 --fixed-pose-steps 0 --steady-steps 0 --steps 50 --warmup 10 > $OUT/bench_gather_legs.log 2>&1
+  grep -h "^{" $OUT/bench_gather_legs.log | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); mg = d['multi_gpu']
+    print('headline %.4f ms' % d['ms_per_step'], ' rccl_ranks', mg.get('rccl_ranks'), ' error', mg.get('gather_error'))
+    for k in ('gather', 'gather_overlap', 'gather_f32', 'gather_f32_overlap', 'gather_root', 'gather_root_f32_overlap'):
+        if k in mg: print('%-26s %.4f ms/step  ok %s' % (k, mg[k]['ms_per_step'], mg[k]['gather_ok']))
+" | tee $OUT/gather_legs.txt
+  ;;
 bench)
-  timeout 900 python bench.py > $OUT/bench_default.log 2>$OUT/bench_default.err; echo "bench exit $?" >> $OUT/bench_default.log
+  ( time timeout 900 python bench.py > $OUT/bench_default.log 2>$OUT/bench_default.err ) 2> $OUT/bench_default.time; echo "bench exit $?" >> $OUT/bench_default.log; tail -3 $OUT/bench_default.time
   tail -c 3000 $OUT/bench_default.log
   timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin --secondary 0 --no-config5 --fixed-pose-steps 0 > $OUT/bench_driver_form.log 2>&1; line $OUT/bench_driver_form.log "driver form --steps 20 --warmup 5"
   ;;
