@@ -582,7 +582,7 @@ def parity_gate(args, rdv):
     sim.reset(poses); ref.reset(poses)
     sets = action_sets((T + 19) // 20, E * A, seed=1000)
     flag_mismatch, es, er = 0, 0.0, 0.0
-    threads = min(os.cpu_count() or 1, 32)
+    threads = min(os.cpu_count() or 1, 16)
     for t in range(T):
         sim.step(sets[t // 20]); ref.step(sets[t // 20], threads)
         if not args.no_reset:
