@@ -164,16 +164,22 @@ class Simulator(object):
             self._noise.ensure(self._b, self._steps_since_full_reset + 1)
         # one ABI call per step (f110_step_host): actions up, the step, the observation written into a
         # page-locked block; the reference hands out fresh arrays every step, so they are copied out
-        hb = self._hb
-        if hb is None:
-            hb = self._hb = self._b.host_block(("scans", "state", "agent_poses", "collisions", "collision_idx", "in_collision"))
-        hb.actions[...] = actions
-        self._b.step_host(hb)
+        if E * A * self._b.B * 8 <= (32 << 20):
+            hb = self._hb
+            if hb is None:
+                hb = self._hb = self._b.host_block(("scans", "state", "agent_poses", "collisions", "collision_idx", "in_collision"))
+            hb.actions[...] = actions
+            self._b.step_host(hb)
+            v = hb.views
+            o = {"scans": v["scans"].copy(), "state": v["state"].T.copy(), "agent_poses": v["agent_poses"].T.copy(),
+                 "collisions": v["collisions"].copy(), "collision_idx": v["collision_idx"].copy(),
+                 "in_collision": v["in_collision"].copy()}
+        else:
+            # big batches through this (host-logic) path: the observation straight into fresh arrays — a page-locked staging
+            # block of hundreds of MB and a second host copy would cost more than the call it saves
+            self._b.step(actions)
+            o = self._b.get("scans", "state", "agent_poses", "collisions", "collision_idx", "in_collision")
         self._steps_since_full_reset += 1
-        v = hb.views
-        o = {"scans": v["scans"].copy(), "state": v["state"].T.copy(), "agent_poses": v["agent_poses"].T.copy(),
-             "collisions": v["collisions"].copy(), "collision_idx": v["collision_idx"].copy(),
-             "in_collision": v["in_collision"].copy()}
         self._state = o["state"]
         self._in_collision = o["in_collision"]
         st = o["state"]
