@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round-4 GPU sessions (one gpurun call each; every phase is bounded):
-#   gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh test bench'
-#   gpurun --timeout 1500 -- 'bash tools/gpu_r4.sh prof pmc pmccfg5 tabench'
+#   gpurun --timeout 3000 -- 'bash tools/gpu_r4.sh test gatherlegs'                      # both builds, smoke, the gather legs at world size 1
+#   gpurun --timeout 3400 -- 'bash tools/gpu_r4.sh prof pmc pmccfg5 pmc4096 tabench manyagents dropin bench'   # everything profiles/r04_* holds
+#   then: python tools/collect_profiles.py r04 65536 1080 3
+# modes: test testfast rates cfg5 manyagents fan dropin gatherlegs bench prof pmc pmc4096 pmccfg5 tabench
 cd "${GRAFT_REPO_ROOT:-.}"
 R="$PWD"; export TMPDIR=/tmp
 OUT=$R/gpurun_out; mkdir -p $OUT
