@@ -42,3 +42,20 @@ for label, kw in (("back to back", {}), ("12 us busy wait between calls", {"gap_
     loop(300, **kw)
     dt, enq, wait = loop(2000, **kw)
     print("%-34s %6.1f us per iteration   [in the call: enqueue %.1f us, wait %.1f us]" % (label, dt, enq, wait))
+
+# per-call distribution (is the mean a mix of discrete modes?)
+for label, kw in (("back to back", {}), ("12 us busy wait between calls", {"gap_us": 12.0}), ("30 us busy wait", {"gap_us": 30.0})):
+    ts = []
+    for _ in range(3000):
+        t0 = time.perf_counter()
+        b.step_host(hb)
+        ts.append((time.perf_counter() - t0) * 1e6)
+        if kw.get("gap_us"):
+            busy(kw["gap_us"])
+    ts = np.array(ts[500:])
+    hist, edges = np.histogram(ts, bins=[0, 30, 35, 40, 45, 50, 60, 70, 80, 90, 100, 120, 1e9])
+    print("%-32s call us: p10 %.1f p50 %.1f p90 %.1f   histogram %s" % (label, np.percentile(ts, 10), np.percentile(ts, 50), np.percentile(ts, 90),
+          " ".join("%s:%d" % (("<%d" % edges[i + 1]) if edges[i + 1] < 1e8 else ">120", h) for i, h in enumerate(hist) if h)))
+    # autocorrelation at lag 1: do slow and fast calls alternate?
+    z = ts - ts.mean()
+    print("    lag-1 autocorrelation %.2f   first 24 calls: %s" % (float((z[1:] * z[:-1]).sum() / (z * z).sum()), " ".join("%.0f" % v for v in ts[:24])))
