@@ -223,7 +223,8 @@ class F110VecEnv(object):
     toggle_list, near_starts, checkpoint_done in info; () for the leanest loop); everything stays
     available in HBM through `device_views()`.  `env.action_buffer` ([E][A][2], page-locked) can be
     filled in place and step(None) called: no copy of the actions at all.  step_async() /
-    step_wait() split the call the way gym.vector.VectorEnv does.
+    step_wait() split the call the way gym.vector.VectorEnv does (between the two, `action_buffer` belongs to the
+    GPU: the kernels read it in place — write the next actions only after step_wait()).
 
     Domain randomisation over tracks: `extra_maps=[(yaml_path, ext), ...]` registers further maps
     (slots 1, 2, ...; `map` is slot 0) and `env_map=[slot per env]` assigns them; `set_env_maps()`
