@@ -44,6 +44,28 @@ def test_lap_logic_single_env_scalar_form_equals_the_vectorised_one_and_the_refe
             assert np.max(np.abs(b.lap_times[0] - g["ep%d_lap_time" % ep][k])) < 1e-12
 
 
+def test_lap_logic_scalar_and_vectorised_forms_agree_on_random_walks():
+    """update_single (what the single-env F110Env uses) == update on random walks through and around the start zone:
+    any agent count, any ego, collisions of ego and non-ego cars, start frames rotated by the ego's heading"""
+    from f1tenth_gym_amd.env import _LapLogic
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        A = int(rng.integers(1, 6)); ego = int(rng.integers(0, A))
+        a, b = _LapLogic(1, A, ego), _LapLogic(1, A, ego)
+        start = np.concatenate([rng.uniform(-3, 3, (1, A, 2)), rng.uniform(-3.2, 3.2, (1, A, 1))], axis=2)
+        a.reset(start); b.reset(start)
+        for k in range(300):
+            pos = start[0, :, :2] + np.stack([1.2 * np.sin(k / 9.0 + np.arange(A)), 0.6 * np.cos(k / 13.0 + np.arange(A))], axis=1) \
+                + rng.normal(0.0, 0.05, (A, 2))        # in and out of the start zone, a different phase per car
+            col = (rng.random(A) < 0.01).astype(np.float64)
+            da, ta = a.update(pos[:, 0], pos[:, 1], col, 0.01)
+            db, tb = b.update_single(list(pos[:, 0]), list(pos[:, 1]), col, 0.01)
+            assert bool(da[0]) == db and np.array_equal(ta[0], tb), (trial, k)
+            for f in ("toggle_list", "near_starts", "lap_counts", "lap_times", "current_time"):
+                assert np.array_equal(getattr(a, f), getattr(b, f)), (trial, k, f)
+        assert a.toggle_list.max() >= 2
+
+
 def test_lap_logic_vectorised_envs_are_independent():
     from f1tenth_gym_amd.env import _LapLogic
     e = gold("env_episode")
