@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_round4.py::test_observation_gather_at_world_size_two_on_one_device: two THREADS are the two ranks
+"""Worker of tests/test_gpu_round4.py::test_observation_gather_with_several_ranks_on_one_device: two THREADS are the two ranks
 (tests/rccl_stub/librccl.so.1 stands in for RCCL, see its header), each with its own BatchSim handle on device 0 and its own
 shard of envs.  Every gather form is checked on both ranks against what the peer really holds at that step:
 all-gather f64 in the step's stream, overlapped with the next step (double-buffered), float32 transport, gather-to-root
@@ -10,7 +10,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import f1tenth_gym_amd as amd
 from _util import load_map_image, bench_start_poses
 
-WORLD, E, A, B, T = 2, 24, 2, 1080, 6
+WORLD = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+E, A, B, T = 24 if WORLD <= 2 else 6, 2, 1080, 6 if WORLD <= 2 else 4
 N = E * A
 img, res, origin = load_map_image("example_map")
 uid = amd.BatchSim.comm_unique_id()
@@ -33,8 +34,8 @@ def rank_main(rank):
         assert s.comm_info() == (WORLD, rank)
         rng = np.random.default_rng(100 + rank)
         legs = (("gather", False, False, None), ("gather_overlap", True, False, None), ("gather_f32", False, True, None),
-                ("gather_f32_overlap", True, True, None), ("gather_root0", False, False, 0), ("gather_root1", False, False, 1),
-                ("gather_root1_f32_overlap", True, True, 1))
+                ("gather_f32_overlap", True, True, None), ("gather_root0", False, False, 0), ("gather_root1", False, False, WORLD - 1),
+                ("gather_root1_f32_overlap", True, True, WORLD - 1))
         for leg, overlap, f32, root in legs:
             recv_here = root is None or root == rank
             s.comm_set_overlap(overlap)
@@ -90,6 +91,6 @@ for th in threads:
 for th in threads:
     th.join(240)
 alive = [th.is_alive() for th in threads]
-print("RESULT " + json.dumps({"errors": errors, "checks": checks, "hung": alive}))
+print("RESULT " + json.dumps({"errors": errors, "checks": checks, "hung": alive, "world": WORLD, "steps": T}))
 sys.stdout.flush()
 os._exit(0 if not errors and not any(alive) else 1)
