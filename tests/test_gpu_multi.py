@@ -109,3 +109,26 @@ def test_bench_two_gpus_one_invocation_three_legs():
     for leg in ("gather", "gather_overlap"):
         assert mg[leg]["gather_ok"] is True and mg[leg]["value"] > 0
     assert d["config"]["env_resets_in_timed_region"] >= 0 and "roofline" in d
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_ranks_sharing_one_device_without_the_gather(world):
+    """`python bench.py --gpus N` end to end on REAL hardware with every rank on device 0 (F110_BENCH_DEVICE): the launcher
+    in bench.py spawns the ranks, the socket control plane runs between real processes, every rank steps its own shard on
+    the GPU, NUMA binding per rank, the job's time is the max over ranks, rank 0 prints the one line.  No collective
+    (RCCL refuses several ranks on one device; the gather's N > 1 paths are covered by tests/rccl_stub)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "F110_BENCH_RDV")}
+    env["F110_BENCH_DEVICE"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "40", "--warmup", "5", "--agents", "4096",
+                          "--preroll", "60", "--no-gather-legs"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-800:]
+    d = json.loads(lines[0])
+    mg = d["multi_gpu"]
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["agents_total"] == 4096 * world
+    assert len(mg["per_rank_ms_per_step"]) == world and len(mg["numa"]) == world and all(t > 0 for t in mg["per_rank_ms_per_step"])
+    assert abs(d["value"] - 4096 * world * 40 / (d["ms_per_step"] * 40e-3)) < 1e-6 * d["value"]       # all ranks' agent-steps over the max time
+    assert d["ms_per_step"] >= max(mg["per_rank_ms_per_step"]) * 0.999
+    assert "gather" not in mg and mg.get("gather_error") is None and "roofline" in d
+    assert d["config"]["env_resets_in_timed_region"] > 0
