@@ -416,12 +416,13 @@ class Workload(object):
         for t in range(first, first + steps):
             self.one(t)
         gpu_ms = sim.timer_end_ms()       # records + waits for the end event on the stream
+        blocks = sim.step_groups()[2]     # env blocks the last timed step was submitted as (the library's choice unless --groups)
         sim.sync()
         mine = time.perf_counter() - t0   # this rank's own time (reported per rank); the job's time is max over ranks
         rdv.barrier()
         elapsed = time.perf_counter() - t0
         out = {"elapsed_s": elapsed, "rank_s": mine, "gpu_ms": gpu_ms, "n_reset": int(self.d_count.download()[0]), "steps": steps,
-               "warmup": warmup, "preroll": preroll}
+               "warmup": warmup, "preroll": preroll, "env_blocks": blocks}
         if mode == "profile":
             n, scan_ms, dyn_ms, fin_ms = sim.profile_read()
             out.update({"scan_ms_avg": scan_ms / max(n, 1), "dyn_ms_avg": dyn_ms / max(n, 1), "fin_ms_avg": fin_ms / max(n, 1), "n_prof": n})
@@ -531,7 +532,10 @@ def roofline_record(args, n_agents, beams, timed, prof, cnt, tiles=1):
         k_gbs = scan_bytes / (k_ms * 1e-3) / 1e9
         rec.update({"kernel": scan_kernel_name(args, beams), "kernel_ms_avg": k_ms, "kernel_alg_bytes_per_launch": scan_bytes,
                     "kernel_achieved": k_gbs, "kernel_frac": k_gbs / HBM_PEAK_GBS,
-                    "kernel_timing": "HIP events around every launch in a replay of the same steps (%d launches)" % prof["n_prof"],
+                    "kernel_timing": "HIP events around every launch in a replay of the same steps (%d launches)" % prof["n_prof"]
+                                     + ("; the timed steps ran as TWO env blocks on two streams (each kernel twice per step over half the envs, overlapping), the "
+                                        "replay runs one block: the kernel_* entries describe one launch over the whole batch" if timed.get("env_blocks", 1) > 1 else ""),
+                    "env_blocks_per_step": timed.get("env_blocks"),
                     "integrate_collide_ms_avg": prof["dyn_ms_avg"], "finalize_ms_avg": prof["fin_ms_avg"]})
         if pmc:
             rec["hbm_measured_frac"] = pmc["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -776,7 +780,7 @@ def leg_record(rdv, total_agents, t):
     oks = rdv.gather(-1.0 if t.get("gather_ok") is None else float(bool(t["gather_ok"])))
     return {"value": total_agents * t["steps"] / elapsed, "ms_per_step": 1e3 * elapsed / t["steps"],
             "per_rank_ms_per_step": per_rank, "per_rank_ms_per_step_min": min(per_rank), "per_rank_ms_per_step_max": max(per_rank),
-            "env_resets_in_timed_region": int(rdv.sum(t["n_reset"])),
+            "env_resets_in_timed_region": int(rdv.sum(t["n_reset"])), "env_blocks": t.get("env_blocks"),
             "gather_ok": None if all(o < 0 for o in oks) else bool(all(o != 0.0 for o in oks))}
 
 
@@ -851,6 +855,7 @@ def main(argv=None):
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
                    "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64", 4: "padded_rowmajor_f64 + lds_window_codes"}[args.layout],
                    "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks, "step_groups": args.groups, "step_graph": args.graph,
+                   "env_blocks_per_step": head.get("env_blocks"),   # 1 = every kernel once per step over the whole batch; 2 = two halves of the envs on two streams (include/f110.h step_groups)
                    "parallelism": "env-sharded x%d, %s" % (n_gpus, ("RCCL all-gather of the observation (scans + 7 scalars per agent) after every step" + (" (overlapped with the next step, double-buffered)" if args.gather_overlap else "")) if args.gather
                                                            else "no data-path collective"),
                    "preroll_steps": args.preroll,

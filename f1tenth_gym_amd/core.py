@@ -478,6 +478,13 @@ class BatchSim(object):
         check(_ffi.lib().f110_comm_gather_obs(self._h, ptr(d_recv_scans), ptr(d_recv_scalars), _ffi.GATHER_F32 if f32 else _ffi.GATHER_F64,
                                               -1 if root is None else int(root)), self._h)
 
+    def step_groups(self):
+        """(env blocks the handle can submit a step as, candidate streams probed at creation, blocks of the most recent
+        step_device) — f110_step_groups"""
+        g, p, l = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        check(_ffi.lib().f110_step_groups(self._h, C.byref(g), C.byref(p), C.byref(l)), self._h)
+        return int(g.value), int(p.value), int(l.value)
+
     def comm_info(self):
         """(n_ranks, rank) as RCCL reports them"""
         n, r = C.c_int32(0), C.c_int32(-1)

@@ -50,6 +50,7 @@ struct ExpSwitches {
     int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
     int scan_env_counter = 0;  // 1: the scan kernel also counts finished tasks per env (fusion feasibility A/B)
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
+    int group_split = 0;       // two env groups: percent of the envs in the first (0 = even)
     int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
     uint64_t scan_trace = 0;   // device address of a caller-owned [waves][8] uint64 buffer: clock stamps, hardware id, samples of every scan wave (0 = off)
 };
@@ -110,9 +111,14 @@ struct f110_sim {
     // env groups: the step of G > 1 independent env blocks runs on G streams of its own (no event
     // between the kernels of a group, no dependency between groups; see f110_step_device)
     int groups = 1;
-    std::vector<hipStream_t> gstreams;
+    std::vector<hipStream_t> gstreams;   // two groups: the main stream and the side stream (borrowed); more: streams of their own
+    std::vector<hipStream_t> gowned;
     std::vector<hipEvent_t> gevents;
     hipEvent_t ev_main = nullptr;
+    bool groups_auto = true;    // cfg.step_groups == 0: two blocks only for steps that come back to back, at the sizes where it pays
+    bool touched = true;        // something other than f110_step_device went through the handle since the last step
+    int last_blocks = 0;        // env blocks the most recent f110_step_device was submitted as
+    int group_probes = 0;       // candidates the two-group form probed for a stream that runs next to the main stream
     bool groups_busy = false;   // group streams hold work the main stream has not been joined with
     bool main_dirty = true;     // the main stream holds work the group streams have not waited for
     // device RNG for the scan noise (f110_set_noise_rng)
@@ -239,6 +245,7 @@ static int join_groups(f110_sim *h)
     }
     if (!h->groups_busy) return F110_OK;
     for (size_t g = 0; g < h->gstreams.size(); ++g) {
+        if (h->gstreams[g] == h->stream) continue;
         HIPCHK(h, hipEventRecord(h->gevents[g], h->gstreams[g]));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->gevents[g], 0));
     }
@@ -254,6 +261,7 @@ static int join_groups(f110_sim *h)
         HIPCHK(h, hipSetDevice((h)->cfg.device_id));      \
         TRY(join_groups(h));                              \
         (h)->main_dirty = true;                           \
+        (h)->touched = true;                              \
     } while (0)
 
 // RAII scratch for the unit entry points
@@ -473,6 +481,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
     else if (k == "integrate_duo") h->exp.integrate_duo = value;
     else if (k == "integrate_fan") h->exp.integrate_fan = value;
+    else if (k == "group_split") h->exp.group_split = value;
     else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
     else if (k == "scan_trace_lo") h->exp.scan_trace = (h->exp.scan_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "collide_mode") {
@@ -520,6 +529,28 @@ static void default_beam_tables(const f110_config &c, std::vector<double> &sa, s
     }
 }
 
+// kernels_f110.hpp "do two streams make progress independently of each other?"; *yes is false whenever in doubt
+static hipError_t streams_concurrent(hipStream_t a, hipStream_t b, bool *yes)
+{
+    *yes = false;
+    unsigned *d = nullptr, hres[2] = {0u, 0u};
+    hipError_t e = hipMalloc(&d, 2 * sizeof(unsigned));
+    if (e != hipSuccess) return e;
+    do {
+        if ((e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned), a)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(a)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(b)) != hipSuccess) break;
+        hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, a, d, d + 1, 30000ull);   // at most 300 us
+        hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, b, d);
+        if ((e = hipStreamSynchronize(a)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(b)) != hipSuccess) break;
+        if ((e = hipMemcpy(hres, d, sizeof hres, hipMemcpyDeviceToHost)) != hipSuccess) break;
+        *yes = hres[1] != 0u;
+    } while (0);
+    (void)hipFree(d);
+    return e;
+}
+
 int f110_create(const f110_config *cfg, f110_sim **out)
 {
     if (!cfg || !out) return fail(nullptr, F110_ERR_INVALID, "f110_create: null argument");
@@ -535,8 +566,8 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     if (!kExperimental) {
         if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_PADDED_F64)
             return fail(nullptr, F110_ERR_STATE, "map_layout %d is available in the experimental build only (libf110_hip_exp.so)", cfg->map_layout);
-        if (cfg->step_groups > 1 || cfg->step_graph != 0)
-            return fail(nullptr, F110_ERR_STATE, "step_groups / step_graph are available in the experimental build only (libf110_hip_exp.so)");
+        if (cfg->step_groups > 2 || cfg->step_graph != 0)
+            return fail(nullptr, F110_ERR_STATE, "step_groups > 2 / step_graph are available in the experimental build only (libf110_hip_exp.so)");
     }
     if ((long long)cfg->num_envs * cfg->num_agents * (long long)cfg->num_beams > 0xFFFFFF00LL) return fail(nullptr, F110_ERR_INVALID, "num_envs*num_agents*num_beams must stay below 2^32");
     int ndev = 0;
@@ -583,12 +614,17 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     CKH(hipEventCreate(&h->ev_end));
     CKH(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
     {
-        // env groups: 0 = automatic.  Small batches are bound by dependent chains
-        // (longest ray, RK4, window set-up) and kernel boundaries, which independent env blocks
-        // on their own streams overlap; big batches fill the chip with one block.
+        // env groups: envs are independent of each other, so two halves of the batch need not run in lockstep.
+        // Steps that the caller enqueues back to back (f110_step_device, nothing else through the handle in between)
+        // are submitted as two env blocks on two streams: one block's latency-bound kernels, tails and the VALU-bound
+        // finalize run under the other block's texture-bound scan, and the blocks drift apart over consecutive steps.
+        // 0 = automatic (two blocks when steps come back to back AND the size is one where it pays: round 4,
+        // profiles/r04_groups_sizes.txt: +2 .. +25 % up to 32 768 agents and for A != 2, +0.2 .. +1.6 % for A = 2 above
+        // 49 152 agents, which stay one block), 1 = always one block, 2 = always two (a caller that synchronises every
+        // step pays ~25 us of fork / join for it), > 2 = experimental build.
         int G = cfg->step_groups;
-        if (G <= 0) G = 1;   // measured: +4..7 % with 2 groups on a fresh process, but a loss as soon as
-                             // the group streams share a hardware queue — opt-in
+        h->groups_auto = G <= 0;
+        if (G <= 0) G = 2;
         G = std::min(std::min(G, 16), cfg->num_envs);
         h->groups = G;
         h->use_graph = cfg->step_graph != 0;
@@ -597,10 +633,45 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         // workgroup's record table); above
         // that — no use case known — the round-1 form (k_collide on the side stream + k_finalize)
         h->collide_mode = (cfg->num_agents >= 2 && cfg->num_agents <= kMaxAgentsMulti) ? 3 : 0;
-        for (int g = 0; g < G && G > 1; ++g) {
+        // two groups: the main stream and ONE more stream that provably runs next to it.  Which hardware queue a stream
+        // lands on depends on what else the process created before; a second stream on the main stream's queue turns
+        // the gain (+2 .. +23 %) into a loss (-9 .. -50 %), so candidates are probed (k_probe_wait) — the side stream
+        // first (unused by the in-kernel pair tests), then up to six fresh ones; with none, the step stays one block.
+        const bool duo = G == 2 && (h->collide_mode == 3 || cfg->num_agents == 1);   // (the older forms launch k_collide on the side stream)
+        if (h->groups_auto && !duo) G = h->groups = 1;
+        if (duo) {
+            hipStream_t second = nullptr;
+            std::vector<hipStream_t> rejected;
+            for (int attempt = 0; attempt < 7 && !second; ++attempt) {
+                hipStream_t cand = h->side_stream;
+                if (attempt > 0) CKH(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+                bool yes = false;
+                const hipError_t ep = streams_concurrent(h->stream, cand, &yes);
+                if (ep == hipSuccess && yes) {
+                    second = cand;
+                    if (attempt > 0) h->gowned.push_back(cand);
+                } else if (attempt > 0) {
+                    rejected.push_back(cand);   // kept until the search ends, so that the next candidate lands elsewhere
+                }
+                h->group_probes = attempt + 1;
+                if (ep != hipSuccess) break;
+            }
+            for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+            if (!second) G = h->groups = 1;
+            else {
+                hipEvent_t ge = nullptr;
+                h->gstreams.push_back(h->stream);
+                h->gevents.push_back(nullptr);
+                h->gstreams.push_back(second);
+                CKH(hipEventCreateWithFlags(&ge, hipEventDisableTiming));
+                h->gevents.push_back(ge);
+            }
+        }
+        for (int g = 0; g < G && G > 1 && !duo; ++g) {
             hipStream_t gs = nullptr;
             hipEvent_t ge = nullptr;
             CKH(hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+            h->gowned.push_back(gs);
             h->gstreams.push_back(gs);
             CKH(hipEventCreateWithFlags(&ge, hipEventDisableTiming));
             h->gevents.push_back(ge);
@@ -765,8 +836,9 @@ void f110_destroy(f110_sim *h)
     for (float *p : h->scan_f32)
         if (p) (void)hipFree(p);
     for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-    for (hipStream_t gs : h->gstreams) (void)hipStreamDestroy(gs);
-    for (hipEvent_t ge : h->gevents) (void)hipEventDestroy(ge);
+    for (hipStream_t gs : h->gowned) (void)hipStreamDestroy(gs);
+    for (hipEvent_t ge : h->gevents)
+        if (ge) (void)hipEventDestroy(ge);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     {
         void *rp[] = {h->d_rtask[0], h->d_rtask[1], h->d_rflags[0], h->d_rflags[1], h->d_rlist[0], h->d_rlist[1], h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
@@ -2350,13 +2422,27 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     return F110_OK;
 }
 
+constexpr int kGroupsAutoMaxAgents = 32768;   // A = 2 above this: one block (f110_create "env groups")
+
 // how the env axis is cut into `groups` blocks: whole envs, whole 64-agent waves where possible
 static int group_envs(const f110_sim *h)
 {
     const int E = h->cfg.num_envs, G = h->groups;
     int per = (E + G - 1) / G;
+#ifdef F110_EXPERIMENTAL
+    if (G == 2 && h->exp.group_split > 0) per = std::max(1, (int)((long long)E * h->exp.group_split / 100));   // probe: uneven halves
+#endif
     if (per >= 64) per = (per + 63) / 64 * 64;
     return per;
+}
+
+int f110_step_groups(f110_sim *h, int32_t *groups, int32_t *probes, int32_t *last)
+{
+    if (!h) return fail(h, F110_ERR_INVALID, "null argument");
+    if (groups) *groups = h->groups;
+    if (probes) *probes = h->group_probes;
+    if (last) *last = h->last_blocks;
+    return F110_OK;
 }
 
 int f110_step_device(f110_sim *h, const double *d_actions)
@@ -2392,7 +2478,10 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     const bool prof = h->profiling && h->prof_used + 4 <= 4 * 65536;
     // the env groups need the agent-aligned scan (a launch per agent range); per-kernel profiling
     // brackets the kernels of ONE stream, so a profiled step runs as one block on the main stream
-    const bool grouped = kExperimental && h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0;
+    // (two groups borrow the side stream, which the older collide forms use themselves)
+    const bool grouped = h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0 &&
+                         !(h->gstreams[0] == h->stream && h->collide_mode != 3 && A > 1) &&
+                         (!h->groups_auto || (!h->touched && (N <= kGroupsAutoMaxAgents || A != 2)));
     if (!grouped) {
         TRY(join_groups(h));
         h->main_dirty = true;
@@ -2447,24 +2536,23 @@ int f110_step_device(f110_sim *h, const double *d_actions)
             TRY(step_range(h, h->stream, 0, N, d_actions, cmode, prof ? ev : nullptr));
         }
     } else {
-#ifdef F110_EXPERIMENTAL
         if (h->main_dirty) {
             HIPCHK(h, hipEventRecord(h->ev_main, h->stream));
-            for (hipStream_t gs : h->gstreams) HIPCHK(h, hipStreamWaitEvent(gs, h->ev_main, 0));
+            for (hipStream_t gs : h->gstreams)
+                if (gs != h->stream) HIPCHK(h, hipStreamWaitEvent(gs, h->ev_main, 0));
             h->main_dirty = false;
         }
         const int per = group_envs(h), E = h->cfg.num_envs;
-        const int mode = h->collide_mode == 3 && A == 2 ? 3 : ((A == 2 || A == 4) ? 1 : 2);
+        const int mode = h->collide_mode == 3 ? 3 : ((A == 2 || A == 4) ? 1 : 2);
         for (int g = 0; g < h->groups; ++g) {
             const int e0 = g * per, e1 = std::min(E, e0 + per);
             if (e0 >= e1) break;
             TRY(step_range(h, h->gstreams[g], e0 * A, (e1 - e0) * A, d_actions, mode == 0 ? 2 : mode, nullptr));
         }
         h->groups_busy = true;
-#else
-        (void)A;
-#endif
     }
+    h->touched = false;
+    h->last_blocks = grouped ? h->groups : 1;
     h->noise_ub += 1;
     HIPCHK(h, hipGetLastError());
     return F110_OK;

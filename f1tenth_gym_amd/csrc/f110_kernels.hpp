@@ -2738,6 +2738,21 @@ __global__ void __launch_bounds__(256) k_pack_obs(AgentArrays a, double *__restr
     cols[6 * N + i] = a.collisions[i];
 }
 
+// ---- do two streams make progress independently of each other? ------------------------------------------------------
+// ROCm maps HIP streams onto a few hardware queues; two streams on ONE queue run their kernels one after the other, and
+// env groups (f110_step_device) then cost time instead of saving it.  The mapping cannot be queried, but it can be
+// observed: a kernel on stream a waits (bounded: `ticks` of the 100 MHz clock) for a flag that a kernel enqueued
+// afterwards on stream b sets.  It sees the flag only if b's kernel ran while it was waiting.
+__global__ void k_probe_wait(unsigned *flag, unsigned *seen_out, unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned seen = 0;
+    while ((seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(16);
+    *seen_out = seen;
+}
+__global__ void k_probe_set(unsigned *flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // float32 transport of the observation gather (f110_comm_gather_obs, F110_GATHER_F32): round-to-nearest of every range
 __global__ void __launch_bounds__(256) k_scans_to_f32(const double *__restrict__ src, float *__restrict__ dst, size_t n)
 {

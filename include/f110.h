@@ -80,7 +80,9 @@ typedef struct f110_config {
     int32_t map_layout;    /* F110_MAP_* */
     int32_t scan_block;    /* threads per scan workgroup (0 = default) */
     int32_t scan_tasks_per_wave; /* consecutive 64-ray tasks each wave walks (0 = default) */
-    int32_t step_groups;   /* experimental build: independent env blocks stepped on streams of their own (product: 0 or 1) */
+    int32_t step_groups;   /* env blocks per step: 0 = automatic (f110_step_device calls that come back to back are submitted as
+                              two halves of the envs on two streams, at the batch sizes where that pays; anything else in one
+                              block), 1 = always one block, 2 = always two, > 2 = experimental build.  Results do not depend on it. */
     int32_t step_graph;    /* experimental build: 1 = submit the step as one captured HIP graph (product: 0) */
     double fov, eps, max_range;
     double time_step, lidar_dist, ttc_thresh;
@@ -343,6 +345,11 @@ int f110_comm_all_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scala
 #define F110_GATHER_F64 0
 #define F110_GATHER_F32 1
 int f110_comm_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scalars, int32_t transport, int32_t root);
+/* how the step is submitted (f110_config.step_groups): *groups = env blocks the handle can submit a step as (2 = two halves of
+ * the envs on two streams that were OBSERVED to run next to each other when the handle was created; 1 = one block),
+ * *probes = candidate streams that observation tried, *last = blocks the most recent f110_step_device was submitted as.
+ * Any pointer may be NULL.  Bookkeeping for benchmarks and tests; no reference counterpart. */
+int f110_step_groups(f110_sim *h, int32_t *groups, int32_t *probes, int32_t *last);
 /* size and rank of the communicator as RCCL itself reports them (ncclCommCount / ncclCommUserRank) */
 int f110_comm_info(f110_sim *h, int32_t *n_ranks, int32_t *rank);
 /* enable = 1: the gather OVERLAPS the following step.  The scans are double-buffered (a second
