@@ -83,7 +83,7 @@ def test_product_library_refuses_the_lab(amd):
         s.close()
         return
     assert _ffi.lib().f110_is_experimental() == 0
-    for kw in ({"map_layout": 1}, {"map_layout": 2}, {"map_layout": 4}, {"step_groups": 2}, {"step_graph": 1}, {"exp": {"collide_mode": 0}}):
+    for kw in ({"map_layout": 1}, {"map_layout": 2}, {"map_layout": 4}, {"step_groups": 3}, {"step_graph": 1}, {"exp": {"collide_mode": 0}}):
         with pytest.raises(_ffi.ExperimentalOnly):
             amd.BatchSim(num_envs=2, num_agents=2, **kw)
 

@@ -72,7 +72,7 @@ prof)
   cd /tmp
   timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats -o stats -- python $R/bench.py $H > $OUT/prof_stats.log 2>&1
   python $R/tools/summarize_prof.py stats $OUT/prof_stats $OUT/kernel_stats.txt 300; rm -rf $OUT/prof_stats
-  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats4k -o stats -- python $R/bench.py $H --agents 4096 > $OUT/prof_stats4k.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats4k -o stats -- python $R/bench.py $H --agents 4096 --groups 1 > $OUT/prof_stats4k.log 2>&1
   python $R/tools/summarize_prof.py stats $OUT/prof_stats4k $OUT/kernel_stats_4096.txt 300; rm -rf $OUT/prof_stats4k
   timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats5 -o stats -- python $R/bench.py $C5 > $OUT/prof_stats5.log 2>&1
   python $R/tools/summarize_prof.py stats $OUT/prof_stats5 $OUT/kernel_stats_cfg5.txt 100; rm -rf $OUT/prof_stats5
@@ -90,7 +90,7 @@ pmc)
     rm -rf $OUT/pmc_$i
   done
   # HBM traffic of the scan kernel for the two other bench legs (FETCH_SIZE, WRITE_SIZE)
-  for cfg in "4096:--agents 4096" "cfg5:--agents 65536 --beams 4096 --map-tiles 2 --steps 100 --warmup 20 --preroll 100"; do
+  for cfg in "4096:--agents 4096 --groups 1" "cfg5:--agents 65536 --beams 4096 --map-tiles 2 --steps 100 --warmup 20 --preroll 100"; do
     tagc=${cfg%%:*}; argsc=${cfg#*:}; n=300; [ "$tagc" = cfg5 ] && n=100
     for c in FETCH_SIZE WRITE_SIZE; do
       timeout 300 rocprofv3 --pmc $c --kernel-include-regex "k_scan_rays|k_scan_dirs" -T -f csv -d $OUT/tr_$c -o p -- python $R/bench.py --only-headline $argsc > $OUT/tr_${tagc}_$c.log 2>&1
@@ -108,7 +108,7 @@ pmc4096)
   i=0
   for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_BUSY_CYCLES" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_TA_BUSY GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
     i=$((i+1))
-    timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays" -T -f csv -d $OUT/p4k_$i -o p -- python $R/bench.py $H --agents 4096 > $OUT/p4k_$i.log 2>&1
+    timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays" -T -f csv -d $OUT/p4k_$i -o p -- python $R/bench.py $H --agents 4096 --groups 1 > $OUT/p4k_$i.log 2>&1
     python $R/tools/summarize_prof.py pmc $OUT/p4k_$i $OUT/pmc_4096_pass$i.json - 300
     rm -rf $OUT/p4k_$i
   done
