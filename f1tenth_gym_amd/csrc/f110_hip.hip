@@ -618,9 +618,8 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         // Steps that the caller enqueues back to back (f110_step_device, nothing else through the handle in between)
         // are submitted as two env blocks on two streams: one block's latency-bound kernels, tails and the VALU-bound
         // finalize run under the other block's texture-bound scan, and the blocks drift apart over consecutive steps.
-        // 0 = automatic (two blocks when steps come back to back AND the size is one where it pays: round 4,
-        // profiles/r04_groups_sizes.txt: +2 .. +25 % up to 32 768 agents and for A != 2, +0.2 .. +1.6 % for A = 2 above
-        // 49 152 agents, which stay one block), 1 = always one block, 2 = always two (a caller that synchronises every
+        // 0 = automatic (two blocks when steps come back to back AND the size is one where it pays: env_blocks_pay),
+        // 1 = always one block, 2 = always two (a caller that synchronises every
         // step pays ~25 us of fork / join for it), > 2 = experimental build.
         int G = cfg->step_groups;
         h->groups_auto = G <= 0;
@@ -2422,7 +2421,19 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     return F110_OK;
 }
 
-constexpr int kGroupsAutoMaxAgents = 32768;   // A = 2 above this: one block (f110_create "env groups")
+// step_groups = 0: do two env blocks pay for N agents, A per env?  bench.py's steady-regime workload, one block -> two blocks
+// (profiles/r04_groups_bench_sweep.txt, ms per step):  A = 2:  1024 +2.8 %, 2048 +0.6 %, 3072 -1.6 %, 4096 -1.3 %, 6144 +1.7 %,
+// 8192 +5.8 %, 16 384 +9.5 %, 32 768 +3.7 %, 65 536 +1.7 %;  A = 1 / 4 / 8 at 16 384: +7.2 / +6.9 / +10.3 %, at 65 536: +5.7 / +4.1 / +4.4 %,
+// at 4096: -0.9 / -0.1 / +3.8 %.  Around 3000 .. 5000 agents the step IS its longest ray's chain of dependent samples: two
+// blocks have two such chains side by side and nothing to hide under them (a heavier finalize, A >= 8, changes that).
+// A = 2 above 32 768 agents stays one block for +1.7 %: one launch per kernel and step keeps the headline's per-kernel
+// accounting (rocprofv3 durations, PMC per dispatch) directly readable.
+static bool env_blocks_pay(int N, int A)
+{
+    if (A == 2 && N > 32768) return false;
+    if (A <= 4 && N >= 2560 && N <= 5120) return false;
+    return true;
+}
 
 // how the env axis is cut into `groups` blocks: whole envs, whole 64-agent waves where possible
 static int group_envs(const f110_sim *h)
@@ -2481,7 +2492,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     // (two groups borrow the side stream, which the older collide forms use themselves)
     const bool grouped = h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0 &&
                          !(h->gstreams[0] == h->stream && h->collide_mode != 3 && A > 1) &&
-                         (!h->groups_auto || (!h->touched && (N <= kGroupsAutoMaxAgents || A != 2)));
+                         (!h->groups_auto || (!h->touched && env_blocks_pay(N, A)));
     if (!grouped) {
         TRY(join_groups(h));
         h->main_dirty = true;
