@@ -2051,6 +2051,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
 // Same functions on the same operands as collide_agent / k_finalize: bit-identical (test_finalize_multi_*).
 constexpr int kMaxRec = 64;      // A <= 8: a workgroup's record table
 constexpr int kMaxRecBig = 256;  // 9 <= A <= 16: one env per workgroup, up to 240 records
+// phase 1 of k_finalize_multi: 4 R corner tasks (an atan2, a square root, two divisions each) on the first three waves, R disc
+// culls and then R / 2 pair tests on the fourth (round 4; round 3: corners on two waves, 7.5 rounds of them at 16 cars).
+// What a task needs of its two AGENTS — ray-cast heading, atan2(sin, cos) of it, cos / sin of the opponent's snapshot
+// heading — is computed once per agent in a phase of its own (MultiAgentLds), not 4 (A - 1) times (doubling probes at 16
+// cars, round 4: corners 77 us, culls 17, pair tests 5, window items 135 of the kernel's 250).
+constexpr int kMultiCornerThreads = 192;
+struct MultiAgentLds {   // one per agent of the workgroup
+    double ex, ey, eth, head;      // live position, ray-cast heading, atan2(sin(eth), cos(eth))
+    double ox, oy, co, so;         // :574 snapshot position, cos / sin of the snapshot heading
+    double blen, bwid, rad;        // the box this agent draws around its opponents (RaceCar.ray_cast_agents :223: its OWN length / width), half its diagonal
+};
 template <int MAXREC>
 __global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B, int G)
 {
@@ -2058,6 +2069,8 @@ __global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B
     __shared__ double s_rec[MAXREC][12];   // ex, ey, eth, the opponent's box (8), pad
     __shared__ int s_idx[MAXREC][4], s_cl[MAXREC], s_ch[MAXREC], s_hit[MAXREC];
     __shared__ int s_lo[MAXREC], s_off[MAXREC + 1], s_agent[MAXREC], s_ahit[MAXREC], s_wsum[4];
+    constexpr int MAXAG = MAXREC == 64 ? 32 : 16;   // agents per workgroup: G A (A - 1) <= 64 -> G A <= 32; the 256-record table takes ONE env of <= 16
+    __shared__ MultiAgentLds s_ag[MAXAG];
     const int t = (int)threadIdx.x;
     const int A = a.agents_per_env, N = a.n_agents_total;
     const int per_env = A * (A - 1), pairs_env = per_env / 2;
@@ -2065,24 +2078,35 @@ __global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B
     int envs = (end - first) / A;
     envs = envs < G ? envs : G;                 // (whole envs only: ranges are env-aligned)
     const int R = envs * per_env, P = envs * pairs_env, AGN = envs * A;
-    if (t < 128) {
+    if (t < AGN) {   // everything that is per agent, once
+        const int i = first + t;
+        MultiAgentLds m;
+        m.ex = a.state[i];
+        m.ey = a.state[(size_t)N + i];
+        const double th_live = a.state[4 * (size_t)N + i];   // == the :574 snapshot heading: nothing has zeroed it yet
+        m.eth = a.in_collision[i] ? 0.0 : th_live;
+        double ce_, se_;
+        cos_sin(m.eth, ce_, se_);
+        m.head = atan2(se_, ce_);
+        m.ox = a.snap_pose[i];
+        m.oy = a.snap_pose[(size_t)N + i];
+        cos_sin(a.snap_pose[2 * (size_t)N + i], m.co, m.so);
+        const size_t prow = (size_t)(a.params_per_agent ? i : t % A) * NPARAMS;
+        m.blen = a.params[prow + P_LENGTH];
+        m.bwid = a.params[prow + P_WIDTH];
+        m.rad = 0.5 * sqrt(m.blen * m.blen + m.bwid * m.bwid);
+        s_ag[t] = m;
+    }
+    __syncthreads();
+    if (t < kMultiCornerThreads) {
         // corner `sub` of record `rec`'s opponent box -> beam index
-        for (int q = t; q < 4 * R; q += 128) {
+        for (int q = t; q < 4 * R; q += kMultiCornerThreads) {
             const int rec = q >> 2, sub = q & 3;
             const int e = rec / per_env, w = rec - e * per_env, me = w / (A - 1), k = w - me * (A - 1), oj = k < me ? k : k + 1;
-            const int i = first + e * A + me, o = first + e * A + oj;
-            const double ex = a.state[i], ey = a.state[(size_t)N + i];
-            const double th_live = a.state[4 * (size_t)N + i];   // == the :574 snapshot heading: nothing has zeroed it yet
-            const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
-            const int wall = a.in_collision[i];
-            const double eth = wall ? 0.0 : th_live;
-            const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
-            const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
+            const MultiAgentLds &mm = s_ag[e * A + me], &mo = s_ag[e * A + oj];
+            const double ex = mm.ex, ey = mm.ey, eth = mm.eth, head = mm.head;
             double v[8];
-            box_vertices(ox, oy, oth, blen, bwid, v);
-            double ce_, se_;
-            cos_sin(eth, ce_, se_);
-            const double head = atan2(se_, ce_);
+            box_vertices_cs(mo.ox, mo.oy, mo.co, mo.so, mm.blen, mm.bwid, v);
             const double px = sub == 0 ? v[0] : (sub == 1 ? v[2] : (sub == 2 ? v[4] : v[6]));
             const double py = sub == 0 ? v[1] : (sub == 1 ? v[3] : (sub == 2 ? v[5] : v[7]));
             const double dx = px - ex, dy = py - ey;
@@ -2098,46 +2122,34 @@ __global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B
                 s_agent[rec] = e * A + me;
             }
         }
-    } else if (t < 192) {
+    } else {
         // the disc cull of record `rec`
-        for (int rec = t - 128; rec < R; rec += 64) {
+        for (int rec = t - kMultiCornerThreads; rec < R; rec += 256 - kMultiCornerThreads) {
             const int e = rec / per_env, w = rec - e * per_env, me = w / (A - 1), k = w - me * (A - 1), oj = k < me ? k : k + 1;
-            const int i = first + e * A + me, o = first + e * A + oj;
-            const double ex = a.state[i], ey = a.state[(size_t)N + i];
-            const double th_live = a.state[4 * (size_t)N + i];
-            const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o];
-            const int wall = a.in_collision[i];
-            const double eth = wall ? 0.0 : th_live;
-            const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
-            const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
-            double ce_, se_;
-            cos_sin(eth, ce_, se_);
-            const double head = atan2(se_, ce_);
-            const double dx = ox - ex, dy = oy - ey;
+            const MultiAgentLds &mm = s_ag[e * A + me], &mo = s_ag[e * A + oj];
+            const double eth = mm.eth, head = mm.head;
+            const double dx = mo.ox - mm.ex, dy = mo.oy - mm.ey;
             const double norm = sqrt(dx * dx + dy * dy);
             const double dir = atan2(dy, dx);
             int cl, ch;
-            disc_beam_range_from(norm, eth, dir, head, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
+            disc_beam_range_from(norm, eth, dir, head, mm.rad, a.scan_angles, B, a.angle_inc, cl, ch);
             s_cl[rec] = cl;
             s_ch[rec] = ch;
         }
-    } else {
         // collision_multiple's pair (p < q) of env e, boxes with the Simulator's length / width (:549)
         const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
-        for (int pr = t - 192; pr < P; pr += 64) {
+        for (int pr = t - kMultiCornerThreads; pr < P; pr += 256 - kMultiCornerThreads) {
             const int e = pr / pairs_env;
             int w = pr - e * pairs_env, p = 0;
             while (w >= A - 1 - p) { w -= A - 1 - p; ++p; }   // row p of the upper triangle holds A - 1 - p pairs
             const int q = p + 1 + w;
-            const int ip = first + e * A + p, iq = first + e * A + q;
-            const double px = a.snap_pose[ip], py = a.snap_pose[(size_t)N + ip], pth = a.snap_pose[2 * (size_t)N + ip];
-            const double qx = a.snap_pose[iq], qy = a.snap_pose[(size_t)N + iq], qth = a.snap_pose[2 * (size_t)N + iq];
+            const MultiAgentLds &mp = s_ag[e * A + p], &mq = s_ag[e * A + q];
             int hit = 0;
-            const double cdx = qx - px, cdy = qy - py;
+            const double cdx = mq.ox - mp.ox, cdy = mq.oy - mp.oy;
             if (cdx * cdx + cdy * cdy <= reach * reach) {
                 double lower[8], higher[8];
-                box_vertices(px, py, pth, a.box_length, a.box_width, lower);
-                box_vertices(qx, qy, qth, a.box_length, a.box_width, higher);
+                box_vertices_cs(mp.ox, mp.oy, mp.co, mp.so, a.box_length, a.box_width, lower);
+                box_vertices_cs(mq.ox, mq.oy, mq.co, mq.so, a.box_length, a.box_width, higher);
                 hit = gjk_overlap(lower, higher) ? 1 : 0;
             }
             s_hit[pr] = hit;
@@ -2256,10 +2268,7 @@ __global__ void __launch_bounds__(256) k_finalize_multi(AgentArrays a, int32_t B
 // Same functions on the same operands as collide_agent / k_finalize: bit-identical (test_finalize_multi_*,
 // tests/golden/sim_rollout_multi.npz = the reference itself at A = 3, 4, 8).
 constexpr int kMaxAgentsMulti = 256;   // agents per env this kernel takes (its per-agent LDS table)
-struct MultiAgentLds {   // one per agent of the workgroup
-    double ex, ey, eth, head;      // live position, ray-cast heading, atan2(sin(eth), cos(eth))
-    double ox, oy, co, so;         // :574 snapshot position, cos / sin of the snapshot heading
-};
+// (MultiAgentLds: above, shared with k_finalize_multi)
 // dynamic LDS of k_finalize_multi for `agents` agents per workgroup (host and device agree through this one function):
 // the agent table, a tile's boxes / near distances, a tile's int tables, the scan offsets, the partners
 __host__ __device__ inline size_t multi_lds_bytes(int agents, int maxrec)
@@ -2303,6 +2312,10 @@ __global__ void __launch_bounds__(256) k_finalize_multi_tiled(AgentArrays a, int
         m.ox = a.snap_pose[i];
         m.oy = a.snap_pose[(size_t)N + i];
         cos_sin(a.snap_pose[2 * (size_t)N + i], m.co, m.so);
+        const size_t prow = (size_t)(a.params_per_agent ? i : ag % A) * NPARAMS;
+        m.blen = a.params[prow + P_LENGTH];
+        m.bwid = a.params[prow + P_WIDTH];
+        m.rad = 0.5 * sqrt(m.blen * m.blen + m.bwid * m.bwid);
         s_ag[ag] = m;
         s_partner[ag] = -1;
     }
@@ -2339,12 +2352,10 @@ __global__ void __launch_bounds__(256) k_finalize_multi_tiled(AgentArrays a, int
             const int e = gr / per_env, w = gr - e * per_env, me = w / (A - 1), k = w - me * (A - 1), oj = k < me ? k : k + 1;
             const int ia = e * A + me;
             const MultiAgentLds &mm = s_ag[ia], &mo = s_ag[e * A + oj];
-            const size_t prow = (size_t)(a.params_per_agent ? first + ia : me) * NPARAMS;
-            const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
+            const double blen = mm.blen, bwid = mm.bwid, rad = mm.rad;
             const double dx = mo.ox - mm.ex, dy = mo.oy - mm.ey;
             const double norm = sqrt(dx * dx + dy * dy);
             const double dir = atan2(dy, dx);
-            const double rad = 0.5 * sqrt(blen * blen + bwid * bwid);
             int cl, ch;
             disc_beam_range_from(norm, mm.eth, dir, mm.head, rad, a.scan_angles, B, a.angle_inc, cl, ch);
             s_cl[rec] = cl;
