@@ -2035,12 +2035,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
 // with one lane per agent (a serial loop over the A - 1 opponents: box, GJK, two beam windows, 80 bytes of windows
 // and boxes through HBM per ordered pair, a side stream with an event fork / join around the scan) becomes one
 // kernel behind the scan:
+//   agents    (round 4) what a record needs of its two agents, once per agent into LDS (MultiAgentLds);
 //   records   every ORDERED pair (agent i, opponent o) of the workgroup's envs, R = G A (A - 1) <= MAXREC (64 for A <= 8,
 //             256 with one env per workgroup for A <= 16): the four
 //             corners of o's box (drawn with i's length / width, RaceCar.ray_cast_agents :223) -> beam indices on
-//             threads 0-127 (four per record), the disc cull on threads 128-191 (one per record);
+//             threads 0-191 (four per record), the disc cull on threads 192-255 (one per record);
 //   pairs     every UNORDERED pair (p < q) of an env, P = G A (A - 1) / 2: collision_multiple's GJK in the reference's
-//             (lower, higher) argument order on threads 192-255 — once, not once per side;
+//             (lower, higher) argument order on threads 192-255 behind the culls — once, not once per side;
 //   agents    flags (Simulator's collision OR :588-589; collision_idx = the LARGEST colliding partner, the reference's
 //             last writer), check_ttc's side effects, step count, re-seat: thread a of the first G A;
 //   windows   all records' beam windows flattened into one item list over the 256 threads, as in the pair kernel.  Two
