@@ -233,6 +233,8 @@ static int dmalloc(f110_sim *h, T **p, size_t count)
         if (rc_ != F110_OK) return rc_; \
     } while (0)
 
+static int group_envs(const f110_sim *h);   // envs per env block (defined with f110_step_device)
+
 // The group streams' outstanding work becomes a dependency of the main stream (stream-ordered, no
 // host wait).  Every entry point except the step itself starts with it, so the env groups are an
 // internal detail: anything enqueued or read through the handle sees completed steps.
@@ -1767,20 +1769,46 @@ int f110_episode_step_device(f110_sim *h, const double *d_actions)
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
     TRY(f110_step_device(h, d_actions));
+    if (h->last_blocks == 2 && h->groups_busy) {
+        // the step went out as two env blocks: each block's _check_done behind it on the block's own stream (an env's
+        // lap bookkeeping reads that env's agents only), no join — the device-resident loop stays two independent halves
+        const int per = group_envs(h), E = h->cfg.num_envs;
+        for (int g = 0; g < 2; ++g) {
+            const int e0 = g * per, e1 = std::min(E, e0 + per);
+            if (e0 >= e1) break;
+            hipLaunchKernelGGL(k_episode, grid1d(e1 - e0, 256), dim3(256), 0, h->gstreams[g], h->dev, h->ep, e1 - e0, e0);
+        }
+        HIPCHK(h, hipGetLastError());
+        return F110_OK;
+    }
     ENTER(h);   // _check_done reads every group's poses and flags
     hipLaunchKernelGGL(k_episode, grid1d(h->cfg.num_envs, 256), dim3(256), 0, h->stream, h->dev, h->ep, h->cfg.num_envs);
     HIPCHK(h, hipGetLastError());
+    h->touched = false;   // the next step may split: what this call left on the main stream is forked from (main_dirty)
     return F110_OK;
 }
 
 int f110_episode_reset_done_device(f110_sim *h, int32_t *d_count)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
-    ENTER(h);
     if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
+    if (h->last_blocks == 2 && h->groups_busy && !h->touched) {   // behind a two-block f110_episode_step_device: per block, no join
+        HIPCHK(h, hipSetDevice(h->cfg.device_id));
+        const int per = group_envs(h), E = h->cfg.num_envs, A = h->cfg.num_agents;
+        for (int g = 0; g < 2; ++g) {
+            const int e0 = g * per, e1 = std::min(E, e0 + per);
+            if (e0 >= e1) break;
+            hipLaunchKernelGGL(k_episode_reset_done, grid1d((e1 - e0) * A, 256), dim3(256), 0, h->gstreams[g], h->dev, h->ep, d_count, e0 * A, (e1 - e0) * A);
+            hipLaunchKernelGGL(k_episode_clear_done, grid1d(e1 - e0, 256), dim3(256), 0, h->gstreams[g], h->ep, e1 - e0, e0);
+        }
+        HIPCHK(h, hipGetLastError());
+        return F110_OK;
+    }
+    ENTER(h);
     hipLaunchKernelGGL(k_episode_reset_done, grid1d(h->N, 256), dim3(256), 0, h->stream, h->dev, h->ep, d_count);
     hipLaunchKernelGGL(k_episode_clear_done, grid1d(h->cfg.num_envs, 256), dim3(256), 0, h->stream, h->ep, h->cfg.num_envs);
     HIPCHK(h, hipGetLastError());
+    h->touched = false;   // (as in f110_episode_step_device: the loop step / reset_done / step / ... may split from its second round on)
     return F110_OK;
 }
 
@@ -2845,12 +2873,29 @@ int f110_pure_pursuit_device(f110_sim *h, const double *d_waypoints, int32_t M, 
 {
     TRY(check_planner_args(h, d_waypoints, M, lookahead));
     if (!d_actions) return fail(h, F110_ERR_INVALID, "pure pursuit: null actions buffer");
-    ENTER(h);
     const int N = h->N;
     const double *st = h->dev.state;
+    if (h->last_blocks == 2 && h->groups_busy && !h->touched) {
+        // a closed device-side loop (plan, step, plan, ...) behind a two-block step: each block's agents are planned for on the
+        // block's own stream (a pose in, an action out, per agent), so the two halves of the batch stay independent
+        HIPCHK(h, hipSetDevice(h->cfg.device_id));
+        const int per = group_envs(h), E = h->cfg.num_envs, A = h->cfg.num_agents;
+        for (int g = 0; g < 2; ++g) {
+            const int e0 = g * per, e1 = std::min(E, e0 + per);
+            if (e0 >= e1) break;
+            const size_t i0 = (size_t)e0 * A;
+            const int n = (e1 - e0) * A;
+            hipLaunchKernelGGL(k_pure_pursuit, grid1d((size_t)n * kPlanLanes, 256), dim3(256), 0, h->gstreams[g], d_waypoints, M, st + i0, st + N + i0,
+                               st + 4 * (size_t)N + i0, 1, n, lookahead, vgain, wheelbase, max_reacquire, d_actions + 2 * i0);
+        }
+        HIPCHK(h, hipGetLastError());
+        return F110_OK;
+    }
+    ENTER(h);
     hipLaunchKernelGGL(k_pure_pursuit, grid1d((size_t)N * kPlanLanes, 256), dim3(256), 0, h->stream, d_waypoints, M, st, st + N, st + 4 * (size_t)N, 1, N, lookahead,
                        vgain, wheelbase, max_reacquire, d_actions);
     HIPCHK(h, hipGetLastError());
+    h->touched = false;   // (the next step may split: it forks from what this call left on the main stream)
     return F110_OK;
 }
 

@@ -2542,10 +2542,11 @@ __global__ void k_reset_collided(AgentArrays a, const double *__restrict__ start
 // policy on the GPU never has to read poses back to decide `done`.
 // (struct EpisodeArrays: defined next to AgentArrays, the finalize kernels take it too)
 
-__global__ void __launch_bounds__(256) k_episode(AgentArrays a, EpisodeArrays ep, int num_envs)
+// (envs env0 .. env0 + num_envs - 1: the whole batch, or one env block on that block's stream)
+__global__ void __launch_bounds__(256) k_episode(AgentArrays a, EpisodeArrays ep, int num_envs, int env0 = 0)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= num_envs) return;
+    const int e = env0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= env0 + num_envs) return;
     const int N = a.n_agents_total, A = a.agents_per_env;
     const double ct = ep.current_time[e] + ep.timestep;  // f110_env.py:295
     ep.current_time[e] = ct;
@@ -2773,11 +2774,12 @@ __global__ void __launch_bounds__(256) k_scans_to_f32(const double *__restrict__
 }
 
 // re-seat every env whose done flag is set (F110Env.reset :319-334 without its zero-action step)
-__global__ void __launch_bounds__(256) k_episode_reset_done(AgentArrays a, EpisodeArrays ep, int32_t *__restrict__ n_reset)
+// (agents i0 .. i0 + count - 1; count < 0: all)
+__global__ void __launch_bounds__(256) k_episode_reset_done(AgentArrays a, EpisodeArrays ep, int32_t *__restrict__ n_reset, int i0 = 0, int count = -1)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = i0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int N = a.n_agents_total, A = a.agents_per_env;
-    if (i >= N) return;
+    if (i >= (count < 0 ? N : i0 + count)) return;
     const int e = i / A;
     if (!ep.done[e]) return;
 #pragma unroll
@@ -2799,10 +2801,10 @@ __global__ void __launch_bounds__(256) k_episode_reset_done(AgentArrays a, Episo
 }
 
 // done[] is read by every lane of the env above and cleared here, in a separate launch
-__global__ void k_episode_clear_done(EpisodeArrays ep, int num_envs)
+__global__ void k_episode_clear_done(EpisodeArrays ep, int num_envs, int env0 = 0)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < num_envs) ep.done[e] = 0;
+    const int e = env0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e < env0 + num_envs) ep.done[e] = 0;
 }
 
 __global__ void k_episode_reset(AgentArrays a, EpisodeArrays ep, const double *__restrict__ poses,
