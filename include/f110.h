@@ -214,6 +214,8 @@ typedef struct f110_episode_views {
 int f110_episode_init(f110_sim *h, int32_t ego_idx);
 int f110_episode_reset(f110_sim *h, const double *h_poses, const double *h_rot,
                        const uint8_t *h_env_mask);
+/* (These two, like f110_pure_pursuit_device, keep a device-resident loop in its env blocks: behind a step that went out as two
+ * env blocks — f110_config.step_groups — they run per block on the block's stream; an env's bookkeeping reads that env only.) */
 int f110_episode_step_device(f110_sim *h, const double *d_actions); /* f110_step_device + _check_done */
 int f110_episode_reset_done_device(f110_sim *h, int32_t *d_count);  /* re-seat envs whose done flag is set */
 int f110_episode_get(f110_sim *h, const f110_episode_host *out);
