@@ -531,7 +531,7 @@ static void default_beam_tables(const f110_config &c, std::vector<double> &sa, s
     }
 }
 
-// kernels_f110.hpp "do two streams make progress independently of each other?"; *yes is false whenever in doubt
+// f110_kernels.hpp "do two streams make progress independently of each other?"; *yes is false whenever in doubt
 static hipError_t streams_concurrent(hipStream_t a, hipStream_t b, bool *yes)
 {
     *yes = false;
@@ -627,6 +627,7 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         h->groups_auto = G <= 0;
         if (G <= 0) G = 2;
         G = std::min(std::min(G, 16), cfg->num_envs);
+        if (h->groups_auto && cfg->step_graph != 0) G = 1;   // (lab: the captured-graph step is one block)
         h->groups = G;
         h->use_graph = cfg->step_graph != 0;
         // pair tests + opponent windows inside the finalize kernel: A = 2 (k_finalize_pair_roles) and every A up to
@@ -645,7 +646,10 @@ int f110_create(const f110_config *cfg, f110_sim **out)
             std::vector<hipStream_t> rejected;
             for (int attempt = 0; attempt < 7 && !second; ++attempt) {
                 hipStream_t cand = h->side_stream;
-                if (attempt > 0) CKH(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+                if (attempt > 0 && hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) {
+                    (void)hipGetLastError();   // no more streams to be had: the search ends, the step stays one block
+                    break;
+                }
                 bool yes = false;
                 const hipError_t ep = streams_concurrent(h->stream, cand, &yes);
                 if (ep == hipSuccess && yes) {
