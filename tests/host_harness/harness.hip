@@ -370,4 +370,40 @@ void hh_noise_rows(const uint64_t *state_inc, double scale, int rows, int B, dou
     state_out[1] = state.lo;
 }
 
+// box_vertices against box_vertices_cs fed with cos_sin of the same heading (what the role-parallel finalize kernels do once per
+// agent), and the opponent window computed the straightforward way (opponent_beam_window: per corner vertex_beam_index, then
+// disc_beam_range) against the kernels' decomposition (head = atan2(sin, cos) of the ray-cast heading once, box from the
+// cached cos / sin, per corner vertex_beam_from_angles, disc_beam_range_from): out = {ref_lo, ref_hi, lo, hi} twice
+void hh_box_and_window(const double *ego3, const double *opp3, double length, double width, const double *scan_angles, int B, double angle_inc,
+                       double *v_plain, double *v_cs, int *win_plain, int *win_table)
+{
+    const double ex = ego3[0], ey = ego3[1], eth = ego3[2], ox = opp3[0], oy = opp3[1], oth = opp3[2];
+    box_vertices(ox, oy, oth, length, width, v_plain);
+    double co, so;
+    cos_sin(oth, co, so);
+    box_vertices_cs(ox, oy, co, so, length, width, v_cs);
+    const double R = 0.5 * sqrt(length * length + width * width);
+    opponent_beam_window(ex, ey, eth, v_plain, ox, oy, R, scan_angles, B, angle_inc, win_plain[0], win_plain[1], win_plain[2], win_plain[3]);
+    // the kernels' way
+    double ce, se;
+    cos_sin(eth, ce, se);
+    const double head = atan2(se, ce);
+    int idx[4];
+    for (int sub = 0; sub < 4; ++sub) {
+        const double dx = v_cs[2 * sub] - ex, dy = v_cs[2 * sub + 1] - ey;
+        const double norm = sqrt(dx * dx + dy * dy);
+        idx[sub] = vertex_beam_from_angles(head, atan2(dy / norm, dx / norm), scan_angles, B, angle_inc);
+    }
+    int a = idx[0] < idx[1] ? idx[0] : idx[1], b = idx[2] < idx[3] ? idx[2] : idx[3];
+    win_table[0] = a < b ? a : b;
+    a = idx[0] > idx[1] ? idx[0] : idx[1];
+    b = idx[2] > idx[3] ? idx[2] : idx[3];
+    win_table[1] = a > b ? a : b;
+    const double cdx = ox - ex, cdy = oy - ey;
+    int cl, ch;
+    disc_beam_range_from(sqrt(cdx * cdx + cdy * cdy), eth, atan2(cdy, cdx), head, R, scan_angles, B, angle_inc, cl, ch);
+    win_table[2] = win_table[0] > cl ? win_table[0] : cl;
+    win_table[3] = win_table[1] < ch ? win_table[1] : ch;
+}
+
 }  // extern "C"

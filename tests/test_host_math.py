@@ -454,3 +454,31 @@ def test_pure_pursuit_planner(hh):
                 assert goal.value == (li if li >= 0 else M + li)
             assert np.max(np.abs(act - g["actions"][k])) < 1e-14
 
+
+
+def test_per_agent_table_decomposition_of_the_opponent_window(hh):
+    """what k_finalize_multi / k_finalize_multi_tiled keep per AGENT (cos / sin of the snapshot heading, the ray-cast heading's
+    atan2) and then combine per record must be the straightforward computation bit for bit: box_vertices_cs(cos_sin(th)) ==
+    box_vertices(th), and corner beam indices + disc cull from the cached pieces == opponent_beam_window — opponents
+    everywhere around the ego (in front, exactly behind: the +-pi wrap, touching, far), headings of every size"""
+    rng = np.random.default_rng(2024)
+    B = 1080
+    fov = 4.7
+    angles = np.ascontiguousarray(np.linspace(-fov / 2., fov / 2., B))
+    inc = fov / (B - 1)
+    ap = angles.ctypes.data_as(_dp)
+    n_empty = n_full = 0
+    for k in range(6000):
+        eth = rng.uniform(-np.pi, np.pi) * rng.choice([1.0, 1.0, 7.0, 1e3])
+        dist = rng.choice([0.3, 0.6, 1.5, 5.0, 25.0]) * rng.uniform(0.8, 1.2)
+        bearing = rng.uniform(-np.pi, np.pi) if k % 5 else np.pi * rng.choice([-1.0, 1.0]) + rng.uniform(-1e-3, 1e-3)   # every fifth: right behind
+        ego = np.array([rng.uniform(-20, 20), rng.uniform(-20, 20), eth])
+        opp = np.array([ego[0] + dist * np.cos(eth + bearing), ego[1] + dist * np.sin(eth + bearing), rng.uniform(-np.pi, np.pi) * rng.choice([1.0, 50.0])])
+        v1, v2 = np.empty(8), np.empty(8)
+        w1, w2 = np.zeros(4, dtype=np.int32), np.zeros(4, dtype=np.int32)
+        hh.hh_box_and_window(ego.ctypes.data_as(_dp), opp.ctypes.data_as(_dp), C.c_double(0.58), C.c_double(0.31), ap, B, C.c_double(inc),
+                             v1.ctypes.data_as(_dp), v2.ctypes.data_as(_dp), w1.ctypes.data_as(_ip), w2.ctypes.data_as(_ip))
+        assert np.array_equal(v1, v2), k
+        assert np.array_equal(w1, w2), (k, w1, w2)
+        n_empty += int(w1[3] < w1[2]); n_full += int(w1[3] - w1[2] > B // 2)
+    assert n_empty > 0 and n_full > 0   # both ends of the window logic were exercised
