@@ -397,7 +397,7 @@ def gen_sim(ns):
 
 
 # ------------------------------------------------------------------- multi-agent sim rollout
-def gen_sim_multi(ns):
+def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 520, 240, 110, 90)), name="sim_rollout_multi"):
     """Simulator.step with A = 3, 4 and 8 cars on example_map (base_classes.py:553-612 loops over A
     agents; collision_models.py:184-212 all pairs; base_classes.py:206-227 every opponent per ego).
     The cars start as a bunched train on the raceline (0.8 m apart, alternating lateral offsets, so that
@@ -408,7 +408,7 @@ def gen_sim_multi(ns):
     bc = ns.base_classes
     w = raceline()
     out = {}
-    for A, k0, T in ((3, 40, 220), (4, 300, 220), (8, 520, 240)):
+    for A, k0, T, wall_from, mid_full in cases:
         ref_loader.fresh_racecar_class(ns)
         sim = bc.Simulator(dict(DEFAULT_PARAMS), A, 12345, time_step=0.01, integrator=bc.Integrator.RK4)
         sim.set_map(EXAMPLE_MAP + ".yaml", ".png")
@@ -423,14 +423,14 @@ def gen_sim_multi(ns):
         acts = np.empty((T, A, 2)); states = np.empty((T, A, 7)); cols = np.empty((T, A))
         incol = np.empty((T, A), dtype=np.int32); cidx = np.empty((T, A)); snap = np.empty((T, A, 3))
         sub = np.empty((T, A, 45)); ssum = np.empty((T, A))
-        full_steps = [0, 90, T - 1]
+        full_steps = [0, mid_full, T - 1]
         a = np.zeros((A, 2))
         waller = A // 2
         for t in range(T):
             if t % 25 == 0:
                 for i in range(A):
                     a[i] = [rng.uniform(-0.06, 0.06), 6.5 - 5.0 * i / (A - 1) + rng.uniform(-0.4, 0.4)]
-            if t >= 110:
+            if t >= wall_from:
                 a[waller] = [0.41, 5.0]
             acts[t] = a
             obs = sim.step(a)
@@ -452,7 +452,14 @@ def gen_sim_multi(ns):
             A, np.nonzero(incol.any(axis=1))[0][:4], np.nonzero(incol.any(axis=0))[0], len(gjk_steps), gjk_steps[:3],
             sorted({(int(i), int(j)) for row in cidx for i, j in enumerate(row) if j >= 0})[:10]))
     ref_loader.fresh_racecar_class(ns)
-    save("sim_rollout_multi", params=pvec(DEFAULT_PARAMS), seed=np.array([12345]), agent_counts=np.array([3, 4, 8]), **out)
+    save(name, params=pvec(DEFAULT_PARAMS), seed=np.array([12345]), agent_counts=np.array([c[0] for c in cases]), **out)
+
+
+def gen_sim_many(ns):
+    """the same scenario with 12 and 20 cars (round 4: the product steps 9 .. 16 cars per env with the 256-record form of
+    k_finalize_multi and more with k_finalize_multi_tiled; until now those two were pinned to the oracle only).  Shorter
+    runs — the un-jitted reference needs seconds per step at this size — with the wall hit moved forward accordingly."""
+    gen_sim_multi(ns, cases=((12, 100, 130, 45, 60), (20, 610, 120, 40, 60)), name="sim_rollout_many")
 
 
 # ------------------------------------------------------------------- env, 2 agents, ego_idx = 1
@@ -673,7 +680,7 @@ def gen_planner(ns):
          tlad=np.array([tlad]), vgain=np.array([vgain]), wheelbase=np.array([wheelbase]), max_reacquire=np.array([20.0]))
 
 
-GROUPS = {"planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
+GROUPS = {"sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
           "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "waypoint_follow": gen_waypoint_follow}
 
