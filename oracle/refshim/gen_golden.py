@@ -463,8 +463,8 @@ def gen_sim_many(ns):
 
 
 # ------------------------------------------------------------------- env, 2 agents, ego_idx = 1
-def gen_env2(ns):
-    """F110Env(num_agents=2, ego_idx=1) — the reference's default agent count (f110_env.py:133-136)
+def gen_env2(ns, three=False):
+    """(three=True: gen_env3 below.)  F110Env(num_agents=2, ego_idx=1) — the reference's default agent count (f110_env.py:133-136)
     with the ego in slot 1 — through three episodes on example_map, each started by env.reset:
       0  both cars leave the start zone and reverse back into it twice at different speeds, with
          different start headings (the zone of BOTH cars is laid out in the EGO's start frame,
@@ -474,7 +474,7 @@ def gen_env2(ns):
       2  car 0 rear-ends the ego: GJK sets both flags, done."""
     ns = ref_loader.load_reference(with_env=True)
     ref_loader.fresh_racecar_class(ns)
-    env = ns.f110_env.F110Env(map=EXAMPLE_MAP, map_ext='.png', num_agents=2, ego_idx=1, seed=12345)
+    env = ns.f110_env.F110Env(map=EXAMPLE_MAP, map_ext='.png', num_agents=3 if three else 2, ego_idx=2 if three else 1, seed=12345)
     w = raceline()
     obs_ego = []
     keys = ("x", "y", "th", "v", "w", "lap_time", "lap_count", "done", "toggle", "near", "col", "ckpt", "scan_sum")
@@ -517,6 +517,39 @@ def gen_env2(ns):
         print("    episode %d: %d steps, toggles %s, collisions %s, done %s" % (ep, t, env.toggle_list, rec["col"][-1], done))
         return rec
 
+    if three:
+        # episode 0: laps of three cars — two side by side, the ego 2 m behind them; done only when ALL three have 4 toggles
+        def laps3(t, env):
+            a = np.zeros((3, 2))
+            for i, sp in ((0, 1.8), (1, 2.6), (2, 2.2)):
+                a[i, 1] = sp if env.toggle_list[i] % 2 == 0 else -sp
+            return a
+        rec = run(0, [pose_at(0, lat=0.45, dth=-0.5), pose_at(0, lat=1.45), pose_at(w.shape[0] - 10, lat=0.95)], laps3, 4000)
+        print("      collision steps:", np.nonzero(np.array(rec["col"]).any(axis=1))[0][:10])
+        assert rec["done"][-1] and not np.any(np.array(rec["col"])) and np.all(rec["toggle"][-1] >= 4)
+        fin = [int(np.argmax(np.array(rec["toggle"])[:, i] >= 4)) for i in range(3)]
+        assert len(set(fin)) == 3, fin
+
+        # episode 1: the two non-ego cars hit the wall one after the other, the episode goes on; then the ego does
+        def walls3(t, env):
+            return np.array([[0.41 if t >= 40 else 0.0, 5.0], [0.41 if t >= 120 else 0.0, 4.5], [0.2 if t >= 220 else 0.0, 4.0]])
+        rec = run(1, [pose_at(120), pose_at(160), pose_at(200)], walls3, 1500)
+        col = np.array(rec["col"])
+        first = [int(np.argmax(col[:, i] > 0)) for i in range(3)]
+        assert col[:, 0].any() and col[:, 1].any() and first[0] < first[1] < first[2] and rec["done"][-1] and not rec["done"][first[1]], first
+
+        # episode 2: car 0 rear-ends car 1 (two non-egos: flags set, the episode goes on), then reaches the slow ego ahead
+        def ram3(t, env):
+            return np.array([[0.0, 7.0], [0.0, 3.0], [0.0, 1.0]])
+        rec = run(2, [pose_at(400), pose_at(408), pose_at(440)], ram3, 1500)
+        col = np.array(rec["col"])
+        first01 = int(np.argmax((col[:, 0] > 0) & (col[:, 1] > 0)))
+        assert rec["done"][-1] and col[-1, 2] == 1 and 0 < first01 < len(col) - 1 and not rec["done"][first01], first01
+        ref_loader.fresh_racecar_class(ns)
+        assert set(obs_ego) == {0}
+        save("env_episode_3agents", ego_idx=np.array([2]), obs_ego_idx=np.array([obs_ego[0]]), seed=np.array([12345]), **out)
+        return
+
     # episode 0: laps.  the cars sit side by side (1 m apart, mid-track); car 0's heading is 0.5 rad off the ego's
     def laps(t, env):
         a = np.zeros((2, 2))
@@ -546,6 +579,13 @@ def gen_env2(ns):
     ref_loader.fresh_racecar_class(ns)
     assert set(obs_ego) == {0}
     save("env_episode_2agents", ego_idx=np.array([1]), obs_ego_idx=np.array([obs_ego[0]]), seed=np.array([12345]), **out)
+
+
+def gen_env3(ns):
+    """F110Env(num_agents=3, ego_idx=2): the done rule over MORE than two agents (f110_env.py:244: every agent's toggles,
+    the ego's collision only) — laps of three cars finishing at three different steps, two non-ego wall hits that end
+    nothing before the ego's does, a contact between the two non-egos that ends nothing before one of them reaches the ego."""
+    gen_env2(ns, three=True)
 
 
 # ----------------------------------------------------------------------------------- env
@@ -682,7 +722,7 @@ def gen_planner(ns):
 
 GROUPS = {"sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
-          "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "waypoint_follow": gen_waypoint_follow}
+          "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "env3": gen_env3, "waypoint_follow": gen_waypoint_follow}
 
 
 def main(argv):
