@@ -397,7 +397,7 @@ def gen_sim(ns):
 
 
 # ------------------------------------------------------------------- multi-agent sim rollout
-def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 520, 240, 110, 90)), name="sim_rollout_multi"):
+def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 520, 240, 110, 90)), name="sim_rollout_multi", variants=None):
     """Simulator.step with A = 3, 4 and 8 cars on example_map (base_classes.py:553-612 loops over A
     agents; collision_models.py:184-212 all pairs; base_classes.py:206-227 every opponent per ego).
     The cars start as a bunched train on the raceline (0.8 m apart, alternating lateral offsets, so that
@@ -410,8 +410,15 @@ def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 
     out = {}
     for A, k0, T, wall_from, mid_full in cases:
         ref_loader.fresh_racecar_class(ns)
-        sim = bc.Simulator(dict(DEFAULT_PARAMS), A, 12345, time_step=0.01, integrator=bc.Integrator.RK4)
+        var = (variants or {}).get(A, {})
+        pdict = dict(DEFAULT_PARAMS); pdict.update(var.get("params", {}))
+        sim = bc.Simulator(pdict, A, 12345, time_step=0.01, integrator=getattr(bc.Integrator, var.get("integrator", "RK4")),
+                           lidar_dist=var.get("lidar_dist", 0.0))
         sim.set_map(EXAMPLE_MAP + ".yaml", ".png")
+        if variants is not None:
+            out["a%d_params" % A] = pvec(pdict)
+            out["a%d_integrator" % A] = np.array([{"RK4": 1, "Euler": 2}[var.get("integrator", "RK4")]])
+            out["a%d_lidar_dist" % A] = np.array([var.get("lidar_dist", 0.0)])
         start = np.empty((A, 3))
         for i in range(A):
             k = (k0 + 4 * i) % w.shape[0]
@@ -453,6 +460,15 @@ def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 
             sorted({(int(i), int(j)) for row in cidx for i, j in enumerate(row) if j >= 0})[:10]))
     ref_loader.fresh_racecar_class(ns)
     save(name, params=pvec(DEFAULT_PARAMS), seed=np.array([12345]), agent_counts=np.array([c[0] for c in cases]), **out)
+
+
+def gen_sim_variants(ns):
+    """the same scenario away from the defaults every other Simulator fixture uses: 2 cars under the EULER integrator with the
+    lidar 0.275 m ahead of the rear axle (base_classes.py:69 lidar_dist, :373-380), and 3 longer, wider, heavier cars on
+    slipperier tyres (the opponent's box is drawn with the EGO's length / width, :223; GJK with the Simulator's, :549)."""
+    gen_sim_multi(ns, cases=((2, 40, 200, 120, 80), (3, 300, 200, 110, 90)), name="sim_rollout_variants",
+                  variants={2: {"integrator": "Euler", "lidar_dist": 0.275},
+                            3: {"lidar_dist": 0.275, "params": {"length": 0.72, "width": 0.40, "m": 4.2, "I": 0.06, "mu": 0.8, "lf": 0.18, "lr": 0.19}}})
 
 
 def gen_sim_many(ns):
@@ -720,7 +736,7 @@ def gen_planner(ns):
          tlad=np.array([tlad]), vgain=np.array([vgain]), wheelbase=np.array([wheelbase]), max_reacquire=np.array([20.0]))
 
 
-GROUPS = {"sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
+GROUPS = {"sim_variants": gen_sim_variants, "sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
           "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "env3": gen_env3, "waypoint_follow": gen_waypoint_follow}
 
