@@ -415,6 +415,13 @@ def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 
         sim = bc.Simulator(pdict, A, 12345, time_step=0.01, integrator=getattr(bc.Integrator, var.get("integrator", "RK4")),
                            lidar_dist=var.get("lidar_dist", 0.0))
         sim.set_map(EXAMPLE_MAP + ".yaml", ".png")
+        if var.get("agent_params"):   # Simulator.update_params(params, agent_idx) :503-519: a parameter set per agent slot
+            rows = []
+            for i in range(A):
+                pi = dict(pdict); pi.update(var["agent_params"].get(i, {}))
+                sim.update_params(pi, agent_idx=i)
+                rows.append(pvec(pi))
+            out["a%d_agent_params" % A] = np.array(rows)
         if variants is not None:
             out["a%d_params" % A] = pvec(pdict)
             out["a%d_integrator" % A] = np.array([{"RK4": 1, "Euler": 2}[var.get("integrator", "RK4")]])
@@ -465,10 +472,15 @@ def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 
 def gen_sim_variants(ns):
     """the same scenario away from the defaults every other Simulator fixture uses: 2 cars under the EULER integrator with the
     lidar 0.275 m ahead of the rear axle (base_classes.py:69 lidar_dist, :373-380), and 3 longer, wider, heavier cars on
-    slipperier tyres (the opponent's box is drawn with the EGO's length / width, :223; GJK with the Simulator's, :549)."""
-    gen_sim_multi(ns, cases=((2, 40, 200, 120, 80), (3, 300, 200, 110, 90)), name="sim_rollout_variants",
+    slipperier tyres (the opponent's box is drawn with the EGO's length / width, :223; GJK with the Simulator's, :549), and 4
+    cars that all differ (Simulator.update_params per agent slot)."""
+    gen_sim_multi(ns, cases=((2, 40, 200, 120, 80), (3, 300, 200, 110, 90), (4, 520, 200, 110, 90)), name="sim_rollout_variants",
                   variants={2: {"integrator": "Euler", "lidar_dist": 0.275},
-                            3: {"lidar_dist": 0.275, "params": {"length": 0.72, "width": 0.40, "m": 4.2, "I": 0.06, "mu": 0.8, "lf": 0.18, "lr": 0.19}}})
+                            3: {"lidar_dist": 0.275, "params": {"length": 0.72, "width": 0.40, "m": 4.2, "I": 0.06, "mu": 0.8, "lf": 0.18, "lr": 0.19}},
+                            # four DIFFERENT cars (update_params per slot): every ego draws its opponents with its OWN length / width (:223),
+                            # collision_multiple uses the Simulator's (:549)
+                            4: {"agent_params": {0: {"length": 0.50, "width": 0.27, "m": 3.2}, 1: {"length": 0.70, "width": 0.38, "mu": 0.85},
+                                                 3: {"length": 0.62, "width": 0.24, "a_max": 7.5}}}})
 
 
 def gen_sim_many(ns):
