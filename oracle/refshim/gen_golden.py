@@ -414,7 +414,7 @@ def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 
         pdict = dict(DEFAULT_PARAMS); pdict.update(var.get("params", {}))
         sim = bc.Simulator(pdict, A, 12345, time_step=0.01, integrator=getattr(bc.Integrator, var.get("integrator", "RK4")),
                            lidar_dist=var.get("lidar_dist", 0.0))
-        sim.set_map(EXAMPLE_MAP + ".yaml", ".png")
+        sim.set_map(os.path.join(GOLD, "maps", var.get("map", "example_map")) + ".yaml", ".png")
         if var.get("agent_params"):   # Simulator.update_params(params, agent_idx) :503-519: a parameter set per agent slot
             rows = []
             for i in range(A):
@@ -423,6 +423,7 @@ def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 
                 rows.append(pvec(pi))
             out["a%d_agent_params" % A] = np.array(rows)
         if variants is not None:
+            out["a%d_map" % A] = np.array([var.get("map", "example_map")])
             out["a%d_params" % A] = pvec(pdict)
             out["a%d_integrator" % A] = np.array([{"RK4": 1, "Euler": 2}[var.get("integrator", "RK4")]])
             out["a%d_lidar_dist" % A] = np.array([var.get("lidar_dist", 0.0)])
@@ -432,6 +433,8 @@ def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 
             th = w[k, 3] + np.pi / 2
             lat = 0.12 * (1 if i % 2 else -1)
             start[i] = [w[k, 1] - lat * np.sin(th), w[k, 2] + lat * np.cos(th), th]
+        if "start" in var:
+            start = np.array(var["start"], dtype=float)
         sim.reset(start)
         rng = np.random.default_rng(900 + A)
         acts = np.empty((T, A, 2)); states = np.empty((T, A, 7)); cols = np.empty((T, A))
@@ -474,13 +477,16 @@ def gen_sim_variants(ns):
     lidar 0.275 m ahead of the rear axle (base_classes.py:69 lidar_dist, :373-380), and 3 longer, wider, heavier cars on
     slipperier tyres (the opponent's box is drawn with the EGO's length / width, :223; GJK with the Simulator's, :549), and 4
     cars that all differ (Simulator.update_params per agent slot)."""
-    gen_sim_multi(ns, cases=((2, 40, 200, 120, 80), (3, 300, 200, 110, 90), (4, 520, 200, 110, 90)), name="sim_rollout_variants",
+    gen_sim_multi(ns, cases=((2, 40, 200, 120, 80), (3, 300, 200, 110, 90), (4, 520, 200, 110, 90), (5, 0, 160, 60, 80)), name="sim_rollout_variants",
                   variants={2: {"integrator": "Euler", "lidar_dist": 0.275},
                             3: {"lidar_dist": 0.275, "params": {"length": 0.72, "width": 0.40, "m": 4.2, "I": 0.06, "mu": 0.8, "lf": 0.18, "lr": 0.19}},
                             # four DIFFERENT cars (update_params per slot): every ego draws its opponents with its OWN length / width (:223),
                             # collision_multiple uses the Simulator's (:549)
                             4: {"agent_params": {0: {"length": 0.50, "width": 0.27, "m": 3.2}, 1: {"length": 0.70, "width": 0.38, "mu": 0.85},
-                                                 3: {"length": 0.62, "width": 0.24, "a_max": 7.5}}}})
+                                                 3: {"length": 0.62, "width": 0.24, "a_max": 7.5}}},
+                            # another track: berlin (resolution 0.05 — not a power of two; the table's last cell is 0, so rays end where
+                            # they leave the map), five cars fanning out from a loose cluster in its free middle
+                            5: {"map": "berlin", "start": [[0.0, 0.0, 0.3], [0.9, 0.5, 2.0], [-0.8, 0.6, 4.1], [0.4, -0.9, 5.3], [-0.7, -0.8, 1.1]]}})
 
 
 def gen_sim_many(ns):
