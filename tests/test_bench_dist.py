@@ -221,3 +221,27 @@ def test_bench_refuses_a_mismatched_world():
     outs = [p.communicate(timeout=120) for p in procs]
     assert all(p.returncode != 0 for p in procs)
     assert not any(o[0].strip() for o in outs)
+
+
+def test_committed_bench_line_meets_the_contract():
+    """the last bench line committed under profiles/ (a real run on an MI355X) carries every key the driver's contract names —
+    a renamed or dropped key shows up here, on the CPU, when the profile is refreshed"""
+    import glob, json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json")))
+    assert files
+    d = json.loads(open(files[-1]).readline())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f64" and "synthetic" in d["data"]
+    assert d["unit"] == "agent-steps/s" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["agents_total"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    assert d["parity_gate"]["ok"] is True
