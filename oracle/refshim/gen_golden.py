@@ -412,7 +412,7 @@ def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 
         ref_loader.fresh_racecar_class(ns)
         var = (variants or {}).get(A, {})
         pdict = dict(DEFAULT_PARAMS); pdict.update(var.get("params", {}))
-        sim = bc.Simulator(pdict, A, 12345, time_step=0.01, integrator=getattr(bc.Integrator, var.get("integrator", "RK4")),
+        sim = bc.Simulator(pdict, A, 12345, time_step=var.get("time_step", 0.01), integrator=getattr(bc.Integrator, var.get("integrator", "RK4")),
                            lidar_dist=var.get("lidar_dist", 0.0))
         sim.set_map(os.path.join(GOLD, "maps", var.get("map", "example_map")) + ".yaml", ".png")
         if var.get("agent_params"):   # Simulator.update_params(params, agent_idx) :503-519: a parameter set per agent slot
@@ -424,6 +424,7 @@ def gen_sim_multi(ns, cases=((3, 40, 220, 110, 90), (4, 300, 220, 110, 90), (8, 
             out["a%d_agent_params" % A] = np.array(rows)
         if variants is not None:
             out["a%d_map" % A] = np.array([var.get("map", "example_map")])
+            out["a%d_time_step" % A] = np.array([var.get("time_step", 0.01)])
             out["a%d_params" % A] = pvec(pdict)
             out["a%d_integrator" % A] = np.array([{"RK4": 1, "Euler": 2}[var.get("integrator", "RK4")]])
             out["a%d_lidar_dist" % A] = np.array([var.get("lidar_dist", 0.0)])
@@ -477,7 +478,7 @@ def gen_sim_variants(ns):
     lidar 0.275 m ahead of the rear axle (base_classes.py:69 lidar_dist, :373-380), and 3 longer, wider, heavier cars on
     slipperier tyres (the opponent's box is drawn with the EGO's length / width, :223; GJK with the Simulator's, :549), and 4
     cars that all differ (Simulator.update_params per agent slot)."""
-    gen_sim_multi(ns, cases=((2, 40, 200, 120, 80), (3, 300, 200, 110, 90), (4, 520, 200, 110, 90), (5, 0, 160, 60, 80)), name="sim_rollout_variants",
+    gen_sim_multi(ns, cases=((2, 40, 200, 120, 80), (3, 300, 200, 110, 90), (4, 520, 200, 110, 90), (5, 0, 160, 60, 80), (6, 150, 120, 60, 50)), name="sim_rollout_variants",
                   variants={2: {"integrator": "Euler", "lidar_dist": 0.275},
                             3: {"lidar_dist": 0.275, "params": {"length": 0.72, "width": 0.40, "m": 4.2, "I": 0.06, "mu": 0.8, "lf": 0.18, "lr": 0.19}},
                             # four DIFFERENT cars (update_params per slot): every ego draws its opponents with its OWN length / width (:223),
@@ -486,7 +487,9 @@ def gen_sim_variants(ns):
                                                  3: {"length": 0.62, "width": 0.24, "a_max": 7.5}}},
                             # another track: berlin (resolution 0.05 — not a power of two; the table's last cell is 0, so rays end where
                             # they leave the map), five cars fanning out from a loose cluster in its free middle
-                            5: {"map": "berlin", "start": [[0.0, 0.0, 0.3], [0.9, 0.5, 2.0], [-0.8, 0.6, 4.1], [0.4, -0.9, 5.3], [-0.7, -0.8, 1.1]]}})
+                            5: {"map": "berlin", "start": [[0.0, 0.0, 0.3], [0.9, 0.5, 2.0], [-0.8, 0.6, 4.1], [0.4, -0.9, 5.3], [-0.7, -0.8, 1.1]]},
+                            # a coarser clock: time_step 0.02 (integration, steer-delay FIFO and iTTC all see it), six cars
+                            6: {"time_step": 0.02}})
 
 
 def gen_sim_many(ns):
