@@ -500,7 +500,7 @@ def gen_sim_many(ns):
 
 
 # ------------------------------------------------------------------- env, 2 agents, ego_idx = 1
-def gen_env2(ns, three=False):
+def gen_env2(ns, three=False, kw=None):
     """(three=True: gen_env3 below.)  F110Env(num_agents=2, ego_idx=1) — the reference's default agent count (f110_env.py:133-136)
     with the ego in slot 1 — through three episodes on example_map, each started by env.reset:
       0  both cars leave the start zone and reverse back into it twice at different speeds, with
@@ -511,7 +511,10 @@ def gen_env2(ns, three=False):
       2  car 0 rear-ends the ego: GJK sets both flags, done."""
     ns = ref_loader.load_reference(with_env=True)
     ref_loader.fresh_racecar_class(ns)
-    env = ns.f110_env.F110Env(map=EXAMPLE_MAP, map_ext='.png', num_agents=3 if three else 2, ego_idx=2 if three else 1, seed=12345)
+    if kw is not None:   # gen_env_kwargs: every constructor keyword away from its default
+        env = ns.f110_env.F110Env(map=EXAMPLE_MAP, map_ext='.png', **kw)
+    else:
+        env = ns.f110_env.F110Env(map=EXAMPLE_MAP, map_ext='.png', num_agents=3 if three else 2, ego_idx=2 if three else 1, seed=12345)
     w = raceline()
     obs_ego = []
     keys = ("x", "y", "th", "v", "w", "lap_time", "lap_count", "done", "toggle", "near", "col", "ckpt", "scan_sum")
@@ -607,6 +610,13 @@ def gen_env2(ns, three=False):
     first0 = int(np.argmax(col[:, 0] > 0)); first1 = int(np.argmax(col[:, 1] > 0))
     assert col[:, 0].any() and first0 < first1 and rec["done"][-1] and not rec["done"][first0], (first0, first1)
 
+    if kw is not None:
+        ref_loader.fresh_racecar_class(ns)
+        save("env_episode_kwargs", ego_idx=np.array([kw["ego_idx"]]), obs_ego_idx=np.array([obs_ego[0]]), seed=np.array([kw["seed"]]),
+             timestep=np.array([kw["timestep"]]), lidar_dist=np.array([kw["lidar_dist"]]), integrator=np.array([kw["integrator"].value]),
+             params=pvec(kw["params"]), **out)
+        return
+
     # episode 2: car 0 rear-ends the ego
     def ram(t, env):
         return np.array([[0.0, 7.0], [0.0, 1.0]])
@@ -616,6 +626,17 @@ def gen_env2(ns, three=False):
     ref_loader.fresh_racecar_class(ns)
     assert set(obs_ego) == {0}
     save("env_episode_2agents", ego_idx=np.array([1]), obs_ego_idx=np.array([obs_ego[0]]), seed=np.array([12345]), **out)
+
+
+def gen_env_kwargs(ns):
+    """F110Env with every constructor keyword away from its default (f110_env.py:103-160): seed 999, timestep 0.02, the Euler
+    integrator, the lidar 0.2 m ahead of the rear axle, other vehicle parameters — two episodes (laps of both cars; a non-ego
+    wall hit, then the ego's).  Pins the keyword plumbing of the drop-in F110Env / F110VecEnv, lap times in units of the
+    new timestep included."""
+    ns2 = ref_loader.load_reference(with_env=True)
+    p = dict(DEFAULT_PARAMS); p.update({"mu": 0.9, "m": 3.9, "length": 0.60, "width": 0.33, "a_max": 8.0, "v_max": 15.0})
+    gen_env2(ns, kw={"num_agents": 2, "ego_idx": 1, "seed": 999, "timestep": 0.02, "integrator": ns2.base_classes.Integrator.Euler,
+                     "lidar_dist": 0.2, "params": p})
 
 
 def gen_env3(ns):
@@ -759,7 +780,7 @@ def gen_planner(ns):
 
 GROUPS = {"sim_variants": gen_sim_variants, "sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
-          "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "env3": gen_env3, "waypoint_follow": gen_waypoint_follow}
+          "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "env3": gen_env3, "env_kwargs": gen_env_kwargs, "waypoint_follow": gen_waypoint_follow}
 
 
 def main(argv):
