@@ -639,6 +639,63 @@ def gen_env_kwargs(ns):
                      "lidar_dist": 0.2, "params": p})
 
 
+def gen_env_updates(ns):
+    """F110Env.update_params (one agent, then all: f110_env.py:364-375) in the middle of an episode and F110Env.update_map
+    (:351-362) between two: 2 agents on example_map — 40 steps, agent 1 gets other parameters, 40 steps, every agent gets a
+    third set, then the ego is steered into the wall — then the SAME env object moves to berlin for a second episode."""
+    ns = ref_loader.load_reference(with_env=True)
+    ref_loader.fresh_racecar_class(ns)
+    env = ns.f110_env.F110Env(map=EXAMPLE_MAP, map_ext='.png', num_agents=2, seed=12345)
+    w = raceline()
+    p1 = dict(DEFAULT_PARAMS); p1.update({"mu": 0.7, "m": 4.4, "a_max": 6.0, "length": 0.66, "width": 0.36})
+    p2 = dict(DEFAULT_PARAMS); p2.update({"mu": 1.2, "C_Sf": 5.4, "C_Sr": 6.1, "a_max": 9.0, "v_max": 12.0, "sv_max": 2.2})
+    keys = ("x", "y", "th", "v", "w", "lap_time", "lap_count", "done", "toggle", "near", "col", "ckpt", "scan_sum")
+    out = {"upd_steps": np.array([40, 80]), "upd_index": np.array([1, -1]), "upd_params": np.array([pvec(p1), pvec(p2)]),
+           "ep1_map": np.array(["berlin"])}
+
+    def run(ep, start, policy, max_steps, hooks):
+        rec = {k: [] for k in keys}
+        acts = []
+
+        def log(obs, done, info):
+            rec["x"].append(list(obs['poses_x'])); rec["y"].append(list(obs['poses_y'])); rec["th"].append(list(obs['poses_theta']))
+            rec["v"].append(list(obs['linear_vels_x'])); rec["w"].append(list(obs['ang_vels_z']))
+            rec["lap_time"].append(np.array(obs['lap_times'], dtype=float).copy()); rec["lap_count"].append(np.array(obs['lap_counts'], dtype=float).copy())
+            rec["done"].append(bool(done)); rec["toggle"].append(np.array(env.toggle_list, dtype=float).copy())
+            rec["near"].append(np.array(env.near_starts, dtype=bool).copy()); rec["col"].append(np.array(obs['collisions'], dtype=float).copy())
+            rec["ckpt"].append(np.array(info['checkpoint_done'], dtype=bool).copy()); rec["scan_sum"].append([float(np.sum(sc)) for sc in obs['scans']])
+        start = np.array(start, dtype=float)
+        obs, r, done, info = env.reset(start.copy())
+        log(obs, done, info)
+        t = 0
+        while t < max_steps and not done:
+            if t in hooks:
+                hooks[t]()
+            a = policy(t)
+            acts.append(a.copy())
+            obs, r, done, info = env.step(a)
+            log(obs, done, info)
+            t += 1
+        out["ep%d_start" % ep] = start
+        out["ep%d_actions" % ep] = np.array(acts)
+        for k in keys:
+            out["ep%d_%s" % (ep, k)] = np.array(rec[k])
+        print("    episode %d: %d steps, collisions %s, done %s" % (ep, t, rec["col"][-1], done))
+        return rec
+
+    def th_at(k):
+        return w[k, 3] + np.pi / 2
+    rec = run(0, [[w[120, 1], w[120, 2], th_at(120)], [w[160, 1], w[160, 2], th_at(160)]],
+              lambda t: np.array([[0.2 if t >= 120 else 0.03 * np.sin(t / 9.0), 5.0], [0.02 * np.cos(t / 7.0), 4.0]]), 1200,
+              {40: lambda: env.update_params(p1, index=1), 80: lambda: env.update_params(p2)})
+    assert rec["done"][-1] and rec["col"][-1][0] == 1 and len(rec["done"]) > 100
+    env.update_map(os.path.join(GOLD, "maps", "berlin.yaml"), ".png")
+    rec = run(1, [[0.0, 0.0, 0.3], [0.9, 0.5, 2.0]], lambda t: np.array([[0.05, 6.0], [-0.05, 3.0]]), 1200, {})
+    assert rec["done"][-1] and rec["col"][-1][0] == 1
+    ref_loader.fresh_racecar_class(ns)
+    save("env_episode_updates", seed=np.array([12345]), **out)
+
+
 def gen_env3(ns):
     """F110Env(num_agents=3, ego_idx=2): the done rule over MORE than two agents (f110_env.py:244: every agent's toggles,
     the ego's collision only) — laps of three cars finishing at three different steps, two non-ego wall hits that end
@@ -780,7 +837,7 @@ def gen_planner(ns):
 
 GROUPS = {"sim_variants": gen_sim_variants, "sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
-          "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "env3": gen_env3, "env_kwargs": gen_env_kwargs, "waypoint_follow": gen_waypoint_follow}
+          "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "env3": gen_env3, "env_kwargs": gen_env_kwargs, "env_updates": gen_env_updates, "waypoint_follow": gen_waypoint_follow}
 
 
 def main(argv):
