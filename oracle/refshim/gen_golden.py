@@ -835,7 +835,229 @@ def gen_planner(ns):
          tlad=np.array([tlad]), vgain=np.array([vgain]), wheelbase=np.array([wheelbase]), max_reacquire=np.array([20.0]))
 
 
-GROUPS = {"sim_variants": gen_sim_variants, "sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
+
+# ------------------------------------------------- round 5: the rest of the public surface
+PKG_MAPS = os.path.join(REPO, "f1tenth_gym_amd", "maps")   # the package's copy of the reference's tracks (vegas, stata_basement ...)
+
+
+def _map_yaml(name):
+    for d in (os.path.join(GOLD, "maps"), PKG_MAPS):
+        if os.path.isfile(os.path.join(d, name + ".yaml")) and os.path.isfile(os.path.join(d, name + ".png")):
+            return os.path.join(d, name + ".yaml")
+    raise FileNotFoundError(name)
+
+
+def _variant_yaml(tmp, name, resolution, origin):
+    """the track's image under ANOTHER resolution / origin (yaw included): yaml + png pair in a scratch directory
+    (the tests rebuild the same pair from the numbers stored in the fixture)"""
+    src = os.path.splitext(_map_yaml(name))[0] + ".png"
+    stem = os.path.join(tmp, "%s_variant" % name)
+    shutil.copyfile(src, stem + ".png")
+    with open(stem + ".yaml", "w") as f:
+        f.write("image: %s.png\nresolution: %r\norigin: [%r, %r, %r]\nnegate: 0\noccupied_thresh: 0.65\nfree_thresh: 0.196\n"
+                % (os.path.basename(stem), resolution, origin[0], origin[1], origin[2]))
+    return stem + ".yaml"
+
+
+def _scan_cases_ctor(ns, map_yaml, poses, num_beams, fov, **ctor):
+    lm = ns.laser_models
+    sim = lm.ScanSimulator2D(num_beams, fov, **ctor)
+    sim.set_map(map_yaml, ".png")
+    scans = np.empty((len(poses), num_beams)); rcs = np.empty((len(poses), num_beams, 2), dtype=np.int32)
+    idx = np.empty((len(poses), num_beams), dtype=np.int32); lookups = np.empty(len(poses), dtype=np.int64)
+    for k, pose in enumerate(poses):
+        with ScanProbe(lm) as pr:
+            scans[k] = sim.scan(np.array(pose), None)
+            rcs[k] = np.array(pr.rcs); idx[k] = np.array(pr.idx); lookups[k] = pr.lookups
+    return sim, scans, rcs, idx, lookups
+
+
+def _poses_in_free_space(sim, rng, n, clearance=0.3):
+    """world poses over free cells close to walls (on the track or just outside it) of a loaded reference ScanSimulator2D
+    (any origin yaw); the last one lies outside the image"""
+    rr, cc = np.nonzero((sim.dt > clearance) & (sim.dt < 1.2))
+    pick = rng.integers(0, len(rr), n)
+    u = (cc[pick] + rng.uniform(0.0, 1.0, n)) * sim.map_resolution
+    v = (rr[pick] + rng.uniform(0.0, 1.0, n)) * sim.map_resolution
+    c, s = sim.orig_c, sim.orig_s
+    poses = np.stack([sim.orig_x + c * u - s * v, sim.orig_y + s * u + c * v, rng.uniform(-7.0, 7.0, n)], axis=1)
+    poses[0::2, 2] = rng.uniform(0.0, 2 * np.pi, len(poses[0::2]))   # headings update_pose's yaw wrap leaves alone (the step-path tests use these)
+    poses[-1, :2] = [sim.orig_x - 3.0 * c + 2.0 * s, sim.orig_y - 3.0 * s - 2.0 * c]
+    return poses
+
+
+SCAN_CTOR_CASES = [
+    # map, num_beams, fov, eps, theta_dis, max_range  (laser_models.py:360-381: every keyword away from its default)
+    ("example_map", 1080, 4.7, 0.03, 720, 8.0),      # 720 directions < 1080 beams: theta_index_increment 0.4992 < 1
+    ("example_map", 541, 4.7, 0.2, 3600, 30.0),      # eps above the resolution (0.0625): the march ends on NON-zero table values
+    ("berlin", 1080, 4.7, 0.2, 2000, 8.0),           # eps = 4 cells of berlin (0.05), short max_range; the table's last cell is 0
+    ("berlin", 360, 6.2, 0.0001, 720, 30.0),         # fov close to a full turn, coarse direction table
+    ("skirk", 777, 3.3, 0.03, 3600, 12.5),
+    ("example_map", 2048, 4.7, 0.0001, 1000, 30.0),  # twice as many beams as directions
+]
+
+
+def gen_scan_ctor(ns):
+    """ScanSimulator2D(num_beams, fov, eps, theta_dis, max_range) away from the defaults + scan(pose, rng, std_dev != 0.01)
+    (laser_models.py:360-381, :429-454)."""
+    import tempfile
+    out = {}
+    for k, (name, beams, fov, eps, theta_dis, max_range) in enumerate(SCAN_CTOR_CASES):
+        rng = np.random.default_rng(1100 + k)
+        lm = ns.laser_models
+        probe = lm.ScanSimulator2D(beams, fov, eps=eps, theta_dis=theta_dis, max_range=max_range)
+        probe.set_map(_map_yaml(name), ".png")
+        poses = _poses_in_free_space(probe, rng, 5)
+        sim, scans, rcs, idx, lk = _scan_cases_ctor(ns, _map_yaml(name), poses, beams, fov, eps=eps, theta_dis=theta_dis, max_range=max_range)
+        std = [0.05, 0.2, 0.001][k % 3]
+        noisy = sim.scan(np.array(poses[0]), np.random.default_rng(4242 + k), std_dev=std)
+        out.update({"c%d_map" % k: np.array([name]), "c%d_ctor" % k: np.array([beams, fov, eps, theta_dis, max_range]),
+                    "c%d_poses" % k: poses, "c%d_scans" % k: scans, "c%d_hit_rc" % k: rcs, "c%d_dir_idx" % k: idx, "c%d_lookups" % k: lk,
+                    "c%d_theta_index_increment" % k: np.array([sim.theta_index_increment]),
+                    "c%d_noise_seed_std" % k: np.array([4242 + k, std]), "c%d_noisy" % k: noisy})
+        nz = int(np.sum(sim.dt[np.clip(rcs[..., 0], 0, sim.dt.shape[0] - 1), np.clip(rcs[..., 1], 0, sim.dt.shape[1] - 1)] > 0))
+        print("    case %d %-12s beams %4d eps %g theta_dis %d max_range %g: lookups %s, rays ending on a non-zero cell %d, at max_range %d"
+              % (k, name, beams, eps, theta_dis, max_range, lk, nz, int(np.sum(scans >= max_range))))
+    save("scan_ctor_variants", n_cases=np.array([len(SCAN_CTOR_CASES)]), **out)
+
+
+ROTATED_CASES = [
+    # base track, resolution, origin [x, y, yaw]   (laser_models.py:55-86 xy_2_rc rotates by -yaw; :417-420 orig_s / orig_c)
+    ("berlin", 0.07, [-3.0, -4.0, 0.3]),
+    ("skirk", 0.0437, [1.5, 2.5, -1.1]),
+    ("example_map", 0.11, [-40.0, -20.0, 2.4]),
+]
+
+
+def gen_scan_rotated(ns):
+    """yaml files whose origin has a yaw and whose resolution is not a power of two: scans from poses over free space, and a
+    2-car Simulator rollout (noise seed 12345, a wall hit) on the first of them."""
+    import tempfile
+    out = {}
+    bc = ns.base_classes
+    with tempfile.TemporaryDirectory() as tmp:
+        for k, (name, res2, org2) in enumerate(ROTATED_CASES):
+            rng = np.random.default_rng(1200 + k)
+            y = _variant_yaml(tmp, name, res2, org2)
+            probe = ns.laser_models.ScanSimulator2D(1080, 4.7)
+            probe.set_map(y, ".png")
+            poses = _poses_in_free_space(probe, rng, 6)
+            sim, scans, rcs, idx, lk = _scan_cases_ctor(ns, y, poses, 1080, 4.7)
+            out.update({"r%d_map" % k: np.array([name]), "r%d_resolution" % k: np.array([res2]), "r%d_origin" % k: np.array(org2),
+                        "r%d_poses" % k: poses, "r%d_scans" % k: scans, "r%d_hit_rc" % k: rcs, "r%d_dir_idx" % k: idx, "r%d_lookups" % k: lk})
+            print("    rotated %d %-12s res %g yaw %g: lookups %s" % (k, name, res2, org2[2], lk))
+        # Simulator rollout on the rotated berlin: two cars side by side in the free middle, car 0 is steered into the wall
+        name, res2, org2 = ROTATED_CASES[0]
+        y = _variant_yaml(tmp, name, res2, org2)
+        ref_loader.fresh_racecar_class(ns)
+        sim = bc.Simulator(dict(DEFAULT_PARAMS), 2, 12345, time_step=0.01, integrator=bc.Integrator.RK4)
+        sim.set_map(y, ".png")
+        ss = bc.RaceCar.scan_simulator
+        rr, cc = np.nonzero((ss.dt > 1.2) & (ss.dt < 1.4))
+        u0, v0 = (cc[0] + 0.5) * res2, (rr[0] + 0.5) * res2
+        c, s = ss.orig_c, ss.orig_s
+        to_world = lambda u, v: [ss.orig_x + c * u - s * v, ss.orig_y + s * u + c * v]
+        start = np.array([to_world(u0, v0) + [org2[2] + 0.2], to_world(u0 + 0.3, v0 + 0.9) + [org2[2] + 0.5]])
+        sim.reset(start.copy())
+        T = 220
+        rng = np.random.default_rng(1299)
+        acts = np.empty((T, 2, 2)); states = np.empty((T, 2, 7)); cols = np.empty((T, 2)); incol = np.empty((T, 2), dtype=np.int32)
+        cidx = np.empty((T, 2)); sub = np.empty((T, 2, 45)); ssum = np.empty((T, 2)); full = {}
+        a = np.zeros((2, 2))
+        for t in range(T):
+            if t % 25 == 0:
+                a = np.array([[rng.uniform(-0.1, 0.1), rng.uniform(3.0, 6.0)], [rng.uniform(-0.2, 0.2), rng.uniform(1.0, 3.0)]])
+            if t >= 60:
+                a[0] = [0.04, 6.0]      # (full lock would circle inside the free space: radius 0.76 m)
+            acts[t] = a
+            obs = sim.step(a.copy())
+            states[t] = np.array([ag.state for ag in sim.agents]); cols[t] = obs['collisions']; cidx[t] = sim.collision_idx
+            incol[t] = [int(ag.in_collision) for ag in sim.agents]
+            for i in range(2):
+                sc = np.asarray(obs['scans'][i]); sub[t, i] = sc[::24]; ssum[t, i] = sc.sum()
+            if t in (0, 70, T - 1):
+                full["sim_scans_t%d" % t] = np.array(obs['scans'])
+        print("    rollout on rotated %s: wall hits at %s, contacts %d" % (name, np.nonzero(incol.any(axis=1))[0][:5], int((cidx >= 0).any(axis=1).sum())))
+        assert incol.any()
+        ref_loader.fresh_racecar_class(ns)
+        out.update({"sim_start": start, "sim_actions": acts, "sim_states": states, "sim_collisions": cols, "sim_in_collision": incol,
+                    "sim_collision_idx": cidx, "sim_scans_sub24": sub, "sim_scans_sum": ssum, "sim_full_steps": np.array([0, 70, T - 1]),
+                    "sim_seed": np.array([12345]), **full})
+    save("scan_rotated_origin", n_cases=np.array([len(ROTATED_CASES)]), params=pvec(DEFAULT_PARAMS), **out)
+
+
+def gen_env_defaults(ns):
+    """`F110Env()` with NO keyword at all (f110_env.py:104-159): the vegas track that ships inside the package, 2 agents, ego_idx 0,
+    seed 12345, RK4, timestep 0.01.  Episode 0: both cars leave the start zone and reverse back into it twice (done on
+    toggles); episode 1: car 1 (not the ego) hits the wall, the episode goes on until the ego does."""
+    ns = ref_loader.load_reference(with_env=True)
+    ref_loader.fresh_racecar_class(ns)
+    env = ns.f110_env.F110Env()
+    assert env.map_path.endswith("maps/vegas.yaml") and env.num_agents == 2 and env.ego_idx == 0 and env.seed == 12345
+    ss = ns.base_classes.RaceCar.scan_simulator
+    # a start on the track: the widest free spot of the lower-left straight; heading = the longest beam of a scan from there
+    dt = ss.dt
+    sub = dt[300:700, 100:600]
+    r0, c0 = np.unravel_index(np.argmax(sub), sub.shape)
+    x0, y0 = ss.orig_x + (100 + c0 + 0.5) * ss.map_resolution, ss.orig_y + (300 + r0 + 0.5) * ss.map_resolution
+    look = ns.laser_models.ScanSimulator2D(720, 2 * np.pi * 719 / 720)
+    look.orig_x, look.orig_y, look.orig_c, look.orig_s = ss.orig_x, ss.orig_y, ss.orig_c, ss.orig_s
+    look.map_height, look.map_width, look.map_resolution, look.dt = ss.map_height, ss.map_width, ss.map_resolution, ss.dt
+    sc = look.scan(np.array([x0, y0, 0.0]), None)
+    th = -np.pi * 719 / 720 + np.argmax(sc) * look.angle_increment
+    left = np.array([-np.sin(th), np.cos(th)])
+    keys = ("x", "y", "th", "v", "w", "lap_time", "lap_count", "done", "toggle", "near", "col", "ckpt", "scan_sum")
+    out = {}
+    obs_ego = []
+
+    def run(ep, start, policy, max_steps):
+        rec = {k: [] for k in keys}
+        acts = []
+
+        def log(obs, done, info):
+            rec["x"].append(list(obs['poses_x'])); rec["y"].append(list(obs['poses_y'])); rec["th"].append(list(obs['poses_theta']))
+            rec["v"].append(list(obs['linear_vels_x'])); rec["w"].append(list(obs['ang_vels_z']))
+            rec["lap_time"].append(np.array(obs['lap_times'], dtype=float).copy()); rec["lap_count"].append(np.array(obs['lap_counts'], dtype=float).copy())
+            rec["done"].append(bool(done)); rec["toggle"].append(np.array(env.toggle_list, dtype=float).copy())
+            rec["near"].append(np.array(env.near_starts, dtype=bool).copy()); rec["col"].append(np.array(obs['collisions'], dtype=float).copy())
+            rec["ckpt"].append(np.array(info['checkpoint_done'], dtype=bool).copy()); rec["scan_sum"].append([float(np.sum(s_)) for s_ in obs['scans']])
+        start = np.array(start, dtype=float)
+        obs, r, done, info = env.reset(start.copy())
+        obs_ego.append(obs['ego_idx'])
+        log(obs, done, info)
+        t = 0
+        while t < max_steps and not done:
+            a = policy(t)
+            acts.append(a.copy())
+            obs, r, done, info = env.step(a)
+            log(obs, done, info)
+            t += 1
+        out["ep%d_start" % ep] = start
+        out["ep%d_actions" % ep] = np.array(acts)
+        for k in keys:
+            out["ep%d_%s" % (ep, k)] = np.array(rec[k])
+        print("    episode %d: %d steps, toggles %s, collisions %s, done %s" % (ep, t, env.toggle_list, rec["col"][-1], done))
+        return rec
+
+    def laps(t):
+        a = np.zeros((2, 2))
+        for i, sp in ((0, 2.4), (1, 1.7)):
+            a[i, 1] = sp if env.toggle_list[i] % 2 == 0 else -sp
+        return a
+    start = [[x0 - 0.4 * left[0], y0 - 0.4 * left[1], th], [x0 + 0.5 * left[0], y0 + 0.5 * left[1], th + 0.15]]
+    rec = run(0, start, laps, 3000)
+    assert rec["done"][-1] and not np.any(np.array(rec["col"])) and np.all(rec["toggle"][-1] >= 4)
+    rec = run(1, start, lambda t: np.array([[0.08 if t >= 150 else 0.0, 4.0], [0.41 if t >= 30 else 0.0, 5.0]]), 1500)
+    col = np.array(rec["col"])
+    first = [int(np.argmax(col[:, i] > 0)) for i in range(2)]
+    print("      first wall hits:", first)
+    assert col[:, 1].any() and first[1] < first[0] and rec["done"][-1] and not rec["done"][first[1]]
+    ref_loader.fresh_racecar_class(ns)
+    assert set(obs_ego) == {0}
+    save("env_episode_defaults", map=np.array(["vegas"]), ego_idx=np.array([0]), obs_ego_idx=np.array([0]), seed=np.array([12345]), **out)
+
+
+GROUPS = {"scan_ctor": gen_scan_ctor, "scan_rotated": gen_scan_rotated, "env_defaults": gen_env_defaults, "sim_variants": gen_sim_variants, "sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
           "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "env3": gen_env3, "env_kwargs": gen_env_kwargs, "env_updates": gen_env_updates, "waypoint_follow": gen_waypoint_follow}
 

@@ -65,3 +65,37 @@ def rel_err(a, b, atol=1e-12):
     with np.errstate(divide="ignore", invalid="ignore"):
         e = np.where(excess > 0.0, excess / mag, 0.0)   # excess > 0 over |b| == 0 -> inf
     return float(np.max(e))
+
+
+PKG_MAPS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "f1tenth_gym_amd", "maps")
+
+
+def map_stem(name):
+    """path without extension of a track's yaml / png pair: tests/golden/maps, else the package's own maps (vegas ...)"""
+    for d in (MAPS, PKG_MAPS):
+        if os.path.isfile(os.path.join(d, name + ".yaml")) and os.path.isfile(os.path.join(d, name + ".png")):
+            return os.path.join(d, name)
+    raise FileNotFoundError(name)
+
+
+@functools.lru_cache(maxsize=None)
+def load_any_map_image(name):
+    """like load_map_image, for any track map_stem finds"""
+    stem = map_stem(name)
+    with open(stem + ".yaml") as f:
+        meta = yaml.safe_load(f)
+    img = np.array(Image.open(stem + ".png"))
+    assert img.ndim == 2 and img.dtype == np.uint8
+    return img, float(meta['resolution']), [float(v) for v in meta['origin']]
+
+
+def write_variant_yaml(tmp_dir, name, resolution, origin):
+    """yaml + png pair under tmp_dir: the track's image under ANOTHER resolution / origin (yaw included), as
+    oracle/refshim/gen_golden.py wrote it for the reference (scan_rotated_origin.npz stores the numbers); -> yaml path"""
+    import shutil
+    stem = os.path.join(str(tmp_dir), "%s_variant" % name)
+    shutil.copyfile(map_stem(name) + ".png", stem + ".png")
+    with open(stem + ".yaml", "w") as f:
+        f.write("image: %s.png\nresolution: %r\norigin: [%r, %r, %r]\nnegate: 0\noccupied_thresh: 0.65\nfree_thresh: 0.196\n"
+                % (os.path.basename(stem), float(resolution), float(origin[0]), float(origin[1]), float(origin[2])))
+    return stem + ".yaml"

@@ -1,0 +1,206 @@
+"""GPU parity tests added in round 5 (-m gpu): the HIP path over the part of the reference's public surface no earlier
+fixture reached — `ScanSimulator2D(num_beams, fov, eps, theta_dis, max_range)` with every keyword away from its default
+(laser_models.py:360-381), yaml origins with a yaw and odd resolutions (laser_models.py:55-86, :417-420), and the
+reference's default `F110Env()` (vegas, f110_env.py:104-159).  All three fixtures were recorded by RUNNING the reference
+(oracle/refshim/gen_golden.py scan_ctor / scan_rotated / env_defaults).  Nothing here reads /root/reference.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from _util import gold, load_any_map_image, map_stem, rel_err, write_variant_yaml
+
+pytestmark = pytest.mark.gpu
+FTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import f1tenth_gym_amd
+    from f1tenth_gym_amd import _ffi
+    assert _ffi.device_count() >= 1, "no MI355X visible: the HIP path cannot run (no CPU fallback)"
+    return f1tenth_gym_amd
+
+
+def _step_scans_at(amd, poses, img, res, origin, layout, reps=1, **ctor):
+    """the scans the STEP kernels produce with the cars at rest at `poses` (zero action from rest leaves the pose alone:
+    pid(0, 0, 0, 0) = 0): one env per pose, one car per env, noise off"""
+    keep = (poses[:, 2] >= 0.0) & (poses[:, 2] <= 2 * np.pi)     # headings update_pose's yaw wrap (base_classes.py:373-380) leaves alone
+    assert keep.sum() >= 2
+    poses = np.ascontiguousarray(np.tile(poses[keep], (reps, 1)))     # reps > 1: a batch large enough for the longest-first task order
+    s = amd.BatchSim(num_envs=len(poses), num_agents=1, map_layout=layout, **ctor)
+    s.set_map_image(img, res, origin)
+    s.reset(poses)
+    s.step(np.zeros((len(poses), 2)))
+    o = s.get("scans", "state", "in_collision")
+    s.close()
+    assert np.array_equal(o["state"][:, [0, 1, 4]], poses) and not o["state"][:, 3].any()
+    n = int(keep.sum())
+    for r in range(1, reps):
+        assert np.array_equal(o["scans"][r * n:(r + 1) * n], o["scans"][:n])
+    return o["scans"][:n], keep
+
+
+# ---------------------------------------------------------------- ScanSimulator2D keywords away from their defaults
+@pytest.mark.parametrize("layout", [0, 3])
+@pytest.mark.parametrize("case", range(6))
+def test_scan_ctor_variants_vs_reference(amd, case, layout):
+    g = gold("scan_ctor_variants")
+    assert int(g["n_cases"][0]) == 6
+    k = case
+    beams, fov, eps, theta_dis, max_range = g["c%d_ctor" % k]
+    beams, theta_dis = int(beams), int(theta_dis)
+    name = str(g["c%d_map" % k][0])
+    poses = g["c%d_poses" % k]
+    sim = amd.ScanSimulator2D(beams, fov, eps=eps, theta_dis=theta_dis, max_range=max_range, map_layout=layout)
+    assert sim.theta_index_increment == g["c%d_theta_index_increment" % k][0]
+    assert sim.set_map(map_stem(name) + ".yaml", ".png") is True
+    ranges, hits, lk = sim.scan_batch(poses, want_hits=True, want_lookups=True)
+    assert np.array_equal(sim.batch.beam_dir_index_batch(poses[:, 2]), g["c%d_dir_idx" % k])
+    assert np.array_equal(hits, g["c%d_hit_rc" % k])
+    assert np.array_equal(ranges, g["c%d_scans" % k])
+    assert np.array_equal(lk, g["c%d_lookups" % k])
+    # the reference's one-pose entry point, with and without its rng / std_dev arguments (laser_models.py:429-454)
+    for i in (0, len(poses) - 1):
+        assert np.array_equal(sim.scan(poses[i], None), g["c%d_scans" % k][i])
+    seed, std = g["c%d_noise_seed_std" % k]
+    assert np.array_equal(sim.scan(poses[0], np.random.default_rng(int(seed)), std_dev=std), g["c%d_noisy" % k])
+    sim.batch.close()
+    # ... and through the kernels env.step() runs (k_scan_rays_agent / k_scan_dirs_agent / k_scan_rays)
+    img, res, origin = load_any_map_image(name)
+    scans, keep = _step_scans_at(amd, poses, img, res, origin, layout, num_beams=beams, fov=fov, eps=eps, theta_dis=theta_dis,
+                                 max_range=max_range)
+    assert np.array_equal(scans, g["c%d_scans" % k][keep])
+    if layout == 3 and case in (0, 1, 2):      # the same through the big-batch form of the scan (12 000+ tasks)
+        scans, keep = _step_scans_at(amd, poses, img, res, origin, layout, reps=400, num_beams=beams, fov=fov, eps=eps, theta_dis=theta_dis,
+                                     max_range=max_range)
+        assert np.array_equal(scans, g["c%d_scans" % k][keep])
+
+
+# ---------------------------------------------------------------- rotated origin, odd resolution
+@pytest.mark.parametrize("layout", [0, 3])
+@pytest.mark.parametrize("case", range(3))
+def test_scan_rotated_origin_vs_reference(amd, case, layout, tmp_path):
+    g = gold("scan_rotated_origin")
+    k = case
+    name = str(g["r%d_map" % k][0])
+    res, origin = float(g["r%d_resolution" % k][0]), [float(v) for v in g["r%d_origin" % k]]
+    assert origin[2] != 0.0
+    poses = g["r%d_poses" % k]
+    yaml_path = write_variant_yaml(tmp_path, name, res, origin)
+    sim = amd.ScanSimulator2D(1080, 4.7, map_layout=layout)
+    sim.set_map(yaml_path, ".png")
+    assert sim.orig_s == np.sin(origin[2]) and sim.orig_c == np.cos(origin[2]) and sim.map_resolution == res
+    ranges, hits, lk = sim.scan_batch(poses, want_hits=True, want_lookups=True)
+    assert np.array_equal(sim.batch.beam_dir_index_batch(poses[:, 2]), g["r%d_dir_idx" % k])
+    assert np.array_equal(hits, g["r%d_hit_rc" % k])
+    assert np.array_equal(ranges, g["r%d_scans" % k])
+    assert np.array_equal(lk, g["r%d_lookups" % k])
+    sim.batch.close()
+    img, _, _ = load_any_map_image(name)
+    for reps in ((1, 300) if layout == 3 else (1,)):
+        scans, keep = _step_scans_at(amd, poses, img, res, origin, layout, reps=reps)
+        assert np.array_equal(scans, g["r%d_scans" % k][keep])
+
+
+@pytest.mark.parametrize("E", [1, 5])
+def test_simulator_rollout_on_rotated_origin_vs_reference(amd, E, tmp_path):
+    """the reference's 2-car Simulator on berlin under resolution 0.07 and an origin yawed by 0.3 rad: 220 steps, seed-12345
+    noise, a wall hit — through the reference-compatible Simulator class (E = 1) and through BatchSim with every env
+    replaying it (E = 5)"""
+    g = gold("scan_rotated_origin")
+    name = str(g["r0_map"][0])
+    res, origin = float(g["r0_resolution"][0]), [float(v) for v in g["r0_origin"]]
+    yaml_path = write_variant_yaml(tmp_path, name, res, origin)
+    acts = g["sim_actions"]
+    T = acts.shape[0]
+    full = {int(t): g["sim_scans_t%d" % t] for t in g["sim_full_steps"]}
+    params = dict(zip(amd._ffi.PARAM_KEYS, g["params"]))
+    worst = 0.0
+    if E == 1:
+        sim = amd.Simulator(params, 2, int(g["sim_seed"][0]))
+        sim.set_map(yaml_path, ".png")
+        sim.reset(g["sim_start"])
+        for t in range(T):
+            obs = sim.step(acts[t])
+            assert np.array_equal(obs['collisions'], g["sim_collisions"][t]), t
+            assert np.array_equal(sim.collision_idx, g["sim_collision_idx"][t]), t
+            assert np.array_equal([int(a.in_collision) for a in sim.agents], g["sim_in_collision"][t]), t
+            sc = np.array(obs['scans'])
+            worst = max(worst, rel_err(np.array([a.state for a in sim.agents]), g["sim_states"][t]),
+                        rel_err(sc[:, ::24], g["sim_scans_sub24"][t]), rel_err(sc.sum(axis=1), g["sim_scans_sum"][t]))
+            if t in full:
+                assert rel_err(sc, full[t]) < FTOL
+    else:
+        s = amd.BatchSim(params, num_envs=E, num_agents=2)
+        s.set_map(yaml_path, ".png")
+        s.set_noise_rng(int(g["sim_seed"][0]), 0.01)
+        s.reset(np.tile(g["sim_start"], (E, 1)))
+        rep = lambda x: np.tile(x, (E,) + (1,) * (x.ndim - 1))
+        for t in range(T):
+            s.step(np.tile(acts[t], (E, 1)))
+            o = s.get("scans", "state", "collisions", "collision_idx", "in_collision")
+            assert np.array_equal(o["collisions"], rep(g["sim_collisions"][t])), t
+            assert np.array_equal(o["collision_idx"], rep(g["sim_collision_idx"][t])), t
+            assert np.array_equal(o["in_collision"], rep(g["sim_in_collision"][t])), t
+            worst = max(worst, rel_err(o["state"], rep(g["sim_states"][t])), rel_err(o["scans"][:, ::24], rep(g["sim_scans_sub24"][t])),
+                        rel_err(o["scans"].sum(axis=1), rep(g["sim_scans_sum"][t])))
+            if t in full:
+                assert rel_err(o["scans"], rep(full[t])) < FTOL
+        s.close()
+    assert worst < FTOL, worst
+    assert g["sim_in_collision"].any()
+
+
+# ---------------------------------------------------------------- F110Env() with no keyword at all
+def _check_env_step(g, ep, k, obs, done, info, toggles, near, vec):
+    e = lambda name: g["ep%d_%s" % (ep, name)][k]
+    pick = (lambda v: np.asarray(v)[0]) if vec else (lambda v: np.asarray(v))
+    got = np.stack([pick(obs['poses_x']), pick(obs['poses_y']), pick(obs['poses_theta']), pick(obs['linear_vels_x']), pick(obs['ang_vels_z'])])
+    assert rel_err(got, np.stack([e("x"), e("y"), e("th"), e("v"), e("w")])) < FTOL, (ep, k)
+    assert np.array_equal(pick(obs['collisions']), e("col")), (ep, k)
+    assert np.array_equal(pick(obs['lap_counts']), e("lap_count")), (ep, k)
+    assert np.max(np.abs(pick(obs['lap_times']) - e("lap_time"))) < 1e-12
+    assert np.array_equal(np.asarray(pick(toggles), dtype=float), e("toggle")), (ep, k)
+    assert np.array_equal(np.asarray(pick(near), dtype=bool), e("near")), (ep, k)
+    assert np.array_equal(np.asarray(pick(info['checkpoint_done']), dtype=bool), e("ckpt")), (ep, k)
+    assert bool(pick(done) if vec else done) == bool(e("done")), (ep, k)
+    if 'scans' in obs:
+        assert rel_err(np.asarray(pick(obs['scans'])).sum(axis=1), e("scan_sum")) < FTOL, (ep, k)
+
+
+def test_f110env_without_keywords_vs_reference(amd):
+    """`F110Env()`: vegas from inside the package, 2 agents, ego_idx 0, seed 12345, RK4, 0.01 s (f110_env.py:104-159)"""
+    g = gold("env_episode_defaults")
+    env = amd.F110Env()
+    assert env.num_agents == 2 and env.ego_idx == 0 and env.timestep == 0.01 and env.seed == 12345
+    assert os.path.basename(env.map_path) == "vegas.yaml"
+    for ep in range(2):
+        obs, r, done, info = env.reset(g["ep%d_start" % ep])
+        assert r == 0.01 and obs['ego_idx'] == 0
+        _check_env_step(g, ep, 0, obs, done, info, env.toggle_list, env.near_starts, False)
+        for t, a in enumerate(g["ep%d_actions" % ep]):
+            obs, r, done, info = env.step(a)
+            _check_env_step(g, ep, t + 1, obs, done, info, env.toggle_list, env.near_starts, False)
+        assert done
+
+
+@pytest.mark.parametrize("E", [1, 4])
+def test_vec_env_without_keywords_vs_reference(amd, E):
+    """the same two episodes through F110VecEnv(E, device_logic=True) with no map / agent keyword: vegas, episode logic on
+    the device"""
+    g = gold("env_episode_defaults")
+    env = amd.F110VecEnv(E, device_logic=True, copy_obs=True)
+    for ep in range(2):
+        start = np.tile(g["ep%d_start" % ep][None], (E, 1, 1))
+        obs, r, done, info = env.reset(start)
+        for k in range(len(g["ep%d_actions" % ep]) + 1):
+            if k:
+                obs, r, done, info = env.step(np.tile(g["ep%d_actions" % ep][k - 1][None], (E, 1, 1)))
+            for e in range(E):
+                sel = {kk: (v[e:e + 1] if isinstance(v, np.ndarray) else v) for kk, v in obs.items()}
+                inf = {kk: v[e:e + 1] for kk, v in info.items()}
+                _check_env_step(g, ep, k, sel, done[e:e + 1], inf, inf['toggle_list'], inf['near_starts'], True)
+        assert done.all()
+    env.sim.batch.close()
