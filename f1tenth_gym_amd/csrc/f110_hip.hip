@@ -52,6 +52,10 @@ struct ExpSwitches {
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
     int group_split = 0;       // two env groups: percent of the envs in the first (0 = even)
     int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
+    int scan_stream = 0;       // 1: the lane-refill scan (k_scan_stream_agent) wherever it applies
+    int stream_refill = 0;     // free lanes that trigger a refill (0 = default)
+    int stream_block = 0;      // threads per persistent workgroup (0 = 512)
+    int stream_grid = 0;       // persistent workgroups (0 = 4 per CU)
     uint64_t scan_trace = 0;   // device address of a caller-owned [waves][8] uint64 buffer: clock stamps, hardware id, samples of every scan wave (0 = off)
 };
 
@@ -484,6 +488,13 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "integrate_duo") h->exp.integrate_duo = value;
     else if (k == "integrate_fan") h->exp.integrate_fan = value;
     else if (k == "group_split") h->exp.group_split = value;
+    else if (k == "scan_stream") h->exp.scan_stream = value;
+    else if (k == "stream_block") h->exp.stream_block = value;
+    else if (k == "stream_grid") h->exp.stream_grid = value;
+    else if (k == "stream_refill") {
+        if (value < 0 || value > 64) return fail(h, F110_ERR_INVALID, "stream_refill must be 0..64");
+        h->exp.stream_refill = value;
+    }
     else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
     else if (k == "scan_trace_lo") h->exp.scan_trace = (h->exp.scan_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "collide_mode") {
@@ -1653,7 +1664,12 @@ static int comm_gather(f110_sim *h, void *d_recv_scans, void *d_recv_scal, int t
     // the scalar block is packed on the main stream, behind the step and before anything (a re-seat, the
     // next step) can change the state it reads; obs_scal[cur] was last read by the gather of two steps ago,
     // which the step that just ran has waited for
-    if (scal) hipLaunchKernelGGL(k_pack_obs, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->obs_scal[cur]);
+    if (scal) {
+        hipLaunchKernelGGL(k_pack_obs, grid1d(N, 256), dim3(256), 0, h->stream, h->dev, h->obs_scal[cur]);
+        // k_pack_obs READS state[] on the main stream: a next step that goes out as two env blocks must fork from it
+        // (its second block's k_integrate would otherwise overwrite the state under the pack) — ADVICE r4
+        h->main_dirty = true;
+    }
     HIPCHK(h, hipEventRecord(h->ev_step_done, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->ev_step_done, 0));
     TRY(gather_on(h->comm_stream, h->scan_bufs[cur]));
@@ -2129,7 +2145,17 @@ static int noise_cache_extend(f110_sim *h, int upto)
 // The experimental build adds collide_mode 1 (pair tests fused into k_integrate) / 2 (k_collide in line), the
 // other layouts' kernels, two-pass dedupe and the forced geometries of f110_exp_set.
 // ev[0..3] (or nullptr): profiling events before integrate / before scan / after scan / after finalize.
-enum ScanKind { SCAN_FLAT, SCAN_AGENT, SCAN_AGENT_SCHED, SCAN_DIRS, SCAN_TWO_PASS, SCAN_WINDOW };
+enum ScanKind { SCAN_FLAT, SCAN_AGENT, SCAN_AGENT_SCHED, SCAN_DIRS, SCAN_TWO_PASS, SCAN_WINDOW, SCAN_STREAM };
+
+// the lane-refill scan (k_scan_stream_agent, experimental build: measured slower): needs the PADDED table and
+// a direction table that fits its LDS copy
+constexpr int kStreamRefillDefault = 48;
+static bool stream_scan_applies(const f110_sim *h, int count)
+{
+    (void)count;
+    if (!kExperimental || h->exp.scan_stream <= 0) return false;
+    return padded_family(h->cfg.map_layout) && h->k.pad && h->dir_stride == 0 && h->k.theta_dis <= 2048 && h->k.num_beams >= 128 && !h->use_graph;
+}
 
 static ScanKind pick_scan(const f110_sim *h, int begin, int count)
 {
@@ -2140,6 +2166,7 @@ static ScanKind pick_scan(const f110_sim *h, int begin, int count)
     }
     if (!(h->multi_map || agent_aligned(h))) return SCAN_FLAT;
     if (kExperimental && h->cfg.map_layout == F110_MAP_WINDOW_LDS && h->d_wcodes && !h->multi_map && !h->exp.no_window) return SCAN_WINDOW;
+    if (stream_scan_applies(h, count)) return SCAN_STREAM;
     if (h->task_order && !h->multi_map && !h->lookups_on && begin == 0 && count == h->N && !h->use_graph && !h->exp.scan_env_counter) return SCAN_AGENT_SCHED;
     return SCAN_AGENT;
 }
@@ -2155,6 +2182,13 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     // (the longest-first list counter) follow the same answer
     const ScanKind scan = pick_scan(h, begin, count);
     dev.sched_count_zero = scan == SCAN_AGENT_SCHED ? h->d_tcount + (h->task_epoch & 1u) : nullptr;
+    int stream_threads = 512, stream_blocks = 0;
+    if (scan == SCAN_STREAM) {   // (experimental build only)
+        stream_blocks = h->num_cus * 4;
+        if (h->exp.stream_block > 0) stream_threads = h->exp.stream_block;
+        if (h->exp.stream_grid > 0) stream_blocks = h->exp.stream_grid;
+        stream_blocks = std::max(1, std::min(stream_blocks, (count + stream_threads / 64 - 1) / (stream_threads / 64)));
+    }
     if (dev.noise_rng && (dev.noise_rng == 2 || h->noise_ub >= (long long)dev.noise_rows)) {
         const int apb = dev.noise_rng == 2 ? 16 : 64;   // per-agent streams: every agent needs a row, keep the waves many
         hipLaunchKernelGGL(k_noise_rows, dim3((count + apb - 1) / apb), dim3(256), 0, st, dev, h->noise_gen, B, apb);
@@ -2327,6 +2361,30 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
                 hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
             break;
         }
+#ifdef F110_EXPERIMENTAL
+        case SCAN_STREAM: {
+            j.first_pose = (uint32_t)begin;
+            StreamCtl ctl{};
+            ctl.refill = (uint32_t)(h->exp.stream_refill > 0 ? h->exp.stream_refill : kStreamRefillDefault);
+            ctl.split = 1u;
+            ctl.count = (uint32_t)count;
+            const dim3 sblock((unsigned)stream_threads);
+            const dim3 sgrid((unsigned)stream_blocks);
+            const size_t slds = (size_t)h->k.theta_dis * sizeof(double2);
+#define STREAM_SCAN(PM, ID)                                                                                                                  \
+    do {                                                                                                                                     \
+        if (cnt) hipLaunchKernelGGL((k_scan_stream_agent<PM, ID, true>), sgrid, sblock, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, ctl); \
+        else hipLaunchKernelGGL((k_scan_stream_agent<PM, ID, false>), sgrid, sblock, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, ctl);    \
+    } while (0)
+            if (stream_threads == 64 && !h->multi_map && h->k.ident_rot && !cnt)
+                hipLaunchKernelGGL((k_scan_stream_agent<false, true, false, true>), dim3((unsigned)ctl.count), dim3(64), 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, ctl);
+            else if (h->multi_map) STREAM_SCAN(true, false);
+            else if (h->k.ident_rot) STREAM_SCAN(false, true);
+            else STREAM_SCAN(false, false);
+#undef STREAM_SCAN
+            break;
+        }
+#endif
         case SCAN_AGENT: {
             const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
             agent_grid(tpa, grid, wpb, h->scan_tasks_per_wave);

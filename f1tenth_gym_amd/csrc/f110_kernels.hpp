@@ -1120,6 +1120,166 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
 #endif
 }
 
+#ifdef F110_EXPERIMENTAL   // round 5: built, bit-identical, measured SLOWER than k_scan_rays_agent — lab only (profiles/r05_stream_scan.txt)
+// ---- K2s: the step's ray march with lane refill ("survivor compaction") -----------------
+// k_scan_rays_agent marches 64 consecutive beams in lock step until the LONGEST of them ends: 38 % of the lanes of its
+// gathers are idle at the headline workload.  Here a wave owns an agent's whole scan as a QUEUE of beams: whenever at
+// least `refill` of its lanes have finished their ray, the finished ranges are stored and the free lanes take the next
+// beams of the queue.  A lane's ray is marched with exactly march_padded's arithmetic, whatever lane and whatever
+// company it runs in, so the results are bit-identical by construction (tools/debug/stream_ab.py: 40 cases).
+// tools/debug/compaction_sim.py prices the schemes on the CPU: packing the survivors at fixed sample counts removes
+// < 10 % of the wave-level gathers (the tail of a task is its few longest rays, which packing cannot shorten); lane
+// refill removes 22-32 %.  On the GPU it still loses (65 536 agents: 0.676 ms per step with k_scan_rays_agent; refill
+// 64 = no refill, i.e. the same lock-step scheme run as ONE wave per agent: 0.775; refill 48 / 32 / 16: 0.728 / 0.755 /
+// 0.802 with one-wave workgroups, 0.746 / 0.778 / 0.816 with persistent 8-wave workgroups): a gather's cost is not flat
+// in its active lanes (tools/debug/ta_bench.hip "partially active waves": 17 + ~0.25 cycles per lane), every refill event
+// adds a store + a noise load to the dependent chain, and waves that live for a whole agent schedule worse than waves of
+// three tasks (as "17 tasks per wave" did in round 3).
+//   * persistent workgroups of 8 waves with a (cos, sin) table copy in LDS (new beams' directions are LDS reads), agents
+//     handed out through a counter in LDS; or (ONE) one agent per one-wave workgroup, launched like k_scan_rays_agent.
+struct StreamCtl {
+    uint32_t refill;        // lanes that must be free before the queue is consulted (1..64)
+    uint32_t count;         // queues of this launch: agents (first_pose .. ) x split
+    uint32_t split, pad_;   // queues per agent (1: a wave owns an agent's whole scan)
+};
+
+// share r of nb: agents [lo, lo + size) of the launch
+__device__ __forceinline__ void stream_share(uint32_t r, uint32_t nb, uint32_t count, uint32_t &lo, uint32_t &size)
+{
+    lo = (uint32_t)(((uint64_t)r * count) / nb);
+    size = (uint32_t)(((uint64_t)(r + 1u) * count) / nb) - lo;
+}
+
+template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool ONE = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8))) k_scan_stream_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
+                                                                                                   const ScanConst *__restrict__ maps_full, StreamCtl ctl)
+{
+    extern __shared__ double2 lds_cs_[];   // [theta_dis]
+    __shared__ uint32_t lds_next;          // the next agent of this workgroup's share
+    // ONE (lab): one agent per one-wave workgroup, launched like k_scan_rays_agent; directions gathered from the HBM table
+    const double2 *lds_cs = ONE ? k.cs : lds_cs_;
+    if (!ONE) {
+        for (int t = threadIdx.x; t < k.theta_dis; t += blockDim.x) lds_cs_[t] = k.cs[t];
+        if (threadIdx.x == 0) lds_next = 0u;
+        __syncthreads();
+    }
+    const int B = k.num_beams;
+    const uint32_t lane = threadIdx.x & 63u;
+    typedef const __attribute__((address_space(4))) uint32_t *cu32_t;
+    // Work distribution.  The launch's agents are cut into gridDim.x equal shares, one per workgroup, XCD-contiguous (the
+    // workgroups of an XCD own neighbouring shares, as in k_scan_rays_agent); a share's agents are handed to whichever of
+    // the workgroup's waves asks next through a counter in LDS.  (Counters in HBM — one per XCD, then one per workgroup
+    // with helpers polling the others — measured 1.6-2.5 ms per launch whatever the batch: 10^5 device-scope atomics and
+    // polls on a few cache lines serialise in one memory channel.)
+    const uint32_t nb = gridDim.x, count = ctl.count;
+    uint32_t own;
+    {
+        const uint32_t q = nb >> 3, rem = nb & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        own = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;
+    }
+    uint32_t nl_acc = 0;
+    ScanConst km = k;
+    const ScanConst *cold = j.k_cold;
+    int cur_slot = -1;
+    const int thresh_live = 64 - (int)ctl.refill;
+    uint32_t lo, size;
+    stream_share(own, nb, count, lo, size);
+    for (;;) {
+        uint32_t ai = 0;
+        if (ONE) {
+            if (size == 0xffffffffu) break;   // (second pass)
+            lo = own; ai = 0u; size = 0xffffffffu;
+        } else {
+            if (lane == 0u) ai = atomicAdd(&lds_next, 1u);
+            ai = __builtin_amdgcn_readfirstlane(ai);
+            if (ai >= size) break;
+        }
+        {
+            const uint32_t item = lo + ai;                       // (agent, part): an agent's scan may be cut into `split` queues
+            const uint32_t pl = item / ctl.split, part = item - pl * ctl.split;
+            const uint32_t p = (PER_ENV_MAP && j.order) ? ((cu32_t)j.order)[pl] : j.first_pose + pl;
+            typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
+            const chdr_t h0 = (chdr_t)(j.hdr) + p;
+            const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
+            const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
+            const int row = uniform_i32(h0->noise_row), slot = uniform_i32(h0->map_slot), fast = uniform_i32(h0->fast);
+            if (PER_ENV_MAP && slot != cur_slot) {
+                cold = maps_full + slot;
+                load_map_fast(km, maps_fast, slot);
+                cur_slot = slot;
+            }
+            const double *nrow = row >= 0 ? j.noise + (size_t)row * (size_t)B : j.ranges + (size_t)p * (size_t)B;
+            const char *base = reinterpret_cast<const char *>(km.pad);
+            const int part_len = (B + (int)ctl.split - 1) / (int)ctl.split;
+            int next = (int)part * part_len;                                 // (uniform) the next beam of the queue
+            const int q_end = next + part_len < B ? next + part_len : B;     // (uniform) one past its last beam
+            int b = -1;            // this lane's beam, -1: free
+            double ux = 0., uy = 0., cux = 0., cuy = 0., d = 0., total = 0., nz = 0.;
+            int n = 0;
+            bool redo = false, alive = false;
+            for (;;) {
+                // ---- event: finished rays out, new beams in
+                if (b >= 0 && !alive) {
+                    double r = (total > km.max_range) ? km.max_range : total;
+                    if (redo | (n > km.pad_max_samples)) {   // (about one ray in 10^7, or an agent whose lidar is outside the padded zone)
+                        const double2 cs = lds_cs[beam_dir_index(k, start, b)];
+                        int hr, hc;
+                        r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, n);
+                    }
+                    if (COUNT) nl_acc += (uint32_t)n;
+                    finish_beam_with(j, p, b, p * (uint32_t)B + (uint32_t)b, row != -1 ? r + nz : r, vel);
+                    b = -1;
+                }
+                if (next < q_end) {
+                    const uint64_t fm = __ballot(b < 0);
+                    if (b < 0) {
+                        const int mine = next + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                        if (mine < q_end) {
+                            b = mine;
+                            const double2 cs = lds_cs[beam_dir_index(k, start, b)];
+                            padded_rate<IDENT>(km, cs.x, cs.y, cux, cuy);
+                            padded_position<IDENT>(km, x, y, ux, uy);
+                            d = d0;
+                            total = d0;
+                            n = 1;
+                            redo = fast == 0;
+                            nz = row != -1 ? nrow[b] : 0.0;
+                            alive = (d > km.eps) & (total <= km.max_range) & !redo;
+                        }
+                    }
+                    next += (int)popc_u64(fm);
+                }
+                if (__ballot(b >= 0) == 0ull) break;   // (the queue is empty and every ray has been written)
+                // ---- march until few enough rays are alive (queue empty: until none is).  (Issuing the gather first and running
+                // the event under it measured slower: 0.746 -> 0.929 ms per step at 65 536 agents.)
+                const int thresh = next < q_end ? thresh_live : 0;
+                uint64_t am = __ballot(alive);
+                while ((int)popc_u64(am) > thresh) {
+                    if (alive) {   // march_padded's loop body, verbatim
+                        ux = fma(d, cux, ux);
+                        uy = fma(d, cuy, uy);
+                        const uint32_t wx = low_word(ux + kFixBig);
+                        const uint32_t wy = low_word(uy + kFixBig);
+                        uint32_t off = mul24(wy >> kFixFracBits, (uint32_t)km.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
+                        if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {
+                            redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
+                            const int fc = (int)floor(ux), fr = (int)floor(uy);
+                            off = mul24((uint32_t)fr, (uint32_t)km.pad_row_bytes) + ((uint32_t)fc << 3);
+                        }
+                        d = *reinterpret_cast<const double *>(base + off);
+                        total += d;
+                        ++n;
+                        alive = (d > km.eps) & (total <= km.max_range) & !redo;
+                    }
+                    am = __ballot(alive);
+                }
+            }
+        }
+    }
+    if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
+}
+#endif  // F110_EXPERIMENTAL (K2s)
+
 #ifdef F110_EXPERIMENTAL   // measured and rejected: not part of the product library
 // ---- K2w: the step's ray march with the agent's neighbourhood staged in LDS ------------------------
 // north_star's "occupancy grid in LDS".  One workgroup = one agent: the kWin x kWin cells around the

@@ -204,3 +204,94 @@ def test_vec_env_without_keywords_vs_reference(amd, E):
                 _check_env_step(g, ep, k, sel, done[e:e + 1], inf, inf['toggle_list'], inf['near_starts'], True)
         assert done.all()
     env.sim.batch.close()
+
+
+# ---------------------------------------------------------------- overlapped gather between two-block steps
+def test_overlapped_obs_gather_between_two_block_steps(amd):
+    """step, step (two env blocks), overlapped gather WITH the scalar block (k_pack_obs reads state[] on the main stream),
+    step (two blocks again) ...: the block gathered after step t must hold step t's poses, not the next step's, for every
+    env of BOTH blocks — compared with a handle that always steps as one block (step_groups = 1)"""
+    from _util import bench_start_poses, load_map_image
+    img, res, origin = load_map_image("example_map")
+    E, A, B, T = 8192, 2, 1080, 14           # 16 384 agents: a size the automatic choice runs as two blocks
+    N = E * A
+    sims = [amd.BatchSim(num_envs=E, num_agents=A, step_groups=g) for g in (0, 1)]
+    poses = bench_start_poses(E, A)
+    for s in sims:
+        s.set_map_image(img, res, origin); s.set_noise_rng(12345, 0.01); s.reset(poses)
+        s.comm_init(1, 0, amd.BatchSim.comm_unique_id()); s.comm_set_overlap(True)
+    if sims[0].step_groups()[0] < 2:
+        pytest.skip("no second stream observed to run concurrently on this box: the handle steps as one block")
+    rng = np.random.default_rng(5)
+    acts = [np.stack([rng.uniform(-0.3, 0.3, N), rng.uniform(1, 7, N)], axis=1) for _ in range(4)]
+    d_act = [[s.device_array((N, 2)) for _ in acts] for s in sims]
+    for s, bufs in zip(sims, d_act):
+        for b, a in zip(bufs, acts):
+            b.upload(a)
+    recv = [[(s.device_array((1, N, B)), s.device_array((1, 7, N))) for _ in range(2)] for s in sims]
+    blocks = set()
+    for cycle in range(T // 4):
+        # step (one block: the download below touched the handle), step (two blocks), gather, step (two blocks), gather, step
+        for k, s in enumerate(sims):
+            s.step_device(d_act[k][0]); s.step_device(d_act[k][1])
+            s.comm_all_gather_obs(*recv[k][0])
+            s.step_device(d_act[k][2])
+            if k == 0:
+                blocks.add(s.step_groups()[2])
+            s.comm_all_gather_obs(*recv[k][1])
+            s.step_device(d_act[k][3])
+        for r in range(2):
+            assert np.array_equal(recv[0][r][1].download(), recv[1][r][1].download()), (cycle, r)     # the [7][N] scalar block
+            assert np.array_equal(recv[0][r][0].download(), recv[1][r][0].download()), (cycle, r)     # the scans
+        assert np.array_equal(sims[0].get("state")["state"], sims[1].get("state")["state"])
+    assert 2 in blocks
+    for s in sims:
+        s.comm_set_overlap(False); s.close()
+
+
+# ---------------------------------------------------------------- lab: the lane-refill scan (survivor compaction)
+@pytest.mark.parametrize("kw", [dict(E=24, A=2, T=40), dict(E=700, A=1, T=20), dict(E=33, A=3, T=25), dict(E=48, A=2, T=25, yaw=0.3),
+                                dict(E=64, A=2, T=25, per_env=True), dict(E=4096, A=2, T=10)])
+def test_lane_refill_scan_is_bit_identical(amd, kw):
+    """k_scan_stream_agent (experimental build; VERDICT r4 item 2, measured slower and not adopted): a wave owns an agent's scan
+    as a queue and re-fills finished lanes — every output equals k_scan_rays_agent's bit for bit, for every refill threshold,
+    with persistent 8-wave workgroups and with one-wave workgroups"""
+    from _util import bench_start_poses, load_map_image
+    img, res, origin = load_map_image("example_map")
+    E, A, T = kw["E"], kw["A"], kw["T"]
+    org = [origin[0], origin[1], kw.get("yaw", 0.0)]
+
+    def run(exp):
+        s = amd.BatchSim(num_envs=E, num_agents=A, exp=exp)
+        s.set_map_image(img, res, org)
+        if kw.get("per_env"):
+            slot = s.add_map_image(*load_map_image("berlin"))
+            s.set_env_maps(np.arange(E) % 2 * slot)
+        s.set_noise_rng(12345, 0.01)
+        poses = bench_start_poses(E, A, gap_wp=5)
+        if kw.get("yaw"):
+            c, sn = np.cos(org[2]), np.sin(org[2])
+            dx, dy = poses[:, 0] - origin[0], poses[:, 1] - origin[1]
+            poses = np.stack([org[0] + c * dx - sn * dy, org[1] + sn * dx + c * dy, poses[:, 2] + org[2]], axis=1)
+        if kw.get("per_env"):
+            poses = poses.reshape(E, A, 3).copy(); poses[1::2] = [[0.0, 0.0, 0.3], [0.9, 0.5, 2.0]]; poses = poses.reshape(-1, 3)
+        s.reset(poses)
+        s.scan_lookup_count(enable=True, read=False)
+        rng = np.random.default_rng(7)
+        outs = []
+        for t in range(T):
+            s.step(np.stack([rng.uniform(-0.3, 0.3, E * A), rng.uniform(1.0, 7.0, E * A)], axis=1))
+            if t % 6 == 0 or t == T - 1:
+                outs.append(s.get("scans", "state", "collisions", "collision_idx", "in_collision"))
+        lk = s.scan_lookup_count()
+        s.close()
+        return outs, lk
+
+    ref, lk0 = run({"scan_stream": 0})
+    for exp in ({"scan_stream": 1}, {"scan_stream": 1, "stream_refill": 16}, {"scan_stream": 1, "stream_refill": 1}, {"scan_stream": 1, "stream_refill": 64},
+                {"scan_stream": 1, "stream_block": 64, "stream_refill": 32}):
+        got, lk1 = run(exp)
+        assert lk0 == lk1, exp
+        for a, b in zip(ref, got):
+            for key in a:
+                assert np.array_equal(a[key], b[key]), (exp, key)
