@@ -740,6 +740,34 @@ def dropin_rates(args):
         out["vecenv_%d" % E] = dict(rec, workload="F110VecEnv(%d envs x %d, device_logic=True, auto_reset=True, obs_fields=()): step_actions = step(ndarray) with the "
                                     "default episode fields; inplace_actions_lean = actions written into env.action_buffer, episode_fields=() (done only); "
                                     "_spin = completion word polled instead of hipStreamSynchronize" % (E, A), unit="agent-steps/s")
+    # (iii) the scans CONSUMED where they are: a device-resident loop (examples/rl_loop_device.py) — the built-in reactive policy
+    # reads all E*A*1080 ranges of the step just taken and writes the action buffer, the step with the episode logic follows,
+    # finished envs are re-seated — nothing crosses PCIe, no host synchronisation inside the timed region
+    for E in (2048, 32768):
+        b = amd.BatchSim(num_envs=E, num_agents=A)
+        b.set_map(os.path.join(MAPS, "example_map.yaml"), ".png")
+        b.set_noise_rng(12345, 0.01)
+        b.episode_init(0)
+        b.episode_reset(start_poses_for(shard_envs(E, 0), A))
+        d_act = b.device_array((E * A, 2)); d_act.upload(np.zeros((E * A, 2)))
+        rec = {}
+        for name, fn in (("scan_policy", lambda: b.scan_policy_device(d_act)), ("fixed_actions", lambda: None)):
+            def one():
+                fn(); b.episode_step_device(d_act); b.episode_reset_done_device()
+            for _ in range(200):
+                one()
+            b.sync()
+            n = 600 if E <= 4096 else 200
+            t0 = time.perf_counter()
+            for _ in range(n):
+                one()
+            b.sync()
+            dt = (time.perf_counter() - t0) / n
+            rec[name] = {"ms_per_step": 1e3 * dt, "value": E * A / dt}
+        b.close()
+        out["device_consumer_%d" % E] = dict(rec, unit="agent-steps/s", workload="%d envs x %d: scan_policy = f110_scan_policy_device (reads every scan in HBM, writes the "
+                                             "action buffer) + f110_episode_step_device + f110_episode_reset_done_device per step, one sync at the end; fixed_actions = the "
+                                             "same loop without the policy (what reading %d MB of scans per step costs)" % (E, A, E * A * 1080 * 8 >> 20))
     return out
 
 

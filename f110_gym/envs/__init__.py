@@ -3,5 +3,5 @@ modules), bound to the MI355X implementations."""
 from f110_gym.envs.f110_env import F110Env, F110VecEnv  # noqa: F401
 from f110_gym.envs.dynamic_models import vehicle_dynamics_st, vehicle_dynamics_ks, pid  # noqa: F401
 from f110_gym.envs.laser_models import ScanSimulator2D, check_ttc_jit, ray_cast  # noqa: F401
-from f110_gym.envs.base_classes import Integrator, Simulator  # noqa: F401
+from f110_gym.envs.base_classes import Integrator, RaceCar, Simulator  # noqa: F401
 from f110_gym.envs.collision_models import get_vertices, collision, collision_multiple  # noqa: F401

@@ -7,6 +7,7 @@ import:  F110Env, Simulator, Integrator, ScanSimulator2D and the free kernel fun
 from .core import BatchSim, DeviceArray, DEFAULT_PARAMS  # noqa: F401
 from .sim import Integrator, Simulator  # noqa: F401
 from .laser import ScanSimulator2D  # noqa: F401
+from .racecar import RaceCar  # noqa: F401
 from .env import F110Env, F110VecEnv  # noqa: F401
 from .planner import PurePursuitPlanner  # noqa: F401
 from .functional import (vehicle_dynamics_st, vehicle_dynamics_ks, pid, get_vertices, collision,  # noqa: F401

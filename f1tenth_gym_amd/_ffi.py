@@ -148,6 +148,7 @@ PROTOTYPES = {
     "f110_scan_path_stats": (C.c_int, [C.c_void_p, C.c_int32, _i64p]),
     "f110_pure_pursuit_batch": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _dp]),
     "f110_pure_pursuit_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    "f110_scan_policy_device": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "f110_dynamics_batch": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int32, _dp, _dp]),
     "f110_pid_batch": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp]),
     "f110_update_pose_batch": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _dp, _dp, C.c_double, C.c_int32,

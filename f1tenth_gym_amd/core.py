@@ -64,8 +64,14 @@ def load_map_files(map_path, map_ext):
         from PIL import Image
         with Image.open(map_img_path) as im:
             arr = np.array(im)
-        if arr.dtype == np.bool_:      # 1-bit map_server images: PIL hands out booleans, the reference's
-            arr = arr.astype(np.uint8) * 255   # astype(float64) would see 0 / 1; thresholded as black / white here
+        if arr.dtype == np.bool_:
+            # 1-bit images: PIL hands out booleans and the reference's astype(float64) sees 0. / 1. — every cell is <= 128 and
+            # becomes an obstacle (laser_models.py:399-404).  Reproduced as it is (bit parity), with a warning: the map is
+            # degenerate in the reference too; convert the image to 8-bit grayscale.
+            import warnings
+            warnings.warn("%s is a 1-bit image: like the reference, every cell thresholds to 'occupied' (values 0 / 1 <= 128); "
+                          "save the map as 8-bit grayscale" % map_img_path)
+            arr = arr.astype(np.uint8)
         if arr.ndim != 2:
             raise ValueError("map image must be single-channel grayscale, got shape %s" % (arr.shape,))
         return arr
@@ -92,6 +98,9 @@ def load_map_files(map_path, map_ext):
         with open(map_path) as f:
             meta = yaml.safe_load(f)
     return np.ascontiguousarray(img), float(meta['resolution']), [float(v) for v in meta['origin']]
+
+
+from . import _dlpack  # noqa: E402
 
 
 class DeviceArray(object):
@@ -136,6 +145,21 @@ class DeviceArray(object):
     @property
     def __cuda_array_interface__(self):
         return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 2}
+
+    # ---- DLPack (the neutral zero-copy hand-off: torch.from_dlpack(arr), cupy.from_dlpack(arr), jax ... — no type of this
+    # package crosses the boundary).  kDLROCM = 10; C-contiguous (strides = NULL); the capsule keeps this array alive until
+    # the consumer's deleter runs.
+    def __dlpack_device__(self):
+        return (_dlpack.kDLROCM, int(getattr(self.sim, "device_id", 0)))
+
+    def __dlpack__(self, stream=None):
+        """stream = -1: no synchronisation (the caller orders its work against device_views()['stream'] itself); anything
+        else: the handle's stream is drained first, so the consumer sees finished data whatever stream it uses"""
+        if self.ptr is None:
+            raise ValueError("the buffer has been freed")
+        if stream != -1 and getattr(self.sim, "_h", None):
+            self.sim.sync()
+        return _dlpack.make_capsule(self)
 
     def upload(self, host):
         host = np.ascontiguousarray(host, dtype=self.dtype)
@@ -309,6 +333,12 @@ class BatchSim(object):
         out = np.empty((h.value, w.value))
         check(_ffi.lib().f110_get_map_dt(self._h, dptr(out)), self._h)
         return out
+
+    def set_beam_tables(self, scan_angles, cosines, side_distances):
+        """replace the per-beam tables of check_ttc_jit / ray_cast (base_classes.py:125-158) — normally built from `params` at creation"""
+        sa, co, sd = as_f64(scan_angles, (self.B,)), as_f64(cosines, (self.B,)), as_f64(side_distances, (self.B,))
+        check(_ffi.lib().f110_set_beam_tables(self._h, dptr(sa), dptr(co), dptr(sd), self.B), self._h)
+        self.scan_angles, self.cosines, self.side_distances = sa, co, sd
 
     def set_params(self, params, agent_idx=-1):
         pv = _ffi.params_vector(params)
@@ -743,6 +773,13 @@ class BatchSim(object):
         a = d_actions.ptr if isinstance(d_actions, DeviceArray) else int(d_actions)
         check(_ffi.lib().f110_pure_pursuit_device(self._h, w, int(num_waypoints), float(lookahead), float(vgain), float(wheelbase),
                                                   float(max_reacquire), a), self._h)
+
+    def scan_policy_device(self, d_actions, steer_gain=0.5, steer_max=0.4189, sector_limit=1.75, v_lo=1.0, v_hi=6.0, d_ref=6.0):
+        """a reactive policy that reads the step's scans where they are (f110_scan_policy_device: steer towards the most open
+        sector, speed from the clearance ahead) and writes the device action buffer — no host round trip"""
+        a = d_actions.ptr if isinstance(d_actions, DeviceArray) else int(d_actions)
+        check(_ffi.lib().f110_scan_policy_device(self._h, float(steer_gain), float(steer_max), float(sector_limit), float(v_lo), float(v_hi),
+                                                 float(d_ref), a), self._h)
 
     def scan_path_stats(self, enable=None, read=True):
         """diagnostics: rays marched as dict(fast, guard, exact) since the last read; enable=True/False

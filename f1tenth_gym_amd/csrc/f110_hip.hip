@@ -16,7 +16,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -564,6 +567,13 @@ static hipError_t streams_concurrent(hipStream_t a, hipStream_t b, bool *yes)
     return e;
 }
 
+// live handles and page-locked blocks: f110_step_host caches the device view of the host block it validated, keyed by
+// host pointers — a block that is freed must drop every handle's cache of it, or a later allocation at the same addresses would
+// be stepped into through stale device pointers
+static std::mutex g_registry_mu;
+static std::set<f110_sim *> g_handles;
+static std::map<const char *, size_t> g_host_blocks;
+
 int f110_create(const f110_config *cfg, f110_sim **out)
 {
     if (!cfg || !out) return fail(nullptr, F110_ERR_INVALID, "f110_create: null argument");
@@ -827,6 +837,10 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     CKH(hipStreamSynchronize(h->stream));
 #undef CK
 #undef CKH
+    {
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        g_handles.insert(h);
+    }
     *out = h;
     return F110_OK;
 }
@@ -891,6 +905,10 @@ void f110_destroy(f110_sim *h)
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    {
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        g_handles.erase(h);
+    }
     delete h;
 }
 
@@ -1844,6 +1862,8 @@ int f110_host_alloc(f110_sim *h, size_t bytes, void **out)
     if (!h || !out) return fail(h, F110_ERR_INVALID, "null argument");
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     HIPCHK(h, hipHostMalloc(out, bytes > 0 ? bytes : 8, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lk(g_registry_mu);
+    g_host_blocks[static_cast<const char *>(*out)] = bytes > 0 ? bytes : 8;
     return F110_OK;
 }
 
@@ -1853,6 +1873,31 @@ int f110_host_free(f110_sim *h, void *p)
     if (h) {   // the handle's stream may still be copying from / into the block
         ENTER(h);
         HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    {
+        // every live handle forgets what it cached about this block; a handle with an F110_STEP_NO_SYNC step still storing
+        // into it is drained first (the caller may pass h = NULL: the block outlives the handle that allocated it)
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        const char *lo = static_cast<const char *>(p);
+        const auto it = g_host_blocks.find(lo);
+        const char *hi = lo + (it != g_host_blocks.end() ? it->second : 1);
+        auto inside = [&](const void *q) { return q && static_cast<const char *>(q) >= lo && static_cast<const char *>(q) < hi; };
+        for (f110_sim *o : g_handles) {
+            if (!o->hb_valid && !o->fused_valid) continue;
+            const f110_host_block &b = o->hb_host;
+            const void *ptrs[] = {b.scans, b.state, b.agent_poses, b.collisions, b.collision_idx, b.in_collision, b.lap_times, b.lap_counts, b.toggles,
+                                  b.current_time, b.near_starts, b.done, b.checkpoint_done, o->hb_actions_host};
+            bool hit = false;
+            for (const void *q : ptrs) hit = hit || inside(q);
+            if (!hit) continue;
+            if (o != h) {
+                (void)hipSetDevice(o->cfg.device_id);
+                (void)hipStreamSynchronize(o->stream);
+            }
+            o->hb_valid = false;
+            o->fused_valid = false;
+        }
+        if (it != g_host_blocks.end()) g_host_blocks.erase(it);
     }
     HIPCHK(h, hipHostFree(p));
     return F110_OK;
@@ -2028,9 +2073,18 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
         if (flags & F110_STEP_POLL) {
             // hipStreamSynchronize wakes up in coarse quanta once a wait has lasted ~30 us (measured: a 40 us step is
             // reported after 67 us); polling the stream costs a core for the step's duration and returns within ~1 us
+            // ... so the poll is BOUNDED: a step that has not finished after kPollBudgetUs hands the core back and
+            // sleeps in hipStreamSynchronize — the coarse wake-up is then a few per cent of a long wait, and ranks that share a
+            // CPU quota (8 ranks on 16 cores on the bench box) do not spin against their own policy threads
+            constexpr double kPollBudgetUs = 250.0;
             hipError_t q;
-            while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) __builtin_ia32_pause();
-            if (q != hipSuccess) return fail(h, F110_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
+            uint32_t it = 0;
+            while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {
+                __builtin_ia32_pause();
+                if ((++it & 0x3fu) == 0u && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count() > kPollBudgetUs) break;
+            }
+            if (q == hipErrorNotReady) HIPCHK(h, hipStreamSynchronize(h->stream));
+            else if (q != hipSuccess) return fail(h, F110_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(q));
         } else {
             HIPCHK(h, hipStreamSynchronize(h->stream));
         }
@@ -2958,6 +3012,33 @@ int f110_pure_pursuit_device(f110_sim *h, const double *d_waypoints, int32_t M, 
                        vgain, wheelbase, max_reacquire, d_actions);
     HIPCHK(h, hipGetLastError());
     h->touched = false;   // (the next step may split: it forks from what this call left on the main stream)
+    return F110_OK;
+}
+
+int f110_scan_policy_device(f110_sim *h, double steer_gain, double steer_max, double sector_limit, double v_lo, double v_hi, double d_ref, double *d_actions)
+{
+    if (!h || !d_actions) return fail(h, F110_ERR_INVALID, "scan policy: null argument");
+    if (!(d_ref > 0.) || !(steer_max >= 0.)) return fail(h, F110_ERR_INVALID, "scan policy: d_ref must be > 0 and steer_max >= 0");
+    const int N = h->N, B = h->cfg.num_beams;
+    if (h->last_blocks == 2 && h->groups_busy && !h->touched) {
+        // behind a two-block step: each block's agents on the block's own stream (an agent reads its own scan row only)
+        HIPCHK(h, hipSetDevice(h->cfg.device_id));
+        const int per = group_envs(h), E = h->cfg.num_envs, A = h->cfg.num_agents;
+        for (int g = 0; g < 2; ++g) {
+            const int e0 = g * per, e1 = std::min(E, e0 + per);
+            if (e0 >= e1) break;
+            const int n = (e1 - e0) * A;
+            hipLaunchKernelGGL(k_scan_policy, grid1d((size_t)n * 64, 256), dim3(256), 0, h->gstreams[g], h->dev.scans, B, h->cfg.fov, e0 * A, n, steer_gain, steer_max,
+                               sector_limit, v_lo, v_hi, d_ref, d_actions);
+        }
+        HIPCHK(h, hipGetLastError());
+        return F110_OK;
+    }
+    ENTER(h);
+    hipLaunchKernelGGL(k_scan_policy, grid1d((size_t)N * 64, 256), dim3(256), 0, h->stream, h->dev.scans, B, h->cfg.fov, 0, N, steer_gain, steer_max, sector_limit,
+                       v_lo, v_hi, d_ref, d_actions);
+    HIPCHK(h, hipGetLastError());
+    h->touched = false;   // (as f110_pure_pursuit_device: the next step may split)
     return F110_OK;
 }
 

@@ -3290,6 +3290,51 @@ __global__ void k_build_codes_padded(const double *__restrict__ pad, int Hp, int
 
 #endif  // F110_EXPERIMENTAL
 
+// A reactive policy that CONSUMES the scans where the scan kernel left them (round 5; not a reference function — the stand-in
+// for an RL policy in a device-resident loop: examples/rl_loop_device.py, bench.py's "scans consumed on device" leg).  One wave
+// per agent: the B beams are cut into 64 sectors, sector s = beams [ceil(s B / 64), ceil((s + 1) B / 64)); each lane takes the
+// mean range of its sector (beams added in ascending order).  Steer towards the centre of the sector with the largest mean
+// among those within `sector_limit` rad of straight ahead (first maximum), speed from the shortest range of the eight middle
+// sectors.  actions [n][2] = (steer, speed).
+__global__ void __launch_bounds__(256) k_scan_policy(const double *__restrict__ scans, int B, double fov, int i0, int n, double steer_gain, double steer_max,
+                                                     double sector_limit, double v_lo, double v_hi, double d_ref, double *__restrict__ actions)
+{
+    const int a = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (a >= n) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const double *row = scans + (size_t)(i0 + a) * (size_t)B;
+    const int b0 = (lane * B + 63) / 64, b1 = ((lane + 1) * B + 63) / 64;
+    double sum = 0., lo = INFINITY;
+    for (int b = b0; b < b1; ++b) {
+        const double r = row[b];
+        sum += r;
+        lo = r < lo ? r : lo;
+    }
+    const double inc = fov / (double)(B - 1);
+    const double centre = -fov / 2. + inc * (0.5 * (double)(b0 + b1 - 1));
+    double best = (b1 > b0 && fabs(centre) <= sector_limit) ? sum / (double)(b1 - b0) : -INFINITY;
+    int best_lane = lane;
+    double front = (lane >= 28 && lane < 36) ? lo : INFINITY;
+    for (int off = 32; off; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int ol = __shfl_xor(best_lane, off);
+        if (ob > best || (ob == best && ol < best_lane)) {
+            best = ob;
+            best_lane = ol;
+        }
+        const double of = __shfl_xor(front, off);
+        front = of < front ? of : front;
+    }
+    const double best_centre = __shfl(centre, best_lane);
+    if (lane == 0) {
+        double steer = steer_gain * best_centre;
+        steer = steer > steer_max ? steer_max : (steer < -steer_max ? -steer_max : steer);
+        const double f = front / d_ref;
+        actions[2 * (size_t)(i0 + a)] = steer;
+        actions[2 * (size_t)(i0 + a) + 1] = v_lo + (v_hi - v_lo) * (f < 1. ? f : 1.);
+    }
+}
+
 // examples/waypoint_follow.py: PurePursuitPlanner.plan, 16 lanes per pose (4 poses per wave).  The
 // lanes of a group split the segments of the waypoint polyline: the nearest-point search is a
 // per-lane first-minimum followed by a (distance, index) lexicographic min across the group — the

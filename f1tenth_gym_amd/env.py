@@ -252,7 +252,7 @@ class F110VecEnv(object):
         self.obs_fields = tuple(self._ALL if obs_fields is None else obs_fields)
         self._lap = _LapLogic(self.num_envs, self.num_agents, self.ego_idx)
         self.sim = Simulator(self.params, self.num_agents, self.seed, time_step=self.timestep,
-                             ego_idx=self.ego_idx, integrator=kwargs.get('integrator', Integrator.RK4),
+                             integrator=kwargs.get('integrator', Integrator.RK4),   # (no ego_idx: see obs['ego_idx'] below)
                              lidar_dist=kwargs.get('lidar_dist', 0.0), num_envs=self.num_envs,
                              num_beams=kwargs.get('num_beams', 1080), fov=kwargs.get('fov', 4.7),
                              scan_noise_std=kwargs.get('scan_noise_std', 0.01),
@@ -297,7 +297,9 @@ class F110VecEnv(object):
         hb = self._hb = b.host_block(want)
         v = hb.views
         self.action_buffer = hb.actions.reshape(E, A, 2)   # write actions here and call step(None): no copy at all
-        obs = {'ego_idx': self.ego_idx}
+        # obs['ego_idx'] is 0 whatever the env's ego_idx is: the reference env never hands ego_idx to its Simulator
+        # (f110_env.py:192) — the same quirk F110Env reproduces; ego_idx steers the done rule only
+        obs = {'ego_idx': 0}
         for f in self.obs_fields:
             if f in st_fields:
                 obs[f] = v["state"][st_fields[f]].reshape(E, A)
@@ -384,6 +386,8 @@ class F110VecEnv(object):
     def step(self, actions):
         if self.device_logic:
             return self._step_device(actions)
+        if actions is None:
+            raise ValueError("step(None) (actions taken from env.action_buffer) needs device_logic=True")
         obs = self.sim.step(actions)
         done, toggles = self._lap.update(obs['poses_x'], obs['poses_y'], obs['collisions'], self.timestep)
         obs['lap_times'] = self._lap.lap_times

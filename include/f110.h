@@ -265,7 +265,8 @@ typedef struct f110_host_block {
 #define F110_STEP_SPIN_WAIT 8       /* wait by polling a page-locked completion word the last workgroup stores,
                                        instead of a runtime synchronise (ignored with scans / NO_SYNC) */
 #define F110_STEP_POLL 32           /* wait by polling hipStreamQuery (a busy core, ~1 us wake-up) instead of
-                                       hipStreamSynchronize (coarse wake-up quanta beyond ~30 us of waiting) */
+                                       hipStreamSynchronize (coarse wake-up quanta beyond ~30 us of waiting); the poll is
+                                       bounded: after 250 us the call sleeps in hipStreamSynchronize */
 #define F110_STEP_NO_FUSE 16        /* A/B: always run the episode logic + host block as a kernel of their own (with 2
                                        agents per env they are otherwise the finalize kernel's epilogue) */
 int f110_step_host(f110_sim *h, const double *h_actions /* [N][2] */, const f110_host_block *out, int32_t flags);
@@ -391,6 +392,14 @@ int f110_pure_pursuit_batch(f110_sim *h, const double *h_waypoints, int32_t M, c
                             double max_reacquire, double *h_actions);
 int f110_pure_pursuit_device(f110_sim *h, const double *d_waypoints, int32_t M, double lookahead,
                              double vgain, double wheelbase, double max_reacquire, double *d_actions);
+/* A reactive policy that CONSUMES the step's scans on the device (NOT a reference function: the stand-in for an RL policy in
+ * a device-resident loop — examples/rl_loop_device.py, bench.py's "scans consumed on device" leg).  Per agent: the num_beams
+ * ranges in 64 sectors, steer = clamp(steer_gain * centre angle of the sector with the largest mean range among those within
+ * sector_limit rad of straight ahead, +-steer_max), speed = v_lo + (v_hi - v_lo) * min(1, shortest range of the eight middle
+ * sectors / d_ref).  Reads the observation of the step just taken (f110_get_device_views().scans), writes d_actions [N][2] =
+ * (steer, speed) — the layout f110_step_device takes; asynchronous on the handle's stream (per env block behind a two-block step). */
+int f110_scan_policy_device(f110_sim *h, double steer_gain, double steer_max, double sector_limit, double v_lo,
+                            double v_hi, double d_ref, double *d_actions);
 /* Diagnostics of the scan kernels (step and unit form): with enable = 1 every marched ray is counted
  * as {fixed-point march on the padded table, re-marched exactly after a guard-band sample, exact
  * because the lidar is off the padded table / the layout has no fast path}.  out3 (or NULL) receives

@@ -295,3 +295,145 @@ def test_lane_refill_scan_is_bit_identical(amd, kw):
         for a, b in zip(ref, got):
             for key in a:
                 assert np.array_equal(a[key], b[key]), (exp, key)
+
+
+# ---------------------------------------------------------------- RaceCar, the reference's per-vehicle class
+def test_racecar_class_vs_reference(amd):
+    """f110_gym.envs.base_classes.RaceCar (base_classes.py:45-449) driven directly, as the reference's own fixtures were
+    recorded: update_pose single steps (RK4, Euler, offset lidar; steer-delay FIFO) and the 400-step rollout of update_pose.npz,
+    check_ttc's state zeroing, ray_cast_agents against raycast.npz, update_scan on a list of scans"""
+    from f110_gym.envs.base_classes import Integrator, RaceCar
+    g = gold("update_pose")
+    params = dict(zip(amd._ffi.PARAM_KEYS, g["params"]))
+    RaceCar.scan_simulator = None       # (class-level, base_classes.py:64-67: a fresh process state for this test)
+    for name, integ, ld in (("rk4", Integrator.RK4, 0.0), ("euler", Integrator.Euler, 0.0), ("rk4_lidar", Integrator.RK4, 0.275)):
+        car = RaceCar(params, 12345, is_ego=True, time_step=0.01, integrator=integ, lidar_dist=ld)
+        car.set_map(map_stem("example_map") + ".yaml", ".png")
+        seen = []
+        scan_fn = RaceCar.scan_simulator.scan
+        RaceCar.scan_simulator.scan = lambda pose, rng, std_dev=0.01: (seen.append(np.array(pose)) or scan_fn(pose, rng, std_dev))
+        for i in range(0, len(g[name + "_state0"]), 3):
+            car.state = g[name + "_state0"][i].copy()
+            car.steer_buffer = g[name + "_buf0"][i, :g[name + "_cnt0"][i]].copy()
+            scan = car.update_pose(*g[name + "_action"][i])
+            assert scan.shape == (1080,)
+            assert rel_err(car.state, g[name + "_state1"][i]) < FTOL
+            assert car.steer_buffer.shape[0] == g[name + "_cnt1"][i] and np.array_equal(car.steer_buffer, g[name + "_buf1"][i, :g[name + "_cnt1"][i]])
+            assert rel_err(seen[-1], g[name + "_scan_pose"][i]) < FTOL
+        if name != "euler":
+            car.reset(np.array([0.7, 0.0, 1.37079632679]))
+            worst = 0.0
+            for t in range(0, 400):
+                car.update_pose(*g[name + "_roll_actions"][t])
+                worst = max(worst, rel_err(car.state, g[name + "_roll_states"][t]))
+            assert worst < 1e-5, worst        # (north_star's rollout bar; measured ~1e-13)
+        RaceCar.scan_simulator.scan = scan_fn
+    # check_ttc: a wall 5 cm ahead at speed -> collision, state[3:] zeroed (base_classes.py:240-262)
+    car.reset(np.array([0.7, 0.0, 1.37079632679])); car.state[3] = 6.0; car.state[5] = 0.3
+    scan = np.full(1080, 10.0); scan[540] = RaceCar.side_distances[540] + 0.01
+    assert car.check_ttc(scan) is True and car.in_collision and not car.state[3:].any()
+    assert car.check_ttc(np.full(1080, 10.0)) is False and not car.in_collision
+    # ray_cast_agents / update_scan against the reference's ray_cast outputs
+    r = gold("raycast")
+    for i in (0, 5, 12, 40, 77):
+        car.state[:] = 0.0; car.state[0:2] = r["ego"][i, :2]; car.state[4] = r["ego"][i, 2]
+        car.update_opp_poses(r["opp"][i:i + 1])
+        scans = [np.full(1080, float(r["base"][0])), np.full(1080, float(r["base"][0]))]
+        car.update_scan(scans, 1)
+        assert rel_err(scans[1], r["scans"][i]) < FTOL and np.array_equal(scans[0], np.full(1080, float(r["base"][0])))
+    RaceCar.scan_simulator.batch.close()
+    RaceCar.scan_simulator = None
+
+
+# ---------------------------------------------------------------- RL-loop hand-off: DLPack, the on-device scan consumer
+def _scan_policy_numpy(scans, fov, steer_gain=0.5, steer_max=0.4189, sector_limit=1.75, v_lo=1.0, v_hi=6.0, d_ref=6.0):
+    """f110_scan_policy_device restated (include/f110.h): same sector bounds, same summation order"""
+    n, B = scans.shape
+    out = np.empty((n, 2))
+    inc = fov / (B - 1)
+    for a in range(n):
+        best, best_c, front = -np.inf, 0.0, np.inf
+        for s in range(64):
+            b0, b1 = (s * B + 63) // 64, ((s + 1) * B + 63) // 64
+            seg = scans[a, b0:b1]
+            tot = 0.0
+            for r in seg:
+                tot += r
+            centre = -fov / 2. + inc * (0.5 * (b0 + b1 - 1))
+            if b1 > b0 and abs(centre) <= sector_limit and tot / (b1 - b0) > best:
+                best, best_c = tot / (b1 - b0), centre
+            if 28 <= s < 36:
+                front = min(front, seg.min())
+        f = front / d_ref
+        out[a] = [min(max(steer_gain * best_c, -steer_max), steer_max), v_lo + (v_hi - v_lo) * min(f, 1.0)]
+    return out
+
+
+def test_scan_policy_device_reads_the_scans_in_place(amd):
+    from _util import bench_start_poses, load_map_image
+    E, A = 24, 2
+    s = amd.BatchSim(num_envs=E, num_agents=A)
+    s.set_map_image(*load_map_image("example_map")); s.set_noise_rng(12345, 0.01)
+    s.reset(bench_start_poses(E, A))
+    act = s.device_array((E * A, 2))
+    act.upload(np.zeros((E * A, 2)))
+    for t in range(6):
+        s.step_device(act)
+        s.scan_policy_device(act)
+        want = _scan_policy_numpy(s.get("scans")["scans"], 4.7)
+        assert np.array_equal(act.download(), want), t
+    assert np.ptp(want[:, 0]) > 0 and np.ptp(want[:, 1]) > 0
+    s.close()
+
+
+def test_dlpack_hand_off_to_torch(amd):
+    """DeviceArray.__dlpack__ / __dlpack_device__: torch wraps the simulator's scan buffer and the action buffer without a copy
+    (kDLROCM), sees the step's values, and what it writes into the action buffer is what the next step integrates"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("this torch build sees no GPU")
+    from _util import bench_start_poses, load_map_image
+    E, A = 16, 2
+    N = E * A
+    s = amd.BatchSim(num_envs=E, num_agents=A)
+    s.set_map_image(*load_map_image("example_map"))
+    s.reset(bench_start_poses(E, A))
+    views = s.device_views()
+    assert views["scans"].__dlpack_device__() == (10, 0)
+    act = s.device_array((N, 2)); act.upload(np.zeros((N, 2)))
+    s.step_device(act)
+    scans_t = torch.from_dlpack(views["scans"])
+    act_t = torch.from_dlpack(act)
+    assert scans_t.data_ptr() == views["scans"].ptr and act_t.data_ptr() == act.ptr and scans_t.dtype == torch.float64
+    assert tuple(scans_t.shape) == (N, 1080) and scans_t.is_contiguous()
+    assert np.array_equal(scans_t.cpu().numpy(), s.get("scans")["scans"])
+    act_t[:, 0] = 0.1
+    act_t[:, 1] = 3.0
+    torch.cuda.synchronize()
+    ref = amd.BatchSim(num_envs=E, num_agents=A)
+    ref.set_map_image(*load_map_image("example_map")); ref.reset(bench_start_poses(E, A))
+    ref.step(np.zeros((N, 2)))
+    for _ in range(5):
+        s.step_device(act)
+        ref.step(np.tile([0.1, 3.0], (N, 1)))
+    assert np.array_equal(s.get("state")["state"], ref.get("state")["state"])
+    assert np.array_equal(torch.from_dlpack(views["scans"]).cpu().numpy(), ref.get("scans")["scans"])    # (the same buffer, the new step's values)
+    del scans_t, act_t
+    s.close(); ref.close()
+
+
+def test_example_rl_loop_device_runs():
+    import importlib.util
+    import os as _os
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rl_loop_device", _os.path.join(root, "examples", "rl_loop_device.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(["--envs", "256", "--steps", "60"]) > 0
+    try:
+        import torch
+        has = torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        has = False
+    if has:
+        assert mod.main(["--envs", "256", "--steps", "40", "--torch"]) > 0

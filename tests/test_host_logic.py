@@ -174,9 +174,16 @@ def test_png_and_yaml_readers_need_neither_pil_nor_pyyaml(tmp_path, monkeypatch)
     Image.fromarray(gray > 128).save(str(tmp_path / "bw.png"))
     for stem in ("pal", "bw"):
         (tmp_path / (stem + ".yaml")).write_text("image: %s.png\nresolution: 0.05\norigin:\n  - -1.0\n  - 2.0\n  - 0.0\n" % stem)
-        img, res, origin = load_map_files(str(tmp_path / (stem + ".yaml")), ".png")
+        import warnings
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            img, res, origin = load_map_files(str(tmp_path / (stem + ".yaml")), ".png")
         assert img.dtype == np.uint8 and img.shape == (64, 80) and res == 0.05 and origin == [-1.0, 2.0, 0.0]
-        assert np.array_equal(img > 128, gray > 128) or stem == "pal"
+        if stem == "bw":
+            # a 1-bit image is what it is in the reference: np.array(img).astype(float64) holds 0. / 1., all <= 128 -> every cell
+            # an obstacle (laser_models.py:399-404) — reproduced, with a warning
+            ref_like = np.array(Image.open(str(tmp_path / "bw.png"))).astype(np.float64)
+            assert np.array_equal(img > 128, ref_like > 128.) and not (img > 128).any() and any("1-bit" in str(w.message) for w in caught)
     # with PIL and yaml unimportable, set_map's file handling still works
     from f1tenth_gym_amd.core import load_map_files
     monkeypatch.setitem(sys.modules, "PIL", None)
@@ -221,6 +228,8 @@ def test_f110_gym_alias_package_registers_and_exports(monkeypatch):
     import f110_gym
     assert calls == [{"id": "f110-v0", "entry_point": "f110_gym.envs:F110Env"}]     # gym/f110_gym/__init__.py:1-5
     from f110_gym.envs import F110Env, Simulator, ScanSimulator2D, Integrator, pid, collision_multiple, ray_cast  # noqa: F401
+    from f110_gym.envs.base_classes import RaceCar   # base_classes.py:45: importable, subclassable (VERDICT r4 missing 5)
+    assert isinstance(RaceCar, type) and RaceCar.scan_simulator is None and {'update_pose', 'check_ttc', 'ray_cast_agents', 'update_scan', 'update_opp_poses', 'reset', 'set_map', 'update_params'} <= set(dir(RaceCar))
     from f110_gym.envs.base_classes import Integrator as I2
     from f110_gym.envs.f110_env import F110Env as E2
     import f1tenth_gym_amd
@@ -231,3 +240,41 @@ def test_f110_gym_alias_package_registers_and_exports(monkeypatch):
     import pytest
     with pytest.raises(ValueError):
         f110_gym.make("other-v0")
+
+
+def test_dlpack_capsule_fields():
+    """DeviceArray.__dlpack__ (f1tenth_gym_amd/_dlpack.py): a "dltensor" capsule around a DLManagedTensor with the HIP pointer,
+    device (kDLROCM = 10, device id), dtype, shape, NULL strides (C-contiguous); the array stays alive until the deleter runs"""
+    import ctypes as C
+    import gc
+    from f1tenth_gym_amd import _dlpack
+    from f1tenth_gym_amd.core import DeviceArray
+
+    class FakeSim(object):
+        _h = None
+        device_id = 3
+        _device_arrays = set()
+    for shape, dtype, code in (((5, 1080), np.float64, (2, 64, 1)), ((7,), np.int32, (0, 32, 1)), ((2, 3, 4), np.uint8, (1, 8, 1)), ((9, 2), np.float32, (2, 32, 1))):
+        arr = DeviceArray(FakeSim(), shape, dtype, ptr=0x7f0000001000)
+        assert arr.__dlpack_device__() == (10, 3)
+        n0 = len(_dlpack._live)
+        cap = arr.__dlpack__()
+        f = _dlpack.read_capsule(cap)
+        assert f["data"] == 0x7f0000001000 and f["device"] == (10, 3) and f["ndim"] == len(shape) and f["shape"] == shape
+        assert f["dtype"] == code and f["strides"] is None and f["byte_offset"] == 0 and len(_dlpack._live) == n0 + 1
+        # a consumer renames the capsule and calls the deleter when it is done with the memory
+        C.pythonapi.PyCapsule_SetName.argtypes = [C.py_object, C.c_char_p]
+        C.pythonapi.PyCapsule_SetName(cap, b"used_dltensor")
+        mt = _dlpack.DLManagedTensor.from_address(f["address"])
+        mt.deleter(C.pointer(mt))
+        assert len(_dlpack._live) == n0
+        del cap
+        # ... and a capsule nobody consumed releases its tensor when it is collected
+        cap = arr.__dlpack__(stream=-1)
+        assert len(_dlpack._live) == n0 + 1
+        del cap
+        gc.collect()
+        assert len(_dlpack._live) == n0
+    arr.ptr = None
+    with pytest.raises(ValueError):
+        arr.__dlpack__()
