@@ -22,6 +22,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if "--torch" in sys.argv:
+    import torch  # noqa: F401  BEFORE the simulator's library: both then share one libamdhip64.so
 import f1tenth_gym_amd as amd  # noqa: E402
 
 
@@ -58,7 +60,7 @@ def main(argv=None):
     policy = None
     if args.torch:
         import torch
-        stream = torch.cuda.ExternalStream(views["stream"])        # torch enqueues behind the simulator's kernels: no event, no sync
+        stream = torch.cuda.ExternalStream(views["stream"], device=torch.device("cuda", sim.device_id))   # torch enqueues behind the simulator's kernels: no event, no sync
         scans_t = torch.from_dlpack(views["scans"])                # [N][1080] float64, the simulator's own buffer
         act_t = torch.from_dlpack(actions)                         # [N][2], the buffer f110_episode_step_device reads
         g = torch.Generator(device="cuda").manual_seed(0)
@@ -87,7 +89,7 @@ def main(argv=None):
     laps = ep["lap_counts"].download()
     print("%d envs x %d agents, %d steps: %.3f ms per step, %.1f M agent-steps/s; %d env resets, %d envs done right now, max lap count %.0f (%s policy)"
           % (E, A, args.steps, dt / args.steps * 1e3, N * args.steps / dt / 1e6, int(d_resets.download()[0]), done_now, laps.max(),
-             "torch MLP via DLPack" if args.torch else "built-in scan policy"))
+             "torch MLP via DLPack" if args.torch else "built-in scan"))
     sim.close()
     return N * args.steps / dt
 

@@ -55,6 +55,7 @@ struct ExpSwitches {
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
     int group_split = 0;       // two env groups: percent of the envs in the first (0 = even)
     int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
+    int spec_from = 0;         // k_scan_rays_agent in the longest-first window: march_padded_spec from this sample on (0 = plain march)
     int scan_stream = 0;       // 1: the lane-refill scan (k_scan_stream_agent) wherever it applies
     int stream_refill = 0;     // free lanes that trigger a refill (0 = default)
     int stream_block = 0;      // threads per persistent workgroup (0 = 512)
@@ -491,6 +492,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "integrate_duo") h->exp.integrate_duo = value;
     else if (k == "integrate_fan") h->exp.integrate_fan = value;
     else if (k == "group_split") h->exp.group_split = value;
+    else if (k == "spec_from") h->exp.spec_from = value;
     else if (k == "scan_stream") h->exp.scan_stream = value;
     else if (k == "stream_block") h->exp.stream_block = value;
     else if (k == "stream_grid") h->exp.stream_grid = value;
@@ -2409,6 +2411,19 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             // which start first, march at the idle chip's latency — does the shorter chain beat the lost throughput?
             if (h->exp.scan_occupancy > 0 && h->scan_block == 64) slds = (size_t)(160 * 1024 / (4 * h->exp.scan_occupancy)) & ~(size_t)255;
 #endif
+#ifdef F110_EXPERIMENTAL
+            // round 5, measured and not adopted: the tail of a long ray marched two samples per round trip where
+            // the table value repeats (march_padded_spec, bit-identical) — 4096 agents 0.0976 -> 0.103-0.111 ms per step for
+            // spec_from 64 ... 4: the chain gets shorter, the kernel that carries both loops gets slower for every ray
+            if (h->exp.spec_from > 0) {
+                j.spec_from = (uint32_t)h->exp.spec_from;
+                if (h->k.ident_rot)
+                    hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                else
+                    hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, true, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                break;
+            }
+#endif
             if (h->k.ident_rot)
                 hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
             else
@@ -3019,6 +3034,7 @@ int f110_scan_policy_device(f110_sim *h, double steer_gain, double steer_max, do
 {
     if (!h || !d_actions) return fail(h, F110_ERR_INVALID, "scan policy: null argument");
     if (!(d_ref > 0.) || !(steer_max >= 0.)) return fail(h, F110_ERR_INVALID, "scan policy: d_ref must be > 0 and steer_max >= 0");
+    if (h->cfg.num_beams > 2048) return fail(h, F110_ERR_INVALID, "scan policy: at most 2048 beams (the rows are staged in LDS)");
     const int N = h->N, B = h->cfg.num_beams;
     if (h->last_blocks == 2 && h->groups_busy && !h->touched) {
         // behind a two-block step: each block's agents on the block's own stream (an agent reads its own scan row only)
@@ -3028,14 +3044,14 @@ int f110_scan_policy_device(f110_sim *h, double steer_gain, double steer_max, do
             const int e0 = g * per, e1 = std::min(E, e0 + per);
             if (e0 >= e1) break;
             const int n = (e1 - e0) * A;
-            hipLaunchKernelGGL(k_scan_policy, grid1d((size_t)n * 64, 256), dim3(256), 0, h->gstreams[g], h->dev.scans, B, h->cfg.fov, e0 * A, n, steer_gain, steer_max,
+            hipLaunchKernelGGL(k_scan_policy, grid1d((size_t)n * 64, 256), dim3(256), (size_t)4 * B * sizeof(double), h->gstreams[g], h->dev.scans, B, h->cfg.fov, e0 * A, n, steer_gain, steer_max,
                                sector_limit, v_lo, v_hi, d_ref, d_actions);
         }
         HIPCHK(h, hipGetLastError());
         return F110_OK;
     }
     ENTER(h);
-    hipLaunchKernelGGL(k_scan_policy, grid1d((size_t)N * 64, 256), dim3(256), 0, h->stream, h->dev.scans, B, h->cfg.fov, 0, N, steer_gain, steer_max, sector_limit,
+    hipLaunchKernelGGL(k_scan_policy, grid1d((size_t)N * 64, 256), dim3(256), (size_t)4 * B * sizeof(double), h->stream, h->dev.scans, B, h->cfg.fov, 0, N, steer_gain, steer_max, sector_limit,
                        v_lo, v_hi, d_ref, d_actions);
     HIPCHK(h, hipGetLastError());
     h->touched = false;   // (as f110_pure_pursuit_device: the next step may split)

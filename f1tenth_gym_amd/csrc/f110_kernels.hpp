@@ -572,7 +572,7 @@ struct RayJob {
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
     int32_t dir_mode, dir_stride;   // dedupe pass: rays are (agent, distinct direction), dir_stride per agent
     const double *dir_ranges;       // k_expand_beams: [n_poses][dir_stride] raw ranges of the dedupe pass
-    uint32_t first_pose, pad_first; // k_scan_rays_agent: the launch covers agents first_pose .. (env group)
+    uint32_t first_pose, spec_from; // k_scan_rays_agent: the launch covers agents first_pose .. (env group); SPEC: march_padded_spec from this sample on
     unsigned long long *lookups_total;  // COUNT variants: table lookups of every marched ray, summed (or nullptr)
     // longest-first task order (k_scan_rays_agent<.., SCHED>): see TaskSched
     TaskSched sched;   // by value: the kernel argument segment is the one read a wave never waits long for
@@ -903,7 +903,7 @@ __device__ __forceinline__ void load_map_fast(ScanConst &km, const MapFast *__re
 #ifndef F110_SCAN_WAVES_EXPR
 #define F110_SCAN_WAVES_EXPR 8
 #endif
-template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false>
+template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false, bool SPEC = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_SCAN_WAVES_EXPR))) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
                                                           const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
@@ -1049,7 +1049,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
             double ux, uy, cux, cuy;
             padded_position<IDENT>(km, x, y, ux, uy);
             padded_rate<IDENT>(km, cs.x, cs.y, cux, cuy);
-            exact = !march_padded<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl);
+            // SPEC (small batches, round 5): the tail of a long ray two samples per round trip where the table value repeats
+            exact = SPEC ? !march_padded_spec<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl, (int)j.spec_from)
+                         : !march_padded<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl);
         }
         if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
         if (COUNT) nl_acc += (uint32_t)nl;   // measurement variant only (bench.py's L-bar)
@@ -3299,14 +3301,20 @@ __global__ void k_build_codes_padded(const double *__restrict__ pad, int Hp, int
 __global__ void __launch_bounds__(256) k_scan_policy(const double *__restrict__ scans, int B, double fov, int i0, int n, double steer_gain, double steer_max,
                                                      double sector_limit, double v_lo, double v_hi, double d_ref, double *__restrict__ actions)
 {
+    // the agent's row goes through LDS: 64 consecutive ranges per load instruction (4 lines), then every lane walks its own
+    // sector there (reading the sectors straight from HBM touches 64 lines per instruction, 16 x the traffic)
+    extern __shared__ double lds_rows[];   // [4 waves][B]
     const int a = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (a >= n) return;
     const int lane = (int)(threadIdx.x & 63u);
     const double *row = scans + (size_t)(i0 + a) * (size_t)B;
+    double *mine = lds_rows + (size_t)(threadIdx.x >> 6) * (size_t)B;
+    for (int b = lane; b < B; b += 64) mine[b] = row[b];
+    __builtin_amdgcn_wave_barrier();   // (one wave: its LDS writes are in order; the barrier only pins the compiler)
     const int b0 = (lane * B + 63) / 64, b1 = ((lane + 1) * B + 63) / 64;
     double sum = 0., lo = INFINITY;
     for (int b = b0; b < b1; ++b) {
-        const double r = row[b];
+        const double r = mine[b];
         sum += r;
         lo = r < lo ? r : lo;
     }

@@ -704,6 +704,103 @@ F110_HD bool march_padded(const ScanConst &k, double ux, double uy, double cux, 
     return !(redo | (n > k.pad_max_samples));
 }
 
+// march_padded with the tail of a LONG ray marched two samples per memory round trip where the table allows it (round 5).
+// A ray that creeps along a wall reads the same few values d = res * sqrt(1, 2, 4, 5 ...) over and over, and every sample
+// costs a full dependent round trip (~200 ns): the chain of the batch's longest ray is what bounds a small batch's scan.
+// From sample `spec_from` on, together with the sample at u_{n+1} = u_n + d_n cu the ray also reads the cell at
+// u_n + 2 d_n cu — where sample n+2 lies IF d_{n+1} turns out equal to d_n, bit for bit.  It then is
+// fma(d_{n+1}, cu, u_{n+1}) with identical operands, i.e. exactly the position, cell and value the plain loop would have
+// produced one round trip later; otherwise the extra value is dropped.  Same guard band, same sample sequence, same
+// lookup count as march_padded — results are bit-identical by construction (host + GPU tests compare them).
+// The speculative cell is read only while total + d <= max_range: it then lies within max_range of the lidar like every
+// real sample, inside the padded table; beyond that the plain loop would not take the sample either.
+template <bool WANT_CELL>
+F110_HD bool march_padded_spec(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
+                               int &hit_r, int &hit_c, int &lookups, int spec_from)
+{
+    double total = d;
+    int n = 1;
+    bool redo = false;
+    const char *base = reinterpret_cast<const char *>(k.pad);
+    // the cell of a position (march_padded's body): byte offset, guard-band verdict, cell for WANT_CELL
+    auto cell = [&](double px, double py, bool &give_up, int &cc, int &cr) -> uint32_t {
+        const uint32_t wx = low_word(px + kFixBig);
+        const uint32_t wy = low_word(py + kFixBig);
+        uint32_t off = mul24(wy >> kFixFracBits, (uint32_t)k.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
+        cc = (int)(wx >> kFixFracBits);
+        cr = (int)(wy >> kFixFracBits);
+        give_up = false;
+        if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {
+            give_up = (fabs(px - rint(px)) < kPadGuard) | (fabs(py - rint(py)) < kPadGuard);
+            cc = (int)floor(px);
+            cr = (int)floor(py);
+            off = mul24((uint32_t)cr, (uint32_t)k.pad_row_bytes) + ((uint32_t)cc << 3);
+        }
+        return off;
+    };
+    int c1 = 0, r1 = 0;
+    while ((d > k.eps) & (total <= k.max_range) & !redo & (n < spec_from)) {   // the plain loop
+        ux = fma(d, cux, ux);
+        uy = fma(d, cuy, uy);
+        const uint32_t off = cell(ux, uy, redo, c1, r1);
+        if (WANT_CELL) {
+            hit_c = c1;
+            hit_r = r1;
+        }
+        d = *reinterpret_cast<const double *>(base + off);
+        total += d;
+        ++n;
+    }
+    while ((d > k.eps) & (total <= k.max_range) & !redo) {   // two samples per round trip where the value repeats
+        ux = fma(d, cux, ux);
+        uy = fma(d, cuy, uy);
+        const uint32_t off1 = cell(ux, uy, redo, c1, r1);
+        const double sx = fma(d, cux, ux), sy = fma(d, cuy, uy);
+        bool redo2 = false;
+        int c2 = 0, r2 = 0;
+        uint32_t off2 = cell(sx, sy, redo2, c2, r2);
+        if (!(total + d <= k.max_range)) off2 = off1;   // (never accepted then: see above)
+        double v1 = *reinterpret_cast<const double *>(base + off1);
+        double v2 = *reinterpret_cast<const double *>(base + off2);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // both loads are issued before either is waited for (the optimiser otherwise sinks the second one into the branch that
+        // uses it: a second dependent round trip, which is exactly what this loop exists to avoid)
+        asm volatile("" : "+v"(v1), "+v"(v2));
+#endif
+        if (WANT_CELL) {
+            hit_c = c1;
+            hit_r = r1;
+        }
+        const bool same = v1 == d;
+        d = v1;
+        total += v1;
+        ++n;
+        if (same & (d > k.eps) & (total <= k.max_range) & !redo) {
+            ux = sx;
+            uy = sy;
+            redo = redo2;
+            if (WANT_CELL) {
+                hit_c = c2;
+                hit_r = r2;
+            }
+            d = v2;
+            total += v2;
+            ++n;
+        }
+    }
+    if (WANT_CELL && n > 1) {
+        hit_c -= k.pad_border;
+        hit_r -= k.pad_border;
+        if (hit_c < 0 || hit_c >= k.width || hit_r < 0 || hit_r >= k.height) {
+            hit_r = -1;
+            hit_c = -1;
+        }
+    }
+    lookups = n;
+    range = (total > k.max_range) ? k.max_range : total;
+    return !(redo | (n > k.pad_max_samples));
+}
+
 // The exact march for the rays march_padded gives up on, written to keep the fast kernel's
 // register footprint: its constants are fetched from the HBM copy of ScanConst when (if ever) it
 // runs, and it uses the reference's own arithmetic (true divisions, width*resolution formed from

@@ -178,6 +178,11 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
     }
     k.table_rm = dt;
     std::vector<double> padded;
+    int spec_from = 0;   // layout 3 + 100 * s: the PADDED march with two samples per round trip from sample s on (march_padded_spec)
+    if (layout >= 100) {
+        spec_from = layout / 100;
+        layout = layout % 100;
+    }
     if (layout == 3 && setup_padded(k)) {  // same construction as finish_map() + k_build_padded
         padded.assign((size_t)k.pad_width * k.pad_height, k.oob_value);
         for (int r = 0; r < H; ++r)
@@ -202,7 +207,8 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
                 if (k.ident_rot) { padded_position<true>(k, pose[0], pose[1], ux, uy); padded_rate<true>(k, cs[idx].x, cs[idx].y, cux, cuy); }
                 else { padded_position<false>(k, pose[0], pose[1], ux, uy); padded_rate<false>(k, cs[idx].x, cs[idx].y, cux, cuy); }
                 fast = padded_start_ok(k, ux, uy);
-                if (fast) exact = !march_padded<true>(k, ux, uy, cux, cuy, d0, r, hr, hc, nl);
+                if (fast) exact = spec_from ? !march_padded_spec<true>(k, ux, uy, cux, cuy, d0, r, hr, hc, nl, spec_from)
+                                            : !march_padded<true>(k, ux, uy, cux, cuy, d0, r, hr, hc, nl);
                 if (!fast) ++g_pad_far; else if (exact) ++g_pad_guard; else ++g_pad_fast;
             }
             if (exact) r = k.ident_rot ? march_exact_cold<true>(&k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, hr, hc, nl)

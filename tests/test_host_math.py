@@ -175,7 +175,7 @@ def _hh_scan(hh, layout, dt, res, origin, sines, cosines, B, fov, pose, theta_di
 @pytest.mark.parametrize("fixture,mapname,beams,fov", [
     ("scan_example_map", "example_map", 1080, 4.7), ("scan_berlin", "berlin", 1080, 4.7),
     ("scan_example_map_4096", "example_map", 4096, 4.7), ("scan_example_map_271", "example_map", 271, 6.0)])
-@pytest.mark.parametrize("layout", [0, 1, 2, 3])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3, 203, 803, 3203])     # x03: the PADDED march, two samples per round trip from sample x on (march_padded_spec)
 def test_scan_matches_golden(hh, fixture, mapname, beams, fov, layout):
     g = gold(fixture)
     dt, res, origin = oracle_map_dt(mapname)
@@ -202,7 +202,7 @@ def test_scan_generic_path_and_rotated_origin(hh):
             u, v = rng.uniform(5, 15, 2) * res2 / 0.05
             pose = [org[0] + c * u - s * v, org[1] + s * u + c * v, rng.uniform(0, 6.28)]
             ref, ref_hits = so.scan(pose, want_hits=True)
-            for layout in (0, 3):
+            for layout in (0, 3, 203, 1603):
                 ranges, hits, idx, lk = _hh_scan(hh, layout, so.dt, res2, org, so.sines, so.cosines, 1080, 4.7, pose)
                 assert np.array_equal(hits, ref_hits)
                 assert np.array_equal(ranges, ref)

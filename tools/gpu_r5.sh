@@ -28,6 +28,15 @@ stream)   # the lane-refill scan against k_scan_rays_agent (experimental build),
       $P $n scan_stream=1 stream_block=256 stream_grid=2048 stream_refill=48
     done 2>&1 | grep agents; } | tee $OUT/stream_scan.txt
   ;;
+spec)   # march_padded_spec (two samples per round trip in a long ray's tail) in the longest-first window, experimental build
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  F110_LIB_VARIANT=experimental F110_EXP=spec_from=S python bench.py --only-headline --steps 300 --warmup 30 --agents N (spec_from 0 = the plain march)"
+    for n in 2048 4096 8192; do for sp in 0 64 32 16 8 4; do
+      F110_LIB_VARIANT=experimental F110_EXP=spec_from=$sp timeout 100 python bench.py --only-headline --steps 300 --warmup 30 --agents $n 2>/dev/null | grep "^{" | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('agents %6d spec_from %2d  %8.2f M agent-steps/s  %.4f ms/step' % ($n, $sp, d['value']/1e6, d['ms_per_step']))
+"; done; done; } | tee $OUT/spec_march.txt
+  ;;
 bench)
   timeout 900 python bench.py > $OUT/bench_default.log 2>&1; grep -h '^{' $OUT/bench_default.log | tail -1 > $OUT/bench_default.json; cut -c1-600 $OUT/bench_default.json
   ;;
