@@ -80,7 +80,6 @@ def parse_args(argv=None):
     ap.add_argument("--scan-tasks", type=int, default=int(os.environ.get("F110_SCAN_TASKS", "0")),
                     help="consecutive 64-ray tasks per wave (0 = default)")
     ap.add_argument("--groups", type=int, default=0, help="env groups stepped on streams of their own (0 = the library's default)")
-    ap.add_argument("--graph", type=int, default=-1, help="1: submit each step as one captured HIP graph; 0: separate launches; -1: the library's default")
     ap.add_argument("--gather", action="store_true",
                     help="RCCL all-gather of every rank's scans after each step (BASELINE config 4; off by default)")
     ap.add_argument("--gather-overlap", action="store_true",
@@ -308,7 +307,7 @@ class Workload(object):
             img = np.tile(img, (self.tiles, self.tiles))
         self.sim = sim = BatchSim(num_envs=self.E, num_agents=A, num_beams=self.beams, device_id=rdv.local_rank,
                                   map_layout=args.layout, scan_block=args.scan_block, scan_tasks_per_wave=args.scan_tasks,
-                                  step_groups=args.groups, **({} if args.graph < 0 else {"step_graph": args.graph}))
+                                  step_groups=args.groups)
         sim.set_map_image(img, res, origin)
         self.max_total = max_total_steps
         noise = "off" if args.no_noise else args.noise
@@ -464,11 +463,9 @@ class Workload(object):
 
 
 def scan_kernel_name(args, beams):
-    if args.layout == 4 and beams < 1498 and (-beams) % 64 * 100 <= 3 * beams:
-        return "k_scan_rays_window"
     aligned = args.layout == 3 and beams < 1498 and (-beams) % 64 * 100 <= 3 * beams
     if beams >= 1498:
-        return "k_scan_dirs_agent" if args.layout in (3, 4) else "k_scan_rays (direction dedupe) + k_expand_beams"
+        return "k_scan_dirs_agent" if args.layout == 3 else "k_scan_rays"
     return "k_scan_rays_agent" if aligned else "k_scan_rays"
 
 
@@ -881,8 +878,8 @@ def main(argv=None):
                               "pure_pursuit": "reference pure-pursuit planner evaluated on the device every step (closed loop, planner time included)",
                               "parked": "zero actions: every car stays on its start pose"}[args.policy],
                    "agents_per_gpu": args.agents, "agents_total": total_agents, "beams": args.beams,
-                   "map_layout": {0: "rowmajor_f64", 1: "tiled4x4_f64", 2: "code8_lds_lut", 3: "padded_rowmajor_f64", 4: "padded_rowmajor_f64 + lds_window_codes"}[args.layout],
-                   "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks, "step_groups": args.groups, "step_graph": args.graph,
+                   "map_layout": {0: "rowmajor_f64", 3: "padded_rowmajor_f64"}[args.layout],
+                   "scan_block": args.scan_block, "scan_tasks_per_wave": args.scan_tasks, "step_groups": args.groups,
                    "env_blocks_per_step": head.get("env_blocks"),   # 1 = every kernel once per step over the whole batch; 2 = two halves of the envs on two streams (include/f110.h step_groups)
                    "parallelism": "env-sharded x%d, %s" % (n_gpus, ("RCCL all-gather of the observation (scans + 7 scalars per agent) after every step" + (" (overlapped with the next step, double-buffered)" if args.gather_overlap else "")) if args.gather
                                                            else "no data-path collective"),

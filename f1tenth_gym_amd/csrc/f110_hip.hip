@@ -43,13 +43,7 @@ constexpr bool kExperimental = false;
 // f110_exp_set keys (experimental build; the product keeps the defaults)
 struct ExpSwitches {
     int scan_flat = 0;         // 1: the flat ray kernel instead of the agent-aligned one
-    int dedupe_two_pass = 0;   // 1: march distinct directions into a buffer, then k_expand_beams
-    int no_window = 0;         // 1: F110_MAP_WINDOW_LDS handles step with the PADDED kernel
-    int finalize_lanes = 0;    // 8 / 16 / 32 / 64 lanes per agent in k_finalize*, 0 = by batch size
-    int finalize_flat = -1;    // A = 2: 1 the workgroup-flattened window loop, 0 fixed lanes per agent, -1 = default
-    int finalize_roles = -1;   // A = 2: 1 the prologue dealt by role (k_finalize_pair_roles), 0 by agent (k_finalize_pair_flat), -1 = default
     int long_prio = 0;         // 1: the longest-first pass's waves raise their issue priority (s_setprio 3)
-    int pair_always = 0;       // A = 2: 1 = pair test inside the finalize kernel also for big batches without the in-step re-seat
     int scan_occupancy = 0;    // 4: run the step's scan kernel at 4 waves/SIMD (fusion feasibility A/B)
     int scan_env_counter = 0;  // 1: the scan kernel also counts finished tasks per env (fusion feasibility A/B)
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
@@ -62,16 +56,6 @@ struct ExpSwitches {
     int stream_grid = 0;       // persistent workgroups (0 = 4 per CU)
     uint64_t scan_trace = 0;   // device address of a caller-owned [waves][8] uint64 buffer: clock stamps, hardware id, samples of every scan wave (0 = off)
 };
-
-// A = 2 finalize: the workgroup-flattened window loop (k_finalize_pair_flat) or fixed lanes per agent
-// (round 3, measured: 65 536 agents 0.763 -> 0.726 ms per step, 16 384: 0.252 -> 0.239, 4096: 0.108 -> 0.107)
-constexpr bool kFinalizeFlatDefault = true;
-// ... and its prologue dealt by role (k_finalize_pair_roles) or by agent (k_finalize_pair_flat, experimental build)
-#ifdef F110_EXPERIMENTAL
-constexpr bool kFinalizeRolesDefault = true;
-#else
-constexpr bool kFinalizeRolesDefault = true;   // the product has only this form
-#endif
 
 struct f110_sim {
     f110_config cfg{};
@@ -86,14 +70,7 @@ struct f110_sim {
     int scan_tasks_per_wave = 1, num_cus = 256;  // consecutive 64-ray tasks per wave
     bool scan_tasks_auto = false;                // chosen by batch size (f110_config.scan_tasks_per_wave = 0)
     double ttc_side_max = INFINITY, ttc_cos_max = INFINITY;  // see f110_set_beam_tables
-    uint8_t *d_codes = nullptr;
-    double *d_dir_ranges = nullptr;  // dedupe pass output [N][dir_stride]
     int dir_stride = 0;              // > 0: dedupe enabled
-    uint32_t dir_magic = 0, dir_shift = 0;
-    double *d_lut = nullptr;
-    uint8_t *d_wcodes = nullptr;     // WINDOW_LDS: 1-byte codes of the padded table, row-major
-    double *d_wlut = nullptr;
-    uint32_t wcode_pitch = 0;
     int scan_block = 64;
     double *d_params_all = nullptr;   // [N][18] when f110_set_params_batch is active
     double *d_params = nullptr, *d_noise = nullptr, *d_scan_angles = nullptr, *d_beam_cos = nullptr, *d_side = nullptr;
@@ -113,7 +90,7 @@ struct f110_sim {
     ScanConst k_uploaded{};
     unsigned long long *d_path_stats = nullptr;  // [3], see f110_scan_path_stats
     bool path_stats_on = false;
-    double *d_dt_row = nullptr, *d_dt_tiled = nullptr, *d_dt_pad = nullptr, *d_actions = nullptr, *d_poses = nullptr;
+    double *d_dt_row = nullptr, *d_dt_pad = nullptr, *d_actions = nullptr, *d_poses = nullptr;
     double2 *d_cs = nullptr;
     uint8_t *d_mask = nullptr;
     // env groups: the step of G > 1 independent env blocks runs on G streams of its own (no event
@@ -141,29 +118,15 @@ struct f110_sim {
     unsigned long long *d_lookups = nullptr;  // f110_scan_lookup_count
     bool lookups_on = false;
     // the single-block step captured as a HIP graph (f110_config.step_graph): one submission per step
-    struct StepGraph {
-        AgentArrays dev;
-        ScanConst k;
-        ExpSwitches exp;
-        double noise_scale;
-        const double *actions;
-        int flags;
-        hipGraphExec_t exec;
-    };
-    std::vector<StepGraph> graphs;
-    bool use_graph = false;
     int collide_mode = 0;        // where the pair tests run: 0 side stream, 1 fused into k_integrate, 2 in line, 3 inside k_finalize (A = 2)
     // longest-first order of the scan tasks (TaskSched, small batches): double-buffered flags / lists / counters
     bool task_order = false;
     uint32_t *d_tflags[2] = {nullptr, nullptr}, *d_tlist[2] = {nullptr, nullptr}, *d_tcount = nullptr;
-    uint32_t *d_rflags[2] = {nullptr, nullptr}, *d_rlist[2] = {nullptr, nullptr}, *d_rtask[2] = {nullptr, nullptr};   // the ray-level lists (TaskSched::r*)
     TaskSched tsched[2]{};           // [parity], passed to the scan by value
     bool sched_allocated = false;
     uint32_t task_cap_alloc = 0;
     uint32_t task_epoch = 2, task_cap = 0, task_thr = 96;   // epochs start above the flags' initial 0
     uint32_t task_cap_div = 32, task_rev = 0;                // list capacity = tasks / task_cap_div; 1 = newest list entries first
-    uint32_t ray_cap = 0, ray_thr = 96, ray_waves = 2048;
-    bool ray_pass = false;   // until it is measured to pay (f110_exp_set ray_pass)
     ExpSwitches exp;
     uint32_t *d_env_done = nullptr;   // [num_envs] scan_env_counter probe
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
@@ -299,7 +262,7 @@ struct Scratch {
     }
 };
 
-static inline bool padded_family(int layout) { return layout == F110_MAP_PADDED_F64 || layout == F110_MAP_WINDOW_LDS; }
+static inline bool padded_family(int layout) { return layout == F110_MAP_PADDED_F64; }
 
 static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
@@ -370,10 +333,6 @@ static scan_rays_fn pick_rays(const ScanConst &k, int layout)
 {
 #define SEL(L) (k.res_pow2 ? (k.ident_rot ? k_scan_rays<L, true, true, STEP> : k_scan_rays<L, true, false, STEP>) \
                            : (k.ident_rot ? k_scan_rays<L, false, true, STEP> : k_scan_rays<L, false, false, STEP>))
-#ifdef F110_EXPERIMENTAL
-    if (layout == F110_MAP_CODE8) return SEL(LAYOUT_CODE8);
-    if (layout == F110_MAP_TILED_F64) return SEL(LAYOUT_TILED);
-#endif
     if (padded_family(layout) && k.pad) return SEL(LAYOUT_PADDED);
     return SEL(LAYOUT_ROWMAJOR);
 #undef SEL
@@ -388,18 +347,6 @@ static dim3 rays_grid(RayJob &j, int block, int tasks_per_wave)
     return dim3((waves + wpb - 1) / wpb);
 }
 
-// Cached step graphs (experimental build) hold raw device pointers: whenever the handle frees or replaces a
-// buffer a launch reads (maps, window codes, noise buffers, per-env map tables, beam tables, parameter sets)
-// the cache is dropped — after the stream has drained, so no exec is destroyed while it may still run.
-static int graphs_clear(f110_sim *h)
-{
-    if (h->graphs.empty()) return F110_OK;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-    h->graphs.clear();
-    return F110_OK;
-}
-
 // longest-first order of the step's scan tasks (TaskSched): buffers on first use, then on / off
 static int task_order_setup(f110_sim *h, bool on)
 {
@@ -408,30 +355,20 @@ static int task_order_setup(f110_sim *h, bool on)
         h->task_order = false;
         return F110_OK;
     }
-    const size_t n_rays = (size_t)h->N * (size_t)h->cfg.num_beams;
     if (!h->sched_allocated) {
         h->task_cap_alloc = (uint32_t)std::max<size_t>(64, kExperimental ? n_tasks : n_tasks / h->task_cap_div);
-        h->ray_cap = (uint32_t)std::max<size_t>(256, n_rays / 512);
         for (int q = 0; q < 2; ++q) {
             TRY(dmalloc(h, &h->d_tflags[q], n_tasks));
             TRY(dmalloc(h, &h->d_tlist[q], (size_t)h->task_cap_alloc));
             HIPCHK(h, hipMemsetAsync(h->d_tflags[q], 0, sizeof(uint32_t) * n_tasks, h->stream));
-            if (kExperimental) {   // the ray-level lists belong to the ray pass, which only the lab build has: the product's r* stay null
-                TRY(dmalloc(h, &h->d_rflags[q], n_rays));
-                TRY(dmalloc(h, &h->d_rlist[q], (size_t)h->ray_cap));
-                TRY(dmalloc(h, &h->d_rtask[q], n_tasks));
-                HIPCHK(h, hipMemsetAsync(h->d_rtask[q], 0, sizeof(uint32_t) * n_tasks, h->stream));
-                HIPCHK(h, hipMemsetAsync(h->d_rflags[q], 0, sizeof(uint32_t) * n_rays, h->stream));
-            }
         }
-        TRY(dmalloc(h, &h->d_tcount, 4));   // {task count 0, 1, ray count 0, 1}
+        TRY(dmalloc(h, &h->d_tcount, 4));   // {task count of parity 0, of parity 1, spare, spare}
         HIPCHK(h, hipMemsetAsync(h->d_tcount, 0, 4 * sizeof(uint32_t), h->stream));
         h->sched_allocated = true;
     }
     h->task_cap = std::min<uint32_t>(h->task_cap_alloc, (uint32_t)std::max<size_t>(64, n_tasks / h->task_cap_div));
     for (int q = 0; q < 2; ++q)   // struct q is used at steps of parity q: it reads what parity q^1 wrote
-        h->tsched[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr,
-                          h->d_rflags[q ^ 1], h->d_rflags[q], h->d_rtask[q ^ 1], h->d_rtask[q], h->d_rlist[q ^ 1], h->d_rlist[q], h->d_tcount + 2 + (q ^ 1), h->d_tcount + 2 + q, h->ray_cap, h->ray_thr};
+        h->tsched[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr};
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->task_order = true;
     return F110_OK;
@@ -475,18 +412,9 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     if (!kExperimental) return fail(h, F110_ERR_STATE, "f110_exp_set(%s) is available in the experimental build only (libf110_hip_exp.so)", key);
     ENTER(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    TRY(graphs_clear(h));
     const std::string k(key);
     if (k == "scan_flat") h->exp.scan_flat = value;
-    else if (k == "dedupe_two_pass") h->exp.dedupe_two_pass = value;
-    else if (k == "no_window") h->exp.no_window = value;
-    else if (k == "finalize_lanes") {
-        if (value != 0 && value != 8 && value != 16 && value != 32 && value != 64) return fail(h, F110_ERR_INVALID, "finalize_lanes must be 0, 8, 16, 32 or 64");
-        h->exp.finalize_lanes = value;
-    } else if (k == "finalize_flat") h->exp.finalize_flat = value;
-    else if (k == "pair_always") h->exp.pair_always = value;
     else if (k == "long_prio") h->exp.long_prio = value;
-    else if (k == "finalize_roles") h->exp.finalize_roles = value;
     else if (k == "scan_occupancy") h->exp.scan_occupancy = value;
     else if (k == "scan_env_counter") h->exp.scan_env_counter = value;
     else if (k == "integrate_duo") h->exp.integrate_duo = value;
@@ -505,7 +433,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "collide_mode") {
         if (value < 0 || value > 3) return fail(h, F110_ERR_INVALID, "collide_mode must be 0..3");
         h->collide_mode = value;
-    } else if (k == "step_graph") h->use_graph = value != 0;
+    }
     else if (k == "task_order") return task_order_setup(h, value != 0);
     else if (k == "task_cap_div" || k == "task_rev") {
         if (k == "task_rev") h->task_rev = value != 0;
@@ -514,11 +442,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     } else if (k == "task_thr") {
         h->task_thr = (uint32_t)value;
         if (h->task_order) return task_order_setup(h, true);
-    } else if (k == "ray_pass") h->ray_pass = value != 0;
-    else if (k == "ray_thr") {
-        h->ray_thr = (uint32_t)value;
-        if (h->task_order) return task_order_setup(h, true);
-    } else if (k == "ray_waves") h->ray_waves = (uint32_t)std::max(64, value);
+    }
     else
         return fail(h, F110_ERR_INVALID, "f110_exp_set: unknown key '%s'", key);
     return F110_OK;
@@ -585,15 +509,15 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         return fail(nullptr, F110_ERR_INVALID, "f110_create: num_envs/num_agents >= 1, num_beams/theta_dis >= 2 required");
     if (cfg->integrator != F110_INTEGRATOR_RK4 && cfg->integrator != F110_INTEGRATOR_EULER)
         return fail(nullptr, F110_ERR_INVALID, "Invalid Integrator Specified. Please choose RK4 or Euler");
-    if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_TILED_F64 && cfg->map_layout != F110_MAP_CODE8 &&
-        cfg->map_layout != F110_MAP_PADDED_F64 && cfg->map_layout != F110_MAP_WINDOW_LDS)
+    if (cfg->map_layout == F110_MAP_TILED_F64 || cfg->map_layout == F110_MAP_CODE8 || cfg->map_layout == F110_MAP_WINDOW_LDS)
+        return fail(nullptr, F110_ERR_INVALID, "map_layout %d (4x4 tiles / byte codes + LUT / LDS window) was measured slower in rounds 1-4 and retired in round 5: "
+                    "use F110_MAP_PADDED_F64 (3) or F110_MAP_ROWMAJOR_F64 (0)", cfg->map_layout);
+    if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_PADDED_F64)
         return fail(nullptr, F110_ERR_INVALID, "unknown map_layout %d", cfg->map_layout);
-    if (!kExperimental) {
-        if (cfg->map_layout != F110_MAP_ROWMAJOR_F64 && cfg->map_layout != F110_MAP_PADDED_F64)
-            return fail(nullptr, F110_ERR_STATE, "map_layout %d is available in the experimental build only (libf110_hip_exp.so)", cfg->map_layout);
-        if (cfg->step_groups > 2 || cfg->step_graph != 0)
-            return fail(nullptr, F110_ERR_STATE, "step_groups > 2 / step_graph are available in the experimental build only (libf110_hip_exp.so)");
-    }
+    if (cfg->step_graph != 0)
+        return fail(nullptr, F110_ERR_INVALID, "step_graph (the step as one captured HIP graph) was measured slower (graph launch ~250 us on ROCm 7.2) and retired in round 5");
+    if (!kExperimental && cfg->step_groups > 2)
+        return fail(nullptr, F110_ERR_STATE, "step_groups > 2 is available in the experimental build only (libf110_hip_exp.so)");
     if ((long long)cfg->num_envs * cfg->num_agents * (long long)cfg->num_beams > 0xFFFFFF00LL) return fail(nullptr, F110_ERR_INVALID, "num_envs*num_agents*num_beams must stay below 2^32");
     int ndev = 0;
     {
@@ -652,7 +576,6 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         G = std::min(std::min(G, 16), cfg->num_envs);
         if (h->groups_auto && cfg->step_graph != 0) G = 1;   // (lab: the captured-graph step is one block)
         h->groups = G;
-        h->use_graph = cfg->step_graph != 0;
         // pair tests + opponent windows inside the finalize kernel: A = 2 (k_finalize_pair_roles) and every A up to
         // kMaxAgentsMulti = 256 (k_finalize_multi up to 16, k_finalize_multi_tiled above: an env's ordered pairs in tiles of a
         // workgroup's record table); above
@@ -810,17 +733,12 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         k.dir_guard = g > 1e-8 ? g : 1e-8;
     }
     if (k.theta_inc < 1.0 && B >= 64) {
-        // more beams than table directions: march each distinct direction once (k_expand_beams)
+        // more beams than table directions: march each distinct direction once (k_scan_dirs_agent)
         int stride = (int)std::ceil((B - 1) * k.theta_inc) + 2;
         stride = std::min(stride, cfg->theta_dis);
         stride = (stride + 63) / 64 * 64;
         if (stride < B && (long long)N * stride < 0xFFFFFF00LL) {
-            h->dir_stride = stride;   // (the two-pass form's [N][stride] buffer is allocated when that form first runs)
-            RayJob tmp{};
-            tmp.n_rays = (uint32_t)N * (uint32_t)stride;
-            set_div_magic(tmp, (uint32_t)stride);
-            h->dir_magic = tmp.div_magic;
-            h->dir_shift = tmp.div_shift;
+            h->dir_stride = stride;
         }
     }
     CK(f110_set_params(h, -1, cfg->params));
@@ -867,20 +785,19 @@ void f110_destroy(f110_sim *h)
         if (p) (void)hipFree(p);
     for (float *p : h->scan_f32)
         if (p) (void)hipFree(p);
-    for (auto &g : h->graphs) (void)hipGraphExecDestroy(g.exec);
     for (hipStream_t gs : h->gowned) (void)hipStreamDestroy(gs);
     for (hipEvent_t ge : h->gevents)
         if (ge) (void)hipEventDestroy(ge);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
     {
-        void *rp[] = {h->d_rtask[0], h->d_rtask[1], h->d_rflags[0], h->d_rflags[1], h->d_rlist[0], h->d_rlist[1], h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_wcodes, h->d_wlut, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
+        void *rp[] = {h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
         for (void *p : rp)
             if (p) (void)hipFree(p);
     }
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
-                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_tiled, h->d_dt_pad, h->d_codes, h->d_dir_ranges, h->d_lut, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k, h->d_params_all};
+                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_pad, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k, h->d_params_all};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ms : h->extra_maps) {
@@ -928,7 +845,6 @@ static void fill_map_fields(ScanConst &k, int H, int W, double res, double ox, d
 {
     k.height = H;
     k.width = W;
-    k.tiles_w = (W + 3) / 4;
     k.row_bytes = W * 8;
     k.res = res;
     k.inv_res = 1.0 / res;
@@ -948,29 +864,14 @@ static void fill_map_fields(ScanConst &k, int H, int W, double res, double ox, d
 
 static int finish_map(f110_sim *h, int H, int W, double res, double ox, double oy, double oc, double os)
 {
-    TRY(graphs_clear(h));
     ScanConst &k = h->k;
     h->multi_map = false;       // slot 0 changed: f110_set_env_maps has to be called again
     h->dev.maps_full = nullptr;
     h->dev.env_map = nullptr;
     fill_map_fields(k, H, W, res, ox, oy, oc, os);
     HIPCHK(h, hipMemcpyAsync(&k.oob_value, h->d_dt_row + ((size_t)H * W - 1), sizeof(double), hipMemcpyDeviceToHost, h->stream));
-#ifdef F110_EXPERIMENTAL
-    if (h->cfg.map_layout == F110_MAP_TILED_F64) {
-        const int tiles_h = (H + 3) / 4;
-        if (h->d_dt_tiled) { (void)hipFree(h->d_dt_tiled); h->d_dt_tiled = nullptr; }
-        const size_t total = (size_t)k.tiles_w * tiles_h * 16;
-        TRY(dmalloc(h, &h->d_dt_tiled, total));
-        hipLaunchKernelGGL(k_retile, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_row, H, W, k.tiles_w, tiles_h, h->d_dt_tiled);
-        HIPCHK(h, hipGetLastError());
-        k.table = h->d_dt_tiled;
-        k.table_rm = h->d_dt_row;
-    } else
-#endif
-    {
-        k.table = h->d_dt_row;
-        k.table_rm = h->d_dt_row;
-    }
+    k.table = h->d_dt_row;
+    k.table_rm = h->d_dt_row;
     k.pad = nullptr;
     if (h->d_dt_pad) { (void)hipFree(h->d_dt_pad); h->d_dt_pad = nullptr; }
     if (padded_family(h->cfg.map_layout) && setup_padded(k)) {
@@ -995,53 +896,6 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
             h->d_dt_row = nullptr;
         }
     }
-#ifdef F110_EXPERIMENTAL
-    if (h->cfg.map_layout == F110_MAP_CODE8) {
-        // the 255 smallest distinct table values (one-time host sort of the downloaded table)
-        std::vector<double> vals((size_t)H * W);
-        HIPCHK(h, hipMemcpyAsync(vals.data(), h->d_dt_row, vals.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        vals.erase(std::remove_if(vals.begin(), vals.end(), [](double v) { return v != v; }), vals.end());
-        std::sort(vals.begin(), vals.end());
-        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
-        std::vector<double> lut(256, INFINITY);
-        const int n_lut = (int)std::min<size_t>(vals.size(), (size_t)kLutEntries);
-        for (int i = 0; i < n_lut; ++i) lut[i] = vals[i];
-        const int ctw = (W + 15) / 16, cth = (H + 7) / 8;
-        if (h->d_codes) { (void)hipFree(h->d_codes); h->d_codes = nullptr; }
-        if (!h->d_lut) TRY(dmalloc(h, &h->d_lut, (size_t)256));
-        const size_t total = (size_t)ctw * cth * 128;
-        TRY(dmalloc(h, &h->d_codes, total));
-        HIPCHK(h, hipMemcpyAsync(h->d_lut, lut.data(), 256 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_build_codes, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_row, H, W, ctw, cth, h->d_lut, n_lut, h->d_codes);
-        HIPCHK(h, hipGetLastError());
-        k.codes = h->d_codes;
-        k.lut = h->d_lut;
-        k.code_tile_row_bytes = ctw * 128;
-    }
-    if (h->d_wcodes) { (void)hipFree(h->d_wcodes); h->d_wcodes = nullptr; }
-    if (h->cfg.map_layout == F110_MAP_WINDOW_LDS && k.pad && k.pad_border >= kWin / 2 + kPadSlack + 18) {
-        // the k_scan_rays_window form: 1-byte codes over the padded table + the exact value LUT (the 255
-        // smallest distinct table values, one-time host sort of the downloaded table)
-        std::vector<double> vals((size_t)H * W);
-        HIPCHK(h, hipMemcpyAsync(vals.data(), h->d_dt_row, vals.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        vals.erase(std::remove_if(vals.begin(), vals.end(), [](double v) { return v != v; }), vals.end());
-        std::sort(vals.begin(), vals.end());
-        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
-        std::vector<double> lut(256, INFINITY);
-        const int n_lut = (int)std::min<size_t>(vals.size(), (size_t)kLutEntries);
-        for (int i = 0; i < n_lut; ++i) lut[i] = vals[i];
-        if (!h->d_wlut) TRY(dmalloc(h, &h->d_wlut, (size_t)256));
-        HIPCHK(h, hipMemcpyAsync(h->d_wlut, lut.data(), 256 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        h->wcode_pitch = (uint32_t)(k.pad_width + 15) / 16u * 16u;
-        const size_t total = (size_t)k.pad_height * h->wcode_pitch;
-        TRY(dmalloc(h, &h->d_wcodes, total));
-        hipLaunchKernelGGL(k_build_codes_padded, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_pad, k.pad_height, k.pad_width, (int)h->wcode_pitch,
-                           h->d_wlut, n_lut, h->d_wcodes);
-        HIPCHK(h, hipGetLastError());
-    }
-#endif
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->has_map = true;
     return F110_OK;
@@ -1114,8 +968,6 @@ static int add_map_slot(f110_sim *h, double *d_dt_row, int H, int W, double res,
     ms.k = h->k;   // beam / trig / range constants are shared; the map fields follow
     fill_map_fields(ms.k, H, W, res, ox, oy, oc, os);
     ms.k.table = ms.k.table_rm = d_dt_row;
-    ms.k.codes = nullptr;
-    ms.k.lut = nullptr;
     HIPCHK(h, hipMemcpyAsync(&ms.k.oob_value, d_dt_row + ((size_t)H * W - 1), sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (!setup_padded(ms.k)) {
@@ -1169,7 +1021,6 @@ int f110_set_env_maps(f110_sim *h, const int32_t *h_env_map)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     ENTER(h);
-    TRY(graphs_clear(h));
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h_env_map) {   // back to one map for everybody
         h->multi_map = false;
@@ -1274,7 +1125,6 @@ int f110_set_beam_tables(f110_sim *h, const double *sa, const double *co, const 
     if (!h || !sa || !co || !sd) return fail(h, F110_ERR_INVALID, "null argument");
     ENTER(h);
     if (B != h->cfg.num_beams) return fail(h, F110_ERR_INVALID, "beam tables must have num_beams=%d entries (got %d)", h->cfg.num_beams, B);
-    TRY(graphs_clear(h));   // ttc_side_max / ttc_cos_max below are launch arguments
     HIPCHK(h, hipMemcpyAsync(h->d_scan_angles, sa, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_beam_cos, co, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_side, sd, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
@@ -1301,7 +1151,6 @@ int f110_set_params_batch(f110_sim *h, const double *h_params)
 {
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     ENTER(h);
-    TRY(graphs_clear(h));
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     if (!h_params) {   // back to one parameter set per agent slot
         h->dev.params = h->d_params;
@@ -1335,7 +1184,6 @@ static int noise_cache_extend(f110_sim *h, int upto);
 
 static void noise_release(f110_sim *h)
 {
-    (void)graphs_clear(h);
     if (h->d_noise) { (void)hipFree(h->d_noise); h->d_noise = nullptr; }
     if (h->d_rng_state) { (void)hipFree(h->d_rng_state); h->d_rng_state = nullptr; }
     if (h->d_rng_seed) { (void)hipFree(h->d_rng_seed); h->d_rng_seed = nullptr; }
@@ -2201,7 +2049,7 @@ static int noise_cache_extend(f110_sim *h, int upto)
 // The experimental build adds collide_mode 1 (pair tests fused into k_integrate) / 2 (k_collide in line), the
 // other layouts' kernels, two-pass dedupe and the forced geometries of f110_exp_set.
 // ev[0..3] (or nullptr): profiling events before integrate / before scan / after scan / after finalize.
-enum ScanKind { SCAN_FLAT, SCAN_AGENT, SCAN_AGENT_SCHED, SCAN_DIRS, SCAN_TWO_PASS, SCAN_WINDOW, SCAN_STREAM };
+enum ScanKind { SCAN_FLAT, SCAN_AGENT, SCAN_AGENT_SCHED, SCAN_DIRS, SCAN_STREAM };
 
 // the lane-refill scan (k_scan_stream_agent, experimental build: measured slower): needs the PADDED table and
 // a direction table that fits its LDS copy
@@ -2210,20 +2058,16 @@ static bool stream_scan_applies(const f110_sim *h, int count)
 {
     (void)count;
     if (!kExperimental || h->exp.scan_stream <= 0) return false;
-    return padded_family(h->cfg.map_layout) && h->k.pad && h->dir_stride == 0 && h->k.theta_dis <= 2048 && h->k.num_beams >= 128 && !h->use_graph;
+    return padded_family(h->cfg.map_layout) && h->k.pad && h->dir_stride == 0 && h->k.theta_dis <= 2048 && h->k.num_beams >= 128;
 }
 
 static ScanKind pick_scan(const f110_sim *h, int begin, int count)
 {
     const bool padded = padded_family(h->cfg.map_layout) && h->k.pad;
-    if (h->dir_stride > 0) {
-        if (padded && !(kExperimental && h->exp.dedupe_two_pass)) return SCAN_DIRS;
-        return (kExperimental && !h->multi_map) ? SCAN_TWO_PASS : SCAN_FLAT;   // product: every beam is marched
-    }
+    if (h->dir_stride > 0) return padded ? SCAN_DIRS : SCAN_FLAT;   // (no PADDED table: every beam is marched)
     if (!(h->multi_map || agent_aligned(h))) return SCAN_FLAT;
-    if (kExperimental && h->cfg.map_layout == F110_MAP_WINDOW_LDS && h->d_wcodes && !h->multi_map && !h->exp.no_window) return SCAN_WINDOW;
     if (stream_scan_applies(h, count)) return SCAN_STREAM;
-    if (h->task_order && !h->multi_map && !h->lookups_on && begin == 0 && count == h->N && !h->use_graph && !h->exp.scan_env_counter) return SCAN_AGENT_SCHED;
+    if (h->task_order && !h->multi_map && !h->lookups_on && begin == 0 && count == h->N && !h->exp.scan_env_counter) return SCAN_AGENT_SCHED;
     return SCAN_AGENT;
 }
 
@@ -2279,8 +2123,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     // events.  (Round 2 kept the side-stream form for big batches stepped without the in-step re-seat — crashed cars
     // pile up, their windows grow to all beams, and fixed lanes per agent then serialise — the flattened window loop
     // balances that inside the workgroup: 65 536 parked cars 0.624 -> 0.579 ms, crashed cars piling up 0.899 -> 0.852.)
-    const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0 &&
-                                  (kFinalizeFlatDefault || h->dev.reseat_poses != nullptr || N < 8192 || (kExperimental && h->exp.pair_always));
+    const bool pair_in_finalize = multi && collide_mode == 3 && A == 2 && (begin % 2) == 0;
     const bool multi_in_finalize = multi && collide_mode == 3 && A > 2 && A <= kMaxAgentsMulti && (begin % A) == 0 && (count % A) == 0;
     const bool no_collide_launch = fused_integrate || pair_in_finalize || multi_in_finalize;
     const bool side_collide = multi && !no_collide_launch && !(kExperimental && collide_mode == 2);
@@ -2355,42 +2198,6 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
 #undef DIRS_SCAN
             break;
         }
-#ifdef F110_EXPERIMENTAL
-        case SCAN_TWO_PASS: {
-            if (!h->d_dir_ranges) TRY(dmalloc(h, &h->d_dir_ranges, (size_t)N * h->dir_stride));
-            RayJob jd = j;  // pass 1: one ray per (agent, distinct direction)
-            jd.n_rays = (uint32_t)N * (uint32_t)h->dir_stride;
-            jd.ranges = h->d_dir_ranges;
-            jd.dir_mode = 1;
-            jd.dir_stride = h->dir_stride;
-            jd.div_magic = h->dir_magic;
-            jd.div_shift = h->dir_shift;
-            const dim3 gd = rays_grid(jd, h->scan_block, h->scan_tasks_per_wave);
-            hipLaunchKernelGGL(pick_rays<true>(h->k, h->cfg.map_layout), gd, block, 0, st, jd, h->k);
-            j.dir_stride = h->dir_stride;  // pass 2: every beam picks its direction's range
-            j.dir_ranges = h->d_dir_ranges;
-            j.lookups_total = nullptr;
-            hipLaunchKernelGGL(k_expand_beams, grid1d(j.n_rays, 256), dim3(256), 0, st, j, h->k);
-            break;
-        }
-        case SCAN_WINDOW: {
-            // one workgroup per agent, its neighbourhood of the table staged in LDS
-            const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
-            agent_grid(tpa, grid, wpb, h->scan_tasks_per_wave);
-            j.win_codes = h->d_wcodes;
-            j.win_lut = h->d_wlut;
-            j.win_pitch = h->wcode_pitch;
-            const dim3 wgrid((unsigned)count), wblock(256);
-            if (h->k.ident_rot) {
-                if (cnt) hipLaunchKernelGGL((k_scan_rays_window<true, true>), wgrid, wblock, 0, st, j, h->k, tpa);
-                else hipLaunchKernelGGL((k_scan_rays_window<true, false>), wgrid, wblock, 0, st, j, h->k, tpa);
-            } else {
-                if (cnt) hipLaunchKernelGGL((k_scan_rays_window<false, true>), wgrid, wblock, 0, st, j, h->k, tpa);
-                else hipLaunchKernelGGL((k_scan_rays_window<false, false>), wgrid, wblock, 0, st, j, h->k, tpa);
-            }
-            break;
-        }
-#endif
         case SCAN_AGENT_SCHED: {
             // longest-first: last step's long tasks are served by the first blocks of the launch
             const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
@@ -2400,11 +2207,10 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             j.epoch_r = h->task_epoch - 1u;
             j.epoch_w = h->task_epoch;
             j.long_blocks = (h->task_cap + wpb - 1) / wpb;
-            j.ray_blocks = (kExperimental && h->ray_pass) ? (std::min(h->ray_cap, h->ray_waves) + wpb - 1) / wpb : 0u;
             j.long_prio = (uint32_t)h->exp.long_prio;
             j.long_rev = h->task_rev;
             h->task_epoch += 1u;
-            const dim3 sgrid(grid.x + j.long_blocks + j.ray_blocks);
+            const dim3 sgrid(grid.x + j.long_blocks);
             size_t slds = 0;
 #ifdef F110_EXPERIMENTAL
             // probe: fewer waves per SIMD (an LDS reservation per one-wave workgroup) so that last step's long tasks,
@@ -2510,48 +2316,21 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         const bool narrow = h->dev.reseat_poses != nullptr;
         // (with the pair test inside the kernel a group also carries that prologue: 16 lanes from 8192 agents up)
         int lanes = narrow && N >= 131072 ? 8 : (narrow && N >= (pair_in_finalize ? 8192 : 32768) ? 16 : 64);
-        bool flat = pair_in_finalize && kFinalizeFlatDefault;
-#ifdef F110_EXPERIMENTAL
-        if (h->exp.finalize_lanes) lanes = h->exp.finalize_lanes;
-        if (h->exp.finalize_flat >= 0) flat = pair_in_finalize && h->exp.finalize_flat != 0;
-#endif
-        if (pair_in_finalize && flat) {
-            // the window loop flattened over the workgroup: AG agents per 256 threads (256 / AG lanes each in the
-            // prologue).  More agents per workgroup = fewer prologue waves and a better-balanced item list; small
-            // batches want the workgroups many (measured: 65 536 agents AG 32 / 16 / 4: 0.726 / 0.738 / 0.815 ms;
-            // 4096 agents AG 16 / 4: 0.1047 / 0.1053)
+        if (pair_in_finalize) {
+            // k_finalize_pair_roles: the window loop flattened over the workgroup, AG agents per 256 threads, the prologue dealt
+            // by role.  More agents per workgroup = fewer prologue waves and a better-balanced item list; small batches want
+            // the workgroups many (measured: 65 536 agents AG 32 / 16 / 4: 0.726 / 0.738 / 0.815 ms; 4096 agents AG 16 / 4:
+            // 0.1047 / 0.1053).  (Rounds 2-3's forms — fixed lanes per agent, the prologue dealt by agent — were retired in round 5.)
             lanes = N >= 32768 ? 8 : (N >= 4096 ? 16 : 64);
-#ifdef F110_EXPERIMENTAL
-            if (h->exp.finalize_lanes) lanes = h->exp.finalize_lanes;
-#endif
-            bool roles = kFinalizeRolesDefault;
-#ifdef F110_EXPERIMENTAL
-            if (h->exp.finalize_roles >= 0) roles = h->exp.finalize_roles != 0;
-#endif
-            if (roles) {
-                if (h->fuse_request && begin == 0 && count == N && !dev.reseat_poses) {   // f110_step_host: host block + episode logic as this kernel's epilogue
-                    dev.fused_host = h->d_fused;
-                    dev.fused_seq = h->fuse_seq;
-                    h->fused_done = true;
-                }
-                if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_roles<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
-                else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_roles<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
-                else hipLaunchKernelGGL(k_finalize_pair_roles<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
+            if (h->fuse_request && begin == 0 && count == N && !dev.reseat_poses) {   // f110_step_host: host block + episode logic as this kernel's epilogue
+                dev.fused_host = h->d_fused;
+                dev.fused_seq = h->fuse_seq;
+                h->fused_done = true;
             }
-#ifdef F110_EXPERIMENTAL
-            else if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_flat<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
-            else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_flat<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
-            else hipLaunchKernelGGL(k_finalize_pair_flat<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
-#endif
+            if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_roles<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
+            else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_roles<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
+            else hipLaunchKernelGGL(k_finalize_pair_roles<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
         }
-#ifdef F110_EXPERIMENTAL
-        else if (pair_in_finalize) {   // round 2's form: fixed lanes per agent (A/B)
-            if (lanes == 8) hipLaunchKernelGGL(k_finalize_pair<8>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
-            else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
-            else if (lanes == 32) hipLaunchKernelGGL(k_finalize_pair<32>, dim3((count + 7) / 8), dim3(256), 0, st, dev, B);
-            else hipLaunchKernelGGL(k_finalize_pair<64>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
-        }
-#endif
         else if (multi_in_finalize) {
             const int envs = count / A;   // whole envs per workgroup
             if (A * (A - 1) <= kMaxRec) {
@@ -2567,10 +2346,6 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             hipLaunchKernelGGL(k_finalize<8>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
         else if (lanes == 16)
             hipLaunchKernelGGL(k_finalize<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
-#ifdef F110_EXPERIMENTAL
-        else if (lanes == 32)
-            hipLaunchKernelGGL(k_finalize<32>, dim3((count + 7) / 8), dim3(256), 0, st, dev, B);
-#endif
         else
             hipLaunchKernelGGL(k_finalize<64>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
     } else {
@@ -2661,47 +2436,6 @@ int f110_step_device(f110_sim *h, const double *d_actions)
                 if (!(ev[i] = prof_event(h))) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
         }
         const int cmode = h->collide_mode;
-#ifdef F110_EXPERIMENTAL
-        if (h->use_graph && !prof) {
-            // the four launches and the fork/join of the side stream as ONE graph submission.  A graph is
-            // valid for one set of launch arguments: every value a launch depends on is part of the key
-            // (the agent arrays incl. re-seat / noise pointers, the scan constants, the action buffer, which
-            // optional kernels run, the switches); anything else that a launch reads through a pointer the
-            // handle may free and re-allocate (maps, beam tables, parameters) drops the cache (graphs_clear)
-            if (!cold_consts(h)) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
-            const int flags = (h->lookups_on ? 1 : 0) | (h->path_stats_on ? 2 : 0) | (cmode << 2) |
-                              ((h->dev.noise_rng && (h->dev.noise_rng == 2 || h->noise_ub >= (long long)h->dev.noise_rows)) ? 16 : 0);
-            hipGraphExec_t exec = nullptr;
-            for (auto &g : h->graphs)
-                if (g.actions == d_actions && g.flags == flags && g.noise_scale == h->noise_gen.scale && std::memcmp(&g.exp, &h->exp, sizeof(ExpSwitches)) == 0 &&
-                    std::memcmp(&g.dev, &h->dev, sizeof(AgentArrays)) == 0 && std::memcmp(&g.k, &h->k, sizeof(ScanConst)) == 0) {
-                    exec = g.exec;
-                    break;
-                }
-            if (!exec) {
-                if (h->graphs.size() >= 64) TRY(graphs_clear(h));
-                hipGraph_t graph = nullptr;
-                HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-                const int rc = step_range(h, h->stream, 0, N, d_actions, cmode, nullptr);
-                const hipError_t ec = hipStreamEndCapture(h->stream, &graph);
-                if (rc != F110_OK) return rc;
-                if (ec != hipSuccess || !graph) return fail(h, F110_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ec));
-                const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                if (ei != hipSuccess) return fail(h, F110_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
-                f110_sim::StepGraph g;
-                g.dev = h->dev;
-                g.k = h->k;
-                g.exp = h->exp;
-                g.noise_scale = h->noise_gen.scale;
-                g.actions = d_actions;
-                g.flags = flags;
-                g.exec = exec;
-                h->graphs.push_back(g);
-            }
-            HIPCHK(h, hipGraphLaunch(exec, h->stream));
-        } else
-#endif
         {
             TRY(step_range(h, h->stream, 0, N, d_actions, cmode, prof ? ev : nullptr));
         }

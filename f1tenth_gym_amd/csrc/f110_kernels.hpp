@@ -303,8 +303,7 @@ __device__ __forceinline__ void integrate_store(const AgentArrays &a, const Scan
     }
     a.in_collision[i] = 0;  // raised by k_scan_rays when any beam's iTTC is under the threshold
     if (a.sched_count_zero && i == a.agent_begin) {
-        a.sched_count_zero[0] = 0u;   // this step's task list ...
-        a.sched_count_zero[2] = 0u;   // ... and ray list (TaskSched::count_w / rcount_w)
+        a.sched_count_zero[0] = 0u;   // this step's task list (TaskSched::count_w)
     }
 }
 
@@ -532,12 +531,6 @@ __global__ void __launch_bounds__(256) k_collide(AgentArrays a, int32_t B)
 // launch.  flags_r[task] == epoch_r marks "on the list" (the normal blocks skip those tasks); this step's
 // long tasks go to list_w / flags_w for the next step (stamped epoch_w; stale stamps never match again, so
 // nothing is ever cleared).  Stale or missing entries only cost speed: every task is marched exactly once.
-// the ray-level pass below was measured not to pay: it exists in the experimental build only
-#ifdef F110_EXPERIMENTAL
-constexpr bool kRayPassBuilt = true;
-#else
-constexpr bool kRayPassBuilt = false;
-#endif
 
 struct TaskSched {
     const uint32_t *flags_r;
@@ -547,21 +540,6 @@ struct TaskSched {
     const uint32_t *count_r;
     uint32_t *count_w;   // zeroed by k_integrate of the same step
     uint32_t cap, thr;
-    // The same idea one level down (round 3): a RAY that took more than `rthr` lookups in the previous step is
-    // listed by its number, stamped in rflags (one epoch word per ray), skipped by the lane that would
-    // normally march it, and marched by a wave of its own at the front of the launch, which reads the table a
-    // 16 x 16-cell block at a time (march_padded_block): one memory round trip per ~10 samples of a ray that
-    // creeps along a wall instead of one per sample.  The scan of a small batch ends when its longest ray
-    // ends; this shortens exactly that chain.  rcount_w sits two words behind count_w.
-    const uint32_t *rflags_r;
-    uint32_t *rflags_w;
-    const uint32_t *rtask_r;   // [n_tasks] epoch stamps: some ray of this task is on the ray list (only then do the
-    uint32_t *rtask_w;         //           task's lanes look at their per-ray stamps)
-    const uint32_t *rlist_r;
-    uint32_t *rlist_w;
-    const uint32_t *rcount_r;
-    uint32_t *rcount_w;
-    uint32_t rcap, rthr;
 };
 
 struct RayJob {
@@ -570,13 +548,12 @@ struct RayJob {
     uint32_t tasks_per_wave;  // consecutive tasks each wave walks
     int32_t n_poses;
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
-    int32_t dir_mode, dir_stride;   // dedupe pass: rays are (agent, distinct direction), dir_stride per agent
-    const double *dir_ranges;       // k_expand_beams: [n_poses][dir_stride] raw ranges of the dedupe pass
+    int32_t pad_dir, dir_stride;    // k_scan_dirs_agent: distinct directions per agent, rounded up to whole 64-direction tasks
     uint32_t first_pose, spec_from; // k_scan_rays_agent: the launch covers agents first_pose .. (env group); SPEC: march_padded_spec from this sample on
     unsigned long long *lookups_total;  // COUNT variants: table lookups of every marched ray, summed (or nullptr)
     // longest-first task order (k_scan_rays_agent<.., SCHED>): see TaskSched
     TaskSched sched;   // by value: the kernel argument segment is the one read a wave never waits long for
-    uint32_t epoch_r, epoch_w, long_blocks, ray_blocks;
+    uint32_t epoch_r, epoch_w, long_blocks, pad_blocks;
     // fusion-feasibility probe (experimental build): per-env count of finished scan tasks, reset by the last arriver
     uint32_t *env_done;
     uint32_t tasks_per_env, long_prio;
@@ -589,11 +566,6 @@ struct RayJob {
     // block order hands each XCD's L2 the agents of as few tracks as possible however the caller interleaved
     // them (nullptr: agent order)
     const uint32_t *order;
-    // k_scan_rays_window: 1-byte codes of the padded table (row-major, `win_pitch` bytes per row, a multiple
-    // of 16) and the 256-entry exact value LUT (entry 255 unused: code 255 = "read the float64 table")
-    const uint8_t *win_codes;
-    const double *win_lut;
-    uint32_t win_pitch, pad_win;
     const double *pose_x, *pose_y, *dir_start;  // [n_poses] (unit path)
     double *ranges;           // [n_poses][B]
     // STEP only
@@ -659,7 +631,7 @@ __device__ __forceinline__ LaneHdr load_lane_hdr(const RayHdr *hdr, uint32_t p)
     return o;
 }
 
-// noise + iTTC + store for one beam (shared by k_scan_rays and k_expand_beams).
+// noise + iTTC + store for one beam (k_scan_rays, k_scan_dirs_agent).
 // check_ttc_jit is an any-over-beams: every hitting lane raises the agent's flag.
 // r > max(side) + thresh*(1+1e-9)*max|cos|*|v| implies r - side_distances[b] >
 // thresh*(1+1e-12)*|v*cosines[b]|, i.e. the "no hit" branch of ttc_beam_hit, so the per-beam
@@ -703,14 +675,8 @@ __device__ __forceinline__ double trace_from_first(const ScanConst &k, const Sca
 template <int LAYOUT, bool POW2, bool IDENT, bool STEP>
 __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
 {
-    __shared__ double lut_lds[LAYOUT == LAYOUT_CODE8 ? 256 : 1];
-    if (LAYOUT == LAYOUT_CODE8) {
-        // stage the 2 KB value LUT once per workgroup; every wave then walks j.tasks_per_wave
-        // consecutive 64-ray tasks so the fill is amortised
-        for (int t = threadIdx.x; t < kLutEntries; t += blockDim.x) lut_lds[t] = k.lut[t];
-        __syncthreads();
-    }
-    const uint32_t B = (STEP && j.dir_mode) ? (uint32_t)j.dir_stride : (uint32_t)k.num_beams;
+    const double *lut_lds = nullptr;   // (the byte-code layout's value table: retired in round 5)
+    const uint32_t B = (uint32_t)k.num_beams;
     const uint32_t tpw = j.tasks_per_wave;
     const uint32_t lane = threadIdx.x & 63u;
     // Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md).  Re-map so that each
@@ -736,19 +702,6 @@ __global__ void __launch_bounds__(256) k_scan_rays(RayJob j, ScanConst k)
             const LaneHdr hd = load_lane_hdr(j.hdr, p);
             hr = -1;
             hc = -1;
-            if (j.dir_mode) {
-                // dedupe pass: "beam" b is the b-th distinct table direction of agent p's scan;
-                // raw range only (noise / iTTC / beam expansion happen in k_expand_beams)
-                if (b < hd.n_dirs) {
-                    int didx = hd.i0 + b;
-                    if (didx >= k.theta_dis) didx -= k.theta_dis;
-                    const double2 cs = k.cs[didx];
-                    j.ranges[ray] = trace_from_first<LAYOUT, POW2, IDENT, false>(k, j.k_cold, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl,
-                                                                                 path);
-                    nl_acc += (uint32_t)nl;
-                }
-                continue;
-            }
             const double2 cs = k.cs[beam_dir_index(k, hd.start, b)];
             r = trace_from_first<LAYOUT, POW2, IDENT, false>(k, j.k_cold, lut_lds, hd.x, hd.y, hd.fast != 0, cs.x, cs.y, hd.d0, hr, hc, nl, path);
             nl_acc += (uint32_t)nl;
@@ -794,95 +747,6 @@ struct MapFast {
 };
 static_assert(sizeof(MapFast) == 64, "MapFast is read as one 64-byte scalar load");
 
-// march_padded for ONE ray marched by a whole wave (every lane holds the same position): identical arithmetic,
-// but the table is read a 16 x 16-cell block at a time — lane l keeps the cells of rows (l >> 4) + 4 q,
-// q = 0..3, column (l & 15) of the block in four registers, one load instruction per row group, all in flight
-// together — and a sample that lands inside the block is a v_readlane, not a trip through the memory system.
-// A ray that creeps along a wall takes 5-13 samples per block.  The block the ray will enter next (13 cells
-// further along its direction) is requested as soon as the current one is entered, so that its (cold: nobody
-// else has touched those lines) fetch runs under the samples of the current block; a sample that jumps further
-// than a block (open space: the step is the distance to the nearest wall) is read on its own.
-__device__ __forceinline__ bool march_padded_block(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
-                                                   int &lookups, int &blocks)
-{
-    blocks = 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    const char *base = reinterpret_cast<const char *>(k.pad);
-    const int lead_c = cux >= 0. ? 2 : 13, lead_r = cuy >= 0. ? 2 : 13;   // (uniform) the entry cell sits near the trailing edge
-    const double cmax = fmax(fabs(cux), fabs(cuy));                      // cells per metre along the dominant axis
-    const int step_c = __builtin_amdgcn_readfirstlane((int)rint(13.0 * cux / cmax));
-    const int step_r = __builtin_amdgcn_readfirstlane((int)rint(13.0 * cuy / cmax));
-    const double far = 12.0 / cmax;                                      // a step longer than this leaves any block
-    const uint32_t lane_off = (lane >> 4) * (uint32_t)k.pad_row_bytes + ((lane & 15u) << 3);
-    const uint32_t r4 = 4u * (uint32_t)k.pad_row_bytes;
-    int bc = -0x10000, br = -0x10000, nbc = -0x10000, nbr = -0x10000;   // origins of the current / the requested block
-    double v0 = 0., v1 = 0., v2 = 0., v3 = 0., n0 = 0., n1 = 0., n2 = 0., n3 = 0.;
-    auto origin = [&](int c, int lead, int hi) { c -= lead; return c < 0 ? 0 : (c > hi ? hi : c); };
-    double total = d;
-    int n = 1;
-    bool redo = false;
-    while ((d > k.eps) & (total <= k.max_range) & !redo) {
-        const bool jump = d > far;
-        ux = fma(d, cux, ux);
-        uy = fma(d, cuy, uy);
-        const uint32_t wx = low_word(ux + kFixBig);
-        const uint32_t wy = low_word(uy + kFixBig);
-        int cc = (int)(wx >> kFixFracBits), cr = (int)(wy >> kFixFracBits);
-        if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {   // march_padded's guard band, verbatim
-            redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
-            cc = (int)floor(ux);
-            cr = (int)floor(uy);
-        }
-        cc = __builtin_amdgcn_readfirstlane(cc);
-        cr = __builtin_amdgcn_readfirstlane(cr);
-        int dc = cc - bc, dr = cr - br;
-        if ((((uint32_t)dc) | ((uint32_t)dr)) >= 16u) {   // wave-uniform: not in the current block
-            const int ndc = cc - nbc, ndr = cr - nbr;
-            const bool in_next = (((uint32_t)ndc) | ((uint32_t)ndr)) < 16u;
-            if (!in_next && __builtin_amdgcn_readfirstlane((int)jump)) {
-                // a long step in open space: one cell, no block
-                d = *reinterpret_cast<const double *>(base + (mul24((uint32_t)cr, (uint32_t)k.pad_row_bytes) + ((uint32_t)cc << 3)));
-                total += d;
-                ++n;
-                continue;
-            }
-            if (in_next) {   // the requested block becomes the current one (its loads have had a block's worth of samples to land)
-                bc = nbc; br = nbr;
-                v0 = n0; v1 = n1; v2 = n2; v3 = n3;
-            } else {
-                bc = origin(cc, lead_c, k.pad_width - 16);
-                br = origin(cr, lead_r, k.pad_height - 16);
-                const char *p0 = base + (mul24((uint32_t)br, (uint32_t)k.pad_row_bytes) + ((uint32_t)bc << 3)) + lane_off;
-                v0 = *reinterpret_cast<const double *>(p0);
-                v1 = *reinterpret_cast<const double *>(p0 + r4);
-                v2 = *reinterpret_cast<const double *>(p0 + 2u * r4);
-                v3 = *reinterpret_cast<const double *>(p0 + 3u * r4);
-                ++blocks;
-            }
-            {   // request the block after this one
-                nbc = origin(cc + step_c, lead_c, k.pad_width - 16);
-                nbr = origin(cr + step_r, lead_r, k.pad_height - 16);
-                const char *p1 = base + (mul24((uint32_t)nbr, (uint32_t)k.pad_row_bytes) + ((uint32_t)nbc << 3)) + lane_off;
-                n0 = *reinterpret_cast<const double *>(p1);
-                n1 = *reinterpret_cast<const double *>(p1 + r4);
-                n2 = *reinterpret_cast<const double *>(p1 + 2u * r4);
-                n3 = *reinterpret_cast<const double *>(p1 + 3u * r4);
-            }
-            dc = cc - bc;
-            dr = cr - br;
-        }
-        const int q = dr >> 2;
-        const double vq = q == 0 ? v0 : (q == 1 ? v1 : (q == 2 ? v2 : v3));
-        const int src = ((dr & 3) << 4) | dc;
-        d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(vq), src), __builtin_amdgcn_readlane(__double2loint(vq), src));
-        total += d;
-        ++n;
-    }
-    lookups = n;
-    range = (total > k.max_range) ? k.max_range : total;
-    return !(redo | (n > k.pad_max_samples));
-}
-
 // the per-env map's constants through the scalar cache (one 64-byte record), pinned to SGPRs
 __device__ __forceinline__ void load_map_fast(ScanConst &km, const MapFast *__restrict__ maps_fast, int slot)
 {
@@ -920,56 +784,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
     uint32_t trace_samples = 0;
 #endif
     if (SCHED) {
-        if (kRayPassBuilt && blk < j.ray_blocks) {
-            // ---- ray pass: last step's longest RAYS, one per wave, newest list entries (= the rays that finished
-            // last, i.e. the longest) first
-            const TaskSched &sc = j.sched;
-            const uint32_t nw = j.ray_blocks * (blockDim.x >> 6);
-            uint32_t cnt = *(cu32_t)sc.rcount_r;
-            cnt = cnt < sc.rcap ? cnt : sc.rcap;
-            typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
-            for (uint32_t w = __builtin_amdgcn_readfirstlane((blk * blockDim.x + threadIdx.x) >> 6); w < cnt; w += nw) {
-                const uint32_t ray = ((cu32_t)sc.rlist_r)[cnt - 1u - w];
-                if (ray >= j.n_rays || ((cu32_t)sc.rflags_r)[ray] != j.epoch_r) continue;   // (every slot below cnt was written this epoch; belt and braces)
-                const uint32_t p = ray / B;
-                const int b = (int)(ray - p * B);
-                const chdr_t h0 = (chdr_t)(j.hdr) + p;
-                const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
-                const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
-                const int row = uniform_i32(h0->noise_row), fast = uniform_i32(h0->fast);
-                const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;
-                const double nz = row != -1 ? nrow[b] : 0.0;
-                const double2 cs = k.cs[beam_dir_index(k, start, b)];
-                int hr = -1, hc = -1, nl, nblk = 0;
-                double r = 0.;
-                bool exact = fast == 0;
-                if (fast) {
-                    double ux, uy, cux, cuy;
-                    padded_position<IDENT>(k, x, y, ux, uy);
-                    padded_rate<IDENT>(k, cs.x, cs.y, cux, cuy);
-                    exact = !march_padded_block(k, ux, uy, cux, cuy, d0, r, nl, nblk);
-                }
-                if (j.path_stats && lane == 0u) {   // diagnostics: rays / block fetches / samples of the ray pass
-                    atomicAdd(&j.path_stats[0], 1ull);
-                    atomicAdd(&j.path_stats[1], (unsigned long long)nblk);
-                    atomicAdd(&j.path_stats[2], (unsigned long long)nl);
-                }
-                if (exact) r = march_exact_cold<IDENT>(j.k_cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
-                if (lane == 0u) {
-                    if (nl > (int)sc.rthr) {   // still long: stays on the list
-                        const uint32_t pos = atomicAdd(sc.rcount_w, 1u);
-                        if (pos < sc.rcap) {
-                            sc.rlist_w[pos] = ray;
-                            sc.rflags_w[ray] = j.epoch_w;
-                            sc.rtask_w[p * tasks_per_agent + ((uint32_t)b >> 6)] = j.epoch_w;
-                        }
-                    }
-                    finish_beam_with(j, p, b, ray, row != -1 ? r + nz : r, vel);
-                }
-            }
-            return;
-        }
-        blk -= j.ray_blocks;
         if (blk < j.long_blocks) {   // the first blocks of the launch serve last step's long tasks, one per wave
             const TaskSched &sc = j.sched;
             const uint32_t wl = __builtin_amdgcn_readfirstlane((blk * blockDim.x + threadIdx.x) >> 6);
@@ -985,7 +799,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
         }
     }
     if (!long_pass) {
-        const uint32_t nb = gridDim.x - (SCHED ? j.long_blocks + j.ray_blocks : 0u), q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
+        const uint32_t nb = gridDim.x - (SCHED ? j.long_blocks : 0u), q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
         blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // XCD-contiguous, as k_scan_rays
     }
     const uint32_t wave = (blk * blockDim.x + threadIdx.x) >> 6;
@@ -1021,10 +835,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
         if (SCHED && !long_pass && stamp == j.epoch_r) continue;   // served by the long pass
         const int b = (int)((task - pl * tasks_per_agent) * 64u + lane);
         if (b >= (int)B) continue;
-        // a ray the ray pass marches (stamped in the previous step) is skipped by its lane; the stamp is requested
-        // here and looked at after the noise sample and the direction have been requested too (one round trip)
-        uint32_t ray_stamp = 0u;
-        if (SCHED && kRayPassBuilt && j.ray_blocks && ((cu32_t)j.sched.rtask_r)[task] == j.epoch_r) ray_stamp = j.sched.rflags_r[p * B + (uint32_t)b];
         if (PER_ENV_MAP && slot != cur_slot) {   // wave-uniform
             cold = maps_full + slot;
             load_map_fast(km, maps_fast, slot);
@@ -1041,11 +851,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
             trace_ops = wall_clock64();
         }
 #endif
-        const bool mine = !(SCHED && kRayPassBuilt && j.ray_blocks && ray_stamp == j.epoch_r);   // false: the ray pass has this ray
         int hr = -1, hc = -1, nl = 0;
         double r = 0.;
-        bool exact = mine && fast == 0;
-        if (mine && fast) {
+        bool exact = fast == 0;
+        if (fast) {
             double ux, uy, cux, cuy;
             padded_position<IDENT>(km, x, y, ux, uy);
             padded_rate<IDENT>(km, cs.x, cs.y, cux, cuy);
@@ -1067,26 +876,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
             trace_samples += (uint32_t)m;
         }
 #endif
-        if (SCHED && kRayPassBuilt && j.ray_blocks) {
-            // this step's long rays go on the ray list for the next step: one atomic per wave that has any
-            const TaskSched &sc = j.sched;
-            const bool listed = nl > (int)sc.rthr;
-            const uint64_t lm = __ballot(listed);
-            if (lm != 0ull) {
-                uint32_t pos = 0u;
-                if (lane == (uint32_t)__builtin_ctzll(lm)) pos = atomicAdd(sc.rcount_w, (uint32_t)popc_u64(lm));
-                pos = (uint32_t)__shfl((int)pos, __builtin_ctzll(lm)) + (uint32_t)popc_u64(lm & ((1ull << lane) - 1ull));
-                if (listed && pos < sc.rcap) {
-                    sc.rlist_w[pos] = p * B + (uint32_t)b;
-                    sc.rflags_w[p * B + (uint32_t)b] = j.epoch_w;
-                    sc.rtask_w[task] = j.epoch_w;   // (every listed lane stores the same word)
-                }
-            }
-        }
         if (SCHED) {
             const TaskSched &sc = j.sched;
             if (__ballot(nl > (int)sc.thr) != 0ull && lane == 0u) {
-                // lane 0 (beam task*64, always a valid beam; nl = 0 if the ray pass has its ray) appends the task for the next step
+                // lane 0 (beam task*64, always a valid beam) appends the task for the next step
                 const uint32_t pos = atomicAdd(sc.count_w, 1u);
                 if (pos < sc.cap) {
                     sc.list_w[pos] = task;
@@ -1094,7 +887,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
                 }
             }
         }
-        if (mine) finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
+        finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
         if (ENVCNT && lane == 0u) {
             // probe: what a per-env completion counter costs (one returning agent-scope atomic per task; the
             // arrival that completes the env resets the counter, as a fused finalize would before it runs)
@@ -1282,112 +1075,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8))) k
 }
 #endif  // F110_EXPERIMENTAL (K2s)
 
-#ifdef F110_EXPERIMENTAL   // measured and rejected: not part of the product library
-// ---- K2w: the step's ray march with the agent's neighbourhood staged in LDS ------------------------
-// north_star's "occupancy grid in LDS".  One workgroup = one agent: the kWin x kWin cells around the
-// lidar (1-byte codes of the padded table, 16 KB) and the exact 256-entry value LUT (2 KB) are staged
-// with coalesced 16-byte loads; a sample that lands inside the window costs two LDS reads (code,
-// value) and no vector-memory instruction; a sample outside it, or on a cell whose value is not one
-// of the 255 LUT values (code 255), reads the float64 table exactly as k_scan_rays_agent does.
-// Same march arithmetic (march_padded), hence the same bits.  The window origin is folded into the
-// fixed-point constant, so the word pair is window-relative: both cells inside <=> (wx | wy) < kWin<<16.
-constexpr int kWin = 128;   // cells per side (power of two: one OR + one compare decides "inside")
-
-template <bool IDENT, bool COUNT>
-__global__ void __launch_bounds__(256) k_scan_rays_window(RayJob j, ScanConst k, uint32_t tasks_per_agent)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t win[kWin * kWin];
-    __shared__ double lut[256];
-    const uint32_t B = (uint32_t)k.num_beams;
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint32_t blk = blockIdx.x;
-    {
-        const uint32_t nb = gridDim.x, q = nb >> 3, rem = nb & 7u, x = blk & 7u, i = blk >> 3;
-        blk = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;  // XCD-contiguous, as k_scan_rays
-    }
-    const uint32_t p = j.first_pose + blk;
-    typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
-    const chdr_t h0 = (chdr_t)(j.hdr) + p;
-    const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
-    const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
-    const int row = uniform_i32(h0->noise_row), fast = uniform_i32(h0->fast);
-    double ux0 = 0., uy0 = 0.;
-    int x0 = 0, y0 = 0;
-    if (fast) {   // workgroup-uniform
-        padded_position<IDENT>(k, x, y, ux0, uy0);
-        x0 = (((int)ux0) - kWin / 2) & ~15;   // 16-byte aligned rows
-        y0 = ((int)uy0) - kWin / 2;
-        const uint8_t *src = j.win_codes + (size_t)y0 * j.win_pitch + x0;
-#pragma unroll
-        for (int i = 0; i < kWin * kWin / 16 / 256; ++i) {
-            const uint32_t r = (threadIdx.x >> 3) + 32u * i, c16 = (threadIdx.x & 7u) << 4;
-            *reinterpret_cast<uint4 *>(win + r * kWin + c16) = *reinterpret_cast<const uint4 *>(src + (size_t)r * j.win_pitch + c16);
-        }
-        lut[threadIdx.x] = j.win_lut[threadIdx.x];
-    }
-    __syncthreads();
-    const double fixx = kFixBig - (double)x0, fixy = kFixBig - (double)y0;   // exact: integers below 2^16
-    const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;   // scalar
-    const __attribute__((address_space(1))) char *base = (const __attribute__((address_space(1))) char *)(k.pad);
-    uint32_t nl_acc = 0, lds_acc = 0;
-    for (uint32_t task = wv; task < tasks_per_agent; task += 4u) {
-        const int b = (int)(task * 64u + lane);
-        if (b >= (int)B) continue;
-        const double nz = row != -1 ? nrow[b] : 0.0;
-        const double2 cs = k.cs[beam_dir_index(k, start, b)];
-        int hr = -1, hc = -1, nl = 1;
-        double r = 0.;
-        bool exact = fast == 0;
-        if (fast) {
-            double ux = ux0, uy = uy0, cux, cuy;
-            padded_rate<IDENT>(k, cs.x, cs.y, cux, cuy);
-            double d = d0, total = d0;
-            bool redo = false;
-            while ((d > k.eps) & (total <= k.max_range) & !redo) {
-                ux = fma(d, cux, ux);
-                uy = fma(d, cuy, uy);
-                const uint32_t wx = low_word(ux + fixx);   // window-relative 16.16 words
-                const uint32_t wy = low_word(uy + fixy);
-                uint32_t code = 255u;
-                bool have_off = false;
-                uint32_t off = 0u;
-                if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {
-                    // march_padded's guard band: floor in full precision, give up inside kPadGuard
-                    redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
-                    off = mul24((uint32_t)(int)floor(uy), (uint32_t)k.pad_row_bytes) + ((uint32_t)(int)floor(ux) << 3);
-                    have_off = true;
-                } else if ((wx | wy) < ((uint32_t)kWin << kFixFracBits)) {
-                    code = win[((wy >> kFixFracBits) << 7) | (wx >> kFixFracBits)];
-                }
-                // the LUT read is unconditional (entry 255 is a dummy) and the table read goes through an
-                // explicit global pointer: left as two arms of one `if`, the compiler merges them into a
-                // single FLAT load of a selected pointer — which travels the texture path for every lane
-                d = lut[code];
-                if (COUNT) lds_acc += code != 255u ? 1u : 0u;
-                if (code == 255u) {
-                    if (!have_off)
-                        off = mul24((uint32_t)(((int32_t)wy >> kFixFracBits) + y0), (uint32_t)k.pad_row_bytes) +
-                              ((uint32_t)(((int32_t)wx >> kFixFracBits) + x0) << 3);
-                    d = *reinterpret_cast<const __attribute__((address_space(1))) double *>(base + off);
-                }
-                total += d;
-                ++nl;
-            }
-            r = (total > k.max_range) ? k.max_range : total;
-            exact = redo | (nl > k.pad_max_samples);
-        }
-        if (exact) r = march_exact_cold<IDENT>(j.k_cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
-        if (COUNT) nl_acc += (uint32_t)nl;
-        finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + nz : r, vel);
-    }
-    if (COUNT) {
-        wave_add_lookups(j.lookups_total, nl_acc);
-        wave_add_lookups(j.lookups_total + 1, lds_acc);   // [1]: samples served by the LDS window
-    }
-}
-
-#endif  // F110_EXPERIMENTAL
-
 // iTTC + store for one beam whose noise sample has been added already
 __device__ __forceinline__ void finish_beam_with(const RayJob &j, uint32_t p, int b, uint32_t ray, double r, double vel)
 {
@@ -1502,28 +1189,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_D
     if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
 }
 
-#ifdef F110_EXPERIMENTAL   // two-pass dedupe: superseded by k_scan_dirs_agent
-// ---- K2b: beam expansion of the dedupe pass ---------------------------------------------------
-// More beams than table directions (BASELINE config 5: 4096 beams, theta_dis = 2000 -> 1497
-// distinct directions per scan): beams that share a table index from the same origin are the same
-// ray.  k_scan_rays (dir_mode) marches each distinct direction once; here every beam picks its
-// direction's range, then gets its own noise sample and iTTC test.  Bit-identical to marching
-// every beam, ~2.7x fewer table gathers.
-__global__ void __launch_bounds__(256) k_expand_beams(RayJob j, ScanConst k)
-{
-    const uint32_t B = (uint32_t)k.num_beams;
-    const uint32_t ray = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ray >= j.n_rays) return;
-    const uint32_t p = j.div_magic ? (__umulhi(ray, j.div_magic) >> j.div_shift) : ray / B;
-    const int b = (int)(ray - p * B);
-    const LaneHdr hd = load_lane_hdr(j.hdr, p);
-    int s = beam_dir_index(k, hd.start, b) - hd.i0;
-    if (s < 0) s += k.theta_dis;
-    const double r = j.dir_ranges[(size_t)p * j.dir_stride + s];
-    finish_beam(j, B, p, b, ray, r, hd.row, hd.vel);
-}
-
-#endif  // F110_EXPERIMENTAL
 
 // ---- scan noise generated on the device --------------------------------------------
 // rng.normal(0., std, num_beams) of laser_models.py:450-452 — NumPy's PCG64 + ziggurat, restated in
@@ -1704,225 +1369,6 @@ __global__ void __launch_bounds__(256) k_finalize(AgentArrays a, int32_t B)
     }
 }
 
-// ---- K3p: finalize for two-agent envs, pair test and opponent window computed in place ------------------
-// What k_collide prepares for k_finalize — the GJK flag of the env's one pair and the beam window the
-// opponent can occupy — costs a second stream and an event fork/join per step (14 us).  With
-// two agents per env the work is small enough to sit at the top of k_finalize, spread over the lanes an
-// agent has there: lanes 0-3 take one box corner each (vertex_beam_index), lane 4 the disc cull, lane 5
-// the pair test; group shuffles combine them.  Only the window for the heading that is actually live
-// (zeroed or not) is needed here, where k_collide had to prepare both.  Same functions on the same
-// inputs as k_collide + k_finalize: bit-identical.
-template <int kFinalizeLanes>
-__global__ void __launch_bounds__(256) k_finalize_pair(AgentArrays a, int32_t B)
-{
-    constexpr int kFinalizeAgents = 256 / kFinalizeLanes;
-    const int i = a.agent_begin + (int)(blockIdx.x * kFinalizeAgents + threadIdx.x / kFinalizeLanes), tid = threadIdx.x & (kFinalizeLanes - 1);
-    const int N = a.n_agents_total;
-    if (i >= a.agent_begin + a.agent_count) return;   // whole groups leave together
-    const int me = i & 1, o = i ^ 1;                   // env-aligned ranges: the pair is (2e, 2e + 1)
-    const int wall = a.in_collision[i];
-    const double ex = a.state[i], ey = a.state[(size_t)N + i];
-    const double th_live = a.state[4 * (size_t)N + i];   // == the :574 snapshot heading: nothing has zeroed it yet
-    const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
-    const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
-    const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
-    const double eth = wall ? 0.0 : th_live;
-    double v[8];   // the opponent drawn with MY length / width (RaceCar.ray_cast_agents :223)
-    box_vertices(ox, oy, oth, blen, bwid, v);
-    int idx = 0, cl = 0, ch = B - 1, hit = 0;
-    {
-        // One instruction stream for lanes 0-4: the arc tangent of the heading that both
-        // vertex_beam_index and disc_beam_range take is computed once, and the arc tangent of the
-        // direction to "my point" — a box corner (normalised, :296-300) for lanes 0-3, the box centre
-        // (as it is, disc_beam_range) for lane 4 — in one call.  The same operations on the same operands
-        // as the two functions, only not twice.
-        double ce_, se_;
-        cos_sin(eth, ce_, se_);
-        const double head = atan2(se_, ce_);
-        const double px = tid == 0 ? v[0] : (tid == 1 ? v[2] : (tid == 2 ? v[4] : (tid == 3 ? v[6] : ox)));
-        const double py = tid == 0 ? v[1] : (tid == 1 ? v[3] : (tid == 2 ? v[5] : (tid == 3 ? v[7] : oy)));
-        const double dx = px - ex, dy = py - ey;
-        const double norm = sqrt(dx * dx + dy * dy);
-        const double qx = tid < 4 ? dx / norm : dx, qy = tid < 4 ? dy / norm : dy;
-        const double dir = atan2(qy, qx);
-        if (tid < 4) {
-            idx = vertex_beam_from_angles(head, dir, a.scan_angles, B, a.angle_inc);
-        } else if (tid == 4) {
-            disc_beam_range_from(norm, eth, dir, head, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
-        } else if (tid == 5) {
-            // collision_multiple on the env's one pair, boxes with the Simulator's length / width (:549)
-            const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
-            const double cdx = ox - ex, cdy = oy - ey;
-            if (cdx * cdx + cdy * cdy <= reach * reach) {
-                double mine[8], other[8];
-                box_vertices(ex, ey, th_live, a.box_length, a.box_width, mine);
-                box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
-                hit = (me == 0 ? gjk_overlap(mine, other) : gjk_overlap(other, mine)) ? 1 : 0;
-            }
-        }
-    }
-    const int i0 = __shfl(idx, 0, kFinalizeLanes), i1 = __shfl(idx, 1, kFinalizeLanes), i2 = __shfl(idx, 2, kFinalizeLanes),
-              i3 = __shfl(idx, 3, kFinalizeLanes);
-    cl = __shfl(cl, 4, kFinalizeLanes);
-    ch = __shfl(ch, 4, kFinalizeLanes);
-    hit = __shfl(hit, 5, kFinalizeLanes);
-    int ref_lo = i0 < i1 ? i0 : i1, t2 = i2 < i3 ? i2 : i3;
-    ref_lo = ref_lo < t2 ? ref_lo : t2;
-    int ref_hi = i0 > i1 ? i0 : i1;
-    t2 = i2 > i3 ? i2 : i3;
-    ref_hi = ref_hi > t2 ? ref_hi : t2;
-    const int lo = ref_lo > cl ? ref_lo : cl, hi = ref_hi < ch ? ref_hi : ch;
-    if (tid == 0) {
-        if (wall) {
-            a.state[3 * (size_t)N + i] = 0.;
-            a.state[4 * (size_t)N + i] = 0.;
-            a.state[5 * (size_t)N + i] = 0.;
-            a.state[6 * (size_t)N + i] = 0.;
-        }
-        a.collisions[i] = (hit || wall) ? 1.0 : 0.0;
-        a.collision_idx[i] = hit ? (double)(1 - me) : -1.0;
-        a.step_count[i] += 1;
-    }
-    double *sc = a.scans + (size_t)i * B;
-    for (int b = lo + tid; b <= hi; b += kFinalizeLanes) {
-        const double bt = eth + a.scan_angles[b];
-        const double r0 = sc[b];
-        double v3x, v3y;
-        sincos(bt + kPi / 2., &v3y, &v3x);
-        const double r = box_range(ex, ey, v3x, v3y, v, r0);
-        if (r < r0) sc[b] = r;
-    }
-    if (a.reseat_poses && tid == 0) {
-        // the ego's collisions value of this step: the pair flag (the same test for both agents) OR its wall flag
-        const int ego = (i & ~1) + a.reseat_ego;
-        if (hit || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
-    }
-}
-
-// ---- K3f: k_finalize_pair with the window loop flattened over the workgroup (round 3) ---------------------
-// k_finalize_pair gives every agent a fixed share of lanes for its opponent window, so a wave runs as many
-// passes as its widest window needs (a follower sees ~50 beams of the car ahead, the leader none, a car
-// about to be hit a few hundred) and the rest of its lanes idle through them.  Here a 256-thread workgroup
-// takes AG agents: the prologue (pair test, window) runs 256 / AG lanes per agent exactly as before and
-// leaves each agent's record in LDS; an exclusive scan of the AG window lengths turns them into one list of
-// (agent, beam) items, and the 256 threads walk that list — every pass has all lanes busy whatever the
-// split between agents.  Same functions on the same operands per beam: bit-identical to k_finalize_pair.
-template <int AG>
-__global__ void __launch_bounds__(256) k_finalize_pair_flat(AgentArrays a, int32_t B)
-{
-    constexpr int L = 256 / AG;   // lanes per agent in the prologue (lanes 0-5 carry work: L >= 8)
-    static_assert(L >= 8 && (AG & (AG - 1)) == 0 && AG <= 32, "AG is a power of two, at most 32");
-    __shared__ double s_rec[AG][12];   // ex, ey, eth, the opponent's box (8), pad
-    __shared__ int s_lo[AG], s_cnt[AG], s_off[AG + 1];
-    const int slot = threadIdx.x / L, tid = threadIdx.x & (L - 1);
-    const int first = a.agent_begin + (int)blockIdx.x * AG, end = a.agent_begin + a.agent_count;
-    const bool live = first + slot < end;
-    const int i = live ? first + slot : end - 1;   // idle groups shadow the last agent (no stores) so shuffles stay whole
-    const int N = a.n_agents_total;
-    const int me = i & 1, o = i ^ 1;
-    const int wall = a.in_collision[i];
-    const double ex = a.state[i], ey = a.state[(size_t)N + i];
-    const double th_live = a.state[4 * (size_t)N + i];
-    const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
-    const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
-    const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
-    const double eth = wall ? 0.0 : th_live;
-    double v[8];
-    box_vertices(ox, oy, oth, blen, bwid, v);
-    int idx = 0, cl = 0, ch = B - 1, hit = 0;
-    {
-        double ce_, se_;
-        cos_sin(eth, ce_, se_);
-        const double head = atan2(se_, ce_);
-        const double px = tid == 0 ? v[0] : (tid == 1 ? v[2] : (tid == 2 ? v[4] : (tid == 3 ? v[6] : ox)));
-        const double py = tid == 0 ? v[1] : (tid == 1 ? v[3] : (tid == 2 ? v[5] : (tid == 3 ? v[7] : oy)));
-        const double dx = px - ex, dy = py - ey;
-        const double norm = sqrt(dx * dx + dy * dy);
-        const double qx = tid < 4 ? dx / norm : dx, qy = tid < 4 ? dy / norm : dy;
-        const double dir = atan2(qy, qx);
-        if (tid < 4) {
-            idx = vertex_beam_from_angles(head, dir, a.scan_angles, B, a.angle_inc);
-        } else if (tid == 4) {
-            disc_beam_range_from(norm, eth, dir, head, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
-        } else if (tid == 5) {
-            const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
-            const double cdx = ox - ex, cdy = oy - ey;
-            if (cdx * cdx + cdy * cdy <= reach * reach) {
-                double mine[8], other[8];
-                box_vertices(ex, ey, th_live, a.box_length, a.box_width, mine);
-                box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
-                hit = (me == 0 ? gjk_overlap(mine, other) : gjk_overlap(other, mine)) ? 1 : 0;
-            }
-        }
-    }
-    const int i0 = __shfl(idx, 0, L), i1 = __shfl(idx, 1, L), i2 = __shfl(idx, 2, L), i3 = __shfl(idx, 3, L);
-    cl = __shfl(cl, 4, L);
-    ch = __shfl(ch, 4, L);
-    hit = __shfl(hit, 5, L);
-    int ref_lo = i0 < i1 ? i0 : i1, t2 = i2 < i3 ? i2 : i3;
-    ref_lo = ref_lo < t2 ? ref_lo : t2;
-    int ref_hi = i0 > i1 ? i0 : i1;
-    t2 = i2 > i3 ? i2 : i3;
-    ref_hi = ref_hi > t2 ? ref_hi : t2;
-    const int lo = ref_lo > cl ? ref_lo : cl, hi = ref_hi < ch ? ref_hi : ch;
-    if (tid == 0) {
-        if (live) {
-            if (wall) {
-                a.state[3 * (size_t)N + i] = 0.;
-                a.state[4 * (size_t)N + i] = 0.;
-                a.state[5 * (size_t)N + i] = 0.;
-                a.state[6 * (size_t)N + i] = 0.;
-            }
-            a.collisions[i] = (hit || wall) ? 1.0 : 0.0;
-            a.collision_idx[i] = hit ? (double)(1 - me) : -1.0;
-            a.step_count[i] += 1;
-        }
-        s_lo[slot] = lo;
-        s_cnt[slot] = (live && hi >= lo) ? hi - lo + 1 : 0;
-        s_rec[slot][0] = ex;
-        s_rec[slot][1] = ey;
-        s_rec[slot][2] = eth;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) s_rec[slot][3 + c] = v[c];
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {   // exclusive scan of the AG window lengths (AG <= 32: one wave)
-        const int lane = (int)threadIdx.x;
-        int c = lane < AG ? s_cnt[lane] : 0;
-#pragma unroll
-        for (int d = 1; d < AG; d <<= 1) {
-            const int up = __shfl_up(c, d);
-            if (lane >= d) c += up;
-        }
-        if (lane < AG) s_off[lane + 1] = c;
-        if (lane == 0) s_off[0] = 0;
-    }
-    __syncthreads();
-    const int total = s_off[AG];
-    for (int item = (int)threadIdx.x; item < total; item += 256) {
-        int ag = 0;   // the largest ag with s_off[ag] <= item (its window is not empty: item < s_off[ag + 1])
-#pragma unroll
-        for (int st = AG / 2; st; st >>= 1)
-            if (s_off[ag + st] <= item) ag += st;
-        const int b = s_lo[ag] + (item - s_off[ag]);
-        const double bex = s_rec[ag][0], bey = s_rec[ag][1], beth = s_rec[ag][2];
-        double bv[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) bv[c] = s_rec[ag][3 + c];
-        double *sc = a.scans + (size_t)(first + ag) * B;
-        const double bt = beth + a.scan_angles[b];
-        const double r0 = sc[b];
-        double v3x, v3y;
-        sincos(bt + kPi / 2., &v3y, &v3x);
-        const double r = box_range(bex, bey, v3x, v3y, bv, r0);
-        if (r < r0) sc[b] = r;
-    }
-    if (a.reseat_poses && tid == 0 && live) {
-        const int ego = (i & ~1) + a.reseat_ego;
-        if (hit || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
-    }
-}
-
 // ---- f110_step_host's work as the pair kernel's epilogue (round 4) -----------------------------------------------
 // What k_host_block does in a launch of its own, done by the agent threads of k_finalize_pair_roles (lanes t < AG of
 // wave 0; the two agents of an env are lanes t, t ^ 1) once the kernel's own work is finished: the agent's columns into
@@ -2031,15 +1477,16 @@ __device__ __forceinline__ void pair_host_epilogue(const AgentArrays &a, bool ag
     }
 }
 
-// ---- K3r: k_finalize_pair_flat with the prologue laid out by ROLE instead of by agent (round 3) -----------
-// In k_finalize_pair_flat every wave carries all three pieces of the prologue one after the other (divergent
-// branches: corner -> beam index on lanes 0-3 of an agent's group, disc cull on lane 4, pair test on lane 5), so
-// the kernel's vector-ALU work — which is what bounds it (12.6 M wave-instructions x 8 cycles of float64 per
-// launch at 65 536 agents = its 42 us) — is four times one prologue per workgroup.  Here the workgroup's threads
-// are dealt by role: the 4 AG corners fill waves 0-1 completely, the AG disc culls sit in wave 2, the AG / 2
-// pair tests (ONE per env: both agents' calls are the same gjk_overlap(box(2e), box(2e + 1)) on the same
-// numbers) in wave 3; each wave runs only its own piece, the pieces run side by side on the CU's four SIMDs,
-// results meet in LDS.  Same functions on the same operands: bit-identical.  The window loop is unchanged.
+// ---- K3r: finalize for two-agent envs — pair test, opponent window and ray-cast in one kernel (rounds 2-3) ----------
+// What k_collide prepares for k_finalize — the GJK flag of the env's one pair and the beam window the opponent can
+// occupy — costs a second stream and an event fork/join per step (14 us); with two agents per env it sits at the top of
+// the finalize kernel instead.  The workgroup's threads are dealt by ROLE: the 4 AG box corners (-> beam indices) fill
+// waves 0-1, the AG disc culls sit in wave 2, the AG / 2 pair tests (ONE per env: both agents' calls are the same
+// gjk_overlap(box(2e), box(2e + 1)) on the same numbers) in wave 3; each wave runs only its own piece, the pieces run side
+// by side on the CU's four SIMDs, results meet in LDS.  Then the opponent windows of the workgroup's AG agents are
+// flattened into one item list (a crashed pair sees windows of up to all beams; fixed lanes per agent serialise there).
+// Same functions on the same operands as k_collide + k_finalize: bit-identical.  (The earlier forms — fixed lanes per
+// agent, the prologue dealt by agent — were measured slower in round 3 and retired in round 5: DESIGN_HISTORY.md.)
 template <int AG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_finalize_pair_roles(AgentArrays a, int32_t B)   // (6 waves per SIMD = 80 VGPRs: what the kernel needs without its f110_step_host epilogue)
 {
@@ -3224,73 +2671,6 @@ __global__ void k_build_padded(const double *__restrict__ rowmajor, int H, int W
     pad[i] = inside ? rowmajor[(size_t)r * W + c] : rowmajor[(size_t)H * W - 1];
 }
 
-#ifdef F110_EXPERIMENTAL   // tiled / byte-code / window layouts
-__global__ void k_retile(const double *__restrict__ rowmajor, int H, int W, int tiles_w, int tiles_h, double *__restrict__ tiled)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)tiles_w * tiles_h * 16;
-    if (t >= total) return;
-    const size_t tile = t >> 4;
-    const int within = (int)(t & 15);
-    const int r = (int)(tile / tiles_w) * 4 + (within >> 2);
-    const int c = (int)(tile % tiles_w) * 4 + (within & 3);
-    tiled[t] = (r < H && c < W) ? rowmajor[(size_t)r * W + c] : 0.0;
-}
-
-// CODE8 layout: code = rank of the cell's value among the 255 smallest distinct table values
-// (binary search in the ascending LUT), 255 when it is not one of them; 16x8-cell tiles.
-__global__ void k_build_codes(const double *__restrict__ rowmajor, int H, int W, int ctiles_w, int ctiles_h,
-                              const double *__restrict__ lut, int n_lut, uint8_t *__restrict__ codes)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)ctiles_w * ctiles_h * 128;
-    if (t >= total) return;
-    const size_t tile = t >> 7;
-    const int within = (int)(t & 127);
-    const int r = (int)(tile / ctiles_w) * 8 + (within >> 4);
-    const int c = (int)(tile % ctiles_w) * 16 + (within & 15);
-    uint8_t code = 255;
-    if (r < H && c < W) {
-        const double v = rowmajor[(size_t)r * W + c];
-        int lo = 0, hi = n_lut - 1;
-        while (lo <= hi) {
-            const int mid = (lo + hi) >> 1;
-            const double m = lut[mid];
-            if (m == v) {
-                code = (uint8_t)mid;
-                break;
-            }
-            if (m < v) lo = mid + 1; else hi = mid - 1;
-        }
-    }
-    codes[t] = code;
-}
-
-// window layout: the same codes over the PADDED table, row-major, `pitch` bytes per row
-__global__ void k_build_codes_padded(const double *__restrict__ pad, int Hp, int Wp, int pitch, const double *__restrict__ lut, int n_lut,
-                                     uint8_t *__restrict__ codes)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)Hp * pitch) return;
-    const int r = (int)(t / pitch), c = (int)(t % pitch);
-    uint8_t code = 255;
-    if (c < Wp) {
-        const double v = pad[(size_t)r * Wp + c];
-        int lo = 0, hi = n_lut - 1;
-        while (lo <= hi) {
-            const int mid = (lo + hi) >> 1;
-            const double m = lut[mid];
-            if (m == v) {
-                code = (uint8_t)mid;
-                break;
-            }
-            if (m < v) lo = mid + 1; else hi = mid - 1;
-        }
-    }
-    codes[t] = code;
-}
-
-#endif  // F110_EXPERIMENTAL
 
 // A reactive policy that CONSUMES the scans where the scan kernel left them (round 5; not a reference function — the stand-in
 // for an RL policy in a device-resident loop: examples/rl_loop_device.py, bench.py's "scans consumed on device" leg).  One wave

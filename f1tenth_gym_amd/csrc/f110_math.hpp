@@ -405,18 +405,14 @@ F110_HD void fan_finish(double *st, double lidar_dist, double *scan_pose)
 }
 
 // ------------------------------------------------------------------ laser_models.py
-enum { LAYOUT_ROWMAJOR = 0, LAYOUT_TILED = 1, LAYOUT_CODE8 = 2, LAYOUT_PADDED = 3 };
-constexpr int kLutEntries = 255;   // codes 0..254 index the LUT, 255 = escape to the float64 table
+enum { LAYOUT_ROWMAJOR = 0, LAYOUT_PADDED = 3 };   // (1 = 4x4 tiles and 2 = byte codes + LUT: retired in round 5)
 
 struct ScanConst {
-    const double *table;   // distance table in the chosen layout (CODE8: the row-major table)
-    const double *table_rm;  // the row-major float64 table (always present)
-    const uint8_t *codes;  // CODE8: one byte per cell, 16x8-cell tiles (one 128-byte line each)
-    const double *lut;     // CODE8: the 255 smallest distinct table values, ascending (HBM copy)
+    const double *table;   // the distance table dt[r][c] (PADDED: the interior of the padded copy, its row pitch)
+    const double *table_rm;  // the same (a separate row-major original only while a map too large for PADDED is loaded)
     const double2 *cs;     // (cos, sin) of linspace(0, 2pi, theta_dis), interleaved
-    int32_t height, width, tiles_w, theta_dis;
+    int32_t height, width, pad_tiles, theta_dis;
     int32_t num_beams, res_pow2, ident_rot, row_bytes;  // row_bytes = width * 8
-    int32_t code_tile_row_bytes, pad1;                   // CODE8: tiles per tile-row * 128
     double res, inv_res, orig_x, orig_y, orig_c, orig_s;
     double w_res, h_res;   // width*resolution, height*resolution (xy_2_rc :79)
     double oob_value;      // dt[-1,-1]: what an out-of-bounds sample reads (:80-81,:103)
@@ -512,31 +508,17 @@ F110_HD uint32_t mul24(uint32_t a, uint32_t b)
 #endif
 }
 
-// CODE8: the table holds few distinct values near walls (d = res*sqrt(integer)), and those are the
-// ones rays sample: each cell is stored as a 1-byte code into a LUT of the 255 smallest distinct
-// values (staged in LDS by the kernel; `lut` points there), 16x8 cells per 128-byte line.  The
-// LUT holds the exact float64 values, so results are bit-identical; code 255 falls back to the
-// float64 table.  8x fewer bytes and ~2.4x fewer distinct lines per 64-lane gather than float64.
+// One table value.  (Rounds 1-4 also had a 4x4-tiled float64 layout and a 1-byte-code + exact-value-LUT layout behind this
+// function — bit-identical, measured slower, retired in round 5: DESIGN_HISTORY.md.  `lut` is that layout's parameter.)
 template <int LAYOUT>
 F110_HD double table_fetch(const ScanConst &k, int r, int c, const double *lut)
 {
-    if (LAYOUT == LAYOUT_CODE8) {
-        const uint32_t coff = mul24((uint32_t)(r >> 3), (uint32_t)k.code_tile_row_bytes) + ((uint32_t)(c >> 4) << 7) +
-                              ((uint32_t)(r & 7) << 4) + (uint32_t)(c & 15);
-        const uint32_t code = k.codes[coff];
-        if (code != 255u) return lut[code];
-        const uint32_t off = mul24((uint32_t)r, (uint32_t)k.row_bytes) + ((uint32_t)c << 3);
-        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(k.table) + off);
-    }
+    static_assert(LAYOUT == LAYOUT_ROWMAJOR || LAYOUT == LAYOUT_PADDED, "row-major or padded");
+    (void)lut;
     // 32-bit BYTE offset from the (wave-uniform) table base: lets the compiler use the
-    // scalar-base + 32-bit-VGPR-offset form of global_load (tables are < 4 GiB, checked on upload)
-    uint32_t off;
-    if (LAYOUT == LAYOUT_ROWMAJOR || LAYOUT == LAYOUT_PADDED) {  // PADDED: k.table is the plain table (exact path)
-        off = mul24((uint32_t)r, (uint32_t)k.row_bytes) + ((uint32_t)c << 3);
-    } else {
-        const uint32_t tile = mul24((uint32_t)(r >> 2), (uint32_t)k.tiles_w) + (uint32_t)(c >> 2);
-        off = tile * 128u + (uint32_t)(((r & 3) << 2) | (c & 3)) * 8u;
-    }
+    // scalar-base + 32-bit-VGPR-offset form of global_load (tables are < 4 GiB, checked on upload).
+    // PADDED: k.table is the plain table here (the exact path)
+    const uint32_t off = mul24((uint32_t)r, (uint32_t)k.row_bytes) + ((uint32_t)c << 3);
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(k.table) + off);
 }
 

@@ -48,22 +48,18 @@ enum {
 
 enum { F110_INTEGRATOR_RK4 = 1, F110_INTEGRATOR_EULER = 2 }; /* base_classes.py:40-42 */
 
-/* distance-table layouts in HBM (DESIGN.md §data layout).  libf110_hip.so, the product, has
- * F110_MAP_ROWMAJOR_F64 and F110_MAP_PADDED_F64; the other three were built, measured and not adopted and
- * exist in libf110_hip_exp.so (built with -DF110_EXPERIMENTAL) only — f110_create of the product refuses them. */
+/* distance-table layouts in HBM.  Values 1 (4x4-cell tiles), 2 (1-byte codes + exact value LUT in LDS) and
+ * 4 (a 128x128-cell window of byte codes per agent in LDS) existed in the experimental build through round 4 — bit-identical,
+ * measured slower (DESIGN_HISTORY.md) — and were retired in round 5: f110_create refuses them (F110_ERR_INVALID). */
 enum {
     F110_MAP_ROWMAJOR_F64 = 0, /* dt[r][c] as the reference stores it */
-    F110_MAP_TILED_F64 = 1,    /* 4x4-cell tiles, one 128-byte line per tile */
-    F110_MAP_CODE8 = 2,        /* 1-byte code per cell (16x8-cell tiles) + 255-entry exact float64
-                                  value LUT staged in LDS; code 255 escapes to the row-major table */
+    F110_MAP_TILED_F64 = 1,    /* retired */
+    F110_MAP_CODE8 = 2,        /* retired */
     F110_MAP_PADDED_F64 = 3,   /* dt[r][c] inside a border of out-of-bounds cells (max_range wide), so
                                   the march loop needs no range test, with fixed-point cell addressing
                                   and an exact re-march for samples in the guard band (the fastest
                                   layout; maps too large for it run as F110_MAP_ROWMAJOR_F64) */
-    F110_MAP_WINDOW_LDS = 4  /* F110_MAP_PADDED_F64 plus, for the step, the 128x128 cells around each
-                                  lidar staged in LDS as 1-byte codes with the exact value LUT (one
-                                  workgroup per agent); samples outside the window, and everything
-                                  else, behave as F110_MAP_PADDED_F64 */
+    F110_MAP_WINDOW_LDS = 4    /* retired */
 };
 
 /* Simulator(params, num_agents, seed, time_step, ego_idx, integrator, lidar_dist)
@@ -83,7 +79,7 @@ typedef struct f110_config {
     int32_t step_groups;   /* env blocks per step: 0 = automatic (f110_step_device calls that come back to back are submitted as
                               two halves of the envs on two streams, at the batch sizes where that pays; anything else in one
                               block), 1 = always one block, 2 = always two, > 2 = experimental build.  Results do not depend on it. */
-    int32_t step_graph;    /* experimental build: 1 = submit the step as one captured HIP graph (product: 0) */
+    int32_t step_graph;    /* must be 0 (the step as one captured HIP graph: measured slower, retired in round 5; the field keeps the struct layout) */
     double fov, eps, max_range;
     double time_step, lidar_dist, ttc_thresh;
     double params[F110_NPARAMS]; /* initial vehicle params for every agent slot */
@@ -106,12 +102,15 @@ int f110_is_experimental(void);
 /* The switchboard of the experimental build — every variant that was measured against the default and not
  * adopted, for the A/B tests and the profiles.  The product library refuses every key
  * (F110_ERR_STATE) and reads no environment variable; a step of the product has ONE dispatch per (agents per
- * env, beams) case.  Keys: scan_flat, dedupe_two_pass, no_window, finalize_lanes (0|8|16|32|64),
- * finalize_flat (-1|0|1), finalize_roles (-1|0|1), pair_always, collide_mode (0 side stream | 1 fused into k_integrate | 2 in line | 3 inside
- * k_finalize), step_graph, task_order, task_thr, task_cap_div (list capacity = tasks / div), task_rev (walk the list from its newest
- * entry), ray_pass, ray_thr, ray_waves, scan_occupancy, scan_env_counter (fusion probes), integrate_duo (-1|0|1: k_integrate in one wave or two per 64 agents), scan_trace_hi / scan_trace_lo (the two
- * halves of the device address of a caller-owned [launch waves][8] uint64 buffer that every wave of the step's scan kernel stamps with
- * its begin / end clock, CU and samples: tools/debug/scan_timeline.py; 0 = off). */
+ * env, beams) case.  Keys: scan_flat, collide_mode (0 side stream | 1 fused into k_integrate | 2 in line | 3 inside k_finalize),
+ * task_order, task_thr, task_cap_div (list capacity = tasks / div), task_rev (walk the list from its newest entry), long_prio,
+ * scan_occupancy, scan_env_counter (fusion probes), integrate_duo (-1|0|1: k_integrate in one wave or two per 64 agents),
+ * integrate_fan (-1|0|1), group_split, scan_trace_hi / scan_trace_lo (the two halves of the device address of a caller-owned
+ * [launch waves][8] uint64 buffer that every wave of the step's scan kernel stamps with its begin / end clock, CU and samples:
+ * tools/debug/scan_timeline.py; 0 = off); round 5: scan_stream (1: the lane-refill scan k_scan_stream_agent), stream_refill,
+ * stream_block, stream_grid, spec_from (the tail of long rays two samples per round trip).  Retired in round 5 with the code they
+ * switched (numbers in DESIGN_HISTORY.md): dedupe_two_pass, no_window, finalize_lanes / _flat / _roles, pair_always, step_graph,
+ * ray_pass / ray_thr / ray_waves. */
 int f110_exp_set(f110_sim *h, const char *key, int32_t value);
 
 int f110_create(const f110_config *cfg, f110_sim **out);
@@ -445,7 +444,7 @@ int f110_noise_rows_batch(f110_sim *h, const uint64_t *h_state_inc4, double std_
                           int32_t num_beams, double *h_out, uint64_t *h_state_out2);
 /* Measurement aid (bench.py's L-bar): with enable = 1 the step's scan kernels sum the table lookups
  * of every ray they march (the reference's dependent gathers, laser_models.py:129-143).  out2 (or
- * NULL) receives and clears {the sum, how many of them the LDS window of F110_MAP_WINDOW_LDS served};
+ * NULL) receives and clears {the sum, 0 (round 1-4: how many of them the retired LDS-window layout served)};
  * enable = -1 leaves the switch as it is.  Off by default. */
 int f110_scan_lookup_count(f110_sim *h, int32_t enable, int64_t *out2);
 /* table index int(theta_index) of every beam for M headings (get_scan :167-184) */

@@ -14,8 +14,7 @@ def pytest_configure(config):
 
 # what the product library refuses BY DESIGN (include/f110.h: F110_ERR_STATE "... experimental build only"): the
 # layouts, step forms and switches that were measured and not adopted.  Only these turn into a skip.
-LAB_ONLY = (r"map_layout [124] is available in the experimental build only",
-            r"step_groups > 2 / step_graph are available in the experimental build only",
+LAB_ONLY = (r"step_groups > 2 is available in the experimental build only",
             r"f110_exp_set\([a-z_0-9]+\) is available in the experimental build only")
 
 

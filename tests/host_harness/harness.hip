@@ -123,7 +123,7 @@ void hh_padded_stats(long long *out)
     g_pad_fast = g_pad_guard = g_pad_far = 0;
 }
 
-// layout: 0 row-major, 1 tiled 4x4, 2 byte codes + LUT, 3 padded + fixed-point addressing
+// layout: 0 row-major, 3 padded + fixed-point addressing (+ 100 s: march_padded_spec from sample s on)
 void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, double oy, double oc, double os,
              const double *sines, const double *cosines, int theta_dis, int B, double fov, double eps,
              double max_range, const double *pose, double *ranges, int *hit_rc, int *dir_idx, long long *lookups)
@@ -133,7 +133,7 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
     std::vector<double2> cs(theta_dis);
     for (int i = 0; i < theta_dis; ++i) cs[i] = make_double2(cosines[i], sines[i]);
     k.cs = cs.data();
-    k.height = H; k.width = W; k.tiles_w = (W + 3) / 4; k.row_bytes = W * 8; k.theta_dis = theta_dis; k.num_beams = B;
+    k.height = H; k.width = W; k.row_bytes = W * 8; k.theta_dis = theta_dis; k.num_beams = B;
     k.res = res; k.inv_res = 1.0 / res;
     int e; k.res_pow2 = (frexp(res, &e) == 0.5) ? 1 : 0;
     k.orig_x = ox; k.orig_y = oy; k.orig_c = oc; k.orig_s = os;
@@ -147,35 +147,7 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
     k.inv_theta_dis = 1.0 / (double)theta_dis;
     std::vector<double> lut(256, INFINITY);
     std::vector<uint8_t> codes;
-    if (layout == 2) {  // CODE8: same construction as finish_map() + k_build_codes
-        std::vector<double> vals(dt, dt + (size_t)H * W);
-        std::sort(vals.begin(), vals.end());
-        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
-        const int n_lut = (int)std::min<size_t>(vals.size(), (size_t)kLutEntries);
-        for (int i = 0; i < n_lut; ++i) lut[i] = vals[i];
-        const int ctw = (W + 15) / 16, cth = (H + 7) / 8;
-        codes.assign((size_t)ctw * cth * 128, 255);
-        for (int r = 0; r < H; ++r)
-            for (int c = 0; c < W; ++c) {
-                const double v = dt[(size_t)r * W + c];
-                const auto it = std::lower_bound(lut.begin(), lut.begin() + n_lut, v);
-                if (it != lut.begin() + n_lut && *it == v)
-                    codes[((size_t)(r >> 3) * ctw + (c >> 4)) * 128 + ((r & 7) << 4) + (c & 15)] = (uint8_t)(it - lut.begin());
-            }
-        k.codes = codes.data();
-        k.lut = lut.data();
-        k.code_tile_row_bytes = ctw * 128;
-        k.table = dt;
-    } else if (layout == 1) {
-        const int th = (H + 3) / 4;
-        tiled.assign((size_t)k.tiles_w * th * 16, 0.0);
-        for (int r = 0; r < H; ++r)
-            for (int c = 0; c < W; ++c)
-                tiled[((size_t)(r >> 2) * k.tiles_w + (c >> 2)) * 16 + ((r & 3) << 2 | (c & 3))] = dt[(size_t)r * W + c];
-        k.table = tiled.data();
-    } else {
-        k.table = dt;
-    }
+    k.table = dt;
     k.table_rm = dt;
     std::vector<double> padded;
     int spec_from = 0;   // layout 3 + 100 * s: the PADDED march with two samples per round trip from sample s on (march_padded_spec)
@@ -213,12 +185,6 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
             }
             if (exact) r = k.ident_rot ? march_exact_cold<true>(&k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, hr, hc, nl)
                                        : march_exact_cold<false>(&k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, hr, hc, nl);
-        } else if (layout == 2) {
-            if (k.res_pow2) { if (k.ident_rot) RUN(2, true, true); else RUN(2, true, false); }
-            else { if (k.ident_rot) RUN(2, false, true); else RUN(2, false, false); }
-        } else if (layout == 1) {
-            if (k.res_pow2) { if (k.ident_rot) RUN(1, true, true); else RUN(1, true, false); }
-            else { if (k.ident_rot) RUN(1, false, true); else RUN(1, false, false); }
         } else {
             if (k.res_pow2) { if (k.ident_rot) RUN(0, true, true); else RUN(0, true, false); }
             else { if (k.ident_rot) RUN(0, false, true); else RUN(0, false, false); }
@@ -254,7 +220,7 @@ void hh_scan_generic(const double *dt, int H, int W, double res, double ox, doub
     std::vector<double2> cs(theta_dis);
     for (int i = 0; i < theta_dis; ++i) cs[i] = make_double2(cosines[i], sines[i]);
     k.cs = cs.data(); k.table = dt;
-    k.height = H; k.width = W; k.tiles_w = (W + 3) / 4; k.row_bytes = W * 8; k.theta_dis = theta_dis; k.num_beams = B;
+    k.height = H; k.width = W; k.row_bytes = W * 8; k.theta_dis = theta_dis; k.num_beams = B;
     k.res = res; k.inv_res = 1.0 / res; k.orig_x = ox; k.orig_y = oy; k.orig_c = oc; k.orig_s = os;
     k.w_res = W * res; k.h_res = H * res; k.oob_value = dt[(size_t)H * W - 1];
     k.eps = eps; k.max_range = max_range; k.fov = fov;

@@ -65,7 +65,7 @@ def test_product_library_reads_no_environment():
     assert b"getenv" not in blob
     L = C.CDLL(build.build())
     L.f110_last_error.restype = C.c_char_p
-    assert L.f110_exp_set(None, b"finalize_flat", 1) != 0
+    assert L.f110_exp_set(None, b"scan_stream", 1) != 0
 
 
 def test_product_never_imports_the_oracle():

@@ -105,7 +105,7 @@ def test_bad_integrator_raises(amd, unit):
 
 
 # ---------------------------------------------------------------------------- scan (a8-a12)
-@pytest.mark.parametrize("layout", [0, 1, 2, 3])
+@pytest.mark.parametrize("layout", [0, 3])
 @pytest.mark.parametrize("fixture,mapname,beams,fov", [
     ("scan_example_map", "example_map", 1080, 4.7), ("scan_berlin", "berlin", 1080, 4.7),
     ("scan_example_map_4096", "example_map", 4096, 4.7), ("scan_example_map_271", "example_map", 271, 6.0)])
@@ -127,7 +127,7 @@ def test_scan_generic_paths_vs_oracle(amd, orc):
     dt, res, origin = oracle_map_dt("example_map")
     sub = np.ascontiguousarray(dt[600:1000, 900:1300])
     rng = np.random.default_rng(11)
-    for layout in (0, 1, 2, 3):
+    for layout in (0, 3):
         for res2, org in [(0.05, [-3.0, -4.0, 0.3]), (0.0625, [1.0, 2.0, -1.1]), (0.07, [0.0, 0.0, 0.0])]:
             so = orc.ScanOracle(1080, 4.7)
             so.set_map_dt(sub * (res2 / res), res2, org)
@@ -242,7 +242,7 @@ def _noise(T, B=1080, seed=12345):
     return np.random.default_rng(seed).normal(0., 0.01, size=(T, B))
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2, 3])
+@pytest.mark.parametrize("layout", [0, 3])
 def test_sim_rollout_vs_golden(amd, layout):
     g = gold("sim_rollout")
     img, res, origin = load_map_image("example_map")
@@ -337,7 +337,7 @@ def _drive(amd, orc, E, A, T, layout=0, seed=0, beams=1080, reset_every=None, ch
     return stats
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2, 3])
+@pytest.mark.parametrize("layout", [0, 3])
 def test_step_vs_oracle_64_envs_200_steps(amd, orc, layout):
     """the parity gate that accompanies every timing: first 64 envs x 200 steps"""
     st = _drive(amd, orc, 64, 2, 200, layout=layout, reset_every=10, check_every=5)
@@ -348,10 +348,10 @@ def test_step_vs_oracle_64_envs_200_steps(amd, orc, layout):
 
 def test_step_4096_beams_dedupe_vs_oracle(amd, orc):
     """more beams than table directions: the step marches each distinct direction once and
-    expands to beams (k_expand_beams); must equal the oracle that marches every beam"""
+    writes the beams that share it (k_scan_dirs_agent; row-major table: every beam is marched); must equal the oracle"""
     st = _drive(amd, orc, 10, 2, 40, beams=4096, reset_every=8)
     assert st["flag_mismatch"] == 0 and st["state"] < NORTH_STAR and st["scan"] < 1e-12, st
-    st = _drive(amd, orc, 7, 1, 25, beams=2500, layout=1)
+    st = _drive(amd, orc, 7, 1, 25, beams=2500, layout=3)
     assert st["flag_mismatch"] == 0 and st["scan"] < 1e-12, st
 
 
@@ -372,7 +372,7 @@ def test_config5_4096_beams_tiled_big_map(amd, orc):
     big_img = np.tile(img, (2, 2))
     big_dt = np.tile(dt, (2, 2))        # NOT the EDT of the tiled image; used via set_map_dt on both sides
     so = orc.ScanOracle(4096, 4.7); so.set_map_dt(big_dt, res, origin)
-    s = amd.BatchSim(num_envs=1, num_agents=1, num_beams=4096, map_layout=1)
+    s = amd.BatchSim(num_envs=1, num_agents=1, num_beams=4096, map_layout=0)
     s.set_map_dt(big_dt, res, origin)
     poses = bench_start_poses(12, 1)
     ranges, hits = s.scan_batch(poses, want_hits=True)
@@ -466,7 +466,7 @@ def test_vec_env_auto_reset(amd):
     assert seen_done
 
 
-@pytest.mark.parametrize("layout,tasks,block", [(0, 1, 64), (0, 3, 128), (1, 2, 256), (2, 4, 64), (2, 1, 256), (3, 4, 64), (3, 1, 256)])
+@pytest.mark.parametrize("layout,tasks,block", [(0, 1, 64), (0, 3, 128), (0, 2, 256), (3, 4, 64), (3, 1, 256), (3, 2, 128)])
 def test_scan_launch_geometries_bit_exact(amd, orc, layout, tasks, block):
     """map layout / tasks-per-wave / workgroup size only change scheduling and storage:
     unit scans equal the golden vectors and a stepped batch equals the oracle bit-for-bit on scans"""
@@ -562,7 +562,7 @@ def test_step_other_maps_params_euler_lidar_offset(amd, orc):
     map), Euler integrator, lidar offset, per-agent vehicle params, noise table shorter than the
     episode (wraps)"""
     rng = np.random.default_rng(17)
-    for mapname, integ, ld, layout in [("berlin", 1, 0.0, 0), ("skirk", 2, 0.275, 1), ("berlin", 1, 0.275, 2), ("skirk", 1, 0.275, 3), ("berlin", 2, 0.0, 3)]:
+    for mapname, integ, ld, layout in [("berlin", 1, 0.0, 0), ("skirk", 2, 0.275, 0), ("berlin", 1, 0.275, 3), ("skirk", 1, 0.275, 3), ("berlin", 2, 0.0, 3)]:
         img, res, origin = load_map_image(mapname)
         dt, _, _ = oracle_map_dt(mapname)
         E, A, T = 9, 3, 50

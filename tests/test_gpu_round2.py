@@ -442,107 +442,10 @@ def test_bench_refuses_more_gpus_than_visible():
     assert out.returncode != 0 and "refusing" in out.stderr and not out.stdout.strip()
 
 
-# ---------------------------------------------------------------------------- LDS-window scan (layout 4)
-@pytest.mark.parametrize("mapname", ["example_map", "berlin"])
-def test_window_lds_layout_step_equals_padded_layout(amd, orc, mapname):
-    """map_layout 4 (k_scan_rays_window: the 128x128 cells around each lidar staged in LDS as 1-byte
-    codes + exact value LUT) must reproduce map_layout 3 bit for bit — same march arithmetic, values
-    through an exact LUT — including lidars near / off the map edge, resets and the lookup count;
-    and match the oracle on the bench inputs"""
-    img, res, origin = load_map_image(mapname)
-    E, A, T = 40, 2, 60
-    sims = []
-    for layout in (3, 4):
-        s = amd.BatchSim(num_envs=E, num_agents=A, map_layout=layout)
-        s.set_map_image(img, res, origin)
-        s.set_noise_rng(12345, 0.01)
-        sims.append(s)
-    rng = np.random.default_rng(3)
-    if mapname == "example_map":
-        poses = bench_start_poses(E, A)
-    else:
-        base = np.stack([rng.uniform(-0.5, 0.5, E), rng.uniform(-0.5, 0.5, E), rng.uniform(0, 6.28, E)], axis=1)
-        poses = np.repeat(base, A, axis=0) + np.stack([rng.uniform(-0.8, 0.8, E * A), rng.uniform(-0.8, 0.8, E * A), rng.uniform(-0.5, 0.5, E * A)], axis=1)
-    poses[-2:, :2] += 400.0     # one env far off the map: the exact path for whole scans
-    poses[-4:-2, 0] = origin[0] - 2.0   # one just outside the left edge (window over the border cells)
-    for s in sims:
-        s.reset(poses); s.scan_lookup_count(enable=True, read=True)
-    for t in range(T):
-        if t % 15 == 0:
-            act = _actions(rng, E * A)
-        for s in sims:
-            s.step(act)
-        oa = sims[0].get("scans", "state", "collisions", "in_collision"); ob = sims[1].get("scans", "state", "collisions", "in_collision")
-        for kk in oa:
-            assert np.array_equal(oa[kk], ob[kk], equal_nan=True), (kk, t)
-        if t == 30:
-            mask = (rng.random(E) < 0.4).astype(np.uint8)
-            for s in sims:
-                s.reset(poses, mask)
-    assert sims[0].scan_lookup_count(enable=False) == sims[1].scan_lookup_count(enable=False)
-    for s in sims:
-        s.close()
 
 
-def test_window_lds_layout_vs_oracle(amd, orc):
-    img, res, origin = load_map_image("example_map")
-    dt, _, _ = oracle_map_dt("example_map")
-    E, A, T = 64, 2, 100
-    noise = np.random.default_rng(12345).normal(0., 0.01, size=(T + 1, 1080))
-    s = amd.BatchSim(num_envs=E, num_agents=A, map_layout=4); s.set_map_image(img, res, origin); s.set_noise_rng(12345, 0.01)
-    ref = orc.SimOracle(E, A); ref.set_map_dt(dt, res, origin); ref.set_noise(noise)
-    poses = bench_start_poses(E, A)
-    s.reset(poses); ref.reset(poses)
-    rng = np.random.default_rng(0)
-    for t in range(T):
-        if t % 20 == 0:
-            act = _actions(rng, E * A)
-        s.step(act); ref.step(act, 8)
-        if t % 10 == 9:
-            mask = (ref.collisions.reshape(E, A)[:, 0] != 0).astype(np.uint8)
-            s.reset(poses, mask); ref.reset(poses, mask)
-        if t % 5 == 0 or t == T - 1:
-            o = s.get("scans", "state", "collisions", "in_collision")
-            assert np.array_equal(o["collisions"], ref.collisions) and np.array_equal(o["in_collision"], ref.in_collision), t
-            assert rel_err(o["state"], ref.state) < NORTH_STAR and rel_err(o["scans"], ref.scans) < NORTH_STAR, t
-    s.close()
 
 
-# ---------------------------------------------------------------------------- HIP-graph step
-@pytest.mark.parametrize("A", [1, 2, 3])
-def test_graph_step_equals_separate_launches(amd, A):
-    """step_graph=1 (the step's launches + side-stream fork/join captured once per action buffer and
-    replayed with hipGraphLaunch) == separate launches, through re-seat arming, resets, a changed
-    action buffer and the noise cache running out (all of which change the launch arguments)"""
-    E, T = 96, 80
-    a = _pair(amd, E, A, step_graph=0); b = _pair(amd, E, A, step_graph=1)
-    poses = bench_start_poses(E, A)
-    rng = np.random.default_rng(6)
-    for s in (a, b):
-        s.set_noise_rng(12345, 0.01, cache_rows=40)
-        s.reset(poses)
-    bufs = [[s.device_array((E * A, 2)) for _ in range(3)] for s in (a, b)]
-    for i in range(3):
-        act = _actions(rng, E * A)
-        bufs[0][i].upload(act); bufs[1][i].upload(act)
-    st = [s.device_array((E * A, 3)) for s in (a, b)]
-    for d in st:
-        d.upload(poses)
-    for t in range(T):
-        if t == 25:
-            for s, d in zip((a, b), st):
-                s.set_auto_reseat(d, 0, None)
-        for k, s in enumerate((a, b)):
-            s.step_device(bufs[k][(t // 7) % 3])
-        if t % 6 == 5 or t == T - 1:
-            oa = a.get("scans", "state", "collisions", "collision_idx", "in_collision", "step_count")
-            ob = b.get("scans", "state", "collisions", "collision_idx", "in_collision", "step_count")
-            for kk in oa:
-                assert np.array_equal(oa[kk], ob[kk]), (kk, t)
-        if t == 50:
-            mask = (rng.random(E) < 0.3).astype(np.uint8)
-            a.reset(poses, mask); b.reset(poses, mask)
-    a.close(); b.close()
 
 
 def test_memory_flat_in_long_auto_reset_loop(amd):
@@ -618,43 +521,6 @@ def test_bench_two_launched_ranks_on_one_gpu():
     assert "roofline" in d and 0.0 < d["roofline"]["frac"] < 1.0 and d["roofline"]["lookups_per_ray"] > 5.0
 
 
-# ---------------------------------------------------------------------------- pair test inside k_finalize
-@pytest.mark.parametrize("lanes", ["8", "16", "64"])
-def test_pair_test_in_finalize_is_bit_identical(amd, monkeypatch, lanes):
-    """two-agent envs: the GJK pair test and the opponent beam window computed at the top of k_finalize
-    (k_finalize_pair, the default for A = 2: no side stream, no events) against k_collide on the side
-    stream + k_finalize: every array incl. collision_idx identical, through wall hits, car-to-car
-    contacts, the fused re-seat and resets, for every lanes-per-agent form"""
-    E, A, T = 200, 2, 120
-    monkeypatch.setenv("F110_EXP", "finalize_lanes=%s,collide_mode=0" % lanes)   # switches of the experimental build
-    a = _pair(amd, E, A)
-    monkeypatch.setenv("F110_EXP", "finalize_lanes=%s,collide_mode=3" % lanes)
-    b = _pair(amd, E, A)
-    poses = bench_start_poses(E, A, gap_wp=3)     # 0.6 m apart: contacts happen
-    rng = np.random.default_rng(21)
-    for s in (a, b):
-        s.set_noise_rng(12345, 0.01); s.reset(poses)
-    st = [s.device_array((E * A, 3)) for s in (a, b)]
-    for d in st:
-        d.upload(poses)
-    n_pair = n_wall = 0
-    for t in range(T):
-        if t % 10 == 0:
-            act = np.stack([rng.uniform(-0.3, 0.3, E * A), rng.uniform(0.5, 7.0, E * A)], axis=1)
-        if t == 60:
-            for s, d in zip((a, b), st):
-                s.set_auto_reseat(d, 0, None)
-        a.step(act); b.step(act)
-        oa = a.get("scans", "state", "collisions", "collision_idx", "in_collision", "step_count")
-        ob = b.get("scans", "state", "collisions", "collision_idx", "in_collision", "step_count")
-        for kk in oa:
-            assert np.array_equal(oa[kk], ob[kk]), (kk, t)
-        n_pair += int((oa["collision_idx"] >= 0).sum()); n_wall += int(oa["in_collision"].sum())
-        if t == 90:
-            mask = (rng.random(E) < 0.3).astype(np.uint8)
-            a.reset(poses, mask); b.reset(poses, mask)
-    assert n_pair > 0 and n_wall > 0, (n_pair, n_wall)
-    a.close(); b.close()
 
 
 # ---------------------------------------------------------------------------- longest-first task order

@@ -15,7 +15,7 @@ img, res, origin = load_map_image("example_map")
 poses = bench_start_poses(E, A)
 sims = []
 for which in ("product dispatch", "round-1 form"):
-    s = amd.BatchSim(num_envs=E, num_agents=A, exp=({} if which == "product dispatch" else {"finalize_flat": 0, "collide_mode": 0, "integrate_duo": 0, "task_order": 0}))
+    s = amd.BatchSim(num_envs=E, num_agents=A, exp=({} if which == "product dispatch" else {"collide_mode": 0, "integrate_duo": 0, "task_order": 0}))
     s.set_map_image(img, res, origin)
     if which == "product dispatch":
         s.set_noise_rng(12345, 0.01, cache_rows=256)
