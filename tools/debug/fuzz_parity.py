@@ -17,8 +17,7 @@ def run(seed, verbose=True, tol=1e-9, stop_when_diverged=False):
     A = int(rng.choice([1, 2, 2, 3, 4])); E = int(rng.integers(1, 40))
     B = int(rng.choice([1080, 1080, 64, 100, 271, 720, 1500, 2500])); fov = float(rng.choice([4.7, 4.7, 6.0, 3.0, 6.28]))
     integ = int(rng.choice([1, 1, 2])); ld = float(rng.choice([0.0, 0.0, 0.275])); layout = int(rng.integers(0, 4))
-    if amd._ffi.VARIANT != "experimental":
-        layout = {1: 0, 2: 3}.get(layout, layout)   # the tiled / byte-code layouts exist in the experimental build only
+    layout = {1: 0, 2: 3}.get(layout, layout)   # (the random draw is kept as it was: layouts 1 / 2 — tiles, byte codes — were retired in round 5)
     T = int(rng.integers(20, 70)); nrows = int(rng.choice([0, 5, T + 2]))
     tasks = int(rng.choice([0, 1, 3])); block = int(rng.choice([0, 64, 128, 256]))
     img, res, origin = load_map_image(mapname); dt, _, _ = oracle_map_dt(mapname)

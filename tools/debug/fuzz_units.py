@@ -106,7 +106,7 @@ print("get_range inf-pattern equal", np.array_equal(np.isinf(go), np.isinf(gr)),
 for mapname in ("example_map", "berlin", "skirk"):
     img, res, origin = load_map_image(mapname); dt, _, _ = oracle_map_dt(mapname)
     H, W = dt.shape
-    for layout in ((0, 1, 2, 3) if amd._ffi.VARIANT == "experimental" else (0, 3)):   # 1 / 2: experimental build only
+    for layout in (0, 3):
         s = amd.BatchSim(num_envs=1, num_agents=1, map_layout=layout); s.set_map_image(img, res, origin)
         so = orc.ScanOracle(1080, 4.7); so.set_map_dt(dt, res, origin)
         kk = 300
