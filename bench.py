@@ -90,7 +90,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-numa", action="store_true", help="do not pin the rank to its GPU's NUMA node")
     ap.add_argument("--config3-legs", action="store_true",
                     help="also run BASELINE configs[3] to the letter (262144 agents over the node, without / with the gather); automatic at --gpus 8")
-    ap.add_argument("--gather-timeout", type=float, default=300.0, help="watchdog (s) per gather leg: communicator init + the leg's steps")
+    ap.add_argument("--gather-timeout", type=float, default=120.0, help="watchdog (s) per gather leg: communicator init + the leg's steps")
+    ap.add_argument("--gather-budget", type=float, default=240.0, help="seconds all gather legs of one invocation may take together: legs that would start later are skipped and listed")
     ap.add_argument("--noise", choices=["rng", "table", "off"], default="rng",
                     help="rng: drawn on the device (default); table: NumPy's rows uploaded (A/B); off")
     ap.add_argument("--no-noise", action="store_true", help="same as --noise off")
@@ -929,21 +930,29 @@ def main(argv=None):
         # run still ends with its one line, `multi_gpu.gather_error` saying what happened.
         rdv.barrier()     # (the other ranks have been waiting here for rank 0's replays)
         err = None
+        t_legs = time.perf_counter()
 
         def gather_pair(work, agents_per_rank, out):
             """the same steps with the observation gather in the step's stream, then overlapped; -> rccl_ranks"""
             for name, overlap, f32, root in (("gather", False, False, None), ("gather_overlap", True, False, None),
                                              ("gather_f32", False, True, None), ("gather_f32_overlap", True, True, None),
                                              ("gather_root", False, False, 0), ("gather_root_f32_overlap", True, True, 0)):
+                # one decision for all ranks (rank 0's clock): a leg that would start after the budget is skipped and listed
+                late = rdv.max(1.0 if (rdv.rank == 0 and time.perf_counter() - t_legs > args.gather_budget) else 0.0) > 0.0
+                if late:
+                    out.setdefault("legs_skipped", []).append(name)
+                    continue
+                ranks_now = None
                 if args.stub:
                     res = stub_run(args, rdv, args.steps, name)
                 else:
                     res, e = guarded(lambda: (work.set_gather(True, overlap, f32, root), work.run(args.steps, args.warmup, "timed"))[1], args.gather_timeout)
                     if e:
                         raise RuntimeError("%s leg: %s" % (name, e))
+                    ranks_now = work.sim.comm_info()[0]     # ncclCommCount of the communicator this leg's collectives ran on
                 rec = leg_record(rdv, agents_per_rank * n_gpus, res)
                 esz = 4 if f32 else 8
-                out[name] = dict(rec, per_gpu_value=rec["value"] / n_gpus,
+                out[name] = dict(rec, per_gpu_value=rec["value"] / n_gpus, rccl_ranks=ranks_now,
                                  bytes_received_per_step={"root" if root is not None else "every_rank": agents_per_rank * (esz * args.beams + 56) * n_gpus},
                                  bytes_sent_per_rank_per_step=agents_per_rank * (esz * args.beams + 56))
             if args.stub:

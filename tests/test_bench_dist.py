@@ -245,3 +245,22 @@ def test_committed_bench_line_meets_the_contract():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     assert d["parity_gate"]["ok"] is True
+
+
+def test_gather_legs_respect_their_time_budget():
+    """VERDICT r4 #6a: the gather legs of one invocation share a time budget (--gather-budget, default 240 s, so that the default
+    `--gpus 8` run stays under five minutes whatever the links do): with a budget the first legs use up, the rest are skipped —
+    the same decision on every rank — and listed; the line is still printed"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "F110_BENCH_RDV")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "2", "--agents", "512",
+                          "--stub", "--gather-budget", "0.1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1000:]
+    mg = _bench_line(out.stdout)["multi_gpu"]
+    assert "gather" in mg and mg["gather"]["value"] > 0          # the first leg starts inside the budget (60 stub steps ~ 0.09 s + 0.03)
+    assert mg.get("legs_skipped") and mg["legs_skipped"][-1] == "gather_root_f32_overlap" and "gather" not in mg["legs_skipped"]
+    assert not (set(mg["legs_skipped"]) & set(k for k in mg if k.startswith("gather")))
+    assert mg.get("gather_error") is None
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2", "--agents", "512", "--stub"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    mg = _bench_line(out.stdout)["multi_gpu"]
+    assert "legs_skipped" not in mg and mg["gather_root_f32_overlap"]["rccl_ranks"] is None     # (stub: no communicator; real runs: ncclCommCount per leg)

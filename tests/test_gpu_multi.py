@@ -25,6 +25,17 @@ def _devices():
     return _ffi.device_count()
 
 
+def _partition_note():
+    """why a 1-GPU box shows one device: the compute partition mode (SPX = one logical device per MI355X; in CPX mode the same GPU
+    shows eight, and the 2- / 4-device tests below then run real multi-rank RCCL on partitions of one package)"""
+    try:
+        out = subprocess.run(["rocm-smi", "--showcomputepartition"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=30).stdout
+        modes = sorted({w for line in out.splitlines() if "artition" in line for w in line.replace(":", " ").split() if w in ("SPX", "DPX", "TPX", "QPX", "CPX")})
+        return "compute partition mode: %s" % (", ".join(modes) if modes else "not reported")
+    except Exception as ex:  # noqa: BLE001
+        return "compute partition mode unknown (%s)" % type(ex).__name__
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -68,7 +79,7 @@ def _check_gather_results(res, world):
 
 def test_two_ranks_two_devices_gather_the_observation():
     if _devices() < 2:
-        pytest.skip("needs 2 HIP devices (this box has %d)" % _devices())
+        pytest.skip("needs 2 HIP devices (this box has %d; %s)" % (_devices(), _partition_note()))
     procs, outs = _launch(2, [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")])
     res = _results(procs, outs)
     assert [r["device"] for r in res] == [0, 1]
@@ -77,7 +88,7 @@ def test_two_ranks_two_devices_gather_the_observation():
 
 def test_four_ranks_four_devices_gather_the_observation():
     if _devices() < 4:
-        pytest.skip("needs 4 HIP devices (this box has %d)" % _devices())
+        pytest.skip("needs 4 HIP devices (this box has %d; %s)" % (_devices(), _partition_note()))
     procs, outs = _launch(4, [sys.executable, os.path.join(ROOT, "tests", "dist_worker.py")], {"F110_DIST_ENVS": "32"})
     _check_gather_results(_results(procs, outs), 4)
 
@@ -95,7 +106,7 @@ def test_two_ranks_sharing_one_device_gather_the_observation():
 
 def test_bench_two_gpus_one_invocation_three_legs():
     if _devices() < 2:
-        pytest.skip("needs 2 HIP devices (this box has %d)" % _devices())
+        pytest.skip("needs 2 HIP devices (this box has %d; %s)" % (_devices(), _partition_note()))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "F110_BENCH_RDV")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--agents", "8192",
                           "--preroll", "60"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
