@@ -49,6 +49,7 @@ struct ExpSwitches {
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
     int group_split = 0;       // two env groups: percent of the envs in the first (0 = even)
     int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
+    int finalize_wave = 0;     // A = 2: 8 / 4 = k_finalize_pair_roles as one-wave workgroups of 8 / 4 agents (0 = the 256-thread form)
     int spec_from = 0;         // k_scan_rays_agent in the longest-first window: march_padded_spec from this sample on (0 = plain march)
     int scan_stream = 0;       // 1: the lane-refill scan (k_scan_stream_agent) wherever it applies
     int stream_refill = 0;     // free lanes that trigger a refill (0 = default)
@@ -420,6 +421,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "integrate_duo") h->exp.integrate_duo = value;
     else if (k == "integrate_fan") h->exp.integrate_fan = value;
     else if (k == "group_split") h->exp.group_split = value;
+    else if (k == "finalize_wave") h->exp.finalize_wave = value;
     else if (k == "spec_from") h->exp.spec_from = value;
     else if (k == "scan_stream") h->exp.scan_stream = value;
     else if (k == "stream_block") h->exp.stream_block = value;
@@ -2327,6 +2329,12 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
                 dev.fused_seq = h->fuse_seq;
                 h->fused_done = true;
             }
+#ifdef F110_EXPERIMENTAL
+            if (h->exp.finalize_wave > 0 && !dev.fused_host) {   // lab: one-wave workgroups (8 or 4 agents each)
+                if (h->exp.finalize_wave == 4) hipLaunchKernelGGL((k_finalize_pair_roles<4, 64>), dim3((count + 3) / 4), dim3(64), 0, st, dev, B);
+                else hipLaunchKernelGGL((k_finalize_pair_roles<8, 64>), dim3((count + 7) / 8), dim3(64), 0, st, dev, B);
+            } else
+#endif
             if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_roles<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
             else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_roles<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
             else hipLaunchKernelGGL(k_finalize_pair_roles<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);

@@ -1487,10 +1487,15 @@ __device__ __forceinline__ void pair_host_epilogue(const AgentArrays &a, bool ag
 // flattened into one item list (a crashed pair sees windows of up to all beams; fixed lanes per agent serialise there).
 // Same functions on the same operands as k_collide + k_finalize: bit-identical.  (The earlier forms — fixed lanes per
 // agent, the prologue dealt by agent — were measured slower in round 3 and retired in round 5: DESIGN_HISTORY.md.)
-template <int AG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k_finalize_pair_roles(AgentArrays a, int32_t B)   // (6 waves per SIMD = 80 VGPRs: what the kernel needs without its f110_step_host epilogue)
+// NT = 256: the product form.  NT = 64 (lab, round 5): the same kernel as ONE wave per workgroup at 8 waves per SIMD — a workgroup
+// that fits any slot a finished scan wave leaves, so that a second env block's finalize can run UNDER the first block's scan
+// (VERDICT r4 item 3); roles then share the wave: corners on lanes 0 .. 4 AG - 1, culls behind them, pair tests behind those.
+template <int AG, int NT = 256>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 8 : 6))) k_finalize_pair_roles(AgentArrays a, int32_t B)   // (6 waves per SIMD = 80 VGPRs: what the kernel needs without its f110_step_host epilogue)
 {
-    static_assert((AG & (AG - 1)) == 0 && AG >= 2 && 4 * AG <= 128, "AG is a power of two, 2..32");
+    static_assert((AG & (AG - 1)) == 0 && AG >= 2 && 4 * AG <= NT / 2, "AG is a power of two, 2..32 (NT = 64: 2..8)");
+    constexpr int R1 = NT == 64 ? 4 * AG : 128, R2 = NT == 64 ? 5 * AG : 192;   // first thread of the cull / the pair-test role
+    static_assert(R2 + AG / 2 <= NT, "the three roles fit the workgroup");
     __shared__ double s_rec[AG][12];   // ex, ey, eth, the opponent's box (8), pad
     __shared__ int s_idx[AG][4], s_cl[AG], s_ch[AG], s_hit[AG / 2];
     __shared__ int s_lo[AG], s_cnt[AG], s_off[AG + 1];
@@ -1500,10 +1505,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     int role = -1, slot = 0, sub = 0;
     if (t < 4 * AG) {                        // waves 0-1: box corner `sub` of agent `slot`'s opponent -> beam index
         role = 0; slot = t >> 2; sub = t & 3;
-    } else if (t >= 128 && t < 128 + AG) {   // wave 2: disc cull of agent `slot`
-        role = 1; slot = t - 128;
-    } else if (t >= 192 && t < 192 + AG / 2) {   // wave 3: the pair test of env (slot, slot + 1)
-        role = 2; slot = 2 * (t - 192);
+    } else if (t >= R1 && t < R1 + AG) {   // wave 2: disc cull of agent `slot`
+        role = 1; slot = t - R1;
+    } else if (t >= R2 && t < R2 + AG / 2) {   // wave 3: the pair test of env (slot, slot + 1)
+        role = 2; slot = 2 * (t - R2);
     }
     if (role >= 0 && first + slot < end) {
         const int i = first + slot, me = i & 1, o = i ^ 1;
@@ -1601,7 +1606,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) k
     }
     __syncthreads();
     const int total = s_off[AG];
-    for (int item = t; item < total; item += 256) {
+    for (int item = t; item < total; item += NT) {
         int ag = 0;   // the largest ag with s_off[ag] <= item (its window is not empty: item < s_off[ag + 1])
 #pragma unroll
         for (int st = AG / 2; st; st >>= 1)

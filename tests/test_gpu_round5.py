@@ -442,3 +442,35 @@ def test_speculative_tail_march_is_bit_identical(amd, spec_from):
         s.close()
     for key in outs[0]:
         assert np.array_equal(outs[0][key], outs[1][key]), key
+
+
+@pytest.mark.parametrize("wave", [8, 4])
+def test_one_wave_pair_finalize_is_bit_identical(amd, wave):
+    """k_finalize_pair_roles<AG, 64> (experimental build): the A = 2 finalize as one-wave workgroups of 8 / 4 agents at 8 waves
+    per SIMD (a workgroup that fits any slot a finished scan wave leaves) against the 256-thread product form — wall hits,
+    contacts with wide windows, the in-step re-seat, a partly filled last workgroup"""
+    from _util import bench_start_poses, load_map_image
+    E, A, T = 203, 2, 90
+    outs = []
+    for fw in (0, wave):
+        s = amd.BatchSim(num_envs=E, num_agents=A, exp={"finalize_wave": fw})
+        s.set_map_image(*load_map_image("example_map")); s.set_noise_rng(12345, 0.01)
+        poses = bench_start_poses(E, A, gap_wp=3)     # 0.6 m apart: contacts happen
+        s.reset(poses)
+        d = s.device_array((E * A, 3)); d.upload(poses)
+        rng = np.random.default_rng(21)
+        rec = []
+        for t in range(T):
+            if t % 10 == 0:
+                act = np.stack([rng.uniform(-0.3, 0.3, E * A), rng.uniform(0.5, 7.0, E * A)], axis=1)
+            if t == 40:
+                s.set_auto_reseat(d, 0, None)
+            s.step(act)
+            rec.append(s.get("scans", "state", "collisions", "collision_idx", "in_collision", "step_count"))
+        outs.append(rec)
+        s.close()
+    n_pair = sum(int((r["collision_idx"] >= 0).sum()) for r in outs[0]); n_wall = sum(int(r["in_collision"].sum()) for r in outs[0])
+    assert n_pair > 0 and n_wall > 0
+    for ra, rb in zip(*outs):
+        for key in ra:
+            assert np.array_equal(ra[key], rb[key]), key

@@ -37,6 +37,15 @@ for l in sys.stdin:
     d = json.loads(l); print('agents %6d spec_from %2d  %8.2f M agent-steps/s  %.4f ms/step' % ($n, $sp, d['value']/1e6, d['ms_per_step']))
 "; done; done; } | tee $OUT/spec_march.txt
   ;;
+finwave)   # the A = 2 finalize as one-wave workgroups (k_finalize_pair_roles<AG, 64>) under one / two env blocks, experimental build
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  F110_LIB_VARIANT=experimental F110_EXP=finalize_wave=W python bench.py --only-headline --steps 300 --warmup 30 --agents N --groups G (W 0 = the 256-thread product form)"
+    for n in 65536 32768; do for g in 1 2; do for fw in 0 8 4; do
+      F110_LIB_VARIANT=experimental F110_EXP=finalize_wave=$fw timeout 100 python bench.py --only-headline --steps 300 --warmup 30 --agents $n --groups $g 2>/dev/null | grep "^{" | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('agents %6d env blocks %d finalize_wave %d  %8.2f M agent-steps/s  %.4f ms/step' % ($n, $g, $fw, d['value']/1e6, d['ms_per_step']))
+"; done; done; done; } | tee $OUT/finalize_wave.txt
+  ;;
 bench)
   timeout 900 python bench.py > $OUT/bench_default.log 2>&1; grep -h '^{' $OUT/bench_default.log | tail -1 > $OUT/bench_default.json; cut -c1-600 $OUT/bench_default.json
   ;;
