@@ -109,11 +109,13 @@ def main():
                 print("skipped %s: measured on other sources than the PMC passes (%s)" % (src, csrc))
                 continue
             shutil.copyfile(os.path.join(SRC, src), os.path.join(DST, dst % tag))
-    # the late-round-3 latency work: sizes, the wave-by-wave timeline, compile-time variants, list switches
-    for src in ("latency_sizes.txt", "scan_timeline_4096.txt", "late_variants.txt", "late_lists.txt", "late_duo.txt", "late_many_agents.txt", "soak_fuzz.txt", "vecenv_rate.txt"):
+    # scratch files of measurement scripts: copied only when they carry THIS session's source hash themselves (gpurun_out/ is scratch
+    # that survives rounds — round 5 found round-3 files re-tagged with the new hash here)
+    for src in ("latency_sizes.txt", "scan_timeline_4096.txt", "stream_scan.txt", "spec_march.txt", "finalize_wave.txt"):
         if os.path.isfile(os.path.join(SRC, src)):
             body = open(os.path.join(SRC, src)).read()
-            open(os.path.join(DST, "%s_%s" % (tag, src)), "w").write(("" if "# csrc" in body else "# csrc %s\n" % csrc) + body)
+            if csrc and ("# csrc %s" % csrc) in body:
+                open(os.path.join(DST, "%s_%s" % (tag, src)), "w").write(body)
     # the A/B sweeps (one JSON line per bench run) as one table
     import glob
     rows = []

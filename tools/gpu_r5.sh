@@ -6,6 +6,15 @@ cd "${GRAFT_REPO_ROOT:-.}"
 R="$PWD"; export TMPDIR=/tmp
 OUT=$R/gpurun_out; mkdir -p $OUT
 python -c "import __graft_entry__ as g; print(g.build())" > $OUT/build.log 2>&1
+{ rocminfo | grep -E "Marketing Name|gfx9|Compute Unit|Max Clock" | head -8; nproc; lscpu | grep -E "Model name|Socket|NUMA node\(s\)|Core\(s\) per socket" | head -4; } > $OUT/box.txt 2>&1
+H="--only-headline --steps 300 --warmup 30"
+C5="--only-headline --agents 65536 --beams 4096 --map-tiles 2 --steps 100 --warmup 20 --preroll 100"
+line() { grep -h '^{' "$1" 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    print('%-34s %8.2f M/s  %.4f ms/step  resets %d' % ('$2', d['value']/1e6, d['ms_per_step'], d['config']['env_resets_in_timed_region']))
+"; }
 for MODE in "$@"; do
 case $MODE in
 test)
@@ -47,7 +56,45 @@ for l in sys.stdin:
 "; done; done; done; } | tee $OUT/finalize_wave.txt
   ;;
 bench)
-  timeout 900 python bench.py > $OUT/bench_default.log 2>&1; grep -h '^{' $OUT/bench_default.log | tail -1 > $OUT/bench_default.json; cut -c1-600 $OUT/bench_default.json
+  ( time timeout 900 python bench.py > $OUT/bench_default.log 2>$OUT/bench_default.err ) 2> $OUT/bench_default.time; echo "bench exit $?" >> $OUT/bench_default.log; tail -3 $OUT/bench_default.time
+  tail -c 2500 $OUT/bench_default.log
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dropin --secondary 0 --no-config5 --fixed-pose-steps 0 > $OUT/bench_driver_form.log 2>&1; line $OUT/bench_driver_form.log "driver form --steps 20 --warmup 5"
+  ;;
+prof)
+  cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats -o stats -- python $R/bench.py $H > $OUT/prof_stats.log 2>&1
+  timeout 60 python $R/tools/summarize_prof.py stats $OUT/prof_stats $OUT/kernel_stats.txt 300; rm -rf $OUT/prof_stats
+  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats4k -o stats -- python $R/bench.py $H --agents 4096 --groups 1 > $OUT/prof_stats4k.log 2>&1
+  timeout 60 python $R/tools/summarize_prof.py stats $OUT/prof_stats4k $OUT/kernel_stats_4096.txt 300; rm -rf $OUT/prof_stats4k
+  timeout 400 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_stats5 -o stats -- python $R/bench.py $C5 > $OUT/prof_stats5.log 2>&1
+  timeout 60 python $R/tools/summarize_prof.py stats $OUT/prof_stats5 $OUT/kernel_stats_cfg5.txt 100; rm -rf $OUT/prof_stats5
+  cd "$R"; head -14 $OUT/kernel_stats.txt; tail -6 $OUT/kernel_stats_4096.txt; tail -6 $OUT/kernel_stats_cfg5.txt
+  ;;
+pmc)
+  cd /tmp
+  i=0
+  for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_TA_BUSY GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays|k_finalize|k_integrate|k_collide" -T -f csv -d $OUT/pmc_$i -o p -- python $R/bench.py $H > $OUT/pmc_$i.log 2>&1
+    timeout 60 python $R/tools/summarize_prof.py pmc $OUT/pmc_$i $OUT/pmc_pass$i.json - 300
+    rm -rf $OUT/pmc_$i
+  done
+  for cfg in "4096:--agents 4096 --groups 1" "cfg5:--agents 65536 --beams 4096 --map-tiles 2 --steps 100 --warmup 20 --preroll 100"; do
+    tagc=${cfg%%:*}; argsc=${cfg#*:}; n=300; [ "$tagc" = cfg5 ] && n=100
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout 300 rocprofv3 --pmc $c --kernel-include-regex "k_scan_rays|k_scan_dirs" -T -f csv -d $OUT/tr_$c -o p -- python $R/bench.py --only-headline $argsc > $OUT/tr_${tagc}_$c.log 2>&1
+      timeout 60 python $R/tools/summarize_prof.py pmc $OUT/tr_$c $OUT/traffic_${tagc}_$c.json - $n
+      rm -rf $OUT/tr_$c
+    done
+    timeout 300 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --kernel-include-regex "k_scan_rays|k_scan_dirs" -T -f csv -d $OUT/tr_vm -o p -- python $R/bench.py --only-headline $argsc > $OUT/tr_${tagc}_vm.log 2>&1
+    timeout 60 python $R/tools/summarize_prof.py pmc $OUT/tr_vm $OUT/traffic_${tagc}_VMEM.json - $n
+    rm -rf $OUT/tr_vm
+  done
+  cd "$R"; ls $OUT/pmc_pass*.json $OUT/traffic_*.json 2>/dev/null | wc -l
+  ;;
+tabench)
+  { echo "# $(date -u) tools/debug/ta_bench.hip on this box"; cat $OUT/box.txt; } > $OUT/ta_bench.txt
+  timeout 120 hipcc --offload-arch=gfx950 -O3 tools/debug/ta_bench.hip -o /tmp/ta_bench > /dev/null 2>&1 && timeout 120 /tmp/ta_bench >> $OUT/ta_bench.txt 2>&1; tail -12 $OUT/ta_bench.txt
   ;;
 esac
 done
