@@ -369,7 +369,7 @@ static int task_order_setup(f110_sim *h, bool on)
     }
     h->task_cap = std::min<uint32_t>(h->task_cap_alloc, (uint32_t)std::max<size_t>(64, n_tasks / h->task_cap_div));
     for (int q = 0; q < 2; ++q)   // struct q is used at steps of parity q: it reads what parity q^1 wrote
-        h->tsched[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr};
+        h->tsched[q] = TaskSched{h->d_tflags[q ^ 1], h->d_tflags[q], h->d_tlist[q ^ 1], h->d_tlist[q], h->d_tcount + (q ^ 1), h->d_tcount + q, h->task_cap, h->task_thr, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, 0u, 0u};
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->task_order = true;
     return F110_OK;

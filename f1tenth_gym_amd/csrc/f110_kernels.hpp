@@ -540,6 +540,13 @@ struct TaskSched {
     const uint32_t *count_r;
     uint32_t *count_w;   // zeroed by k_integrate of the same step
     uint32_t cap, thr;
+    // Reserved words here and in RayJob keep the kernel-argument layout the scan kernels were tuned on: the retired ray pass /
+    // two-pass / LDS-window fields used to sit there, and taking them out moved the hot fields across the boundaries of the
+    // compiler's wide scalar loads — 4096 agents 46.3 -> 44.6 M agent-steps/s, back to 46.7 with the padding (round 5, A/B of
+    // three builds in one session).  Asking for all arguments in ONE batch of scalar loads at the top of the kernel (nine
+    // dependent round trips -> two) is no cure either: 46.7 -> 44.7 M at 4096 agents, no change at 2048 / 8192 / 16 384.
+    const void *reserved_r[8];
+    uint32_t reserved_rcap, reserved_rthr;
 };
 
 struct RayJob {
@@ -549,6 +556,7 @@ struct RayJob {
     int32_t n_poses;
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
     int32_t pad_dir, dir_stride;    // k_scan_dirs_agent: distinct directions per agent, rounded up to whole 64-direction tasks
+    const void *reserved_dir_ranges;
     uint32_t first_pose, spec_from; // k_scan_rays_agent: the launch covers agents first_pose .. (env group); SPEC: march_padded_spec from this sample on
     unsigned long long *lookups_total;  // COUNT variants: table lookups of every marched ray, summed (or nullptr)
     // longest-first task order (k_scan_rays_agent<.., SCHED>): see TaskSched
@@ -566,6 +574,8 @@ struct RayJob {
     // block order hands each XCD's L2 the agents of as few tracks as possible however the caller interleaved
     // them (nullptr: agent order)
     const uint32_t *order;
+    const void *reserved_win[2];
+    uint32_t reserved_win_pitch, pad_win;
     const double *pose_x, *pose_y, *dir_start;  // [n_poses] (unit path)
     double *ranges;           // [n_poses][B]
     // STEP only

@@ -410,9 +410,12 @@ enum { LAYOUT_ROWMAJOR = 0, LAYOUT_PADDED = 3 };   // (1 = 4x4 tiles and 2 = byt
 struct ScanConst {
     const double *table;   // the distance table dt[r][c] (PADDED: the interior of the padded copy, its row pitch)
     const double *table_rm;  // the same (a separate row-major original only while a map too large for PADDED is loaded)
+    const void *reserved_codes;   // (layout 2's byte codes: retired; the fields keep the kernel-argument layout)
+    const void *reserved_lut;
     const double2 *cs;     // (cos, sin) of linspace(0, 2pi, theta_dis), interleaved
     int32_t height, width, pad_tiles, theta_dis;
     int32_t num_beams, res_pow2, ident_rot, row_bytes;  // row_bytes = width * 8
+    int32_t reserved_tile_bytes, pad1;
     double res, inv_res, orig_x, orig_y, orig_c, orig_s;
     double w_res, h_res;   // width*resolution, height*resolution (xy_2_rc :79)
     double oob_value;      // dt[-1,-1]: what an out-of-bounds sample reads (:80-81,:103)
