@@ -46,6 +46,17 @@ for l in sys.stdin:
     d = json.loads(l); print('agents %6d spec_from %2d  %8.2f M agent-steps/s  %.4f ms/step' % ($n, $sp, d['value']/1e6, d['ms_per_step']))
 "; done; done; } | tee $OUT/spec_march.txt
   ;;
+manyagents)
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  bench.py --only-headline --agents 65520|65536 --agents-per-env A --steps 200 --warmup 20 (product library)"
+  for a in 1 2 3 4 8 16 24 32; do
+    n=$(( 65536 / a * a ))
+    timeout 200 python bench.py --only-headline --agents $n --agents-per-env $a --steps 200 --warmup 20 > $OUT/many_$a.log 2>&1; line $OUT/many_$a.log "A=$a product"
+  done; } | tee $OUT/many_agents.txt
+  ;;
+rates)
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  bench.py $H --agents N (product library)"
+  for n in 1024 2048 4096 8192 16384 32768 65536; do timeout 200 python bench.py $H --agents $n > $OUT/rate_$n.log 2>&1; line $OUT/rate_$n.log "agents $n"; done; } | tee $OUT/rates.txt
+  ;;
 finwave)   # the A = 2 finalize as one-wave workgroups (k_finalize_pair_roles<AG, 64>) under one / two env blocks, experimental build
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  F110_LIB_VARIANT=experimental F110_EXP=finalize_wave=W python bench.py --only-headline --steps 300 --warmup 30 --agents N --groups G (W 0 = the 256-thread product form)"
     for n in 65536 32768; do for g in 1 2; do for fw in 0 8 4; do
