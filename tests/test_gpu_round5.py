@@ -250,8 +250,7 @@ def test_overlapped_obs_gather_between_two_block_steps(amd):
 
 
 # ---------------------------------------------------------------- lab: the lane-refill scan (survivor compaction)
-@pytest.mark.parametrize("kw", [dict(E=24, A=2, T=40), dict(E=700, A=1, T=20), dict(E=33, A=3, T=25), dict(E=48, A=2, T=25, yaw=0.3),
-                                dict(E=64, A=2, T=25, per_env=True), dict(E=4096, A=2, T=10)])
+@pytest.mark.parametrize("kw", [dict(E=33, A=3, T=25), dict(E=48, A=2, T=25, yaw=0.3), dict(E=64, A=2, T=25, per_env=True), dict(E=4096, A=2, T=10)])
 def test_lane_refill_scan_is_bit_identical(amd, kw):
     """k_scan_stream_agent (experimental build; VERDICT r4 item 2, measured slower and not adopted): a wave owns an agent's scan
     as a queue and re-fills finished lanes — every output equals k_scan_rays_agent's bit for bit, for every refill threshold,
@@ -420,7 +419,7 @@ def test_example_rl_loop_device_runs():
     assert out.returncode == 0 and "torch MLP via DLPack" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
 
 
-@pytest.mark.parametrize("spec_from", [2, 8, 40])
+@pytest.mark.parametrize("spec_from", [2, 40])
 def test_speculative_tail_march_is_bit_identical(amd, spec_from):
     """march_padded_spec (experimental build, measured slower and not adopted): from sample `spec_from` on a ray also reads the
     cell two steps ahead and takes it when the table value repeats — same samples, same lookups, same ranges as the plain march
