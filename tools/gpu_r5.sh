@@ -46,6 +46,35 @@ for l in sys.stdin:
     d = json.loads(l); print('agents %6d spec_from %2d  %8.2f M agent-steps/s  %.4f ms/step' % ($n, $sp, d['value']/1e6, d['ms_per_step']))
 "; done; done; } | tee $OUT/spec_march.txt
   ;;
+pmcstream)   # why the lane-refill scan loses: the same PMC passes over k_scan_rays_agent and k_scan_stream_agent (experimental build, 65 536 agents)
+  cd /tmp
+  for tag in "base:scan_stream=0" "stream:scan_stream=1,stream_block=64,stream_refill=48"; do
+    nm=${tag%%:*}; ex=${tag#*:}; i=0
+    for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS" "TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum GRBM_GUI_ACTIVE" "TD_TD_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+      i=$((i+1))
+      F110_LIB_VARIANT=experimental F110_EXP=$ex timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays|k_scan_stream" -T -f csv -d $OUT/ps_$i -o p -- python $R/bench.py $H > $OUT/ps_$i.log 2>&1
+      timeout 60 python $R/tools/summarize_prof.py pmc $OUT/ps_$i $OUT/pmcstream_${nm}_$i.json - 300
+      rm -rf $OUT/ps_$i
+    done
+  done
+  cd "$R"; python - <<'PY'
+import json, glob, os
+out = {}
+for f in sorted(glob.glob(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "pmcstream_*_*.json"))):
+    nm = os.path.basename(f).split("_")[1]
+    for k, v in json.load(open(f)).items():
+        rec = out.setdefault(nm, {}).setdefault(k, {"csrc": v.get("csrc"), "dispatches": v["dispatches"], "mean_per_dispatch": {}, "meta": v.get("meta")})
+        rec["mean_per_dispatch"].update(v["mean_per_dispatch"])
+json.dump(out, open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "pmc_stream_vs_base.json"), "w"), indent=1, sort_keys=True)
+for nm, ks in out.items():
+    for k, v in ks.items():
+        m = v["mean_per_dispatch"]
+        cyc = m.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        print(nm, k, "us %.0f" % (cyc / 2400.0), "vmem_rd %.3g wr %.3g valu %.3g salu %.3g lds %.3g" % (m.get("SQ_INSTS_VMEM_RD", 0), m.get("SQ_INSTS_VMEM_WR", 0), m.get("SQ_INSTS_VALU", 0), m.get("SQ_INSTS_SALU", 0), m.get("SQ_INSTS_LDS", 0)),
+              "TA %.2f TD %.2f" % (m.get("TA_TA_BUSY_sum", 0) / 256 / max(cyc, 1), m.get("TD_TD_BUSY_sum", 0) / 256 / max(cyc, 1)),
+              "L1 acc %.3g -> L2 req %.3g (L2 hit %.3f)" % (m.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0), m.get("TCP_TCC_READ_REQ_sum", 0), m.get("TCC_HIT_sum", 0) / max(m.get("TCC_REQ_sum", 1), 1)))
+PY
+  ;;
 manyagents)
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  bench.py --only-headline --agents 65520|65536 --agents-per-env A --steps 200 --warmup 20 (product library)"
   for a in 1 2 3 4 8 16 24 32; do
