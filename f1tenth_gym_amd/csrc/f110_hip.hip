@@ -49,6 +49,7 @@ struct ExpSwitches {
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
     int group_split = 0;       // two env groups: percent of the envs in the first (0 = even)
     int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
+    int pad_tiled = 0;         // 1: the step's scan marches a 4x4-tiled copy of the PADDED table (set before the map is loaded)
     int finalize_wave = 0;     // A = 2: 8 / 4 = k_finalize_pair_roles as one-wave workgroups of 8 / 4 agents (0 = the 256-thread form)
     int spec_from = 0;         // k_scan_rays_agent in the longest-first window: march_padded_spec from this sample on (0 = plain march)
     int scan_stream = 0;       // 1: the lane-refill scan (k_scan_stream_agent) wherever it applies
@@ -91,7 +92,7 @@ struct f110_sim {
     ScanConst k_uploaded{};
     unsigned long long *d_path_stats = nullptr;  // [3], see f110_scan_path_stats
     bool path_stats_on = false;
-    double *d_dt_row = nullptr, *d_dt_pad = nullptr, *d_actions = nullptr, *d_poses = nullptr;
+    double *d_dt_row = nullptr, *d_dt_pad = nullptr, *d_dt_pad_t = nullptr, *d_actions = nullptr, *d_poses = nullptr;
     double2 *d_cs = nullptr;
     uint8_t *d_mask = nullptr;
     // env groups: the step of G > 1 independent env blocks runs on G streams of its own (no event
@@ -421,6 +422,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "integrate_duo") h->exp.integrate_duo = value;
     else if (k == "integrate_fan") h->exp.integrate_fan = value;
     else if (k == "group_split") h->exp.group_split = value;
+    else if (k == "pad_tiled") h->exp.pad_tiled = value;
     else if (k == "finalize_wave") h->exp.finalize_wave = value;
     else if (k == "spec_from") h->exp.spec_from = value;
     else if (k == "scan_stream") h->exp.scan_stream = value;
@@ -799,7 +801,7 @@ void f110_destroy(f110_sim *h)
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
-                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_pad, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k, h->d_params_all};
+                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_pad, h->d_dt_pad_t, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k, h->d_params_all};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ms : h->extra_maps) {
@@ -886,6 +888,17 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
                            h->d_dt_pad);
         HIPCHK(h, hipGetLastError());
         k.pad = h->d_dt_pad;
+        k.pad_t = nullptr;
+        if (h->d_dt_pad_t) { (void)hipFree(h->d_dt_pad_t); h->d_dt_pad_t = nullptr; }
+        if (kExperimental && h->exp.pad_tiled) {   // lab: the same table in 4x4-cell tiles for the step's march
+            const size_t tiles_w = ((size_t)k.pad_width + 3) / 4, tiles_h = ((size_t)k.pad_height + 3) / 4;
+            TRY(dmalloc(h, &h->d_dt_pad_t, tiles_w * tiles_h * 16));
+            k.pad_t_row_bytes = (int32_t)(tiles_w * 128);
+            hipLaunchKernelGGL(k_build_padded_tiled, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_pad, k.pad_width, k.pad_height, (uint32_t)k.pad_t_row_bytes,
+                               h->d_dt_pad_t);
+            HIPCHK(h, hipGetLastError());
+            k.pad_t = h->d_dt_pad_t;
+        }
         if (h->cfg.map_layout == F110_MAP_PADDED_F64) {
             // ONE table per map: the exact paths (k_integrate's first sample, the cold re-march, the unit
             // kernels) address dt[r][c] as table_rm + r * row_bytes + 8 c — point them at the interior of
@@ -2232,6 +2245,12 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
                 break;
             }
 #endif
+#ifdef F110_EXPERIMENTAL
+            if (h->exp.pad_tiled && h->k.pad_t && h->k.ident_rot) {
+                hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true, false, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                break;
+            }
+#endif
             if (h->k.ident_rot)
                 hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
             else
@@ -2282,6 +2301,12 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
                     hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, false, true>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
                 else
                     hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, false, true>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                break;
+            }
+#endif
+#ifdef F110_EXPERIMENTAL
+            if (h->exp.pad_tiled && h->k.pad_t && h->k.ident_rot && !h->multi_map && !cnt) {
+                hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, false, false, false, true>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
                 break;
             }
 #endif

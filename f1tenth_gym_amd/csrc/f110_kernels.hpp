@@ -777,7 +777,7 @@ __device__ __forceinline__ void load_map_fast(ScanConst &km, const MapFast *__re
 #ifndef F110_SCAN_WAVES_EXPR
 #define F110_SCAN_WAVES_EXPR 8
 #endif
-template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false, bool SPEC = false>
+template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false, bool SPEC = false, bool TILED = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_SCAN_WAVES_EXPR))) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
                                                           const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
@@ -870,7 +870,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
             padded_rate<IDENT>(km, cs.x, cs.y, cux, cuy);
             // SPEC (small batches, round 5): the tail of a long ray two samples per round trip where the table value repeats
             exact = SPEC ? !march_padded_spec<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl, (int)j.spec_from)
-                         : !march_padded<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl);
+                         : !march_padded<false, TILED>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl);
         }
         if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
         if (COUNT) nl_acc += (uint32_t)nl;   // measurement variant only (bench.py's L-bar)
@@ -2677,6 +2677,15 @@ __global__ void k_dt_from_d2(const uint32_t *__restrict__ d2, size_t n, double r
 
 // PADDED layout: the table inside a border of `b` cells that read dt[-1,-1], what the reference
 // returns for any out-of-bounds sample (laser_models.py:80-81,103)
+// the padded table again in 4x4-cell tiles (lab, march_padded<.., TILED>): one thread per padded cell
+__global__ void k_build_padded_tiled(const double *__restrict__ pad, int Wp, int Hp, uint32_t tile_row_bytes, double *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Wp * Hp) return;
+    const uint32_t r = (uint32_t)(i / Wp), c = (uint32_t)(i - (size_t)r * Wp);
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(out) + tiled_offset(r, c, tile_row_bytes)) = pad[i];
+}
+
 __global__ void k_build_padded(const double *__restrict__ rowmajor, int H, int W, int b, int Wp, int Hp, double *__restrict__ pad)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

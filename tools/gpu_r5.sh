@@ -75,6 +75,11 @@ for nm, ks in out.items():
               "L1 acc %.3g -> L2 req %.3g (L2 hit %.3f)" % (m.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0), m.get("TCP_TCC_READ_REQ_sum", 0), m.get("TCC_HIT_sum", 0) / max(m.get("TCC_REQ_sum", 1), 1)))
 PY
   ;;
+tiled)   # the scan on a 4x4-tiled copy of the PADDED table (experimental build)
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  tools/debug/tiled_ab.py (parity) + tools/debug/stream_probe.py N pad_tiled=0|1 (experimental build)"
+    F110_LIB_VARIANT=experimental timeout 200 python tools/debug/tiled_ab.py 2>&1 | tail -6
+    for n in 65536 16384 4096; do for pt in 0 1; do F110_LIB_VARIANT=experimental timeout 90 python tools/debug/stream_probe.py $n pad_tiled=$pt 2>&1 | grep agents; done; done; } | tee $OUT/tiled_table.txt
+  ;;
 manyagents)
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  bench.py --only-headline --agents 65520|65536 --agents-per-env A --steps 200 --warmup 20 (product library)"
   for a in 1 2 3 4 8 16 24 32; do
