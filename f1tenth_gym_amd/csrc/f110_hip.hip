@@ -739,9 +739,14 @@ int f110_create(const f110_config *cfg, f110_sim **out)
     if (k.theta_inc < 1.0 && B >= 64) {
         // more beams than table directions: march each distinct direction once (k_scan_dirs_agent)
         int stride = (int)std::ceil((B - 1) * k.theta_inc) + 2;
+        // The direction kernel walks an agent's beams in order of their table index RELATIVE to beam 0's, which must not wrap:
+        // a scan that spans the whole table — fov close to a full turn, e.g. 6.28 with 1000 directions: (B - 1) theta_inc =
+        // 999.5, plus the start's fraction — ends on beam 0's directions again and those beams were left unwritten (found by
+        // round 5's fuzz over constructor arguments).  Such scans march every beam (k_scan_rays_agent).
+        const bool wraps = (B - 1) * k.theta_inc + 1.0 >= (double)cfg->theta_dis;
         stride = std::min(stride, cfg->theta_dis);
         stride = (stride + 63) / 64 * 64;
-        if (stride < B && (long long)N * stride < 0xFFFFFF00LL) {
+        if (!wraps && stride < B && (long long)N * stride < 0xFFFFFF00LL) {
             h->dir_stride = stride;
         }
     }

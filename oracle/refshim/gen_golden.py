@@ -894,6 +894,7 @@ SCAN_CTOR_CASES = [
     ("berlin", 360, 6.2, 0.0001, 720, 30.0),         # fov close to a full turn, coarse direction table
     ("skirk", 777, 3.3, 0.03, 3600, 12.5),
     ("example_map", 2048, 4.7, 0.0001, 1000, 30.0),  # twice as many beams as directions
+    ("skirk", 1500, 6.28, 0.0001, 1000, 30.0),       # fov ~ a full turn on 1000 directions: the last beams land on beam 0's directions again
 ]
 
 
@@ -908,6 +909,8 @@ def gen_scan_ctor(ns):
         probe = lm.ScanSimulator2D(beams, fov, eps=eps, theta_dis=theta_dis, max_range=max_range)
         probe.set_map(_map_yaml(name), ".png")
         poses = _poses_in_free_space(probe, rng, 5)
+        if fov > 6.2:    # the full-turn case: every heading one the step-path tests can use (no yaw wrap in update_pose)
+            poses[:, 2] = rng.uniform(0.0, 2 * np.pi, len(poses))
         sim, scans, rcs, idx, lk = _scan_cases_ctor(ns, _map_yaml(name), poses, beams, fov, eps=eps, theta_dis=theta_dis, max_range=max_range)
         std = [0.05, 0.2, 0.001][k % 3]
         noisy = sim.scan(np.array(poses[0]), np.random.default_rng(4242 + k), std_dev=std)

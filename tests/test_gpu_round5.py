@@ -44,10 +44,10 @@ def _step_scans_at(amd, poses, img, res, origin, layout, reps=1, **ctor):
 
 # ---------------------------------------------------------------- ScanSimulator2D keywords away from their defaults
 @pytest.mark.parametrize("layout", [0, 3])
-@pytest.mark.parametrize("case", range(6))
+@pytest.mark.parametrize("case", range(7))
 def test_scan_ctor_variants_vs_reference(amd, case, layout):
     g = gold("scan_ctor_variants")
-    assert int(g["n_cases"][0]) == 6
+    assert int(g["n_cases"][0]) == 7
     k = case
     beams, fov, eps, theta_dis, max_range = g["c%d_ctor" % k]
     beams, theta_dis = int(beams), int(theta_dis)
@@ -72,7 +72,7 @@ def test_scan_ctor_variants_vs_reference(amd, case, layout):
     scans, keep = _step_scans_at(amd, poses, img, res, origin, layout, num_beams=beams, fov=fov, eps=eps, theta_dis=theta_dis,
                                  max_range=max_range)
     assert np.array_equal(scans, g["c%d_scans" % k][keep])
-    if layout == 3 and case in (0, 1, 2):      # the same through the big-batch form of the scan (12 000+ tasks)
+    if layout == 3 and case in (0, 1, 2, 6):      # the same through the big-batch form of the scan (12 000+ tasks)
         scans, keep = _step_scans_at(amd, poses, img, res, origin, layout, reps=400, num_beams=beams, fov=fov, eps=eps, theta_dis=theta_dis,
                                      max_range=max_range)
         assert np.array_equal(scans, g["c%d_scans" % k][keep])

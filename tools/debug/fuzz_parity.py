@@ -21,10 +21,17 @@ def run(seed, verbose=True, tol=1e-9, stop_when_diverged=False):
     T = int(rng.integers(20, 70)); nrows = int(rng.choice([0, 5, T + 2]))
     tasks = int(rng.choice([0, 1, 3])); block = int(rng.choice([0, 64, 128, 256]))
     img, res, origin = load_map_image(mapname); dt, _, _ = oracle_map_dt(mapname)
+    # round 5: the ScanSimulator2D constructor arguments and the yaw of the map origin join the draw — from a generator of their
+    # own, so that a seed's other choices stay what they were (laser_models.py:360-381: eps, theta_dis, max_range; :417-420: origin[2])
+    rng2 = np.random.default_rng(seed + 7777)
+    eps = float(rng2.choice([1e-4, 1e-4, 1e-4, 0.03, 0.2])); theta_dis = int(rng2.choice([2000, 2000, 2000, 720, 1000, 3600]))
+    max_range = float(rng2.choice([30.0, 30.0, 30.0, 8.0, 12.5])); yaw = float(rng2.choice([0.0, 0.0, 0.3, -1.1, 2.4]))
+    origin = [origin[0], origin[1], yaw]
     s = amd.BatchSim(num_envs=E, num_agents=A, num_beams=B, fov=fov, integrator=integ, lidar_dist=ld, map_layout=layout,
-                     scan_tasks_per_wave=tasks, scan_block=block)
+                     scan_tasks_per_wave=tasks, scan_block=block, eps=eps, theta_dis=theta_dis, max_range=max_range)
     s.set_map_image(img, res, origin)
-    ref = orc.SimOracle(E, A, num_beams=B, fov=fov, integrator=integ, lidar_dist=ld); ref.set_map_dt(dt, res, origin)
+    ref = orc.SimOracle(E, A, num_beams=B, fov=fov, integrator=integ, lidar_dist=ld, eps=eps, theta_dis=theta_dis, max_range=max_range)
+    ref.set_map_dt(dt, res, origin)
     # the oracle builds its beam tables with libm; use the product's NumPy tables on both sides
     if nrows:
         noise = np.random.default_rng(seed + 1).normal(0., 0.01, size=(nrows, B))
@@ -38,8 +45,13 @@ def run(seed, verbose=True, tol=1e-9, stop_when_diverged=False):
     else:
         base = np.stack([rng.uniform(-0.5, 0.5, E), rng.uniform(-0.5, 0.5, E), rng.uniform(0, 6.28, E)], axis=1)
     poses = np.repeat(base, A, axis=0) + np.stack([rng.uniform(-0.8, 0.8, E * A), rng.uniform(-0.8, 0.8, E * A), rng.uniform(-0.5, 0.5, E * A)], axis=1)
+    if yaw != 0.0:   # the map turns about its origin: the cars turn with it
+        c_, s_ = np.cos(yaw), np.sin(yaw)
+        dx, dy = poses[:, 0] - origin[0], poses[:, 1] - origin[1]
+        poses = np.stack([origin[0] + c_ * dx - s_ * dy, origin[1] + s_ * dx + c_ * dy, poses[:, 2] + yaw], axis=1)
     s.reset(poses); ref.reset(poses)
-    tag = "seed %d %s E%d A%d B%d fov%.2f integ%d ld%.3f layout%d T%d noise%d tasks%d blk%d" % (seed, mapname, E, A, B, fov, integ, ld, layout, T, nrows, tasks, block)
+    tag = "seed %d %s E%d A%d B%d fov%.2f integ%d ld%.3f layout%d T%d noise%d tasks%d blk%d eps%g td%d mr%g yaw%g" % (
+        seed, mapname, E, A, B, fov, integ, ld, layout, T, nrows, tasks, block, eps, theta_dis, max_range, yaw)
     for t in range(T):
         if t % 7 == 0:
             act = np.stack([rng.uniform(-0.45, 0.45, E * A), rng.uniform(-4.0, 9.0, E * A)], axis=1)

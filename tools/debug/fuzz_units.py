@@ -119,4 +119,28 @@ for mapname in ("example_map", "berlin", "skirk"):
                 nb += 1
         print("scan", mapname, "layout", layout, "bad poses", nb, "of", kk)
         s.close()
+# ---- round 5: the same with the ScanSimulator2D constructor arguments and the origin's yaw drawn too (laser_models.py:360-381, :417-420)
+for trial in range(10):
+    mapname = str(rng.choice(["example_map", "berlin", "skirk"]))
+    img, res, origin = load_map_image(mapname); dt, _, _ = oracle_map_dt(mapname)
+    H, W = dt.shape
+    B = int(rng.choice([1080, 271, 64, 1500, 2048])); fov = float(rng.choice([4.7, 6.28, 3.0]))
+    eps = float(rng.choice([1e-4, 0.03, 0.2])); theta_dis = int(rng.choice([2000, 720, 1000, 3600])); max_range = float(rng.choice([30.0, 8.0, 12.5]))
+    org = [origin[0], origin[1], float(rng.choice([0.0, 0.3, -1.1, 2.4]))]
+    layout = int(rng.choice([0, 3]))
+    s = amd.BatchSim(num_envs=1, num_agents=1, num_beams=B, fov=fov, eps=eps, theta_dis=theta_dis, max_range=max_range, map_layout=layout)
+    s.set_map_image(img, res, org)
+    so = orc.ScanOracle(B, fov, eps=eps, theta_dis=theta_dis, max_range=max_range); so.set_map_dt(dt, res, org)
+    kk = 60
+    uu, vv = rng.uniform(-0.1, 1.1, kk) * W * res, rng.uniform(-0.1, 1.1, kk) * H * res
+    c_, s_ = np.cos(org[2]), np.sin(org[2])
+    poses = np.stack([org[0] + c_ * uu - s_ * vv, org[1] + s_ * uu + c_ * vv, rng.uniform(-20, 20, kk)], axis=1)
+    ranges, hits, lk = s.scan_batch(poses, want_hits=True, want_lookups=True)
+    nb = 0
+    for i in range(kk):
+        r, h_ = so.scan(poses[i], want_hits=True)
+        if not (np.array_equal(ranges[i], r) and np.array_equal(hits[i], h_) and lk[i] == so.last_lookups):
+            nb += 1
+    print("scan ctor", mapname, "B", B, "fov", fov, "eps", eps, "theta_dis", theta_dis, "max_range", max_range, "yaw", org[2], "layout", layout, "bad poses", nb, "of", kk)
+    s.close()
 u.close()
