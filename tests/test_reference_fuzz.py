@@ -202,3 +202,71 @@ def test_simulator_sweep(case, tmp_path):
         print("case %d: %s A=%d wall-hit steps %d, contact steps %d, state err %.1e scan err %.1e" % (case, name, A, seen["wall"], seen["gjk"], worst_state, worst_scan))
     finally:
         ref_loader.fresh_racecar_class(ns)
+
+
+ENV_CASES = [
+    # map name (None = the env's own default: vegas), agents, ego_idx, integrator, timestep, lidar_dist, steps
+    (None, 2, 0, "RK4", 0.01, 0.0, 110),
+    ("example_map", 1, 0, "Euler", 0.02, 0.1, 260),
+    ("berlin", 3, 2, "RK4", 0.01, 0.275, 60),
+    ("skirk", 2, 1, "RK4", 0.02, 0.0, 70),
+]
+
+
+@pytest.mark.parametrize("case", range(len(ENV_CASES)))
+def test_f110env_sweep(case):
+    """the reference F110Env (f110_env.py:104-349: constructor keywords, reset's zero-action step, _check_done's start-zone
+    toggles in the EGO's start frame, lap counts / times, done on the ego's collision) against the oracle's Simulator under the
+    package's host lap logic (`f1tenth_gym_amd.env._LapLogic`, what F110Env / F110VecEnv's host path run), on random keywords,
+    starts and actions"""
+    from f1tenth_gym_amd.env import _LapLogic
+    name, A, ego, integ, ts, ld, T = ENV_CASES[case]
+    T = max(8, int(round(T * SCALE)))
+    ns = ref_loader.load_reference(with_env=True)
+    rng = np.random.default_rng(9000 + case)
+    seed = int(rng.integers(0, 2 ** 31))
+    params = _random_params(rng)
+    ref_loader.fresh_racecar_class(ns)
+    try:
+        kw = dict(num_agents=A, ego_idx=ego, seed=seed, timestep=ts, integrator=getattr(ns.base_classes.Integrator, integ), lidar_dist=ld, params=dict(params))
+        if name is not None:
+            kw.update(map=os.path.splitext(_map_files(name)[0])[0], map_ext=".png")
+        env = ns.f110_env.F110Env(**kw)
+        scan_sim = ns.base_classes.RaceCar.scan_simulator
+        start = _start_cluster(scan_sim, rng, A)
+        o = orc.SimOracle(1, A, params=params, time_step=ts, integrator={"RK4": 1, "Euler": 2}[integ], lidar_dist=ld)
+        o.set_map_dt(scan_sim.dt, scan_sim.map_resolution, scan_sim.origin)
+        o.set_noise(np.random.default_rng(seed).normal(0., 0.01, size=(T + 2, 1080)))
+        lap = _LapLogic(1, A, ego)
+        obs, r, done, info = env.reset(start.copy())
+        o.reset(start)
+        lap.reset(start.reshape(1, A, 3))
+        worst = 0.0
+        act = np.zeros((A, 2))
+        sp = steer = np.zeros(A)
+        for k in range(T + 1):
+            if k:
+                if (k - 1) % 6 == 0:
+                    sp = rng.uniform(2.0, 4.5, A)
+                    steer = rng.uniform(-0.12, 0.12, A)
+                # forwards until out of the 0.32 m start zone, backwards until in it again (toggles 1, 2, ...; f110_env.py:230-240)
+                act = np.stack([steer, np.where(np.asarray(env.toggle_list) % 2 == 0, sp, -sp)], axis=1)
+                obs, r, done, info = env.step(act.copy())
+            o.step(np.zeros((A, 2)) if k == 0 else act)
+            st = o.state
+            d, ckpt = lap.update(st[:, 0], st[:, 1], o.collisions, ts)
+            assert r == ts and obs['ego_idx'] == 0
+            worst = max(worst, rel_err(np.stack([st[:, 0], st[:, 1], st[:, 4], st[:, 3], st[:, 5]]),
+                                       np.stack([obs['poses_x'], obs['poses_y'], obs['poses_theta'], obs['linear_vels_x'], obs['ang_vels_z']])),
+                        rel_err(o.scans, np.array(obs['scans'])))
+            assert np.array_equal(o.collisions, obs['collisions']), (case, k)
+            assert np.array_equal(lap.toggle_list[0], env.toggle_list) and np.array_equal(lap.near_starts[0], env.near_starts), (case, k)
+            assert np.array_equal(lap.lap_counts[0], obs['lap_counts']) and np.array_equal(ckpt[0], info['checkpoint_done']), (case, k)
+            assert np.max(np.abs(lap.lap_times[0] - np.asarray(obs['lap_times'], dtype=float))) < 1e-12
+            assert bool(d[0]) == bool(done), (case, k)
+            if done:
+                break
+        assert worst < 1e-9, (case, worst)
+        print("env case %d: %s A=%d ego=%d: %d steps, toggles %s, collisions %s, done %s" % (case, name or "vegas (default)", A, ego, k, env.toggle_list, obs['collisions'], done))
+    finally:
+        ref_loader.fresh_racecar_class(ns)
