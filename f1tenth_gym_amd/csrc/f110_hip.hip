@@ -777,6 +777,10 @@ int f110_create(const f110_config *cfg, f110_sim **out)
 void f110_destroy(f110_sim *h)
 {
     if (!h) return;
+    {   // first: no f110_host_free on another thread may look at this handle (or drain its streams) any more
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        g_handles.erase(h);
+    }
     (void)hipSetDevice(h->cfg.device_id);
     for (hipStream_t gs : h->gstreams) (void)hipStreamSynchronize(gs);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -833,10 +837,6 @@ void f110_destroy(f110_sim *h)
     if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
     if (h->ev_end) (void)hipEventDestroy(h->ev_end);
     if (h->stream) (void)hipStreamDestroy(h->stream);
-    {
-        std::lock_guard<std::mutex> lk(g_registry_mu);
-        g_handles.erase(h);
-    }
     delete h;
 }
 
