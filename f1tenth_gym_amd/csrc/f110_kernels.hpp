@@ -1154,6 +1154,42 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_D
                 cur_slot = slot;
             }
         }
+        // first beam whose table index is direction s0 (relative indices never decrease with the beam):
+        // closed-form estimate, then the exact index function decides
+        auto rel_of = [&](int b) {
+            int rr = beam_dir_index(k, start, b) - i0;
+            return rr < 0 ? rr + k.theta_dis : rr;
+        };
+        int b0 = 0;
+        if (s0 > 0) {
+            b0 = (int)ceil(((double)s0 - (start - floor(start))) / k.theta_inc) - 2;
+            b0 = b0 < 0 ? 0 : (b0 >= (int)B ? (int)B - 1 : b0);
+            b0 = __builtin_amdgcn_readfirstlane(b0);
+            while (b0 > 0 && rel_of(b0 - 1) >= s0) --b0;
+            while (b0 < (int)B && rel_of(b0) < s0) ++b0;
+        }
+        // Which beams this task writes, which lane's direction each of them takes and its noise sample are all known BEFORE the
+        // march: the first kPre passes of 64 beams (~175 beams per task at 4096 beams on 2000 directions: three passes) ask for
+        // their noise here, so that the loads fly under the march instead of forming a dependent load -> store round trip per
+        // pass behind it (round 5: the kernel is a latency chain per task — 9 dependent gathers, then three such round trips)
+        constexpr int kPre = 3;
+        const double *nrow = row >= 0 ? j.noise + (size_t)row * B : j.ranges + (size_t)p * B;   // (row -2: this step's noise row, left in the agent's scans[] by k_noise_rows)
+        bool pre_in[kPre];
+        int pre_src[kPre];
+        double pre_nz[kPre];
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            const int b = b0 + (int)lane + 64 * q;
+            bool in = b < (int)B;
+            int src = 0;
+            if (in) {
+                src = rel_of(b) - s0;
+                in = src < 64;
+            }
+            pre_in[q] = in;
+            pre_src[q] = src;
+            pre_nz[q] = (in && row != -1) ? nrow[b] : 0.0;
+        }
         double r_dir = 0.;
         if (s0 + (int)lane < n_dirs) {
             int didx = i0 + s0 + (int)lane;
@@ -1170,21 +1206,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_D
             if (exact) r_dir = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
             if (COUNT) nl_acc += (uint32_t)nl;
         }
-        // first beam whose table index is direction s0 (relative indices never decrease with the beam):
-        // closed-form estimate, then the exact index function decides
-        auto rel_of = [&](int b) {
-            int rr = beam_dir_index(k, start, b) - i0;
-            return rr < 0 ? rr + k.theta_dis : rr;
-        };
-        int b0 = 0;
-        if (s0 > 0) {
-            b0 = (int)ceil(((double)s0 - (start - floor(start))) / k.theta_inc) - 2;
-            b0 = b0 < 0 ? 0 : (b0 >= (int)B ? (int)B - 1 : b0);
-            b0 = __builtin_amdgcn_readfirstlane(b0);
-            while (b0 > 0 && rel_of(b0 - 1) >= s0) --b0;
-            while (b0 < (int)B && rel_of(b0) < s0) ++b0;
+        // the write passes (every lane takes part in every shuffle); the indices are monotone: the first pass with an idle lane is the last
+        bool more = true;
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+            if (more) {
+                const int b = b0 + (int)lane + 64 * q;
+                const double r = __shfl(r_dir, pre_in[q] ? pre_src[q] : 0);
+                if (pre_in[q]) finish_beam_with(j, p, b, p * B + (uint32_t)b, row != -1 ? r + pre_nz[q] : r, vel);
+                if (__ballot(!pre_in[q]) != 0ull) more = false;
+            }
         }
-        for (int b = b0 + (int)lane;; b += 64) {   // every lane takes part in every shuffle
+        for (int b = b0 + (int)lane + 64 * kPre; more; b += 64) {   // (more beams per direction than kPre passes cover: load, then store)
             bool in = b < (int)B;
             int src = 0;
             if (in) {
@@ -1193,7 +1226,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_D
             }
             const double r = __shfl(r_dir, in ? src : 0);
             if (in) finish_beam(j, B, p, b, p * B + (uint32_t)b, r, row, vel);
-            if (__ballot(!in) != 0ull) break;   // the indices are monotone: nothing further belongs to this task
+            if (__ballot(!in) != 0ull) more = false;
         }
     }
     if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
