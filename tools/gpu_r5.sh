@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round-5 GPU sessions (one gpurun call each; EVERY command under its own timeout — a hung rocprofv3 cost 20 GPU-minutes once):
 #   gpurun --timeout 1500 -- 'bash tools/gpu_r5.sh test stream'
-# modes: test testfast stream bench prof
+# modes: test testfast bench prof pmc tabench rates manyagents | lab measurements: stream spec finwave tiled pmcstream
+#   the evidence of a source hash = 'test prof pmc tabench stream spec finwave tiled manyagents rates pmcstream', then
+#   python tools/collect_profiles.py r05 65536 1080 3 (+ cp of the per-mode txt files), commit, then 'bench' (its line quotes the committed PMC traffic)
 cd "${GRAFT_REPO_ROOT:-.}"
 R="$PWD"; export TMPDIR=/tmp
 OUT=$R/gpurun_out; mkdir -p $OUT
