@@ -27,10 +27,13 @@ def run(seed, verbose=True, tol=1e-9, stop_when_diverged=False):
     eps = float(rng2.choice([1e-4, 1e-4, 1e-4, 0.03, 0.2])); theta_dis = int(rng2.choice([2000, 2000, 2000, 720, 1000, 3600]))
     max_range = float(rng2.choice([30.0, 30.0, 30.0, 8.0, 12.5])); yaw = float(rng2.choice([0.0, 0.0, 0.3, -1.1, 2.4]))
     origin = [origin[0], origin[1], yaw]
+    time_step = float(rng2.choice([0.01, 0.01, 0.005, 0.02]))
+    if rng2.random() < 0.12:      # a batch inside the longest-first window of the scan (12 000+ tasks), a few steps of it
+        E = int(rng2.integers(12000 // (A * ((B + 63) // 64)) + 1, 12000 // (A * ((B + 63) // 64)) + 400)); T = int(rng2.integers(5, 10))
     s = amd.BatchSim(num_envs=E, num_agents=A, num_beams=B, fov=fov, integrator=integ, lidar_dist=ld, map_layout=layout,
-                     scan_tasks_per_wave=tasks, scan_block=block, eps=eps, theta_dis=theta_dis, max_range=max_range)
+                     scan_tasks_per_wave=tasks, scan_block=block, eps=eps, theta_dis=theta_dis, max_range=max_range, time_step=time_step)
     s.set_map_image(img, res, origin)
-    ref = orc.SimOracle(E, A, num_beams=B, fov=fov, integrator=integ, lidar_dist=ld, eps=eps, theta_dis=theta_dis, max_range=max_range)
+    ref = orc.SimOracle(E, A, num_beams=B, fov=fov, integrator=integ, lidar_dist=ld, eps=eps, theta_dis=theta_dis, max_range=max_range, time_step=time_step)
     ref.set_map_dt(dt, res, origin)
     # the oracle builds its beam tables with libm; use the product's NumPy tables on both sides
     if nrows:
@@ -50,8 +53,8 @@ def run(seed, verbose=True, tol=1e-9, stop_when_diverged=False):
         dx, dy = poses[:, 0] - origin[0], poses[:, 1] - origin[1]
         poses = np.stack([origin[0] + c_ * dx - s_ * dy, origin[1] + s_ * dx + c_ * dy, poses[:, 2] + yaw], axis=1)
     s.reset(poses); ref.reset(poses)
-    tag = "seed %d %s E%d A%d B%d fov%.2f integ%d ld%.3f layout%d T%d noise%d tasks%d blk%d eps%g td%d mr%g yaw%g" % (
-        seed, mapname, E, A, B, fov, integ, ld, layout, T, nrows, tasks, block, eps, theta_dis, max_range, yaw)
+    tag = "seed %d %s E%d A%d B%d fov%.2f integ%d ld%.3f layout%d T%d noise%d tasks%d blk%d eps%g td%d mr%g yaw%g dt%g" % (
+        seed, mapname, E, A, B, fov, integ, ld, layout, T, nrows, tasks, block, eps, theta_dis, max_range, yaw, time_step)
     for t in range(T):
         if t % 7 == 0:
             act = np.stack([rng.uniform(-0.45, 0.45, E * A), rng.uniform(-4.0, 9.0, E * A)], axis=1)
