@@ -495,3 +495,16 @@ def test_tiled_padded_table_is_bit_identical(amd):
             s.close()
         for key in outs[0]:
             assert np.array_equal(outs[0][key], outs[1][key]), key
+
+
+def test_fuzz_envs_bounded_seeds(amd):
+    """tools/debug/fuzz_envs.py, eight seeds of it: a different track per env (f110_add_map_dt / f110_set_env_maps), a vehicle
+    parameter set per agent or per slot, constructor arguments and yawed origins drawn together, calm actions so that the rollouts
+    run their length through wall hits and car-to-car hits — the HIP step against one CPU oracle per env (400 seeds by hand:
+    profiles/r05_fuzz_envs.txt)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_envs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                           "tools", "debug", "fuzz_envs.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    bad = [sd for sd in range(8) if not fz.run(sd)]
+    assert not bad, bad
