@@ -40,18 +40,21 @@ def beam_tables(num_beams, fov, params):
         angle = -fov / 2. + i * incr
         scan_angles[i] = angle
         cosines[i] = np.cos(angle)
-        if angle > 0:
-            if angle < half_pi:
-                to_side, to_fr = dist_sides / np.sin(angle), dist_fr / np.cos(angle)
-            else:
-                to_side, to_fr = dist_sides / np.cos(angle - np.pi / 2.), dist_fr / np.sin(angle - np.pi / 2.)
-        else:
-            if angle > -half_pi:
-                to_side, to_fr = dist_sides / np.sin(-angle), dist_fr / np.cos(-angle)
-            else:
-                to_side, to_fr = dist_sides / np.cos(-angle - np.pi / 2), dist_fr / np.sin(-angle - np.pi / 2)
+        with np.errstate(divide='ignore'):      # a beam at angle 0 exactly divides by -0.0: side distance -inf, as in the reference, without its warning
+            to_side, to_fr = _edge_distances(angle, dist_sides, dist_fr, half_pi)
         side_distances[i] = min(to_side, to_fr)
     return scan_angles, cosines, side_distances
+
+
+def _edge_distances(angle, dist_sides, dist_fr, half_pi):
+    """from the lidar along a beam to the car's side and to its front / rear edge (base_classes.py:139-156)"""
+    if angle > 0:
+        if angle < half_pi:
+            return dist_sides / np.sin(angle), dist_fr / np.cos(angle)
+        return dist_sides / np.cos(angle - np.pi / 2.), dist_fr / np.sin(angle - np.pi / 2.)
+    if angle > -half_pi:
+        return dist_sides / np.sin(-angle), dist_fr / np.cos(-angle)
+    return dist_sides / np.cos(-angle - np.pi / 2), dist_fr / np.sin(-angle - np.pi / 2)
 
 
 def load_map_files(map_path, map_ext):
