@@ -278,3 +278,17 @@ def test_dlpack_capsule_fields():
     arr.ptr = None
     with pytest.raises(ValueError):
         arr.__dlpack__()
+
+
+def test_every_script_of_the_repo_compiles():
+    """tools/, examples/, oracle/refshim/, bench.py, __graft_entry__.py: syntax only (the GPU-box session scripts and the fuzzers
+    run where no test here can run them; a typo in one would cost a gpurun call)"""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    for sub in ("tools", os.path.join("tools", "debug"), "examples", os.path.join("oracle", "refshim")):
+        files += sorted(glob.glob(os.path.join(root, sub, "*.py")))
+    assert len(files) > 20
+    for f in files:
+        with open(f) as fh:
+            compile(fh.read(), f, "exec")
