@@ -30,6 +30,12 @@ from oracle import orc  # noqa: E402
 pytestmark = pytest.mark.skipif(not ref_loader.reference_available(), reason="needs the reference tree (build container only)")
 SCALE = float(os.environ.get("F110_FUZZ_CASES", "1"))
 PKG_MAPS = os.path.join(os.path.dirname(HERE), "f1tenth_gym_amd", "maps")
+# The reference's single-track model is unstable for some inputs (driving backwards with a light, grippy car is one): yaw
+# and yaw rate run past 1e6 within a few steps.  From there sin / cos of the yaw amplify the 1-ulp differences between C's
+# libm and NumPy's own kernels without bound — the state still agrees to 1e-12 RELATIVE while the scan directions no
+# longer do — so a rollout is compared up to that step (the GPU fuzzers in tools/debug do the same).  None of the
+# hand-written cases below gets there; oracle/refshim/fuzz_live.py's random ones do, now and then.
+DIVERGED = 1e6
 
 
 def _map_files(name):
@@ -192,6 +198,9 @@ def test_simulator_sweep(case, tmp_path):
                 act[0] = [0.41, 7.0]    # car 0 turns as hard as it can at speed: into a wall or a neighbour on the narrow tracks
             obs = sim.step(act.copy())
             o.step(act)
+            if np.abs(o.state).max() > DIVERGED:
+                print("case %d: the reference's dynamics diverged at step %d (|state| > 1e6): compared up to it" % (case, t))
+                break
             assert np.array_equal(o.collisions, obs['collisions']), (case, t)
             assert np.array_equal(o.collision_idx, sim.collision_idx), (case, t)
             assert np.array_equal(o.in_collision, [int(a.in_collision) for a in sim.agents]), (case, t)
@@ -254,6 +263,9 @@ def test_f110env_sweep(case):
                 obs, r, done, info = env.step(act.copy())
             o.step(np.zeros((A, 2)) if k == 0 else act)
             st = o.state
+            if np.abs(st).max() > DIVERGED:
+                print("env case %d: the reference's dynamics diverged at step %d (|state| > 1e6): compared up to it" % (case, k))
+                break
             d, ckpt = lap.update(st[:, 0], st[:, 1], o.collisions, ts)
             assert r == ts and obs['ego_idx'] == 0
             worst = max(worst, rel_err(np.stack([st[:, 0], st[:, 1], st[:, 4], st[:, 3], st[:, 5]]),
