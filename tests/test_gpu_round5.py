@@ -500,7 +500,7 @@ def test_tiled_padded_table_is_bit_identical(amd):
 def test_fuzz_envs_bounded_seeds(amd):
     """tools/debug/fuzz_envs.py, eight seeds of it: a different track per env (f110_add_map_dt / f110_set_env_maps), a vehicle
     parameter set per agent or per slot, constructor arguments and yawed origins drawn together, calm actions so that the rollouts
-    run their length through wall hits and car-to-car hits — the HIP step against one CPU oracle per env (400 seeds by hand:
+    run their length through wall hits and car-to-car hits — the HIP step against one CPU oracle per env (850 seeds by hand:
     profiles/r05_fuzz_envs.txt)"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_envs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
