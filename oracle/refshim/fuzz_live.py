@@ -45,6 +45,8 @@ def main(first, last):
         env = (str(rng.choice(TRACKS[:3])) if rng.random() < 0.8 else None, int(rng.integers(1, 4)), 0, str(rng.choice(["RK4", "Euler"])),
                float(rng.choice([0.01, 0.02])), float(rng.choice([0.0, 0.1, 0.275])), int(rng.integers(60, 200)))
         env = env[:2] + (int(rng.integers(0, env[1])),) + env[3:]
+        if rng.random() < 0.5:      # laps by circling forwards at full lock instead of back and forth through the start zone
+            env = env[:6] + (int(rng.integers(150, 330)), "circle")
         jobs = [("scan", T.SCAN_CASES, scan, T.test_scan_simulator_ctor_and_map_sweep, True),
                 ("sim", T.SIM_CASES, sim, T.test_simulator_sweep, True)]
         if seed % 3 == 0:

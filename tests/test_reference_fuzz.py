@@ -33,9 +33,10 @@ PKG_MAPS = os.path.join(os.path.dirname(HERE), "f1tenth_gym_amd", "maps")
 # The reference's single-track model is unstable for some inputs (driving backwards with a light, grippy car is one): yaw
 # and yaw rate run past 1e6 within a few steps.  From there sin / cos of the yaw amplify the 1-ulp differences between C's
 # libm and NumPy's own kernels without bound — the state still agrees to 1e-12 RELATIVE while the scan directions no
-# longer do — so a rollout's FLOATS are compared up to that step (the GPU fuzzers in tools/debug stop there too); flags and
-# lap bookkeeping go on being compared for as long as they agree (they nearly always do to the end).  None of the
-# hand-written cases below gets there; oracle/refshim/fuzz_live.py's random ones do, the reversing env episodes often.
+# longer do.  So: everything is compared at every step as before, and a rollout whose |state| has passed DIVERGED is compared
+# up to its first difference instead of failing on it (the GPU fuzzers in tools/debug stop at the divergence itself).  The
+# hand-written cases below that get there (the reversing env episodes do) still agree to the end;
+# oracle/refshim/fuzz_live.py's random ones nearly always do.
 DIVERGED = 1e6
 
 
@@ -191,7 +192,7 @@ def test_simulator_sweep(case, tmp_path):
         o.reset(start)
         act = np.zeros((A, 2))
         worst_state = worst_scan = 0.0
-        diverged_at = None
+        diverged_at = stopped_at = None
         seen = {"wall": 0, "gjk": 0}
         for t in range(T):
             if t % 8 == 0:
@@ -206,18 +207,20 @@ def test_simulator_sweep(case, tmp_path):
                 assert np.array_equal(o.collisions, obs['collisions']), (case, t)
                 assert np.array_equal(o.collision_idx, sim.collision_idx), (case, t)
                 assert np.array_equal(o.in_collision, [int(a.in_collision) for a in sim.agents]), (case, t)
-            except AssertionError:
+                es, ec = rel_err(o.state, np.array([a.state for a in sim.agents])), rel_err(o.scans, np.array(obs['scans']))
+                assert es < 1e-9 and ec < 1e-9, (case, t, es, ec)
+            except AssertionError as ex:
                 if diverged_at is None:
                     raise
-                print("case %d: the reference's dynamics diverged at step %d (|state| > 1e6); first different flag at step %d: compared up to it" % (case, diverged_at, t))
+                print("case %d: the reference's dynamics diverged at step %d (|state| > 1e6); first difference at step %d %s: compared up to it" % (case, diverged_at, t, str(ex)[:100]))
+                stopped_at = t
                 break
-            if diverged_at is None:     # floats: up to the divergence; flags: for as long as they agree after it
-                worst_state = max(worst_state, rel_err(o.state, np.array([a.state for a in sim.agents])))
-                worst_scan = max(worst_scan, rel_err(o.scans, np.array(obs['scans'])))
+            worst_state, worst_scan = max(worst_state, es), max(worst_scan, ec)
             seen["wall"] += int(o.in_collision.any()); seen["gjk"] += int((o.collision_idx >= 0).any())
         assert worst_state < 1e-9 and worst_scan < 1e-9, (case, worst_state, worst_scan)
         print("case %d: %s A=%d wall-hit steps %d, contact steps %d, state err %.1e scan err %.1e%s" % (
-            case, name, A, seen["wall"], seen["gjk"], worst_state, worst_scan, "" if diverged_at is None else " (floats compared up to step %d: dynamics diverged)" % diverged_at))
+            case, name, A, seen["wall"], seen["gjk"], worst_state, worst_scan,
+            "" if diverged_at is None else " (dynamics diverged at step %d; compared %s)" % (diverged_at, "to the end" if stopped_at is None else "up to step %d" % stopped_at)))
     finally:
         ref_loader.fresh_racecar_class(ns)
 
@@ -228,6 +231,9 @@ ENV_CASES = [
     ("example_map", 1, 0, "Euler", 0.02, 0.1, 260),
     ("berlin", 3, 2, "RK4", 0.01, 0.275, 60),
     ("skirk", 2, 1, "RK4", 0.02, 0.0, 70),
+    # an optional 8th field "circle": full lock forwards instead of back and forth through the start zone — laps complete without
+    # the reversing that the reference's dynamics rarely survive, so the floats are compared through the lap count's changes too
+    (None, 1, 0, "RK4", 0.02, 0.0, 190, "circle"),
 ]
 
 
@@ -238,7 +244,8 @@ def test_f110env_sweep(case):
     package's host lap logic (`f1tenth_gym_amd.env._LapLogic`, what F110Env / F110VecEnv's host path run), on random keywords,
     starts and actions"""
     from f1tenth_gym_amd.env import _LapLogic
-    name, A, ego, integ, ts, ld, T = ENV_CASES[case]
+    name, A, ego, integ, ts, ld, T = ENV_CASES[case][:7]
+    circle = len(ENV_CASES[case]) > 7 and ENV_CASES[case][7] == "circle"
     T = max(8, int(round(T * SCALE)))
     ns = ref_loader.load_reference(with_env=True)
     rng = np.random.default_rng(9000 + case)
@@ -260,7 +267,7 @@ def test_f110env_sweep(case):
         o.reset(start)
         lap.reset(start.reshape(1, A, 3))
         worst = 0.0
-        diverged_at = None
+        diverged_at = stopped_at = None
         act = np.zeros((A, 2))
         sp = steer = np.zeros(A)
         for k in range(T + 1):
@@ -270,6 +277,8 @@ def test_f110env_sweep(case):
                     steer = rng.uniform(-0.12, 0.12, A)
                 # forwards until out of the 0.32 m start zone, backwards until in it again (toggles 1, 2, ...; f110_env.py:230-240)
                 act = np.stack([steer, np.where(np.asarray(env.toggle_list) % 2 == 0, sp, -sp)], axis=1)
+                if circle:
+                    act = np.stack([np.full(A, 0.4), 0.75 * sp], axis=1)
                 obs, r, done, info = env.step(act.copy())
             o.step(np.zeros((A, 2)) if k == 0 else act)
             st = o.state
@@ -277,26 +286,28 @@ def test_f110env_sweep(case):
                 diverged_at = k
             d, ckpt = lap.update(st[:, 0], st[:, 1], o.collisions, ts)
             assert r == ts and obs['ego_idx'] == 0
-            if diverged_at is None:     # floats: up to the divergence; flags and lap bookkeeping: for as long as they agree after it
-                worst = max(worst, rel_err(np.stack([st[:, 0], st[:, 1], st[:, 4], st[:, 3], st[:, 5]]),
-                                           np.stack([obs['poses_x'], obs['poses_y'], obs['poses_theta'], obs['linear_vels_x'], obs['ang_vels_z']])),
-                            rel_err(o.scans, np.array(obs['scans'])))
             try:
+                err = max(rel_err(np.stack([st[:, 0], st[:, 1], st[:, 4], st[:, 3], st[:, 5]]),
+                                  np.stack([obs['poses_x'], obs['poses_y'], obs['poses_theta'], obs['linear_vels_x'], obs['ang_vels_z']])),
+                          rel_err(o.scans, np.array(obs['scans'])))
+                assert err < 1e-9, (case, k, err)
                 assert np.array_equal(o.collisions, obs['collisions']), (case, k)
                 assert np.array_equal(lap.toggle_list[0], env.toggle_list) and np.array_equal(lap.near_starts[0], env.near_starts), (case, k)
                 assert np.array_equal(lap.lap_counts[0], obs['lap_counts']) and np.array_equal(ckpt[0], info['checkpoint_done']), (case, k)
                 assert np.max(np.abs(lap.lap_times[0] - np.asarray(obs['lap_times'], dtype=float))) < 1e-12
                 assert bool(d[0]) == bool(done), (case, k)
-            except AssertionError:
+            except AssertionError as ex:
                 if diverged_at is None:
                     raise
-                print("env case %d: the reference's dynamics diverged at step %d (|state| > 1e6); first different flag at step %d: compared up to it" % (case, diverged_at, k))
+                print("env case %d: the reference's dynamics diverged at step %d (|state| > 1e6); first difference at step %d %s: compared up to it" % (case, diverged_at, k, str(ex)[:100]))
+                stopped_at = k
                 break
+            worst = max(worst, err)
             if done:
                 break
         assert worst < 1e-9, (case, worst)
         print("env case %d: %s A=%d ego=%d: %d steps, toggles %s, collisions %s, done %s%s" % (
             case, name or "vegas (default)", A, ego, k, env.toggle_list, obs['collisions'], done,
-            "" if diverged_at is None else " (floats compared up to step %d: dynamics diverged)" % diverged_at))
+            "" if diverged_at is None else " (dynamics diverged at step %d; compared %s)" % (diverged_at, "to the end" if stopped_at is None else "up to step %d" % stopped_at)))
     finally:
         ref_loader.fresh_racecar_class(ns)
