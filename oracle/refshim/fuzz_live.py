@@ -1,6 +1,6 @@
 """LIVE reference against the oracle on RANDOM configurations (build container only; test infrastructure).
 
-tests/test_reference_fuzz.py walks 24 hand-written configurations.  This script draws configurations at random — track,
+tests/test_reference_fuzz.py walks 25 hand-written configurations.  This script draws configurations at random — track,
 resolution / origin / yaw overrides, beams, fov, eps, theta_dis, max_range for `ScanSimulator2D`; cars, integrator, time step,
 lidar offset, steps for `Simulator`; the same plus ego index for `F110Env` — adds them to that module's case tables and
 runs its three checks on each (the reference imported from /root/reference through ref_loader, the oracle beside it).
