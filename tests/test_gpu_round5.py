@@ -514,7 +514,7 @@ def test_fuzz_episode_bounded_seeds(amd):
     """tools/debug/fuzz_episode.py, ten seeds of it: F110VecEnv(device_logic=True) — lap toggles, counts, times, done and the auto-reset
     re-seats done by the finalize kernels (f110_env.py:219-306) — equals the host-side bookkeeping (pinned to the live reference
     by tests/test_reference_fuzz.py) over random tracks, 1-4 cars, ego indices, time steps, integrators, partial resets, with half
-    of the envs driven in circles so that laps complete (1 200 seeds by hand: profiles/r05_fuzz_episode.txt)"""
+    of the envs driven in circles so that laps complete (2 200 seeds by hand: profiles/r05_fuzz_episode.txt)"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fuzz_episode", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                                               "tools", "debug", "fuzz_episode.py"))
