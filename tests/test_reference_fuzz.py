@@ -311,3 +311,77 @@ def test_f110env_sweep(case):
             "" if diverged_at is None else " (dynamics diverged at step %d; compared %s)" % (diverged_at, "to the end" if stopped_at is None else "up to step %d" % stopped_at)))
     finally:
         ref_loader.fresh_racecar_class(ns)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_unit_functions_sweep(seed):
+    """the functions under the step, called one by one on random inputs, live reference against the oracle: vehicle_dynamics_st /
+    _ks and pid (dynamic_models.py:24-242) with random parameter sets and states on both sides of every switch, get_vertices /
+    collision / collision_multiple (collision_models.py:113-260) on car-sized quadrilaterals near and through each other,
+    check_ttc_jit, get_range, get_blocked_view_indices, ray_cast (laser_models.py:199-357) on random scans, speeds and opponents"""
+    ns = ref_loader.load_reference()
+    dm, cm, lm = ns.dynamic_models, ns.collision_models, ns.laser_models
+    rng = np.random.default_rng(11000 + seed)
+    n = max(40, int(round(250 * SCALE)))
+    # --- dynamics
+    for i in range(n):
+        p = _random_params(rng)
+        pv = orc.params_vec(p)
+        x = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(-0.45, 0.45), rng.choice([rng.uniform(-3, 20), rng.uniform(-0.6, 0.6)]),
+                      rng.uniform(-7, 7), rng.uniform(-4, 4), rng.uniform(-0.6, 0.6)])
+        if i % 7 == 0:
+            x[2] = rng.choice([p["s_min"], p["s_max"]])     # on a steering limit
+        u = np.array([rng.uniform(-4, 4), rng.uniform(-12, 12)])
+        args = (p["mu"], p["C_Sf"], p["C_Sr"], p["lf"], p["lr"], p["h"], p["m"], p["I"], p["s_min"], p["s_max"], p["sv_min"], p["sv_max"],
+                p["v_switch"], p["a_max"], p["v_min"], p["v_max"])
+        assert rel_err(orc.vehicle_dynamics_st(x, u, pv), dm.vehicle_dynamics_st(x.copy(), u.copy(), *args)) < 1e-12, (seed, i)
+        assert rel_err(orc.vehicle_dynamics_ks(x[:5], u, pv), dm.vehicle_dynamics_ks(x[:5].copy(), u.copy(), *args)) < 1e-12, (seed, i)
+        q = (rng.uniform(-6, 22), rng.uniform(-0.5, 0.5), rng.uniform(-6, 22), rng.uniform(-0.5, 0.5))
+        if i % 5 == 0:
+            q = (q[0], q[3] + rng.choice([0.0, 1e-5, -1e-5, 2e-4]), q[2], q[3])      # around the steering dead band
+        assert np.array_equal(orc.pid(q[0], q[1], q[2], q[3], p["sv_max"], p["a_max"], p["v_max"], p["v_min"]),
+                              dm.pid(q[0], q[1], q[2], q[3], p["sv_max"], p["a_max"], p["v_max"], p["v_min"])), (seed, i)
+    # --- collision
+    hits = 0
+    for i in range(n):
+        L, W = rng.uniform(0.4, 0.7), rng.uniform(0.2, 0.4)
+        pa = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-7, 7)])
+        pb = pa + np.array([rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), rng.uniform(-3.2, 3.2)])
+        va, vb = cm.get_vertices(pa, L, W), cm.get_vertices(pb, L, W)
+        assert rel_err(orc.get_vertices(pa, L, W), va) < 1e-12 and rel_err(orc.get_vertices(pb, L, W), vb) < 1e-12
+        want = bool(cm.collision(va.copy(), vb.copy()))
+        assert bool(orc.collision(va, vb)) == want, (seed, i)
+        hits += want
+        if i % 10 == 0:
+            k = int(rng.integers(2, 7))
+            allv = np.stack([cm.get_vertices(pa + np.array([rng.uniform(-1.2, 1.2), rng.uniform(-1.2, 1.2), rng.uniform(-3, 3)]), L, W) for _ in range(k)])
+            col, idx = cm.collision_multiple(allv.copy())
+            ocol, oidx = orc.collision_multiple(allv)
+            assert np.array_equal(ocol, col) and np.array_equal(oidx, idx), (seed, i)
+    assert n // 8 < hits < n - n // 8
+    # --- ttc, get_range, blocked view, ray_cast
+    beams, fov = 1080, 4.7
+    sa, co, sd = orc.build_beam_tables(beams, fov, 0.31, 0.15875, 0.17145)
+    ttc = touched = 0
+    for i in range(max(10, n // 6)):
+        scan = rng.uniform(0.05, 12.0, beams)
+        vel = rng.choice([rng.uniform(-3, 20), 0.0, rng.uniform(20, 400)])
+        want = bool(lm.check_ttc_jit(scan.copy(), vel, sa, co, sd, 0.005))
+        assert bool(orc.check_ttc(scan, vel, co, sd, 0.005)) == want, (seed, i)
+        ttc += want
+        ego = np.array([rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(-3.1, 3.1)])
+        opp = ego + np.array([rng.uniform(-4, 4), rng.uniform(-4, 4), rng.uniform(-3, 3)])
+        verts = cm.get_vertices(opp, 0.58, 0.31)
+        lo, hi = lm.get_blocked_view_indices(ego, verts.copy(), sa)
+        assert orc.get_blocked_view_indices(ego, verts, sa) == (lo, hi), (seed, i)
+        base = rng.uniform(0.5, 30.0, beams)
+        want_scan = lm.ray_cast(ego, base.copy(), sa, verts.copy())
+        got = orc.ray_cast(ego, base.copy(), sa, verts)
+        assert np.array_equal(got != base, want_scan != base) and rel_err(got, want_scan) < 1e-12, (seed, i)
+        touched += int((want_scan != base).any())
+        for j in range(8):
+            th = rng.uniform(-7, 7)
+            a, b = verts[j % 4], verts[(j + 1) % 4]
+            w, g = lm.get_range(ego, th, a, b), orc.get_range(ego, th, a, b)
+            assert (np.isinf(w) and np.isinf(g)) or abs(g - w) <= 1e-12 * abs(w), (seed, i, j)
+    assert ttc > 0 and touched > 0
