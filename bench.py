@@ -56,8 +56,7 @@ import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)   # (nothing under tests/ is imported: the workload lives in f1tenth_gym_amd/workload.py)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 NOISE_SEED = 12345      # F110Env's default seed (f110_env.py:107)
@@ -112,6 +111,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-config5", action="store_true", help="skip the 65536 x 4096-beam / 3200x3200-table leg")
     ap.add_argument("--only-headline", action="store_true", help="the timed region only (profiling / PMC runs): no replays, no other legs")
     ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--ranks-in-process", action="store_true",
+                    help="the N ranks of --gpus N are THREADS of this one process, each with its own handle (SURVEY 8e's \"one process with 8 "
+                         "handles\"): rank r drives device r, or every rank the device F110_BENCH_DEVICE names.  The same legs, control plane, "
+                         "digests and records as one process per GPU (the contract's launch form, and the default); no NUMA pinning per rank")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)   # tests: no GPU, a sleep stands in for the step
     return ap.parse_args(argv)
 
@@ -123,16 +126,23 @@ class Rendezvous(object):
     environment, the meeting point derived from F110_BENCH_RDV or MASTER_PORT.  Every collective
     is: each rank sends its value to rank 0, rank 0 replies with the reduction."""
 
-    def __init__(self):
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    def __init__(self, ident=None):
+        """ident: None = this process is one rank, identity from the launcher's environment; (world, rank, local_rank, name) =
+        a rank that is a THREAD of this process (--ranks-in-process)"""
+        if ident is None:
+            self.world = int(os.environ.get("WORLD_SIZE", "1"))
+            self.rank = int(os.environ.get("RANK", "0"))
+            self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+            name = os.environ.get("F110_BENCH_RDV") or ("f110-bench-%s-%s" % (os.environ.get("MASTER_PORT", "0"),
+                                                                            os.environ.get("TORCHELASTIC_RUN_ID", "none")))
+            self.in_process = False
+        else:
+            self.world, self.rank, self.local_rank, name = ident
+            self.in_process = True
         if "F110_BENCH_DEVICE" in os.environ:   # testing aid: several ranks on one GPU
             self.local_rank = int(os.environ["F110_BENCH_DEVICE"])
         self.peers, self.sock = [], None
         if self.world > 1:
-            name = os.environ.get("F110_BENCH_RDV") or ("f110-bench-%s-%s" % (os.environ.get("MASTER_PORT", "0"),
-                                                                            os.environ.get("TORCHELASTIC_RUN_ID", "none")))
             addr = "\0" + name    # abstract namespace: nothing to clean up, nothing on disk
             if self.rank == 0:
                 srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
@@ -253,34 +263,78 @@ def spawn_ranks(args, argv):
     return rc
 
 
+def thread_ranks(args, argv):
+    """--ranks-in-process: the N ranks as threads of this process, one handle each (ctypes calls release the GIL; a step is
+    a few microseconds of Python).  Same main() per rank; rank 0 prints the line.  Returns the exit code."""
+    n = args.gpus
+    if not args.stub:
+        from f1tenth_gym_amd import _ffi
+        import __graft_entry__
+        __graft_entry__.build()
+        have = _ffi.device_count()
+        if have < n and "F110_BENCH_DEVICE" not in os.environ:
+            print("bench.py: --gpus %d --ranks-in-process but only %d HIP device(s) visible — refusing to run a smaller job under that label" % (n, have),
+                  file=sys.stderr)
+            return 2
+    name = "f110-bench-threads-%d-%d" % (os.getpid(), int(time.time() * 1e3) % 100000)
+    rcs = [1] * n
+
+    def run(r):
+        try:
+            rcs[r] = main(argv, ident=(n, r, r, name))
+        except SystemExit as ex:
+            rcs[r] = int(ex.code or 0) if not isinstance(ex.code, str) else 1
+            if isinstance(ex.code, str):
+                print(ex.code, file=sys.stderr)
+        except BaseException:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            rcs[r] = 1
+            os._exit(1)   # the other ranks would wait for this one at the next barrier
+    ths = [threading.Thread(target=run, args=(r,), name="rank%d" % r) for r in range(n)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    return max(rcs)
+
+
 # ---------------------------------------------------------------------------------------------
 def shard_envs(total_envs_per_rank, rank):
     """global env ids owned by `rank` (contiguous blocks)"""
-    import numpy as np
-    return np.arange(total_envs_per_rank, dtype=np.int64) + rank * total_envs_per_rank
+    from f1tenth_gym_amd import workload
+    return workload.shard_envs(total_envs_per_rank, rank)
 
 
 def start_poses_for(env_ids, num_agents, gap_wp=10):
-    import numpy as np
-    from _util import raceline
-    w = raceline()
-    n = w.shape[0]
-    poses = np.empty((len(env_ids), num_agents, 3))
-    order = os.environ.get("F110_BENCH_START_ORDER", "")   # experiment only (tools/debug): "sorted" lays the envs out along the track
-    for a in range(num_agents):
-        k = ((env_ids * 7919) % n - a * gap_wp) % n
-        if order == "sorted":
-            k = (np.sort((env_ids * 7919) % n) - a * gap_wp) % n
-        poses[:, a, 0] = w[k, 1]
-        poses[:, a, 1] = w[k, 2]
-        poses[:, a, 2] = w[k, 3] + np.pi / 2
-    return poses.reshape(len(env_ids) * num_agents, 3)
+    from f1tenth_gym_amd import workload
+    # F110_BENCH_START_ORDER: experiment only (tools/debug): "sorted" lays the envs out along the track
+    return workload.start_poses(env_ids, num_agents, gap_wp, order=os.environ.get("F110_BENCH_START_ORDER", ""))
 
 
 def action_sets(n_sets, n_agents, seed):
+    from f1tenth_gym_amd import workload
+    return workload.action_sets(n_sets, n_agents, seed)
+
+
+def rel_err(a, b, atol=1e-12):
+    """the smallest tol with |a - b| <= tol*|b| + atol everywhere (relative to the reference value itself)"""
     import numpy as np
-    rng = np.random.default_rng(seed)
-    return [np.stack([rng.uniform(-0.2, 0.2, n_agents), rng.uniform(2.0, 6.0, n_agents)], axis=1) for _ in range(n_sets)]
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    if not a.size:
+        return 0.0
+    excess = np.maximum(np.abs(a - b) - atol, 0.0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        e = np.where(excess > 0.0, excess / np.abs(b), 0.0)
+    return float(np.max(e))
+
+
+def oracle_map_dt(name="example_map"):
+    """the example track's distance table by the ORACLE's EDT (checker side only: parity_gate / cpu_baseline)"""
+    from oracle import orc
+    from f1tenth_gym_amd.workload import load_map_image
+    img, res, origin = load_map_image(name)
+    return orc.map_dt_from_image(img, res), res, origin
 
 
 class Workload(object):
@@ -290,8 +344,8 @@ class Workload(object):
 
     def __init__(self, args, rdv, n_agents, max_total_steps, beams=None, map_tiles=None, policy=None, no_reset=None):
         import numpy as np
-        from _util import load_map_image
         from f1tenth_gym_amd import BatchSim
+        from f1tenth_gym_amd.workload import load_map_image
         self.args, self.rdv, self.np = args, rdv, np
         self.beams = args.beams if beams is None else beams
         self.tiles = args.map_tiles if map_tiles is None else map_tiles
@@ -332,7 +386,7 @@ class Workload(object):
         self.planner = self.d_plan = self.d_zero = None
         if self.policy == "pure_pursuit":
             from f1tenth_gym_amd import PurePursuitPlanner
-            from _util import raceline
+            from f1tenth_gym_amd.workload import raceline
             w = raceline()
             self.planner = PurePursuitPlanner(np.ascontiguousarray(np.stack([w[:, 1], w[:, 2], w[:, 5]], axis=1)), 0.17145 + 0.15875, sim=sim)
             self.d_plan = sim.device_array((self.N, 2))
@@ -492,17 +546,17 @@ def roofline_record(args, n_agents, beams, timed, prof, cnt, tiles=1):
     b_stream = 216.0 + 8.0 * B
     b_alg = b_stream + 8.0 * B * lbar
     step_gbs = agent_steps_per_s * b_alg / 1e9
-    rec = {"bound": "hbm",
+    # scalars first (the driver's parser keeps a bounded number of keys per object); the prose follows
+    rec = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
+           "traffic": None, "kernel": None, "kernel_ms_avg": None, "kernel_frac": None, "issue_floor_frac": None, "hbm_measured_frac": None,
+           "lookups_per_ray": lbar, "alg_bytes_per_agent_step": b_alg, "b_stream_bytes_per_agent_step": b_stream,
+           "b_stream_frac": agent_steps_per_s * b_stream / 1e9 / HBM_PEAK_GBS,
            "binds": "ta-issue (L2-resident gathers): the table gathers hit L2 (TCC hit 96 %), the CUs' texture address / data path is 85-92 % "
                     "busy; `frac` prices the algorithmic bytes against the HBM peak as SURVEY 8d defines it, `issue_floor_frac` is the "
                     "fraction of the roofline that actually binds",
-           "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
            "definition": "SURVEY 8d: agent-steps/s x B_alg / 8 TB/s over the timed steps; B_alg = 216 + 8*B + 8*B*L-bar bytes per agent-step",
-           "lookups_per_ray": lbar,
            "lookups_counted": "on the device over the same %d steps after the same %d warm-up steps (replay with the counting kernels)%s"
-                              % (cnt["steps"], cnt["warmup"], "; per distinct table direction (dedupe pass)" if dedupe else ""),
-           "alg_bytes_per_agent_step": b_alg, "b_stream_bytes_per_agent_step": b_stream,
-           "b_stream_frac": agent_steps_per_s * b_stream / 1e9 / HBM_PEAK_GBS}
+                              % (cnt["steps"], cnt["warmup"], "; per distinct table direction (dedupe pass)" if dedupe else "")}
     key = "agents=%d,beams=%d,layout=%d" % (n_agents, beams, args.layout) + (",tiles=%d" % tiles if tiles > 1 else "")
     # evidence from profiles/ counts only when it was measured on THIS code: every entry carries the hash of the
     # kernel sources it was collected with (tools/summarize_prof.py), the library reports the hash it was built from
@@ -561,7 +615,7 @@ def roofline_record(args, n_agents, beams, timed, prof, cnt, tiles=1):
 def parity_gate(args, rdv):
     """first 64 envs x 200 steps of the bench inputs: HIP vs oracle (flags exact, floats <= 1e-5)"""
     import numpy as np
-    from _util import load_map_image, oracle_map_dt, rel_err   # |a - b| <= tol*|b| + 1e-12: relative to the reference value itself
+    from f1tenth_gym_amd.workload import load_map_image
     from oracle import orc
     from f1tenth_gym_amd import BatchSim
     A, E, T = args.agents_per_env, 64, 200
@@ -609,7 +663,6 @@ def cpu_baseline(args, seconds):
     code on ONE thread with the same envs (-> the 1 -> N scaling factor), and cpu_1t: the reference's own shape —
     1 env x 2 agents, one thread (BASELINE configs[0], SURVEY 8d "Config 1")."""
     import numpy as np
-    from _util import oracle_map_dt
     from oracle import orc
     A = args.agents_per_env
     dt, res, origin = oracle_map_dt("example_map")
@@ -698,8 +751,8 @@ def dropin_rates(args):
     (ii) F110VecEnv(E, device_logic=True, auto_reset=True): host actions in, `done` + lap arrays out, observations
     left in HBM — one f110_step_host call per step."""
     import numpy as np
-    from _util import MAPS
     import f1tenth_gym_amd as amd
+    from f1tenth_gym_amd.workload import PKG_MAPS as MAPS
     kw = dict(map=os.path.join(MAPS, "example_map"), map_ext=".png", num_agents=args.agents_per_env)
     out = {}
 
@@ -810,14 +863,16 @@ def leg_record(rdv, total_agents, t):
             "gather_ok": None if all(o < 0 for o in oks) else bool(all(o != 0.0 for o in oks))}
 
 
-def main(argv=None):
+def main(argv=None, ident=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     if args.no_noise:
         args.noise = "off"
-    if args.gpus > 1 and "RANK" not in os.environ:
+    if ident is None and args.gpus > 1 and args.ranks_in_process:
+        return thread_ranks(args, argv)
+    if ident is None and args.gpus > 1 and "RANK" not in os.environ:
         return spawn_ranks(args, argv)
-    rdv = Rendezvous()
+    rdv = Rendezvous(ident)
     if rdv.world != args.gpus:
         if rdv.rank == 0:
             print("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, rdv.world), file=sys.stderr)
@@ -826,13 +881,15 @@ def main(argv=None):
     numa = {"pci": None, "numa_node": -1, "cpus_bound": None, "note": "not attempted"}
     if not args.stub:
         import __graft_entry__
-        if rdv.local_rank == 0:
+        if rdv.rank == 0 and not rdv.in_process:   # (thread_ranks has built already)
             __graft_entry__.build()
         rdv.barrier()
         from f1tenth_gym_amd import _ffi
         if _ffi.device_count() <= rdv.local_rank:
             raise SystemExit("bench.py: rank %d needs HIP device %d, %d visible" % (rdv.rank, rdv.local_rank, _ffi.device_count()))
-        if not args.no_numa:
+        if rdv.in_process:
+            numa["note"] = "ranks are threads of one process: no per-rank pinning"
+        elif not args.no_numa:
             from f1tenth_gym_amd import numa as _numa
             numa = _numa.bind_to_device(rdv.local_rank)   # before the first launch: the HIP runtime's threads inherit it
 
@@ -892,6 +949,7 @@ def main(argv=None):
         "multi_gpu": {"per_rank_ms_per_step": head["per_rank_ms_per_step"], "per_rank_ms_per_step_min": head["per_rank_ms_per_step_min"],
                       "per_rank_ms_per_step_max": head["per_rank_ms_per_step_max"], "per_gpu_value": value / n_gpus,
                       "rccl_ranks": rccl_ranks, "numa": numa_all,
+                      "ranks_are": "threads of one process, one handle each (--ranks-in-process)" if rdv.in_process else "one process per GPU",
                       "legs": "headline = no collective on the step path" + ("; gather = f110_comm_all_gather_obs after every step on the step's stream; "
                               "gather_overlap = the same on a stream of its own beside the next step (double-buffered observation); gather_f32 = the scans "
                               "cross the links as float32 (f110_comm_gather_obs); gather_root = only rank 0 receives (grouped ncclSend / ncclRecv)" if gather_legs else "")},
@@ -952,6 +1010,9 @@ def main(argv=None):
                     ranks_now = work.sim.comm_info()[0]     # ncclCommCount of the communicator this leg's collectives ran on
                 rec = leg_record(rdv, agents_per_rank * n_gpus, res)
                 esz = 4 if f32 else 8
+                if not args.stub:   # this rank's device while the leg's receive buffers are allocated (all ranks' memory when they share one device)
+                    free_b, total_b = work.sim.device_mem_info()
+                    rec["device_mem_used_gb_max"] = rdv.max((total_b - free_b) / 1e9)
                 out[name] = dict(rec, per_gpu_value=rec["value"] / n_gpus, rccl_ranks=ranks_now,
                                  bytes_received_per_step={"root" if root is not None else "every_rank": agents_per_rank * (esz * args.beams + 56) * n_gpus},
                                  bytes_sent_per_rank_per_step=agents_per_rank * (esz * args.beams + 56))
@@ -1007,17 +1068,25 @@ def main(argv=None):
         if args.secondary and args.secondary != args.agents:
             k2 = max(args.steps, 300)
             t, p, c = other(args.secondary, k2, max(args.warmup, 30))
+            sec_roof = roofline_record(args, args.secondary, args.beams, t, p, c)
+            flat = line["config"]   # flat scalars: the driver's parser keeps scalars and drops nested objects
+            flat["configs1_agents"], flat["configs1_value"] = args.secondary, args.secondary * k2 / t["elapsed_s"]
+            flat["configs1_frac"], flat["configs1_issue_floor_frac"] = sec_roof["frac"], sec_roof.get("issue_floor_frac")
             line["config"]["secondary"] = {"workload": "%d agents (BASELINE configs[1])" % args.secondary,
                                            "value": args.secondary * k2 / t["elapsed_s"], "ms_per_step": 1e3 * t["elapsed_s"] / k2,
                                            "steps": k2, "env_resets_in_timed_region": t["n_reset"],
-                                           "roofline": roofline_record(args, args.secondary, args.beams, t, p, c)}
+                                           "roofline": sec_roof}
         if not args.no_config5 and args.beams == 1080 and args.map_tiles == 1 and args.agents == 65536:
             k5 = 100
             t, p, c = other(65536, k5, 20, beams=4096, map_tiles=2)
+            c5_roof = roofline_record(args, 65536, 4096, t, p, c, tiles=2)
+            flat = line["config"]
+            flat["configs4_value"], flat["configs4_frac"] = 65536 * k5 / t["elapsed_s"], c5_roof["frac"]
+            flat["configs4_issue_floor_frac"] = c5_roof.get("issue_floor_frac")
             line["config"]["config5"] = {"workload": "65536 agents, 4096 beams, example_map tiled 2x2 = 3200x3200 cells (BASELINE configs[4])",
                                          "value": 65536 * k5 / t["elapsed_s"], "ms_per_step": 1e3 * t["elapsed_s"] / k5, "steps": k5,
                                          "env_resets_in_timed_region": t["n_reset"],
-                                         "roofline": roofline_record(args, 65536, 4096, t, p, c, tiles=2)}
+                                         "roofline": c5_roof}
         if args.fixed_pose_steps > 0 and args.policy == "random":
             w3 = Workload(args, rdv, args.agents, args.fixed_pose_steps + 10, policy="parked", no_reset=True)
             r3 = w3.run(args.fixed_pose_steps, 10, "timed", preroll=0)
@@ -1027,6 +1096,7 @@ def main(argv=None):
                                                     "ms_per_step": 1e3 * r3["elapsed_s"] / args.fixed_pose_steps}
         if not args.no_dropin and args.beams == 1080 and args.map_tiles == 1:
             line["config"]["dropin"] = dropin_rates(args)
+            line["config"]["configs0_f110env_us_per_step"] = line["config"]["dropin"]["f110env_1env"]["us_per_step"]
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             line["parity_gate"] = parity_gate(args, rdv)

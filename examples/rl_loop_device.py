@@ -28,12 +28,8 @@ import f1tenth_gym_amd as amd  # noqa: E402
 
 
 def start_poses(E, A):
-    w = np.loadtxt(os.path.join(ROOT, "tests", "golden", "maps", "example_waypoints.csv"), delimiter=';', skiprows=3)
-    poses = np.empty((E, A, 3))
-    for a in range(A):
-        k = ((np.arange(E) * 7919) % w.shape[0] - a * 10) % w.shape[0]
-        poses[:, a] = np.stack([w[k, 1], w[k, 2], w[k, 3] + np.pi / 2], axis=1)
-    return poses.reshape(-1, 3)
+    from f1tenth_gym_amd import workload
+    return workload.bench_start_poses(E, A)
 
 
 def main(argv=None):
@@ -46,7 +42,8 @@ def main(argv=None):
     E, A = args.envs, args.agents
     N = E * A
     sim = amd.BatchSim(num_envs=E, num_agents=A)
-    sim.set_map(os.path.join(ROOT, "tests", "golden", "maps", "example_map.yaml"), ".png")
+    from f1tenth_gym_amd import workload
+    sim.set_map(workload.map_stem("example_map") + ".yaml", ".png")
     sim.set_noise_rng(12345, 0.01)
     sim.episode_init(0)
     sim.episode_reset(start_poses(E, A))
@@ -68,6 +65,9 @@ def main(argv=None):
         w2 = torch.randn(32, 2, device="cuda", generator=g, dtype=torch.float32) * 0.1
 
         def policy():
+            # back-to-back device steps go out as TWO env blocks on two streams (include/f110.h step_groups); torch sees only
+            # the main one.  The fence orders both blocks in front of torch's reads and the next step behind torch's writes.
+            sim.fence()
             with torch.cuda.stream(stream):
                 x = scans_t[:, ::10].to(torch.float32).clamp_(max=10.0) / 10.0
                 out = torch.tanh(torch.tanh(x @ w1) @ w2)

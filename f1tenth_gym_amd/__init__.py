@@ -9,9 +9,12 @@ from .sim import Integrator, Simulator  # noqa: F401
 from .laser import ScanSimulator2D  # noqa: F401
 from .racecar import RaceCar  # noqa: F401
 from .env import F110Env, F110VecEnv  # noqa: F401
+from .sharded import ShardedVecEnv  # noqa: F401
 from .planner import PurePursuitPlanner  # noqa: F401
-from .functional import (vehicle_dynamics_st, vehicle_dynamics_ks, pid, get_vertices, collision,  # noqa: F401
-                         collision_multiple, check_ttc_jit, ray_cast)
+from .functional import (accl_constraints, steering_constraint, vehicle_dynamics_ks, vehicle_dynamics_st, pid, func_KS, func_ST,  # noqa: F401
+                         perpendicular, tripleProduct, avgPoint, indexOfFurthestPoint, support, collision, collision_multiple,
+                         get_trmtx, get_vertices, get_dt, xy_2_rc, distance_transform, trace_ray, get_scan, check_ttc_jit, cross,
+                         are_collinear, get_range, get_blocked_view_indices, ray_cast)
 
 __version__ = "0.1.0"
 

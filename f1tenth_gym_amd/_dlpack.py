@@ -89,6 +89,11 @@ def make_capsule(arr):
     return _api().PyCapsule_New(addr, _NAME, C.cast(_capsule_destructor, C.c_void_p))
 
 
+def exports_of(sim):
+    """how many DLPack exports of `sim`'s buffers are still held by a consumer (their deleter has not run)"""
+    return sum(1 for (_, _, arr) in list(_live.values()) if getattr(arr, "sim", None) is sim)
+
+
 def read_capsule(capsule):
     """(tests) the fields of a not-yet-consumed "dltensor" capsule"""
     api = _api()

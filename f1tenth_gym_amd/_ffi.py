@@ -126,6 +126,7 @@ PROTOTYPES = {
     "f110_get_obs": (C.c_int, [C.c_void_p, C.POINTER(ObsHost)]),
     "f110_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _i32p]),
     "f110_get_device_views": (C.c_int, [C.c_void_p, C.POINTER(DeviceViews)]),
+    "f110_stream_fence": (C.c_int, [C.c_void_p]),
     "f110_device_mem_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "f110_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "f110_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -161,7 +162,13 @@ PROTOTYPES = {
     "f110_get_range_batch": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp]),
     "f110_edt_sq": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, _u32p]),
     "f110_beam_dir_index_batch": (C.c_int, [C.c_void_p, _dp, C.c_int32, _i32p]),
+    "f110_dt_from_bitmap": (C.c_int, [C.c_void_p, _u8p, C.c_int32, C.c_int32, C.c_double, _dp]),
+    "f110_helper_batch": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int32, C.c_int32, _dp]),
 }
+
+# f110_helper_batch ops (include/f110.h)
+(OP_ACCL_CONSTRAINTS, OP_STEERING_CONSTRAINT, OP_CROSS, OP_ARE_COLLINEAR, OP_PERPENDICULAR, OP_TRIPLE_PRODUCT, OP_AVG_POINT,
+ OP_FURTHEST_POINT, OP_SUPPORT, OP_GET_TRMTX, OP_XY_2_RC, OP_DISTANCE_TRANSFORM, OP_TRACE_RAY) = range(1, 14)
 
 _lib = None
 

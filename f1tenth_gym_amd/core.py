@@ -155,11 +155,19 @@ class DeviceArray(object):
     def __dlpack_device__(self):
         return (_dlpack.kDLROCM, int(getattr(self.sim, "device_id", 0)))
 
-    def __dlpack__(self, stream=None):
+    def __dlpack__(self, stream=None, max_version=None, dl_device=None, copy=None):
         """stream = -1: no synchronisation (the caller orders its work against device_views()['stream'] itself); anything
-        else: the handle's stream is drained first, so the consumer sees finished data whatever stream it uses"""
+        else: the handle's stream is drained first, so the consumer sees finished data whatever stream it uses.
+        max_version / dl_device / copy: the newer protocol's keywords — a version-0 ("dltensor") capsule is what this producer
+        makes whatever max_version says (consumers accept it), the data cannot leave its device and is never copied.
+        Lifetime: the tensor a consumer makes of the capsule views the simulator's memory; BatchSim.close() refuses to free it
+        while such a tensor is alive (drop the tensors first, or close(force=True))."""
         if self.ptr is None:
             raise ValueError("the buffer has been freed")
+        if copy is True:
+            raise BufferError("DeviceArray.__dlpack__ cannot copy (copy=True): it exports the simulator's own buffer")
+        if dl_device is not None and tuple(int(v) for v in dl_device) != self.__dlpack_device__():
+            raise BufferError("DeviceArray lives on %s and cannot be exported to dl_device=%s" % (self.__dlpack_device__(), tuple(dl_device)))
         if stream != -1 and getattr(self.sim, "_h", None):
             self.sim.sync()
         return _dlpack.make_capsule(self)
@@ -242,8 +250,13 @@ class BatchSim(object):
         check(_ffi.lib().f110_exp_set(self._h, str(key).encode(), int(value)), self._h)
 
     # ------------------------------------------------------------------ lifetime
-    def close(self):
+    def close(self, force=False):
+        """frees the handle and every device buffer it owns.  Refused (BufferError) while a DLPack consumer still holds one of
+        them (a torch tensor made by from_dlpack would point at freed memory): drop those tensors first, or force=True"""
         if self._h:
+            if not force and _dlpack.exports_of(self):
+                raise BufferError("%d DLPack export(s) of this simulator's buffers are still alive; delete the tensors made from "
+                                  "them before close(), or close(force=True)" % _dlpack.exports_of(self))
             for fin in list(self._device_arrays):   # device buffers still alive: give them back first
                 fin()
             self._device_arrays.clear()
@@ -262,13 +275,19 @@ class BatchSim(object):
     def __del__(self):
         if getattr(self, "_h", None):
             try:
-                self.close()
+                self.close(force=True)
             except _ffi.F110LibraryError as ex:   # interpreter teardown: report, do not raise from a finaliser
                 import sys
                 print("BatchSim.__del__: %s" % ex, file=sys.stderr)
 
     def sync(self):
         check(_ffi.lib().f110_sync(self._h), self._h)
+
+    def fence(self):
+        """f110_stream_fence: call between this handle's calls and EXTERNAL work on device_views()['stream'] (torch / cupy on an
+        ExternalStream around it): the handle's work in flight — both env blocks of a two-block step — is ordered in front of
+        that work, and the next step runs behind it.  Never blocks the host."""
+        check(_ffi.lib().f110_stream_fence(self._h), self._h)
 
     # ------------------------------------------------------------------ configuration
     def set_map(self, map_path, map_ext):
@@ -869,6 +888,32 @@ class BatchSim(object):
         rows = as_f64(rows, (m, 8))
         out = np.empty((m,))
         check(_ffi.lib().f110_get_range_batch(self._h, dptr(rows), m, dptr(out)), self._h)
+        return out
+
+    _HELPER_WIDTHS = {   # op -> (in width as a function of n, out width)
+        _ffi.OP_ACCL_CONSTRAINTS: (lambda n: 6, 1), _ffi.OP_STEERING_CONSTRAINT: (lambda n: 6, 1), _ffi.OP_CROSS: (lambda n: 4, 1),
+        _ffi.OP_ARE_COLLINEAR: (lambda n: 6, 1), _ffi.OP_PERPENDICULAR: (lambda n: 2, 2), _ffi.OP_TRIPLE_PRODUCT: (lambda n: 6, 2),
+        _ffi.OP_AVG_POINT: (lambda n: 2 * n, 2), _ffi.OP_FURTHEST_POINT: (lambda n: 2 * n + 2, 1), _ffi.OP_SUPPORT: (lambda n: 4 * n + 2, 2),
+        _ffi.OP_GET_TRMTX: (lambda n: 3, 16), _ffi.OP_XY_2_RC: (lambda n: 9, 2), _ffi.OP_DISTANCE_TRANSFORM: (lambda n: 2, 1),
+        _ffi.OP_TRACE_RAY: (lambda n: 3, 1)}
+
+    def helper_batch(self, op, rows, n=4):
+        """f110_helper_batch: `rows` [M][in width of op] -> [M][out width] (the small star-exported functions, include/f110.h)"""
+        in_w, out_w = self._HELPER_WIDTHS[op]
+        rows = as_f64(rows)
+        m = rows.shape[0]
+        rows = as_f64(rows, (m, in_w(int(n))))
+        out = np.empty((m, out_w))
+        check(_ffi.lib().f110_helper_batch(self._h, int(op), dptr(rows), m, int(n), dptr(out)), self._h)
+        return out
+
+    def dt_from_bitmap(self, bitmap, resolution):
+        """get_dt (laser_models.py:40-53): resolution * exact EDT of `bitmap` (nonzero = free), on the device"""
+        img = np.ascontiguousarray(np.asarray(bitmap) != 0, dtype=np.uint8)
+        if img.ndim != 2:
+            raise ValueError("bitmap must be 2-D")
+        out = np.empty(img.shape)
+        check(_ffi.lib().f110_dt_from_bitmap(self._h, img.ctypes.data_as(_ffi._u8p), img.shape[0], img.shape[1], float(resolution), dptr(out)), self._h)
         return out
 
     def edt_sq(self, img):

@@ -132,6 +132,7 @@ struct f110_sim {
     ExpSwitches exp;
     uint32_t *d_env_done = nullptr;   // [num_envs] scan_env_counter probe
     ncclComm_t comm = nullptr;   // optional RCCL communicator for the observation gather
+    bool beams_uniform = true;   // f110_set_beam_tables: scan_angles is (to a quarter of a spacing) the ramp base_classes.py:133-134 builds
     int comm_ranks = 0;
     // overlapped gather (f110_comm_set_overlap): scans are double-buffered, the all-gather of step t
     // runs on comm_stream while step t+1 fills the other buffer
@@ -578,7 +579,6 @@ int f110_create(const f110_config *cfg, f110_sim **out)
         h->groups_auto = G <= 0;
         if (G <= 0) G = 2;
         G = std::min(std::min(G, 16), cfg->num_envs);
-        if (h->groups_auto && cfg->step_graph != 0) G = 1;   // (lab: the captured-graph step is one block)
         h->groups = G;
         // pair tests + opponent windows inside the finalize kernel: A = 2 (k_finalize_pair_roles) and every A up to
         // kMaxAgentsMulti = 256 (k_finalize_multi up to 16, k_finalize_multi_tiled above: an env's ordered pairs in tiles of a
@@ -1140,6 +1140,9 @@ int f110_set_trig_tables(f110_sim *h, const double *s, const double *c, int32_t 
     return F110_OK;
 }
 
+static const char *const kBeamsMsg = "the beam tables (f110_set_beam_tables) are not the uniform ramp scan_angles[i] = scan_angles[0] + i*inc of base_classes.py:133-134: "
+                                     "the step's opponent ray-cast assumes it; such tables are served by f110_raycast_batch / f110_ttc_batch only";
+
 int f110_set_beam_tables(f110_sim *h, const double *sa, const double *co, const double *sd, int32_t B)
 {
     if (!h || !sa || !co || !sd) return fail(h, F110_ERR_INVALID, "null argument");
@@ -1151,6 +1154,17 @@ int f110_set_beam_tables(f110_sim *h, const double *sa, const double *co, const 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     // beam spacing of THIS table (seed of the nearest-beam search in the opponent ray-cast)
     h->dev.angle_inc = (sa[B - 1] - sa[0]) / (B - 1);
+    // The step's opponent ray-cast finds a vertex's beam next to a closed-form estimate (nearest_beam: +-3 entries) and culls by a
+    // disc — both assume the table is the increasing ramp sa[0] + i*inc that RaceCar builds (base_classes.py:133-134).  A table
+    // within a quarter of a beam spacing of that ramp keeps the true argmin inside the searched neighbourhood; anything else
+    // (the free functions ray_cast / check_ttc_jit accept ANY array) is served by the unit entry points only, with the
+    // reference's full argmin (k_raycast_unit), and refused by the step (beams_must_be_uniform).
+    {
+        const double inc = h->dev.angle_inc;
+        bool uni = B >= 2 && inc > 0.0 && inc == inc;
+        for (int i = 0; uni && i < B; ++i) uni = std::fabs(sa[i] - (sa[0] + (double)i * inc)) <= 0.25 * inc;
+        h->beams_uniform = uni;
+    }
     // iTTC early-out of k_scan_rays: with s = max|side|, c = max|cos|, a beam with
     // r > s + thresh*(1+1e-9)*c*|v| has (r - side_b) > thresh*(1+1e-12)*|v*cos_b| and cannot hit.
     {
@@ -1778,6 +1792,7 @@ int f110_episode_step_host(f110_sim *h, const double *h_actions, int32_t auto_re
     if (!h || !h_actions || !h_packed) return fail(h, F110_ERR_INVALID, "null argument");
     if (!h->has_episode) return fail(h, F110_ERR_STATE, "f110_episode_init has not been called");
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    if (!h->beams_uniform) return fail(h, F110_ERR_STATE, kBeamsMsg);
     ENTER(h);
     const size_t N = (size_t)h->N, E = (size_t)h->cfg.num_envs, bytes = f110_episode_packed_bytes(h);
     if (!h->d_packed) HIPCHK(h, hipMalloc(&h->d_packed, bytes));
@@ -1818,6 +1833,7 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
 {
     if (!h || !h_actions || !out) return fail(h, F110_ERR_INVALID, "null argument");
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    if (!h->beams_uniform) return fail(h, F110_ERR_STATE, kBeamsMsg);
     const bool episode = h->has_episode;
     if (!episode && (out->lap_times || out->lap_counts || out->toggles || out->current_time || out->near_starts ||
                      out->checkpoint_done || out->done || (flags & F110_STEP_AUTO_RESET)))
@@ -2432,6 +2448,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
 {
     if (!h || !d_actions) return fail(h, F110_ERR_INVALID, "null argument");
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    if (!h->beams_uniform) return fail(h, F110_ERR_STATE, kBeamsMsg);
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int N = h->N, A = h->cfg.num_agents;
     h->dev.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;
@@ -2500,10 +2517,18 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     return F110_OK;
 }
 
+int f110_stream_fence(f110_sim *h)
+{
+    if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
+    ENTER(h);   // joins the env blocks into the main stream; main_dirty + touched: the next step is one block behind the caller's work
+    return F110_OK;
+}
+
 int f110_step(f110_sim *h, const double *actions)
 {
     if (!h || !actions) return fail(h, F110_ERR_INVALID, "null argument");
     if (!h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    if (!h->beams_uniform) return fail(h, F110_ERR_STATE, kBeamsMsg);
     ENTER(h);   // the previous step (possibly still running on the group streams) reads d_actions
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, sizeof(double) * 2 * h->N, hipMemcpyHostToDevice, h->stream));
     TRY(f110_step_device(h, h->d_actions));
@@ -2807,6 +2832,8 @@ int f110_scan_policy_device(f110_sim *h, double steer_gain, double steer_max, do
     if (!h || !d_actions) return fail(h, F110_ERR_INVALID, "scan policy: null argument");
     if (!(d_ref > 0.) || !(steer_max >= 0.)) return fail(h, F110_ERR_INVALID, "scan policy: d_ref must be > 0 and steer_max >= 0");
     if (h->cfg.num_beams > 2048) return fail(h, F110_ERR_INVALID, "scan policy: at most 2048 beams (the rows are staged in LDS)");
+    if (h->cfg.num_beams < 64) return fail(h, F110_ERR_INVALID, "scan policy: needs at least 64 beams (one per sector)");
+    if (!(sector_limit >= h->cfg.fov / 128.)) return fail(h, F110_ERR_INVALID, "scan policy: sector_limit must be at least fov/128 (half a sector), else no sector is eligible");
     const int N = h->N, B = h->cfg.num_beams;
     if (h->last_blocks == 2 && h->groups_busy && !h->touched) {
         // behind a two-block step: each block's agents on the block's own stream (an agent reads its own scan row only)
@@ -3017,7 +3044,7 @@ int f110_raycast_batch(f110_sim *h, const double *ego, const double *verts, int3
     TRY(s.up(verts, (size_t)8 * m, &dv));
     TRY(s.up(scans, (size_t)m * B, &ds));
     if (minmax) TRY(s.up<int32_t>(nullptr, (size_t)2 * m, &dm));
-    hipLaunchKernelGGL(k_raycast_unit, dim3(m), dim3(128), 0, h->stream, de, dv, m, (int)B, h->d_scan_angles, h->dev.angle_inc, ds, dm);
+    hipLaunchKernelGGL(k_raycast_unit, dim3(m), dim3(128), 0, h->stream, de, dv, m, (int)B, h->d_scan_angles, h->dev.angle_inc, h->beams_uniform ? 1 : 0, ds, dm);
     HIPCHK(h, hipGetLastError());
     TRY(s.down(scans, ds, (size_t)m * B));
     if (minmax) TRY(s.down(minmax, dm, (size_t)2 * m));
@@ -3057,6 +3084,64 @@ int f110_edt_sq(f110_sim *h, const uint8_t *img, int32_t H, int32_t W, uint32_t 
     hipLaunchKernelGGL(k_edt_rows, dim3(H), dim3(256), (size_t)W * sizeof(uint32_t), h->stream, dg, H, W, dd);
     HIPCHK(h, hipGetLastError());
     TRY(s.down(d2, dd, n));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_dt_from_bitmap(f110_sim *h, const uint8_t *img, int32_t H, int32_t W, double resolution, double *dt)
+{
+    if (!h || !img || !dt) return fail(h, F110_ERR_INVALID, "null argument");
+    ENTER(h);
+    if (H < 1 || W < 1 || H > 16384 || W > 16384) return fail(h, F110_ERR_INVALID, "f110_dt_from_bitmap: bad shape %dx%d", H, W);
+    const size_t n = (size_t)H * W;
+    Scratch s(h);
+    uint8_t *dimg;
+    uint32_t *dg, *dd;
+    double *ddt;
+    TRY(s.up(img, n, &dimg));
+    TRY(s.up<uint32_t>(nullptr, n, &dg));
+    TRY(s.up<uint32_t>(nullptr, n, &dd));
+    TRY(s.up<double>(nullptr, n, &ddt));
+    hipLaunchKernelGGL(k_edt_columns, grid1d(W, 64), dim3(64), 0, h->stream, dimg, H, W, dg);
+    hipLaunchKernelGGL(k_edt_rows, dim3(H), dim3(256), (size_t)W * sizeof(uint32_t), h->stream, dg, H, W, dd);
+    hipLaunchKernelGGL(k_dt_from_d2, grid1d(n, 256), dim3(256), 0, h->stream, dd, n, resolution, ddt);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(dt, ddt, n));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return F110_OK;
+}
+
+int f110_helper_batch(f110_sim *h, int32_t op, const double *in, int32_t m, int32_t n, double *out)
+{
+    if (!h || !in || !out || m < 0) return fail(h, F110_ERR_INVALID, "f110_helper_batch: bad argument");
+    ENTER(h);
+    int in_w = 0, out_w = 0;
+    bool bodies = false, needs_map = false;
+    switch (op) {
+    case F110_OP_ACCL_CONSTRAINTS: case F110_OP_STEERING_CONSTRAINT: in_w = 6; out_w = 1; break;
+    case F110_OP_CROSS: in_w = 4; out_w = 1; break;
+    case F110_OP_ARE_COLLINEAR: in_w = 6; out_w = 1; break;
+    case F110_OP_PERPENDICULAR: in_w = 2; out_w = 2; break;
+    case F110_OP_TRIPLE_PRODUCT: in_w = 6; out_w = 2; break;
+    case F110_OP_AVG_POINT: bodies = true; in_w = 2 * n; out_w = 2; break;
+    case F110_OP_FURTHEST_POINT: bodies = true; in_w = 2 * n + 2; out_w = 1; break;
+    case F110_OP_SUPPORT: bodies = true; in_w = 4 * n + 2; out_w = 2; break;
+    case F110_OP_GET_TRMTX: in_w = 3; out_w = 16; break;
+    case F110_OP_XY_2_RC: in_w = 9; out_w = 2; break;
+    case F110_OP_DISTANCE_TRANSFORM: needs_map = true; in_w = 2; out_w = 1; break;
+    case F110_OP_TRACE_RAY: needs_map = true; in_w = 3; out_w = 1; break;
+    default: return fail(h, F110_ERR_INVALID, "f110_helper_batch: unknown op %d", op);
+    }
+    if (bodies && (n < 1 || n > 4096)) return fail(h, F110_ERR_INVALID, "f110_helper_batch: a body needs 1..4096 vertices (got %d)", n);
+    if (needs_map && !h->has_map) return fail(h, F110_ERR_NO_MAP, "Map is not set for scan simulator.");
+    if (m == 0) return F110_OK;
+    Scratch s(h);
+    double *di, *dout;
+    TRY(s.up(in, (size_t)in_w * m, &di));
+    TRY(s.up<double>(nullptr, (size_t)out_w * m, &dout));
+    hipLaunchKernelGGL(k_helper_unit, grid1d(m, 128), dim3(128), 0, h->stream, op, di, m, n, in_w, out_w, dout, h->k);
+    HIPCHK(h, hipGetLastError());
+    TRY(s.down(out, dout, (size_t)out_w * m));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return F110_OK;
 }

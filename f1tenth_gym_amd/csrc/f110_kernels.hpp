@@ -2610,7 +2610,7 @@ __global__ void k_ttc_unit(const double *__restrict__ scans, const double *__res
 }
 
 __global__ void k_raycast_unit(const double *__restrict__ ego, const double *__restrict__ verts, int m, int B,
-                               const double *__restrict__ scan_angles, double angle_inc, double *__restrict__ scans,
+                               const double *__restrict__ scan_angles, double angle_inc, int uniform, double *__restrict__ scans,
                                int32_t *__restrict__ minmax)
 {
     const int p = blockIdx.x, tid = threadIdx.x;
@@ -2618,16 +2618,28 @@ __global__ void k_raycast_unit(const double *__restrict__ ego, const double *__r
     double v[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) v[c] = verts[8 * (size_t)p + c];
-    // circumscribed disc of the quadrilateral: centroid + largest vertex distance
-    const double cx = (((v[0] + v[2]) + v[4]) + v[6]) / 4, cy = (((v[1] + v[3]) + v[5]) + v[7]) / 4;
-    double r2 = 0.0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const double dx = v[2 * c] - cx, dy = v[2 * c + 1] - cy;
-        r2 = fmax(r2, dx * dx + dy * dy);
-    }
     int ref_lo, ref_hi, lo, hi;
-    opponent_beam_window(ex, ey, eth, v, cx, cy, sqrt(r2) * 1.000001, scan_angles, B, angle_inc, ref_lo, ref_hi, lo, hi);
+    if (uniform) {
+        // circumscribed disc of the quadrilateral: centroid + largest vertex distance
+        const double cx = (((v[0] + v[2]) + v[4]) + v[6]) / 4, cy = (((v[1] + v[3]) + v[5]) + v[7]) / 4;
+        double r2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double dx = v[2 * c] - cx, dy = v[2 * c + 1] - cy;
+            r2 = fmax(r2, dx * dx + dy * dy);
+        }
+        opponent_beam_window(ex, ey, eth, v, cx, cy, sqrt(r2) * 1.000001, scan_angles, B, angle_inc, ref_lo, ref_hi, lo, hi);
+    } else {
+        // a scan_angles table that is not the uniform ramp (the free function ray_cast takes any array, laser_models.py:318):
+        // the reference's own full argmin per vertex (:310-313), no closed-form estimate, no disc cull — every beam of the window
+        __shared__ int vidx[4];
+        if (tid < 4) vidx[tid] = nearest_beam_full(scan_angles, B, vertex_view_angle(ex, ey, eth, v[2 * tid], v[2 * tid + 1]));
+        __syncthreads();
+        ref_lo = min(min(vidx[0], vidx[1]), min(vidx[2], vidx[3]));
+        ref_hi = max(max(vidx[0], vidx[1]), max(vidx[2], vidx[3]));
+        lo = ref_lo;
+        hi = ref_hi;
+    }
     if (minmax && tid == 0) {
         minmax[2 * p] = ref_lo;
         minmax[2 * p + 1] = ref_hi;
@@ -2648,6 +2660,125 @@ __global__ void k_get_range_unit(const double *__restrict__ in, int m, double *_
     const double *r = in + 8 * (size_t)i;
     const double bt = r[3];
     out[i] = edge_range(r[0], r[1], cos(bt + kPi / 2.), sin(bt + kPi / 2.), r[4], r[5], r[6], r[7]);
+}
+
+// ---- f110_helper_batch: the small functions `from f110_gym.envs import *` also exposes in the reference, one item per thread.
+// Each case is the reference function's own expression order (the same device functions the step kernels inline).
+__global__ void k_helper_unit(int op, const double *__restrict__ in, int m, int n, int in_w, int out_w, double *__restrict__ out, ScanConst k)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double *a = in + (size_t)in_w * i;
+    double *o = out + (size_t)out_w * i;
+    switch (op) {
+    case F110_OP_ACCL_CONSTRAINTS: {   // dynamic_models.py:29-60  (vel, accl, v_switch, a_max, v_min, v_max)
+        VehicleParams p;
+        p.v[P_VSWITCH] = a[2]; p.v[P_AMAX] = a[3]; p.v[P_VMIN] = a[4]; p.v[P_VMAX] = a[5];
+        o[0] = clamp_accel(a[0], a[1], p);
+        break;
+    }
+    case F110_OP_STEERING_CONSTRAINT: {   // :62-87  (steering_angle, steering_velocity, s_min, s_max, sv_min, sv_max)
+        VehicleParams p;
+        p.v[P_SMIN] = a[2]; p.v[P_SMAX] = a[3]; p.v[P_SVMIN] = a[4]; p.v[P_SVMAX] = a[5];
+        o[0] = clamp_steer_rate(a[0], a[1], p);
+        break;
+    }
+    case F110_OP_CROSS:   // laser_models.py:219-230
+        o[0] = a[0] * a[3] - a[1] * a[2];
+        break;
+    case F110_OP_ARE_COLLINEAR: {   // :232-247  (pt_a, pt_b, pt_c)
+        const double bax = a[2] - a[0], bay = a[3] - a[1];
+        const double cax = a[0] - a[4], cay = a[1] - a[5];
+        o[0] = fabs(bax * cay - bay * cax) < 1e-8 ? 1.0 : 0.0;
+        break;
+    }
+    case F110_OP_PERPENDICULAR:   // collision_models.py:34-48
+        o[0] = a[1];
+        o[1] = -1 * a[0];
+        break;
+    case F110_OP_TRIPLE_PRODUCT:   // :51-64  (a, b, c)
+        triple_product(a[0], a[1], a[2], a[3], a[4], a[5], o[0], o[1]);
+        break;
+    case F110_OP_AVG_POINT: {   // :67-78  np.sum(vertices, axis=0) / n: the rows are added in order
+        double sx = a[0], sy = a[1];
+        for (int q = 1; q < n; ++q) {
+            sx += a[2 * q];
+            sy += a[2 * q + 1];
+        }
+        o[0] = sx / n;
+        o[1] = sy / n;
+        break;
+    }
+    case F110_OP_FURTHEST_POINT: {   // :81-92  np.argmax(vertices.dot(d)): first maximum wins  (vertices [n][2], d)
+        const double dx = a[2 * n], dy = a[2 * n + 1];
+        int best = 0;
+        double bv = a[0] * dx + a[1] * dy;
+        for (int q = 1; q < n; ++q) {
+            const double val = a[2 * q] * dx + a[2 * q + 1] * dy;
+            if (val > bv) {
+                bv = val;
+                best = q;
+            }
+        }
+        o[0] = (double)best;
+        break;
+    }
+    case F110_OP_SUPPORT: {   // :95-110  (vertices1 [n][2], vertices2 [n][2], d)
+        const double *v1 = a, *v2 = a + 2 * n;
+        const double dx = a[4 * n], dy = a[4 * n + 1];
+        int bi = 0, bj = 0;
+        double vi = v1[0] * dx + v1[1] * dy, vj = v2[0] * -dx + v2[1] * -dy;
+        for (int q = 1; q < n; ++q) {
+            const double t1 = v1[2 * q] * dx + v1[2 * q + 1] * dy, t2 = v2[2 * q] * -dx + v2[2 * q + 1] * -dy;
+            if (t1 > vi) {
+                vi = t1;
+                bi = q;
+            }
+            if (t2 > vj) {
+                vj = t2;
+                bj = q;
+            }
+        }
+        o[0] = v1[2 * bi] - v2[2 * bj];
+        o[1] = v1[2 * bi + 1] - v2[2 * bj + 1];
+        break;
+    }
+    case F110_OP_GET_TRMTX: {   // :218-235  H [4][4] row-major
+        double c, s;
+        cos_sin(a[2], c, s);
+        const double H[16] = {c, -s, 0., a[0], s, c, 0., a[1], 0., 0., 1., 0., 0., 0., 0., 1.};
+        for (int q = 0; q < 16; ++q) o[q] = H[q];
+        break;
+    }
+    case F110_OP_XY_2_RC: {   // laser_models.py:55-86  (x, y, orig_x, orig_y, orig_c, orig_s, height, width, resolution) -> (r, c)
+        const double xt = a[0] - a[2], yt = a[1] - a[3];
+        const double xr = xt * a[4] + yt * a[5];
+        const double yr = -xt * a[5] + yt * a[4];
+        const double res = a[8];
+        double r = -1., c = -1.;
+        if (!(xr < 0 || xr >= a[7] * res || yr < 0 || yr >= a[6] * res)) {
+            c = (double)(int)(xr / res);
+            r = (double)(int)(yr / res);
+        }
+        o[0] = r;
+        o[1] = c;
+        break;
+    }
+    case F110_OP_DISTANCE_TRANSFORM: {   // :88-104 on the handle's map  (x, y) -> dt[r, c]
+        int r, c;
+        o[0] = sample_distance<LAYOUT_ROWMAJOR, false, false>(k, nullptr, a[0], a[1], r, c);
+        break;
+    }
+    case F110_OP_TRACE_RAY: {   // :106-146 on the handle's map and (cos, sin) table  (x, y, theta_index) -> range
+        const int ti = (int)a[2];   // int(theta_index) :124; like NumPy, a negative index counts from the table's end
+        const double2 cs = k.cs[ti < 0 ? ti + k.theta_dis : ti];
+        int r, c, nl;
+        o[0] = march_ray<LAYOUT_ROWMAJOR, false, false>(k, nullptr, a[0], a[1], cs.x, cs.y, r, c, nl);
+        break;
+    }
+    default:
+        break;
+    }
 }
 
 // ---- map pipeline: flip + threshold + exact EDT + dt = res*sqrt(d2) ------------------------
@@ -2772,7 +2903,8 @@ __global__ void __launch_bounds__(256) k_scan_policy(const double *__restrict__ 
     }
     const double best_centre = __shfl(centre, best_lane);
     if (lane == 0) {
-        double steer = steer_gain * best_centre;
+        // no eligible sector (none within sector_limit, or every eligible mean is NaN): straight ahead, not the tie-break's lane 0
+        double steer = best > -INFINITY ? steer_gain * best_centre : 0.0;
         steer = steer > steer_max ? steer_max : (steer < -steer_max ? -steer_max : steer);
         const double f = front / d_ref;
         actions[2 * (size_t)(i0 + a)] = steer;

@@ -940,6 +940,39 @@ F110_HD int nearest_beam(const double *scan_angles, int num_beams, double angle_
     return best;
 }
 
+// np.argmin(np.abs(scan_angles - a)) as the reference evaluates it (:310-313): every entry, first minimum wins (a NaN entry
+// wins over every number, as in NumPy).  For tables that are not the uniform ramp of base_classes.py:133-134 — the free
+// functions ray_cast / check_ttc_jit accept any scan_angles array (unit entry points only: f110_raycast_batch).
+F110_HD int nearest_beam_full(const double *scan_angles, int num_beams, double a)
+{
+    int best = 0;
+    double bv = fabs(scan_angles[0] - a);
+    for (int i = 1; i < num_beams; ++i) {
+        const double v = fabs(scan_angles[i] - a);
+        if (v < bv || (v != v && bv == bv)) {
+            bv = v;
+            best = i;
+        }
+    }
+    return best;
+}
+
+// the angle get_blocked_view_indices looks up for one vertex (:296-309): -(heading - direction), wrapped once
+F110_HD double vertex_view_angle(double ex, double ey, double etheta, double vx, double vy)
+{
+    const double dx = vx - ex, dy = vy - ey;
+    const double norm = sqrt(dx * dx + dy * dy);
+    const double ux = dx / norm, uy = dy / norm;
+    double ce, se;
+    cos_sin(etheta, ce, se);
+    double angle = atan2(se, ce) - atan2(uy, ux);
+    if (angle > kPi)
+        angle = angle - 2 * kPi;
+    else if (angle < -kPi)
+        angle = angle + 2 * kPi;
+    return -angle;
+}
+
 // one vertex's beam index of get_blocked_view_indices :282-315
 // get_blocked_view_indices :296-311 for one vertex, with its two arc tangents supplied:
 // head = atan2(sin(etheta), cos(etheta)), dir = atan2(uy, ux) of the normalised lidar -> vertex vector

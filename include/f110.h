@@ -231,7 +231,10 @@ int f110_episode_get(f110_sim *h, const f110_episode_host *out);
 int f110_episode_step_host(f110_sim *h, const double *h_actions, int32_t auto_reset, void *h_packed);
 size_t f110_episode_packed_bytes(const f110_sim *h);
 int f110_host_alloc(f110_sim *h, size_t bytes, void **h_out);   /* page-locked host memory */
-int f110_host_free(f110_sim *h, void *h_ptr);  /* h may be NULL once the handle that allocated it is destroyed */
+/* h may be NULL once the handle that allocated it is destroyed.  Must NOT run concurrently with a step (or any other call) on a
+ * handle that uses the block: the call drains every live handle's stream and drops their cached views of the block without
+ * taking a per-handle lock — the caller serialises it against those handles like any other call on them. */
+int f110_host_free(f110_sim *h, void *h_ptr);
 int f110_episode_device_views(f110_sim *h, f110_episode_views *out);
 
 /* env.step() of a host-driven loop as ONE call (replaces, per step, F110Env.step -> Simulator.step's agent
@@ -312,6 +315,13 @@ typedef struct f110_device_views {
     void *stream;         /* hipStream_t */
 } f110_device_views;
 int f110_get_device_views(f110_sim *h, f110_device_views *out);
+/* Hand f110_device_views.stream to EXTERNAL work (a torch / cupy stream wrapped around it, a user kernel) safely: everything the
+ * handle has in flight — including the second env block of a two-block step, which runs on a stream of its own — is ordered in
+ * front of what the caller enqueues on that stream next, and the following f110_*step* is submitted as ONE block on that stream,
+ * i.e. behind the caller's work (its reads of the observation, its writes of the action buffer).  Call it once per iteration
+ * between the handle's last call and the external work; it enqueues two event waits and never blocks the host.  Without it only
+ * one-block steps (f110_config.step_groups = 1, or any handle that synchronises every step) are ordered against that stream. */
+int f110_stream_fence(f110_sim *h);
 /* free / total bytes of the handle's GPU (hipMemGetInfo) — lets a long run show that memory stays flat */
 int f110_device_mem_info(f110_sim *h, size_t *free_bytes, size_t *total_bytes);
 int f110_device_alloc(f110_sim *h, size_t bytes, void **d_out);
@@ -438,6 +448,35 @@ int f110_get_range_batch(f110_sim *h, const double *h_in, int32_t m, double *h_o
 /* exact squared EDT of a binary image (nonzero = free), laser_models.py:40-53 */
 int f110_edt_sq(f110_sim *h, const uint8_t *h_img, int32_t height, int32_t width,
                 uint32_t *h_d2);
+/* get_dt laser_models.py:40-53: dt = resolution * scipy.ndimage.distance_transform_edt(bitmap) — h_bitmap [height][width]
+ * uint8, nonzero = free space (what edt treats as foreground), as the array is (no flip, no threshold); exact EDT on the
+ * device, h_dt [height][width] float64. */
+int f110_dt_from_bitmap(f110_sim *h, const uint8_t *h_bitmap, int32_t height, int32_t width, double resolution, double *h_dt);
+/* The remaining small functions that `from f110_gym.envs import *` exposes in the reference (envs/__init__.py:2-5), M items per
+ * call, one thread each, in the reference's expression order.  h_in [M][in_width(op, n)], h_out [M][out_width(op)]; n = vertices
+ * per body for the ops that take bodies (the reference calls them with 4), ignored otherwise.
+ *   op                          reference                        in (doubles per item)                                   out
+ *   F110_OP_ACCL_CONSTRAINTS    dynamic_models.py:29-60          vel, accl, v_switch, a_max, v_min, v_max                  accl
+ *   F110_OP_STEERING_CONSTRAINT dynamic_models.py:62-87          steering_angle, steering_velocity, s_min, s_max, sv_min, sv_max   steering_velocity
+ *   F110_OP_CROSS               laser_models.py:219-230          v1[2], v2[2]                                              cross product
+ *   F110_OP_ARE_COLLINEAR       laser_models.py:232-247          pt_a[2], pt_b[2], pt_c[2]                                 0. / 1.
+ *   F110_OP_PERPENDICULAR       collision_models.py:34-48        pt[2]                                                     [2]
+ *   F110_OP_TRIPLE_PRODUCT      collision_models.py:51-64        a[2], b[2], c[2]                                          [2]
+ *   F110_OP_AVG_POINT           collision_models.py:67-78        vertices[n][2]                                            [2]
+ *   F110_OP_FURTHEST_POINT      collision_models.py:81-92        vertices[n][2], d[2]                                      index (as a double)
+ *   F110_OP_SUPPORT             collision_models.py:95-110       vertices1[n][2], vertices2[n][2], d[2]                    [2]
+ *   F110_OP_GET_TRMTX           collision_models.py:218-235      pose[3]                                                   H[4][4] row-major
+ *   F110_OP_XY_2_RC             laser_models.py:55-86            x, y, orig_x, orig_y, orig_c, orig_s, height, width, resolution   r, c (as doubles; -1, -1 out of bounds)
+ *   F110_OP_DISTANCE_TRANSFORM  laser_models.py:88-104           x, y  (the handle's map: f110_set_map_*)                  dt[r, c] (dt[-1, -1] out of bounds)
+ *   F110_OP_TRACE_RAY           laser_models.py:106-146          x, y, theta_index  (the handle's map, trig tables, eps, max_range)   range
+ * (get_scan = f110_scan_batch, get_range = f110_get_range_batch, get_blocked_view_indices = the window of f110_raycast_batch,
+ * get_dt = f110_dt_from_bitmap, the rest of the star-exports have had entry points since round 1.) */
+enum {
+    F110_OP_ACCL_CONSTRAINTS = 1, F110_OP_STEERING_CONSTRAINT, F110_OP_CROSS, F110_OP_ARE_COLLINEAR, F110_OP_PERPENDICULAR,
+    F110_OP_TRIPLE_PRODUCT, F110_OP_AVG_POINT, F110_OP_FURTHEST_POINT, F110_OP_SUPPORT, F110_OP_GET_TRMTX, F110_OP_XY_2_RC,
+    F110_OP_DISTANCE_TRANSFORM, F110_OP_TRACE_RAY
+};
+int f110_helper_batch(f110_sim *h, int32_t op, const double *h_in, int32_t m, int32_t n, double *h_out);
 /* rng.normal(0., std_dev, num_beams) drawn `rows` times in a row from the PCG64 state h_state_inc4
  * (numpy/random/src/distributions/distributions.c random_standard_normal; laser_models.py:450-452):
  * h_out [rows][num_beams]; h_state_out2 (or NULL) = {state.hi, state.lo} after the last draw */

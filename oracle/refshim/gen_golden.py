@@ -1060,7 +1060,118 @@ def gen_env_defaults(ns):
     save("env_episode_defaults", map=np.array(["vegas"]), ego_idx=np.array([0]), obs_ego_idx=np.array([0]), seed=np.array([12345]), **out)
 
 
-GROUPS = {"scan_ctor": gen_scan_ctor, "scan_rotated": gen_scan_rotated, "env_defaults": gen_env_defaults, "sim_variants": gen_sim_variants, "sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
+# ------------------------------------------------------------------- the rest of `from f110_gym.envs import *`
+def gen_star_exports(ns):
+    """Every function the reference's envs/__init__.py:2-5 star-exports that had no fixture of its own: the two constraint
+    functions, the GJK helpers, get_trmtx, cross / are_collinear, xy_2_rc / distance_transform / trace_ray / get_scan as FREE
+    functions (their own argument lists), get_dt, get_blocked_view_indices — and ray_cast / get_blocked_view_indices /
+    check_ttc_jit with scan_angles tables that are NOT the uniform ramp (two concatenated ramps, a jittered ramp, a descending
+    ramp, a short random table): the reference's argmin over the whole table decides there."""
+    lm, cm, dm = ns.laser_models, ns.collision_models, ns.dynamic_models
+    rng = np.random.default_rng(909)
+    out = {}
+    # ---- dynamic_models.py:29-87 (rows straddle every branch: limits reached, v above v_switch, exact ties)
+    n = 400
+    a_in = np.stack([rng.uniform(-7, 25, n), rng.uniform(-15, 15, n), rng.uniform(5, 9, n), rng.uniform(5, 12, n), np.full(n, -5.0), np.full(n, 20.0)], axis=1)
+    a_in[:20, 0] = -5.0; a_in[20:40, 0] = 20.0; a_in[40:50, 1] = -a_in[40:50, 3]; a_in[50:60, 1] = a_in[50:60, 3]; a_in[60:70, 0] = a_in[60:70, 2]
+    out["accl_in"], out["accl_out"] = a_in, np.array([dm.accl_constraints(*r) for r in a_in])
+    s_in = np.stack([rng.uniform(-0.6, 0.6, n), rng.uniform(-5, 5, n), np.full(n, -0.4189), np.full(n, 0.4189), np.full(n, -3.2), np.full(n, 3.2)], axis=1)
+    s_in[:20, 0] = -0.4189; s_in[20:40, 0] = 0.4189; s_in[40:50, 1] = -3.2; s_in[50:60, 1] = 3.2; s_in[60:70, 1] = 0.0
+    out["steer_in"], out["steer_out"] = s_in, np.array([dm.steering_constraint(*r) for r in s_in])
+    # ---- laser_models.py:219-247
+    c_in = rng.uniform(-3, 3, (n, 4))
+    out["cross_in"], out["cross_out"] = c_in, np.array([lm.cross(r[:2], r[2:]) for r in c_in])
+    col_in = rng.uniform(-3, 3, (n, 6))
+    t = rng.uniform(-2, 3, n)
+    col_in[:150, 4:6] = col_in[:150, 0:2] + t[:150, None] * (col_in[:150, 2:4] - col_in[:150, 0:2])            # exactly on the line (up to rounding)
+    col_in[150:200, 4:6] += 0.0
+    col_in[100:150, 5] += rng.choice([1e-9, 3e-9, 1e-8, 3e-8, 1e-7], 50)                                      # around the 1e-8 tolerance
+    out["collinear_in"] = col_in
+    out["collinear_out"] = np.array([float(lm.are_collinear(r[0:2].copy(), r[2:4].copy(), r[4:6].copy())) for r in col_in])
+    # ---- collision_models.py:34-110, 218-235
+    p_in = rng.uniform(-3, 3, (n, 2))
+    out["perp_in"], out["perp_out"] = p_in, np.array([cm.perpendicular(r.copy()) for r in p_in])
+    tp_in = rng.uniform(-3, 3, (n, 6))
+    out["triple_in"], out["triple_out"] = tp_in, np.array([cm.tripleProduct(r[0:2].copy(), r[2:4].copy(), r[4:6].copy()) for r in tp_in])
+    L, W = DEFAULT_PARAMS['length'], DEFAULT_PARAMS['width']
+    poses = np.stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(-4, 7, n)], axis=1)
+    va = np.array([cm.get_vertices(q, L, W) for q in poses])
+    vb = np.array([cm.get_vertices(q + np.array([0.3, -0.2, 0.7]), L, W) for q in poses])
+    d = rng.uniform(-1, 1, (n, 2))
+    d[:40] = 0.0; d[40:80, 0] = 0.0; d[80:120] = (va[80:120, 1] - va[80:120, 0])          # ties: zero direction, axis-aligned, along an edge's normal partner
+    out["body_a"], out["body_b"], out["dir"] = va, vb, d
+    out["avg_out"] = np.array([cm.avgPoint(np.ascontiguousarray(v)) for v in va])
+    out["furthest_out"] = np.array([cm.indexOfFurthestPoint(np.ascontiguousarray(va[i]), np.ascontiguousarray(d[i])) for i in range(n)], dtype=np.int32)
+    out["support_out"] = np.array([cm.support(np.ascontiguousarray(va[i]), np.ascontiguousarray(vb[i]), np.ascontiguousarray(d[i])) for i in range(n)])
+    pent = rng.uniform(-2, 2, (60, 5, 2))                                                    # bodies that are not quadrilaterals
+    out["pent"], out["pent_dir"] = pent, d[:60] + 0.1
+    out["pent_avg"] = np.array([cm.avgPoint(np.ascontiguousarray(v)) for v in pent])
+    out["pent_furthest"] = np.array([cm.indexOfFurthestPoint(np.ascontiguousarray(pent[i]), np.ascontiguousarray(out["pent_dir"][i])) for i in range(60)], dtype=np.int32)
+    out["trmtx_in"], out["trmtx_out"] = poses, np.array([cm.get_trmtx(q) for q in poses])
+    # ---- laser_models.py:40-186 as free functions, on a small synthetic map with a yawed origin
+    H, Wd, res = 96, 128, 0.05
+    bitmap = np.full((H, Wd), 255.0)
+    bitmap[0, :] = bitmap[-1, :] = bitmap[:, 0] = bitmap[:, -1] = 0.0
+    bitmap[30:40, 50:70] = 0.0; bitmap[60:62, 10:100] = 0.0
+    for _ in range(25):
+        r, c = rng.integers(2, H - 2), rng.integers(2, Wd - 2)
+        bitmap[r, c] = 0.0
+    dt = lm.get_dt(bitmap, res)
+    out["bitmap"], out["map_res"], out["dt"] = bitmap.astype(np.uint8), np.array([res]), dt
+    for tag, (ox, oy, oth) in (("a", (-1.3, 0.7, 0.0)), ("b", (0.4, -2.1, 0.6))):
+        oc, os_ = np.cos(oth), np.sin(oth)
+        m = 300
+        # world points: inside the map (cell coordinates -> world through the origin's rotation), plus some outside
+        u = np.stack([rng.uniform(-0.4, Wd * res + 0.4, m), rng.uniform(-0.4, H * res + 0.4, m)], axis=1)
+        u[:40, 0] = np.round(u[:40, 0] / res) * res                                   # on cell boundaries
+        x = ox + oc * u[:, 0] - os_ * u[:, 1]; y = oy + os_ * u[:, 0] + oc * u[:, 1]
+        out["pts_" + tag] = np.stack([x, y], axis=1)
+        out["origin_" + tag] = np.array([ox, oy, oth])
+        out["rc_" + tag] = np.array([lm.xy_2_rc(x[i], y[i], ox, oy, oc, os_, H, Wd, res) for i in range(m)], dtype=np.int32)
+        out["dtval_" + tag] = np.array([lm.distance_transform(x[i], y[i], ox, oy, oc, os_, H, Wd, res, dt) for i in range(m)])
+        theta_dis = 720
+        th = np.linspace(0.0, 2 * np.pi, num=theta_dis)
+        sines, cosines = np.sin(th), np.cos(th)
+        tidx = rng.uniform(0, theta_dis - 1e-6, m)
+        out["theta_idx_" + tag] = tidx
+        out["trace_" + tag] = np.array([lm.trace_ray(x[i], y[i], tidx[i], sines, cosines, 1e-4, ox, oy, oc, os_, H, Wd, res, dt, 4.0) for i in range(m)])
+        nb, fov = 181, 4.2
+        inc = theta_dis * (fov / (nb - 1)) / (2. * np.pi)
+        sp = np.stack([x[40:60], y[40:60], rng.uniform(0, 2 * np.pi, 20)], axis=1)
+        out["scan_poses_" + tag] = sp
+        out["scans_" + tag] = np.array([lm.get_scan(q, theta_dis, fov, nb, inc, sines, cosines, 1e-4, ox, oy, oc, os_, H, Wd, res, dt, 4.0) for q in sp])
+    out["scan_cfg"] = np.array([720, 181, 4.2, 1e-4, 4.0])
+    # ---- scan_angles tables that are not the uniform ramp (laser_models.py:282-346, 188-217)
+    tables = {"two_ramps": np.concatenate([np.linspace(-2.35, 0.5, 90), np.linspace(-0.5, 2.35, 110)]),
+              "jitter": np.linspace(-2.35, 2.35, 200) + rng.uniform(-0.03, 0.03, 200),
+              "descending": np.linspace(2.35, -2.35, 200),
+              "short_random": rng.uniform(-3.1, 3.1, 37),
+              "uniform_ref": np.array([-4.7 / 2. + i * (4.7 / 199) for i in range(200)])}
+    for name, sa in tables.items():
+        B = sa.shape[0]
+        m = 40
+        ego = np.stack([rng.uniform(-5, 5, m), rng.uniform(-5, 5, m), rng.uniform(0, 2 * np.pi, m)], axis=1)
+        dist = rng.uniform(0.35, 5.0, m); bearing = rng.uniform(-np.pi, np.pi, m)
+        dist[:6] = rng.uniform(0.0, 0.25, 6); bearing[6:20] = np.pi + rng.uniform(-0.4, 0.4, 14)
+        opp = np.stack([ego[:, 0] + dist * np.cos(ego[:, 2] + bearing), ego[:, 1] + dist * np.sin(ego[:, 2] + bearing), rng.uniform(0, 2 * np.pi, m)], axis=1)
+        verts = np.array([cm.get_vertices(q, L, W) for q in opp])
+        lo = np.empty(m, dtype=np.int32); hi = np.empty(m, dtype=np.int32); scans = np.empty((m, B))
+        for i in range(m):
+            lo[i], hi[i] = lm.get_blocked_view_indices(ego[i], verts[i], sa)
+            scans[i] = lm.ray_cast(ego[i], np.full(B, 10.0), sa, verts[i])
+        co = np.cos(sa); sd = np.abs(0.3 / np.maximum(np.abs(np.sin(sa)), 0.2))
+        mt = 24
+        tsc = rng.uniform(0.3, 8.0, (mt, B)); vel = rng.uniform(-3, 8, mt); vel[:3] = 0.0
+        for i in range(0, mt, 3):
+            j = rng.integers(0, B); tsc[i, j] = sd[j] + 0.4 * 0.005 * vel[i] * co[j]
+        flags = np.array([int(lm.check_ttc_jit(tsc[i], vel[i], sa, co, sd, 0.005)) for i in range(mt)], dtype=np.int32)
+        out.update({"sa_" + name: sa, "ego_" + name: ego, "verts_" + name: verts, "lo_" + name: lo, "hi_" + name: hi, "rc_scans_" + name: scans,
+                    "ttc_scans_" + name: tsc, "ttc_vel_" + name: vel, "ttc_cos_" + name: co, "ttc_side_" + name: sd, "ttc_flags_" + name: flags})
+    out["tables"] = np.array(sorted(tables))
+    save("star_exports", **out)
+
+
+GROUPS = {"star_exports": gen_star_exports, "scan_ctor": gen_scan_ctor, "scan_rotated": gen_scan_rotated, "env_defaults": gen_env_defaults, "sim_variants": gen_sim_variants, "sim_many": gen_sim_many, "planner": gen_planner, "data": lambda ns: copy_data(), "dynamics": gen_dynamics, "update_pose": gen_update_pose,
           "scan": gen_scan, "ttc": gen_ttc, "collision": gen_collision, "raycast": gen_raycast,
           "sim": gen_sim, "sim_multi": gen_sim_multi, "env": gen_env, "env2": gen_env2, "env3": gen_env3, "env_kwargs": gen_env_kwargs, "env_updates": gen_env_updates, "waypoint_follow": gen_waypoint_follow}
 

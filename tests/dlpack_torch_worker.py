@@ -47,4 +47,44 @@ assert torch.from_dlpack(views["in_collision"]).dtype == torch.int32
 del scans_t, act_t
 torch.cuda.synchronize()
 s.close(); ref.close()
+
+# ---- the documented RL loop (examples/rl_loop_device.py --torch): torch work on an ExternalStream around the
+# handle's main stream, fenced (f110_stream_fence), with the step free to go out as two env blocks (step_groups 0 / 2) — against
+# the same loop on a one-block handle (step_groups 1), where stream order alone is enough.  8192 agents: a size at which the
+# automatic mode splits back-to-back steps.
+def rl_loop(groups, steps=40):
+    E2, A2 = 4096, 2
+    N2 = E2 * A2
+    b = amd.BatchSim(num_envs=E2, num_agents=A2, step_groups=groups)
+    b.set_map_image(*load_map_image("example_map")); b.set_noise_rng(12345, 0.01)
+    b.episode_init(0); b.episode_reset(bench_start_poses(E2, A2))
+    actions = b.device_array((N2, 2)); actions.upload(np.zeros((N2, 2)))
+    v = b.device_views()
+    stream = torch.cuda.ExternalStream(v["stream"], device=torch.device("cuda", b.device_id))
+    sc, ac = torch.from_dlpack(v["scans"]), torch.from_dlpack(actions)
+    b.episode_step_device(actions)
+    blocks = set()
+    for _ in range(steps):
+        b.fence()
+        with torch.cuda.stream(stream):
+            ahead = sc[:, 500:580].min(dim=1).values                       # reads the step's scans ...
+            side = sc[:, 700:900].mean(dim=1) - sc[:, 180:380].mean(dim=1)
+            ac[:, 0] = torch.clamp(0.05 * side, -0.4, 0.4)                 # ... writes the next step's actions
+            ac[:, 1] = torch.clamp(ahead, 1.0, 6.0)
+        b.episode_step_device(actions); b.episode_reset_done_device()
+        b.episode_step_device(actions); b.episode_reset_done_device()      # two steps per policy call: the second may split
+        blocks.add(b.step_groups()[2])
+    out = b.get("state", "scans", "collisions")
+    out["laps"] = b.episode_get()["lap_counts"]
+    del sc, ac
+    torch.cuda.synchronize()
+    b.close()
+    return out, blocks
+
+base, _ = rl_loop(1)
+for gmode in (0, 2):
+    got, blocks = rl_loop(gmode)
+    for key in base:
+        assert np.array_equal(base[key], got[key]), (gmode, key)
+    print("RL LOOP groups=%d blocks seen %s OK" % (gmode, sorted(blocks)))
 print("DLPACK OK")

@@ -1,0 +1,256 @@
+"""GPU tests added in round 6 (-m gpu): BASELINE configs[3] at its real size on one device (8 ranks as threads, the RCCL stand-in),
+`bench.py --gpus 8 --ranks-in-process` through every gather leg at that size, `ShardedVecEnv` against a single handle, the fuzzers
+at a few hundred seeds each, non-uniform `scan_angles` in ray_cast / check_ttc_jit against a reference-generated
+fixture, and the rest of the functions `from f110_gym.envs import *` exposes in the reference against reference-generated rows.
+Nothing here reads /root/reference."""
+import importlib.util
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from _util import bench_start_poses, map_stem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB_DIR = os.path.join(ROOT, "tests", "rccl_stub")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import f1tenth_gym_amd
+    from f1tenth_gym_amd import _ffi
+    assert _ffi.device_count() >= 1, "no MI355X visible: the HIP path cannot run (no CPU fallback)"
+    return f1tenth_gym_amd
+
+
+def _stub_env():
+    """environment in which `librccl.so.1` resolves to tests/rccl_stub (built here if stale)"""
+    lib, src = os.path.join(STUB_DIR, "librccl.so.1"), os.path.join(STUB_DIR, "rccl_stub.hip")
+    if not os.path.isfile(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", lib])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "F110_BENCH_RDV")}
+    env["LD_LIBRARY_PATH"] = STUB_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", "")
+    return env
+
+
+def _result(out):
+    lines = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
+    assert lines, (out.stdout[-1500:], out.stderr[-1500:])
+    return json.loads(lines[0][7:])
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] at its size, one device
+def test_config3_full_size_eight_ranks_on_one_device(amd):
+    """262 144 agents = 8 ranks x 16 384 envs x 2, 1080 beams: every rank checks every peer's 283 MB block of its 2.26 GB receive
+    buffers (digests), the twin envs across block boundaries, and its first 32 envs against the oracle — in the step's stream,
+    overlapped (double-buffered) and as float32 to one root (tests/rccl_stub/config3_full_size.py)"""
+    out = subprocess.run([sys.executable, os.path.join(STUB_DIR, "config3_full_size.py"), "8", "16384"], env=_stub_env(), stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=900)
+    r = _result(out)
+    assert not r["errors"] and not any(r["hung"]) and out.returncode == 0, (r, out.stderr[-1500:])
+    assert r["agents_total"] == 262144 and r["world"] == 8
+    assert min(r["checks"]) > 0 and r["checks"][0] >= 3 * r["steps"] * 8     # rank 0 receives in all three legs
+
+
+def test_bench_config3_eight_ranks_in_process_all_gather_legs(amd):
+    """`python bench.py --gpus 8 --ranks-in-process --agents 32768` on device 0 with the RCCL stand-in: the bench's own Workload,
+    control plane, leg records and digests at BASELINE configs[3]'s size — the headline without a collective and all six gather legs
+    (in stream, overlapped, float32, float32 overlapped, to a root, root + float32 + overlapped), `gather_ok` on every rank"""
+    env = _stub_env()
+    env["F110_BENCH_DEVICE"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--ranks-in-process", "--agents", "32768", "--steps", "8", "--warmup", "2",
+                          "--preroll", "40", "--gather-timeout", "300", "--gather-budget", "600"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-800:]
+    d = json.loads(lines[0])
+    mg = d["multi_gpu"]
+    assert d["n_gpus"] == 8 and d["config"]["agents_total"] == 262144 and d["scaling"] == "weak"
+    assert mg.get("gather_error") is None and not mg.get("legs_skipped"), mg
+    assert mg["rccl_ranks"] == 8 and "threads" in mg["ranks_are"]
+    for leg in ("gather", "gather_overlap", "gather_f32", "gather_f32_overlap", "gather_root", "gather_root_f32_overlap"):
+        assert mg[leg]["gather_ok"] is True and mg[leg]["value"] > 0 and mg[leg]["rccl_ranks"] == 8, (leg, mg[leg])
+        assert len(mg[leg]["per_rank_ms_per_step"]) == 8
+    assert mg["gather"]["bytes_received_per_step"]["every_rank"] == 32768 * (8 * 1080 + 56) * 8
+    assert mg["gather"]["device_mem_used_gb_max"] > 8 * 2.26     # the eight [8][32768][1080] float64 receive buffers were really there
+
+
+# ------------------------------------------------------------------ ShardedVecEnv
+@pytest.mark.parametrize("device_logic", [True, False])
+@pytest.mark.parametrize("devices,sizes", [([0], None), ([0, 0, 0], None), ([0, 0, 0, 0, 0], [1, 9, 3, 20, 4])])
+def test_sharded_vec_env_equals_one_handle(amd, devices, sizes, device_logic):
+    """ShardedVecEnv over several handles (here all on device 0; equal, uneven and hand-picked shard sizes) returns bit for bit
+    what ONE F110VecEnv returns for the same envs: observations, done, lap bookkeeping, through auto-resets and a partial reset"""
+    E, A, T = 37, 2, 70
+    kw = dict(map=map_stem("example_map"), map_ext=".png", num_agents=A, auto_reset=True, device_logic=device_logic)
+    one = amd.F110VecEnv(E, **kw)
+    sh = amd.ShardedVecEnv(E, devices=devices, shard_sizes=sizes, **kw)
+    assert sh.shard_sizes == (sizes or [E // len(devices) + (1 if k < E % len(devices) else 0) for k in range(len(devices))])
+    poses = bench_start_poses(E, A, gap_wp=4).reshape(E, A, 3)
+
+    def same(a, b, what):
+        for key in a[0]:
+            assert np.array_equal(np.asarray(a[0][key]), np.asarray(b[0][key])), (what, key)
+        assert a[1] == b[1] and np.array_equal(a[2], b[2]), (what, "done")
+        assert set(a[3]) == set(b[3])
+        for key in a[3]:
+            assert np.array_equal(a[3][key], b[3][key]), (what, key)
+    same(one.reset(poses), sh.reset(poses), "reset")
+    rng = np.random.default_rng(5)
+    seen_done = 0
+    for t in range(T):
+        act = np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(2.0, 8.0, (E, A))], axis=2)
+        a, b = one.step(act), sh.step(act)
+        same(a, b, "step %d" % t)
+        seen_done += int(np.sum(a[2]))
+        if t == 30:
+            mask = np.arange(E) % 3 == 1
+            same(one.reset(poses, mask), sh.reset(poses, mask), "partial reset")
+    assert seen_done > 0      # the comparison went through re-seats
+    sh.close(); one.sim.batch.close()
+
+
+def test_sharded_vec_env_gathers_the_observation_on_one_device(amd):
+    """gather_obs=True: after each step every shard's device holds every shard's scans + scalars = the single handle's observation in
+    blocks (all-gather float64, and float32 to one root) — four handles on device 0, the RCCL stand-in (tests/rccl_stub/sharded_gather.py)"""
+    out = subprocess.run([sys.executable, os.path.join(STUB_DIR, "sharded_gather.py")], env=_stub_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    r = _result(out)
+    assert not r["errors"] and out.returncode == 0, (r, out.stderr[-1500:])
+    assert r["checks"] == 12 * 4 + 12 * 1      # 12 steps x 4 receiving shards (all-gather), then 12 x the one root
+
+
+# ------------------------------------------------------------------ the rest of `from f110_gym.envs import *` (star_exports.npz: reference-run)
+FTOL = 1e-12
+
+
+def _rel(a, b):
+    from _util import rel_err
+    return rel_err(a, b)
+
+
+def test_star_exported_helpers_vs_reference(amd):
+    """accl_constraints / steering_constraint (dynamic_models.py:29-87), cross / are_collinear (laser_models.py:219-247), perpendicular /
+    tripleProduct / avgPoint / indexOfFurthestPoint / support / get_trmtx (collision_models.py:34-110, :218-235): f110_helper_batch
+    against rows the reference produced — exact (these are sums and products in the reference's order; get_trmtx: cos / sin ulps)"""
+    from _util import gold
+    from f1tenth_gym_amd import _ffi
+    g = gold("star_exports")
+    b = amd.BatchSim(num_envs=1, num_agents=1)
+    assert np.array_equal(b.helper_batch(_ffi.OP_ACCL_CONSTRAINTS, g["accl_in"])[:, 0], g["accl_out"])
+    assert np.array_equal(b.helper_batch(_ffi.OP_STEERING_CONSTRAINT, g["steer_in"])[:, 0], g["steer_out"])
+    assert np.array_equal(b.helper_batch(_ffi.OP_CROSS, g["cross_in"])[:, 0], g["cross_out"])
+    assert np.array_equal(b.helper_batch(_ffi.OP_ARE_COLLINEAR, g["collinear_in"])[:, 0], g["collinear_out"])
+    assert 0 < g["collinear_out"].sum() < len(g["collinear_out"])
+    assert np.array_equal(b.helper_batch(_ffi.OP_PERPENDICULAR, g["perp_in"]), g["perp_out"])
+    assert np.array_equal(b.helper_batch(_ffi.OP_TRIPLE_PRODUCT, g["triple_in"]), g["triple_out"])
+    n = len(g["body_a"])
+    va, vb, d = g["body_a"].reshape(n, 8), g["body_b"].reshape(n, 8), g["dir"]
+    assert np.array_equal(b.helper_batch(_ffi.OP_AVG_POINT, va, n=4), g["avg_out"])
+    assert np.array_equal(b.helper_batch(_ffi.OP_FURTHEST_POINT, np.concatenate([va, d], axis=1), n=4)[:, 0].astype(np.int32), g["furthest_out"])
+    assert np.array_equal(b.helper_batch(_ffi.OP_SUPPORT, np.concatenate([va, vb, d], axis=1), n=4), g["support_out"])
+    pent = g["pent"].reshape(-1, 10)
+    assert np.array_equal(b.helper_batch(_ffi.OP_AVG_POINT, pent, n=5), g["pent_avg"])
+    assert np.array_equal(b.helper_batch(_ffi.OP_FURTHEST_POINT, np.concatenate([pent, g["pent_dir"]], axis=1), n=5)[:, 0].astype(np.int32), g["pent_furthest"])
+    assert _rel(b.helper_batch(_ffi.OP_GET_TRMTX, g["trmtx_in"]).reshape(-1, 4, 4), g["trmtx_out"]) < FTOL
+    b.close()
+    # and through the reference's own signatures (f110_gym.envs star-exports)
+    import f110_gym.envs as envs
+    assert envs.accl_constraints(*g["accl_in"][3]) == g["accl_out"][3] and envs.steering_constraint(*g["steer_in"][25]) == g["steer_out"][25]
+    assert envs.cross(g["cross_in"][0, :2], g["cross_in"][0, 2:]) == g["cross_out"][0]
+    r = g["collinear_in"][5]
+    assert envs.are_collinear(r[0:2], r[2:4], r[4:6]) == bool(g["collinear_out"][5])
+    pt = g["perp_in"][7].copy()
+    assert envs.perpendicular(pt) is pt and np.array_equal(pt, g["perp_out"][7])
+    r = g["triple_in"][9]
+    assert np.array_equal(envs.tripleProduct(r[0:2], r[2:4], r[4:6]), g["triple_out"][9])
+    assert np.array_equal(envs.avgPoint(g["body_a"][11]), g["avg_out"][11]) and np.array_equal(envs.avgPoint(g["pent"][3]), g["pent_avg"][3])
+    assert envs.indexOfFurthestPoint(g["body_a"][90], g["dir"][90]) == g["furthest_out"][90]
+    assert np.array_equal(envs.support(g["body_a"][13], g["body_b"][13], g["dir"][13]), g["support_out"][13])
+    assert _rel(envs.get_trmtx(g["trmtx_in"][2]), g["trmtx_out"][2]) < FTOL
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_free_scan_functions_vs_reference(amd, tag):
+    """get_dt, xy_2_rc, distance_transform, trace_ray, get_scan as FREE functions with the reference's own argument lists
+    (laser_models.py:40-186), on a synthetic map whose origin is plain (a) and yawed by 0.6 rad (b): cells exact, table values
+    and ranges exact (the same additions in the same order; only the table's sqrt and the caller's sin / cos enter, both host-side)"""
+    from _util import gold
+    import f110_gym.envs as envs
+    from f1tenth_gym_amd import _ffi, functional
+    g = gold("star_exports")
+    res = float(g["map_res"][0])
+    dt = envs.get_dt(g["bitmap"].astype(np.float64), res)
+    assert np.array_equal(dt, g["dt"])
+    H, W = dt.shape
+    ox, oy, oth = g["origin_" + tag]
+    oc, os_ = np.cos(oth), np.sin(oth)
+    pts = g["pts_" + tag]
+    m = len(pts)
+    b = amd.BatchSim(num_envs=1, num_agents=1)
+    rows = np.concatenate([pts, np.tile([ox, oy, oc, os_, H, W, res], (m, 1))], axis=1)
+    assert np.array_equal(b.helper_batch(_ffi.OP_XY_2_RC, rows).astype(np.int32), g["rc_" + tag])
+    b.close()
+    assert (g["rc_" + tag][:, 0] < 0).any() and (g["rc_" + tag][:, 0] >= 0).sum() > 100
+    th = np.linspace(0.0, 2 * np.pi, num=720)
+    sines, cosines = np.sin(th), np.cos(th)
+    for i in list(range(0, m, 7)) + [0, 1, 2]:
+        assert envs.xy_2_rc(pts[i, 0], pts[i, 1], ox, oy, oc, os_, H, W, res) == tuple(g["rc_" + tag][i])
+        assert envs.distance_transform(pts[i, 0], pts[i, 1], ox, oy, oc, os_, H, W, res, dt) == g["dtval_" + tag][i]
+        assert envs.trace_ray(pts[i, 0], pts[i, 1], g["theta_idx_" + tag][i], sines, cosines, 1e-4, ox, oy, oc, os_, H, W, res, dt, 4.0) == g["trace_" + tag][i]
+    # every row in one launch each
+    hb = functional._map_sim(dt, res, ox, oy, oc, os_, eps=1e-4, theta_dis=720, max_range=4.0, sines=sines, cosines=cosines)
+    assert np.array_equal(hb.helper_batch(_ffi.OP_DISTANCE_TRANSFORM, pts)[:, 0], g["dtval_" + tag])
+    assert np.array_equal(hb.helper_batch(_ffi.OP_TRACE_RAY, np.concatenate([pts, g["theta_idx_" + tag][:, None]], axis=1))[:, 0], g["trace_" + tag])
+    theta_dis, nb, fov, eps, mr = g["scan_cfg"]
+    inc = int(theta_dis) * (fov / (int(nb) - 1)) / (2. * np.pi)
+    for q, want in zip(g["scan_poses_" + tag], g["scans_" + tag]):
+        got = envs.get_scan(q, int(theta_dis), fov, int(nb), inc, sines, cosines, eps, ox, oy, oc, os_, H, W, res, dt, mr)
+        assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        envs.get_scan(g["scan_poses_" + tag][0], int(theta_dis), fov, int(nb), inc * 1.01, sines, cosines, eps, ox, oy, oc, os_, H, W, res, dt, mr)
+    functional.close_cached_handles()
+
+
+@pytest.mark.parametrize("table", ["two_ramps", "jitter", "descending", "short_random", "uniform_ref"])
+def test_scan_angles_tables_that_are_not_the_uniform_ramp(amd, table):
+    """ray_cast / get_blocked_view_indices / check_ttc_jit with ANY scan_angles array (laser_models.py:282-346, :188-217): two
+    concatenated ramps, a jittered ramp, a descending ramp, 37 random angles — the reference's full first-minimum argmin decides the
+    window there (k_raycast_unit's non-uniform branch); window exact, scans <= 1e-12, flags exact.  The step refuses such tables."""
+    from _util import gold
+    import f110_gym.envs as envs
+    from f1tenth_gym_amd import functional
+    g = gold("star_exports")
+    sa = g["sa_" + table]
+    B = len(sa)
+    ego, verts = g["ego_" + table], g["verts_" + table]
+    m = len(ego)
+    b = amd.BatchSim(num_envs=1, num_agents=1, num_beams=B)
+    b.set_beam_tables(sa, g["ttc_cos_" + table], g["ttc_side_" + table])
+    out, mm = b.raycast_batch(ego, verts, np.full((m, B), 10.0))
+    assert np.array_equal(mm[:, 0], g["lo_" + table]) and np.array_equal(mm[:, 1], g["hi_" + table])
+    assert _rel(out, g["rc_scans_" + table]) < FTOL and (out < 10.0).sum() == (g["rc_scans_" + table] < 10.0).sum()
+    assert np.array_equal(b.ttc_batch(g["ttc_scans_" + table], g["ttc_vel_" + table], 0.005), g["ttc_flags_" + table])
+    if table != "uniform_ref":
+        img, res, origin = __import__("_util").load_map_image("example_map")
+        b.set_map_image(img, res, origin)
+        b.reset(np.array([[0.7, 0.0, 1.37]]))
+        with pytest.raises(Exception, match="uniform ramp"):
+            b.step(np.zeros((1, 2)))
+    b.close()
+    # the reference's signatures, alternating the three functions on one table (cached handle, tables uploaded once)
+    for i in (0, 7, 19, m - 1):
+        assert envs.get_blocked_view_indices(ego[i], verts[i], sa) == (g["lo_" + table][i], g["hi_" + table][i])
+        sc = np.full(B, 10.0)
+        assert envs.ray_cast(ego[i], sc, sa, verts[i]) is sc and _rel(sc, g["rc_scans_" + table][i]) < FTOL
+        j = i % len(g["ttc_vel_" + table])
+        assert envs.check_ttc_jit(g["ttc_scans_" + table][j], g["ttc_vel_" + table][j], sa, g["ttc_cos_" + table], g["ttc_side_" + table], 0.005) == bool(g["ttc_flags_" + table][j])
+    assert len(functional._ctx) >= 1
+    functional.close_cached_handles()

@@ -275,9 +275,42 @@ def test_dlpack_capsule_fields():
         del cap
         gc.collect()
         assert len(_dlpack._live) == n0
+    # the newer protocol keywords (numpy >= 2.1, array-api callers): accepted; a copy or a foreign device is refused, not a TypeError
+    sim = FakeSim()
+    arr = DeviceArray(sim, (4,), np.float64, ptr=0x7f0000002000)
+    cap = arr.__dlpack__(stream=-1, max_version=(1, 0), dl_device=(10, 3), copy=False)
+    assert _dlpack.read_capsule(cap)["data"] == 0x7f0000002000 and _dlpack.exports_of(sim) == 1
+    for kw in ({"copy": True}, {"dl_device": (1, 0)}, {"dl_device": (10, 0)}):
+        with pytest.raises(BufferError):
+            arr.__dlpack__(stream=-1, **kw)
+    del cap
+    gc.collect()
+    assert _dlpack.exports_of(sim) == 0
     arr.ptr = None
     with pytest.raises(ValueError):
         arr.__dlpack__()
+
+
+def test_workload_module_equals_the_test_helpers():
+    """f1tenth_gym_amd/workload.py (what bench.py runs on: shipped example track, raceline, start poses, action sets) is the same data
+    the tests' own helpers read from tests/golden/maps (PIL / PyYAML there, the package's own PNG / yaml readers here)"""
+    from f1tenth_gym_amd import workload
+    from _util import bench_start_poses, load_map_image, raceline
+    img, res, origin = load_map_image("example_map")
+    img2, res2, origin2 = workload.load_map_image("example_map")
+    assert np.array_equal(img, img2) and res == res2 and origin == origin2
+    assert np.array_equal(raceline(), workload.raceline())
+    assert np.array_equal(bench_start_poses(1000, 2), workload.bench_start_poses(1000, 2))
+    assert np.array_equal(bench_start_poses(50, 3, gap_wp=6), workload.start_poses(np.arange(50), 3, 6))
+    assert np.array_equal(workload.start_poses(workload.shard_envs(16, 3), 2), workload.bench_start_poses(64, 2)[96:128])
+
+
+def test_sharded_vec_env_rejects_bad_shardings():
+    """ShardedVecEnv validates the sharding before it touches a device"""
+    from f1tenth_gym_amd import ShardedVecEnv
+    for kw in (dict(devices=[]), dict(devices=[0, 0], shard_sizes=[3, 3]), dict(devices=[0, 0], shard_sizes=[8, 0]), dict(devices=[0], shard_sizes=[4, 4])):
+        with pytest.raises(ValueError):
+            ShardedVecEnv(8, **kw)
 
 
 def test_every_script_of_the_repo_compiles():
