@@ -90,6 +90,10 @@ def main(argv=None):
     print("%d envs x %d agents, %d steps: %.3f ms per step, %.1f M agent-steps/s; %d env resets, %d envs done right now, max lap count %.0f (%s policy)"
           % (E, A, args.steps, dt / args.steps * 1e3, N * args.steps / dt / 1e6, int(d_resets.download()[0]), done_now, laps.max(),
              "torch MLP via DLPack" if args.torch else "built-in scan"))
+    if args.torch:
+        # the tensors made by from_dlpack view the simulator's memory: they go first (BatchSim.close() refuses while they live)
+        del scans_t, act_t, policy
+        torch.cuda.synchronize()
     sim.close()
     return N * args.steps / dt
 

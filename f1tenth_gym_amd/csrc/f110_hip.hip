@@ -895,12 +895,21 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
         k.pad = h->d_dt_pad;
         k.pad_t = nullptr;
         if (h->d_dt_pad_t) { (void)hipFree(h->d_dt_pad_t); h->d_dt_pad_t = nullptr; }
-        if (kExperimental && h->exp.pad_tiled) {   // lab: the same table in 4x4-cell tiles for the step's march
-            const size_t tiles_w = ((size_t)k.pad_width + 3) / 4, tiles_h = ((size_t)k.pad_height + 3) / 4;
-            TRY(dmalloc(h, &h->d_dt_pad_t, tiles_w * tiles_h * 16));
-            k.pad_t_row_bytes = (int32_t)(tiles_w * 128);
+        if (kExperimental && h->exp.pad_tiled) {   // lab: the same table again for the step's march — 1: in 4x4-cell tiles, 2: in row pairs (2 rows x 8 cells per line)
+            const int mode = h->exp.pad_tiled == 2 ? 2 : 1;
+            size_t doubles;
+            if (mode == 2) {
+                k.pad_t_row_bytes = (int32_t)((size_t)k.pad_width * 16);
+                doubles = (((size_t)k.pad_height + 1) / 2) * (size_t)k.pad_width * 2;
+                if ((size_t)k.pad_width * 16 >= (1u << 24) || doubles * 8 >= (1ull << 32)) return fail(h, F110_ERR_INVALID, "pad_tiled=2: the map is too large for 24-bit row-pair pitches");
+            } else {
+                const size_t tiles_w = ((size_t)k.pad_width + 3) / 4, tiles_h = ((size_t)k.pad_height + 3) / 4;
+                k.pad_t_row_bytes = (int32_t)(tiles_w * 128);
+                doubles = tiles_w * tiles_h * 16;
+            }
+            TRY(dmalloc(h, &h->d_dt_pad_t, doubles));
             hipLaunchKernelGGL(k_build_padded_tiled, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_pad, k.pad_width, k.pad_height, (uint32_t)k.pad_t_row_bytes,
-                               h->d_dt_pad_t);
+                               mode, h->d_dt_pad_t);
             HIPCHK(h, hipGetLastError());
             k.pad_t = h->d_dt_pad_t;
         }
@@ -2268,7 +2277,8 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
 #endif
 #ifdef F110_EXPERIMENTAL
             if (h->exp.pad_tiled && h->k.pad_t && h->k.ident_rot) {
-                hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true, false, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                if (h->exp.pad_tiled == 2) hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true, false, false, 2>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                else hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true, false, false, 1>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
                 break;
             }
 #endif
@@ -2327,7 +2337,8 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
 #endif
 #ifdef F110_EXPERIMENTAL
             if (h->exp.pad_tiled && h->k.pad_t && h->k.ident_rot && !h->multi_map && !cnt) {
-                hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, false, false, false, true>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                if (h->exp.pad_tiled == 2) hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, false, false, false, 2>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
+                else hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, false, false, false, 1>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
                 break;
             }
 #endif
@@ -2381,7 +2392,11 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
                 else hipLaunchKernelGGL((k_finalize_pair_roles<8, 64>), dim3((count + 7) / 8), dim3(64), 0, st, dev, B);
             } else
 #endif
-            if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_roles<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
+            if (dev.fused_host) {   // the instantiation that carries the f110_step_host epilogue
+                if (lanes <= 8) hipLaunchKernelGGL((k_finalize_pair_roles<32, 256, true>), dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
+                else if (lanes == 16) hipLaunchKernelGGL((k_finalize_pair_roles<16, 256, true>), dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
+                else hipLaunchKernelGGL((k_finalize_pair_roles<4, 256, true>), dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
+            } else if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_roles<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
             else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_roles<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
             else hipLaunchKernelGGL(k_finalize_pair_roles<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
         }

@@ -777,7 +777,7 @@ __device__ __forceinline__ void load_map_fast(ScanConst &km, const MapFast *__re
 #ifndef F110_SCAN_WAVES_EXPR
 #define F110_SCAN_WAVES_EXPR 8
 #endif
-template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false, bool SPEC = false, bool TILED = false>
+template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false, bool SPEC = false, int TILED = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_SCAN_WAVES_EXPR))) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
                                                           const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
@@ -1533,8 +1533,14 @@ __device__ __forceinline__ void pair_host_epilogue(const AgentArrays &a, bool ag
 // NT = 256: the product form.  NT = 64 (lab, round 5): the same kernel as ONE wave per workgroup at 8 waves per SIMD — a workgroup
 // that fits any slot a finished scan wave leaves, so that a second env block's finalize can run UNDER the first block's scan
 // (VERDICT r4 item 3); roles then share the wave: corners on lanes 0 .. 4 AG - 1, culls behind them, pair tests behind those.
-template <int AG, int NT = 256>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 8 : 6))) k_finalize_pair_roles(AgentArrays a, int32_t B)   // (6 waves per SIMD = 80 VGPRs: what the kernel needs without its f110_step_host epilogue)
+// HOST (round 6): the f110_step_host epilogue is a TEMPLATE parameter, not a run-time branch — the instantiation f110_step_device
+// launches does not carry the epilogue's registers (it spilled 80 bytes per lane under the 80-VGPR cap for code it never ran);
+// the HOST instantiation (small, host-synchronised batches) takes the registers it needs at 4 waves per SIMD.
+#ifndef F110_FIN_WAVES
+#define F110_FIN_WAVES 5   // 5 waves per SIMD = up to 96 VGPRs: the body needs 82 and keeps nothing in scratch (at 6 = 80 VGPRs it kept 80 bytes per lane there)
+#endif
+template <int AG, int NT = 256, bool HOST = false>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 8 : (HOST ? 4 : F110_FIN_WAVES)))) k_finalize_pair_roles(AgentArrays a, int32_t B)
 {
     static_assert((AG & (AG - 1)) == 0 && AG >= 2 && 4 * AG <= NT / 2, "AG is a power of two, 2..32 (NT = 64: 2..8)");
     constexpr int R1 = NT == 64 ? 4 * AG : 128, R2 = NT == 64 ? 5 * AG : 192;   // first thread of the cull / the pair-test role
@@ -1667,7 +1673,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 6
         const double r = box_range(bex, bey, v3x, v3y, bv, r0);
         if (r < r0) sc[b] = r;
     }
-    if (a.fused_host) {   // f110_step_host (wave-uniform): the host block, the episode logic and its re-seat, right here
+    if (HOST) {   // f110_step_host: the host block, the episode logic and its re-seat, right here (a.fused_host is set by the launcher)
         if (a.fused_host->hb.scans) {   // small batches: this workgroup's agents' scans, final once every item above is done
             __syncthreads();
             const int live_agents = (end - first) < AG ? (end - first) : AG;
@@ -2842,12 +2848,13 @@ __global__ void k_dt_from_d2(const uint32_t *__restrict__ d2, size_t n, double r
 // PADDED layout: the table inside a border of `b` cells that read dt[-1,-1], what the reference
 // returns for any out-of-bounds sample (laser_models.py:80-81,103)
 // the padded table again in 4x4-cell tiles (lab, march_padded<.., TILED>): one thread per padded cell
-__global__ void k_build_padded_tiled(const double *__restrict__ pad, int Wp, int Hp, uint32_t tile_row_bytes, double *__restrict__ out)
+__global__ void k_build_padded_tiled(const double *__restrict__ pad, int Wp, int Hp, uint32_t tile_row_bytes, int mode, double *__restrict__ out)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)Wp * Hp) return;
     const uint32_t r = (uint32_t)(i / Wp), c = (uint32_t)(i - (size_t)r * Wp);
-    *reinterpret_cast<double *>(reinterpret_cast<char *>(out) + tiled_offset(r, c, tile_row_bytes)) = pad[i];
+    const uint32_t off = mode == 2 ? pair_offset(r, c, tile_row_bytes) : tiled_offset(r, c, tile_row_bytes);   // 1: 4x4 tiles, 2: row pairs
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(out) + off) = pad[i];
 }
 
 __global__ void k_build_padded(const double *__restrict__ rowmajor, int H, int W, int b, int Wp, int Hp, double *__restrict__ pad)

@@ -652,7 +652,24 @@ F110_HD uint32_t tiled_offset(uint32_t r, uint32_t c, uint32_t tile_row_bytes)
 // TILED (round 5, lab): the same march reading the 4x4-tiled copy of the padded table.  The scan is bound by the lines its
 // gathers pull through the L1s; a ray that moves across rows changes line at every sample of the row-major table and every
 // 2-3 samples of the tiled one (tools/debug: 11.2 -> 8.5 distinct lines per 64-ray gather), for +6 integer operations.
-template <bool WANT_CELL, bool TILED = false>
+// byte offset of padded cell (r, c) in the ROW-PAIR copy (round 6, lab): rows 2p and 2p + 1 interleaved cell by cell, so a
+// 128-byte line holds 8 columns x 2 rows — a ray that moves across rows stays on its line for two rows instead of none
+// (tools/debug/layout_sim.py: 11.4 -> 9.1 distinct lines per 64-ray gather), for two more integer operations per sample
+// (4x4 tiles: 8.6 lines for six).  pair_row_bytes = padded width * 16.
+F110_HD uint32_t pair_offset(uint32_t r, uint32_t c, uint32_t pair_row_bytes)
+{
+    return (mul24(r >> 1, pair_row_bytes) + (c << 4)) | ((r & 1u) << 3);
+}
+
+// TILED: 0 = the row-major padded table (product); 1 = its 4x4-tiled copy; 2 = its row-pair copy (both lab)
+template <int TILED>
+F110_HD uint32_t padded_cell_offset(const ScanConst &k, uint32_t r, uint32_t c)
+{
+    return TILED == 1 ? tiled_offset(r, c, (uint32_t)k.pad_t_row_bytes)
+                      : (TILED == 2 ? pair_offset(r, c, (uint32_t)k.pad_t_row_bytes) : mul24(r, (uint32_t)k.pad_row_bytes) + (c << 3));
+}
+
+template <bool WANT_CELL, int TILED = 0>
 F110_HD bool march_padded(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
                           int &hit_r, int &hit_c, int &lookups)
 {
@@ -665,8 +682,7 @@ F110_HD bool march_padded(const ScanConst &k, double ux, double uy, double cux, 
         uy = fma(d, cuy, uy);
         const uint32_t wx = low_word(ux + kFixBig);
         const uint32_t wy = low_word(uy + kFixBig);
-        uint32_t off = TILED ? tiled_offset(wy >> kFixFracBits, wx >> kFixFracBits, (uint32_t)k.pad_t_row_bytes)
-                             : mul24(wy >> kFixFracBits, (uint32_t)k.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
+        uint32_t off = padded_cell_offset<TILED>(k, wy >> kFixFracBits, wx >> kFixFracBits);
         if (WANT_CELL) {
             hit_c = (int)(wx >> kFixFracBits);
             hit_r = (int)(wy >> kFixFracBits);
@@ -676,7 +692,7 @@ F110_HD bool march_padded(const ScanConst &k, double ux, double uy, double cux, 
             // cell above: take the floor, and give the ray up if it is closer than kPadGuard
             redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
             const int fc = (int)floor(ux), fr = (int)floor(uy);
-            off = TILED ? tiled_offset((uint32_t)fr, (uint32_t)fc, (uint32_t)k.pad_t_row_bytes) : mul24((uint32_t)fr, (uint32_t)k.pad_row_bytes) + ((uint32_t)fc << 3);
+            off = padded_cell_offset<TILED>(k, (uint32_t)fr, (uint32_t)fc);
             if (WANT_CELL) {
                 hit_c = fc;
                 hit_r = fr;

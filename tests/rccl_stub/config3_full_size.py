@@ -125,7 +125,8 @@ def rank_main(rank):
             s.comm_set_overlap(False)
             for d in rs + rc:
                 d.free()
-        s.close(); ref.close()
+        s.close()
+        del ref
     except BaseException as ex:  # noqa: BLE001
         import traceback
         errors.append("rank %d: %r\n%s" % (rank, ex, traceback.format_exc()[-1500:]))

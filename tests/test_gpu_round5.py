@@ -482,7 +482,7 @@ def test_tiled_padded_table_is_bit_identical(amd):
     E, A, T = 1024, 2, 10          # 34 816 tasks: the longest-first form; plus a small batch below
     for E, A, T in ((1024, 2, 10), (37, 3, 25)):
         outs = []
-        for pt in (0, 1):
+        for pt in (0, 1, 2):      # row-major, 4x4 tiles, row pairs (round 6: 2 rows x 8 cells per line, two more integer operations)
             s = amd.BatchSim(num_envs=E, num_agents=A, exp={"pad_tiled": pt})
             s.set_map_image(*load_map_image("example_map")); s.set_noise_rng(12345, 0.01)
             s.reset(bench_start_poses(E, A))
@@ -494,30 +494,37 @@ def test_tiled_padded_table_is_bit_identical(amd):
             outs.append(s.get("scans", "state", "collisions", "in_collision"))
             s.close()
         for key in outs[0]:
-            assert np.array_equal(outs[0][key], outs[1][key]), key
+            assert np.array_equal(outs[0][key], outs[1][key]) and np.array_equal(outs[0][key], outs[2][key]), key
 
 
-def test_fuzz_envs_bounded_seeds(amd):
-    """tools/debug/fuzz_envs.py, eight seeds of it: a different track per env (f110_add_map_dt / f110_set_env_maps), a vehicle
-    parameter set per agent or per slot, constructor arguments and yawed origins drawn together, calm actions so that the rollouts
-    run their length through wall hits and car-to-car hits — the HIP step against one CPU oracle per env (850 seeds by hand:
-    profiles/r05_fuzz_envs.txt)"""
+NESTED = bool(os.environ.get("F110_NESTED_SUITE"))   # the lab build's re-run of the suite runs a few seeds of every chunk
+
+
+def _fuzzer(name):
     import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_envs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                           "tools", "debug", "fuzz_envs.py"))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "debug", name + ".py"))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
-    bad = [sd for sd in range(8) if not fz.run(sd)]
+    return fz
+
+
+@pytest.mark.parametrize("first", range(0, 200, 50))
+def test_fuzz_envs_bounded_seeds(amd, first):
+    """tools/debug/fuzz_envs.py, seeds 0 .. 199 in the driver-run suite (round 6; 8 before, 850 by hand in round 5): a different track
+    per env (f110_add_map_dt / f110_set_env_maps), a vehicle parameter set per agent or per slot, constructor arguments and yawed origins
+    drawn together, calm actions so that the rollouts run their length through wall hits and car-to-car hits — the HIP step against
+    one CPU oracle per env; ~0.3 s per seed on the box"""
+    fz = _fuzzer("fuzz_envs")
+    bad = [sd for sd in range(first, first + (2 if NESTED else 50)) if not fz.run(sd)]
     assert not bad, bad
 
 
-def test_fuzz_episode_bounded_seeds(amd):
-    """tools/debug/fuzz_episode.py, ten seeds of it: F110VecEnv(device_logic=True) — lap toggles, counts, times, done and the auto-reset
-    re-seats done by the finalize kernels (f110_env.py:219-306) — equals the host-side bookkeeping (pinned to the live reference
-    by tests/test_reference_fuzz.py) over random tracks, 1-4 cars, ego indices, time steps, integrators, partial resets, with half
-    of the envs driven in circles so that laps complete (2 200 seeds by hand: profiles/r05_fuzz_episode.txt)"""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_episode", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                                              "tools", "debug", "fuzz_episode.py"))
-    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
-    bad = [sd for sd in range(10) if not fz.run(sd)]
+@pytest.mark.parametrize("first", range(0, 300, 100))
+def test_fuzz_episode_bounded_seeds(amd, first):
+    """tools/debug/fuzz_episode.py, seeds 0 .. 299 in the driver-run suite (round 6; 10 before, 2 200 by hand in round 5):
+    F110VecEnv(device_logic=True) — lap toggles, counts, times, done and the auto-reset re-seats done by the finalize kernels
+    (f110_env.py:219-306) — equals the host-side bookkeeping (pinned to the live reference by tests/test_reference_fuzz.py) over random
+    tracks, 1-4 cars, ego indices, time steps, integrators, partial resets, with half of the envs driven in circles so that laps
+    complete; ~0.1 s per seed on the box"""
+    fz = _fuzzer("fuzz_episode")
+    bad = [sd for sd in range(first, first + (3 if NESTED else 100)) if not fz.run(sd)]
     assert not bad, bad
