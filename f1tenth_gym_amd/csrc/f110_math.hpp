@@ -661,6 +661,26 @@ F110_HD uint32_t pair_offset(uint32_t r, uint32_t c, uint32_t pair_row_bytes)
     return (mul24(r >> 1, pair_row_bytes) + (c << 4)) | ((r & 1u) << 3);
 }
 
+// the same offset straight from the two fixed-point words (cell = word >> 16): five VALU operations — the row-major form takes
+// three — pinned in assembly because the compiler's own selection of the C expression above takes seven (no SDWA word select for
+// the << 4, no v_and_or_b32)
+F110_HD uint32_t pair_offset_words(uint32_t wx, uint32_t wy, uint32_t pair_row_bytes)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t off, t;
+    asm("v_lshrrev_b32 %0, 17, %2\n\t"
+        "v_lshlrev_b32_sdwa %1, %4, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+        "v_mad_u32_u24 %0, %0, %5, %1\n\t"
+        "v_lshrrev_b32 %1, 13, %2\n\t"
+        "v_and_or_b32 %0, %1, 8, %0"
+        : "=&v"(off), "=&v"(t)
+        : "v"(wy), "v"(wx), "v"(4u), "s"(pair_row_bytes));
+    return off;
+#else
+    return pair_offset(wy >> kFixFracBits, wx >> kFixFracBits, pair_row_bytes);
+#endif
+}
+
 // TILED: 0 = the row-major padded table (product); 1 = its 4x4-tiled copy; 2 = its row-pair copy (both lab)
 template <int TILED>
 F110_HD uint32_t padded_cell_offset(const ScanConst &k, uint32_t r, uint32_t c)
@@ -682,7 +702,7 @@ F110_HD bool march_padded(const ScanConst &k, double ux, double uy, double cux, 
         uy = fma(d, cuy, uy);
         const uint32_t wx = low_word(ux + kFixBig);
         const uint32_t wy = low_word(uy + kFixBig);
-        uint32_t off = padded_cell_offset<TILED>(k, wy >> kFixFracBits, wx >> kFixFracBits);
+        uint32_t off = TILED == 2 ? pair_offset_words(wx, wy, (uint32_t)k.pad_t_row_bytes) : padded_cell_offset<TILED>(k, wy >> kFixFracBits, wx >> kFixFracBits);
         if (WANT_CELL) {
             hit_c = (int)(wx >> kFixFracBits);
             hit_r = (int)(wy >> kFixFracBits);
