@@ -49,7 +49,8 @@ struct ExpSwitches {
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
     int group_split = 0;       // two env groups: percent of the envs in the first (0 = even)
     int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
-    int pad_tiled = 0;         // 1: the step's scan marches a 4x4-tiled copy of the PADDED table (set before the map is loaded)
+    int pad_tiled = 0;         // 1 / 2: the step's scan marches a 4x4-tiled / a row-pair copy of the PADDED table (set before the map is loaded)
+    int scan_nt = 0;           // 1: the step's scan stores its ranges non-temporally
     int finalize_wave = 0;     // A = 2: 8 / 4 = k_finalize_pair_roles as one-wave workgroups of 8 / 4 agents (0 = the 256-thread form)
     int spec_from = 0;         // k_scan_rays_agent in the longest-first window: march_padded_spec from this sample on (0 = plain march)
     int scan_stream = 0;       // 1: the lane-refill scan (k_scan_stream_agent) wherever it applies
@@ -424,6 +425,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "integrate_fan") h->exp.integrate_fan = value;
     else if (k == "group_split") h->exp.group_split = value;
     else if (k == "pad_tiled") h->exp.pad_tiled = value;
+    else if (k == "scan_nt") h->exp.scan_nt = value;
     else if (k == "finalize_wave") h->exp.finalize_wave = value;
     else if (k == "spec_from") h->exp.spec_from = value;
     else if (k == "scan_stream") h->exp.scan_stream = value;
@@ -2207,6 +2209,7 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         j.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;   // (step form: only the ray pass counts here)
 #ifdef F110_EXPERIMENTAL
         j.trace = reinterpret_cast<unsigned long long *>(h->exp.scan_trace);
+        j.pad_win = h->exp.scan_nt ? 1u : 0u;   // lab: non-temporal range stores (finish_beam_with)
 #endif
         j.k_cold = cold_consts(h);
         if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");

@@ -1091,6 +1091,14 @@ __device__ __forceinline__ void finish_beam_with(const RayJob &j, uint32_t p, in
     if (vel != 0.0 && !(r > j.ttc_side_max + j.ttc_k * fabs(vel)) &&
         ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh))
         j.wall_flag[p] = 1;
+#ifdef F110_EXPERIMENTAL
+    // lab (round 6): the range stream past the caches, so that a SMALL batch's 35 MB of range writes per step stop
+    // evicting the table lines its dependent chains re-read from L2 every launch (RayJob::pad_win is a spare word: 1 = on)
+    if (j.pad_win) {
+        __builtin_nontemporal_store(r, &j.ranges[ray]);
+        return;
+    }
+#endif
     j.ranges[ray] = r;
 }
 

@@ -109,7 +109,8 @@ int f110_is_experimental(void);
  * [launch waves][8] uint64 buffer that every wave of the step's scan kernel stamps with its begin / end clock, CU and samples:
  * tools/debug/scan_timeline.py; 0 = off); round 5: scan_stream (1: the lane-refill scan k_scan_stream_agent), stream_refill,
  * stream_block, stream_grid, spec_from (the tail of long rays two samples per round trip), finalize_wave (8 | 4: the A = 2 finalize as
- * one-wave workgroups), pad_tiled (1, before the map is loaded: the step's march on a 4x4-tiled copy of the PADDED table).  Retired in round 5 with the code they
+ * one-wave workgroups), pad_tiled (before the map is loaded; 1: the step's march on a 4x4-tiled copy of the PADDED table, round 6: 2 = on a row-pair copy, 2 rows x 8 cells per
+ * line), scan_nt (round 6: 1 = the scan's range stores non-temporal).  Retired in round 5 with the code they
  * switched (numbers in DESIGN_HISTORY.md): dedupe_two_pass, no_window, finalize_lanes / _flat / _roles, pair_always, step_graph,
  * ray_pass / ray_thr / ray_waves. */
 int f110_exp_set(f110_sim *h, const char *key, int32_t value);

@@ -40,10 +40,61 @@ def pvec(p):
     return np.array([p[k] for k in PARAM_KEYS])
 
 
+CHECK = {"on": False, "bad": [], "files": 0}
+
+
 def save(name, **arrays):
+    if CHECK["on"]:
+        return check_against_committed(name, arrays)
     path = os.path.join(GOLD, name + ".npz")
     np.savez_compressed(path, **arrays)
     print("  wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.))
+
+
+def check_against_committed(name, arrays):
+    """--check: what the reference produces NOW (under whatever numba this interpreter has) against the committed fixture, key by
+    key: integer / bool / string arrays must be equal; float arrays are reported exact or with their largest relative difference
+    (<= 1e-9 passes: a compiled reference may differ from the interpreted one in libm ulps of sin / cos / tan / atan2)"""
+    path = os.path.join(GOLD, name + ".npz")
+    CHECK["files"] += 1
+    if not os.path.isfile(path):
+        CHECK["bad"].append("%s: no committed fixture" % name)
+        print("  %-28s MISSING from tests/golden" % (name + ".npz"))
+        return
+    old = np.load(path)
+    worst, exact, n = 0.0, 0, 0
+    for key, val in arrays.items():
+        val = np.asarray(val)
+        n += 1
+        if key not in old.files:
+            CHECK["bad"].append("%s[%s]: not in the committed fixture" % (name, key))
+            continue
+        ref = old[key]
+        if ref.shape != val.shape:
+            CHECK["bad"].append("%s[%s]: shape %s, committed %s" % (name, key, val.shape, ref.shape))
+            continue
+        if val.dtype.kind == "f" and ref.dtype.kind == "f":
+            if np.array_equal(val, ref, equal_nan=True):
+                exact += 1
+                continue
+            with np.errstate(divide="ignore", invalid="ignore"):
+                diff = np.abs(val - ref)
+                rel = np.where(diff > 1e-12, diff / np.abs(ref), 0.0)
+            m = float(np.nanmax(rel)) if rel.size else 0.0
+            if not np.array_equal(np.isnan(val), np.isnan(ref)):
+                m = float("inf")
+            worst = max(worst, m)
+            if not m <= 1e-9:
+                CHECK["bad"].append("%s[%s]: floats differ by %.3g relative" % (name, key, m))
+        else:
+            if np.array_equal(val, ref):
+                exact += 1
+            else:
+                CHECK["bad"].append("%s[%s]: %d of %d entries differ" % (name, key, int(np.sum(val != ref)), val.size))
+    extra = sorted(set(old.files) - set(arrays))
+    if extra:
+        CHECK["bad"].append("%s: committed keys the generator no longer writes: %s" % (name, extra))
+    print("  %-28s %3d keys: %3d exact, largest relative float difference %.3g" % (name + ".npz", n, exact, worst))
 
 
 def copy_data():
@@ -1178,7 +1229,14 @@ GROUPS = {"star_exports": gen_star_exports, "scan_ctor": gen_scan_ctor, "scan_ro
 
 def main(argv):
     os.makedirs(GOLD, exist_ok=True)
-    which = argv or list(GROUPS)
+    if "--check" in argv:
+        # regenerate in memory and DIFF against tests/golden instead of writing: for a maintainer whose interpreter has a working
+        # numba (this image has none) — the reference's @njit functions then run compiled, and the diff shows whether the
+        # interpreted runs that produced the committed fixtures differ from the jitted path (tests/golden/README.md)
+        argv = [a for a in argv if a != "--check"]
+        CHECK["on"] = True
+        os.environ["F110_REAL_NUMBA"] = "1"
+    which = [g for g in (argv or list(GROUPS)) if not (CHECK["on"] and g == "data")]
     # the reference's example scripts import f110_gym.envs.* by name: bind those names to the reference
     # for the duration of the generation only (ref_loader.reference_modules)
     with ref_loader.reference_modules() as ns:
@@ -1187,7 +1245,13 @@ def main(argv):
             print("[%s]" % g)
             GROUPS[g](ns)
             print("  %.1f s" % (time.time() - t))
+    if CHECK["on"]:
+        print("--check: reference decorated with %s; %d fixture file(s) compared, %d problem(s)" % (ref_loader.numba_in_use(), CHECK["files"], len(CHECK["bad"])))
+        for b in CHECK["bad"]:
+            print("  " + b)
+        return 1 if CHECK["bad"] else 0
+    return 0
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    sys.exit(main(sys.argv[1:]))

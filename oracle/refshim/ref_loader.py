@@ -18,6 +18,11 @@ _ENV_DIR = os.path.join(REF_ROOT, "gym", "f110_gym", "envs")
 _loaded = {}
 
 
+def numba_in_use():
+    """what `numba` the loaded reference modules were decorated with: "real numba x.y" or "no-op shim ..." """
+    return _loaded.get("numba", "not loaded yet")
+
+
 def reference_available():
     return os.path.isfile(os.path.join(_ENV_DIR, "laser_models.py"))
 
@@ -62,10 +67,24 @@ def load_reference(with_env=False):
         raise RuntimeError("reference tree not found at %s" % REF_ROOT)
     if "core" not in _loaded:
         shim_dir = os.path.dirname(os.path.abspath(__file__))
+        if "numba" not in sys.modules and os.environ.get("F110_REAL_NUMBA"):
+            # gen_golden.py --check on a machine that HAS numba: the reference's @njit functions run compiled, as its users run them
+            hidden = [p for p in sys.path if os.path.abspath(p or ".") == shim_dir]   # (the shim's own directory may be on the path)
+            for p in hidden:
+                sys.path.remove(p)
+            try:
+                import numba  # noqa: F401
+                _loaded["numba"] = "real numba %s" % getattr(numba, "__version__", "?")
+            except Exception as ex:  # noqa: BLE001 - absent, or broken against this NumPy
+                sys.modules.pop("numba", None)
+                _loaded["numba"] = "no-op shim (real numba is not importable here: %s: %s)" % (type(ex).__name__, str(ex)[:80])
+            finally:
+                sys.path[:0] = hidden
         if "numba" not in sys.modules:
             sys.path.insert(0, shim_dir)
             import numba  # noqa: F401  (the shim)
             sys.path.remove(shim_dir)
+            _loaded.setdefault("numba", "no-op shim")
         pkg = types.ModuleType("f110_gym")
         pkg.__path__ = []
         envs = types.ModuleType("f110_gym.envs")

@@ -62,6 +62,24 @@ pair)   # round 6's one scan experiment: the PADDED table in row pairs (pad_tile
     F110_LIB_VARIANT=experimental timeout 300 python tools/debug/tiled_ab.py 2>&1 | tail -6
     for rep in 1 2; do for n in 65536 16384 4096; do for pt in 0 2 1; do F110_LIB_VARIANT=experimental timeout 90 python tools/debug/stream_probe.py $n pad_tiled=$pt 2>&1 | grep agents; done; done; done; } | tee $OUT/rowpair.txt
   ;;
+pairsweep)   # where do row pairs pay?  small batches (lab build), bench form
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  F110_LIB_VARIANT=experimental F110_EXP=pad_tiled=V python bench.py --only-headline --steps 300 --warmup 30 --agents N, two rounds"
+    for rep in 1 2; do for n in 512 1024 2048 4096 6144 8192 12288 16384 32768; do for v in 0 2; do
+      F110_LIB_VARIANT=experimental F110_EXP=pad_tiled=$v timeout 100 python bench.py --only-headline --steps 300 --warmup 30 --agents $n 2>/dev/null | grep "^{" | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('agents %6d pad_tiled %d  %8.2f M agent-steps/s  %.4f ms/step' % ($n, $v, d['value']/1e6, d['ms_per_step']))
+"; done; done; done; } | tee $OUT/pair_sweep.txt
+  ;;
+ntstore)   # non-temporal range stores for the small batch (experimental build): does the table stay in L2 across launches?
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  F110_LIB_VARIANT=experimental F110_EXP=scan_nt=V python bench.py --only-headline --steps 300 --warmup 30 --agents N, two rounds"
+    for rep in 1 2; do for n in 4096 2048 8192 65536; do for v in 0 1; do
+      F110_LIB_VARIANT=experimental F110_EXP=scan_nt=$v timeout 100 python bench.py --only-headline --steps 300 --warmup 30 --agents $n 2>/dev/null | grep "^{" | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('agents %6d scan_nt %d  %8.2f M agent-steps/s  %.4f ms/step' % ($n, $v, d['value']/1e6, d['ms_per_step']))
+"; done; done; done; } | tee $OUT/nt_store.txt
+  ;;
 pairpmc)   # why: the PMC passes of pmcstream over the scan kernel with pad_tiled = 0 and 2 (experimental build, 65 536 agents)
   cd /tmp
   for tag in "rowmajor:pad_tiled=0" "pairs:pad_tiled=2"; do
@@ -90,6 +108,14 @@ for nm, ks in out.items():
               "TA %.2f TD %.2f" % (m.get("TA_TA_BUSY_sum", 0) / 256 / max(cyc, 1), m.get("TD_TD_BUSY_sum", 0) / 256 / max(cyc, 1)),
               "L1 acc %.3g -> L2 req %.3g (L2 hit %.3f)" % (m.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0), m.get("TCP_TCC_READ_REQ_sum", 0), m.get("TCC_HIT_sum", 0) / max(m.get("TCC_REQ_sum", 1), 1)))
 PY
+  ;;
+envprof)   # where F110Env(num_agents=2).step's time goes: per-kernel durations (rocprofv3), host enqueue / wait, Python around the call
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  tools/debug/f110env_loop.py 3000 (F110Env 1 env x 2 agents)"
+    for i in 1 2 3; do timeout 120 python tools/debug/f110env_loop.py 3000 2>&1 | tail -1; done
+    timeout 120 python tools/debug/idle_gap_probe.py 2>&1 | tail -12
+    cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_env -o stats -- python $R/tools/debug/f110env_loop.py 3000 > $OUT/prof_env.log 2>&1
+    timeout 60 python $R/tools/summarize_prof.py stats $OUT/prof_env $OUT/kernel_stats_f110env.txt 3000; rm -rf $OUT/prof_env; cd "$R"
+    cat $OUT/kernel_stats_f110env.txt | head -30; } | tee $OUT/envprof.txt
   ;;
 finwaves)   # k_finalize_pair_roles at 4 / 5 / 6 waves per SIMD (probe_fin*.so built in the container with -DF110_FIN_WAVES=N): per-kernel HIP events
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  probe_finN.so = -DF110_FIN_WAVES=N; bench.py --steps 300 --warmup 30 (roofline replay: HIP events per kernel), agents 65536 and 4096"
