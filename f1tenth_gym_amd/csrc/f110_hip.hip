@@ -49,14 +49,6 @@ struct ExpSwitches {
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
     int group_split = 0;       // two env groups: percent of the envs in the first (0 = even)
     int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
-    int pad_tiled = 0;         // 1 / 2: the step's scan marches a 4x4-tiled / a row-pair copy of the PADDED table (set before the map is loaded)
-    int scan_nt = 0;           // 1: the step's scan stores its ranges non-temporally
-    int finalize_wave = 0;     // A = 2: 8 / 4 = k_finalize_pair_roles as one-wave workgroups of 8 / 4 agents (0 = the 256-thread form)
-    int spec_from = 0;         // k_scan_rays_agent in the longest-first window: march_padded_spec from this sample on (0 = plain march)
-    int scan_stream = 0;       // 1: the lane-refill scan (k_scan_stream_agent) wherever it applies
-    int stream_refill = 0;     // free lanes that trigger a refill (0 = default)
-    int stream_block = 0;      // threads per persistent workgroup (0 = 512)
-    int stream_grid = 0;       // persistent workgroups (0 = 4 per CU)
     uint64_t scan_trace = 0;   // device address of a caller-owned [waves][8] uint64 buffer: clock stamps, hardware id, samples of every scan wave (0 = off)
 };
 
@@ -93,7 +85,7 @@ struct f110_sim {
     ScanConst k_uploaded{};
     unsigned long long *d_path_stats = nullptr;  // [3], see f110_scan_path_stats
     bool path_stats_on = false;
-    double *d_dt_row = nullptr, *d_dt_pad = nullptr, *d_dt_pad_t = nullptr, *d_actions = nullptr, *d_poses = nullptr;
+    double *d_dt_row = nullptr, *d_dt_pad = nullptr, *d_actions = nullptr, *d_poses = nullptr;
     double2 *d_cs = nullptr;
     uint8_t *d_mask = nullptr;
     // env groups: the step of G > 1 independent env blocks runs on G streams of its own (no event
@@ -424,17 +416,6 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "integrate_duo") h->exp.integrate_duo = value;
     else if (k == "integrate_fan") h->exp.integrate_fan = value;
     else if (k == "group_split") h->exp.group_split = value;
-    else if (k == "pad_tiled") h->exp.pad_tiled = value;
-    else if (k == "scan_nt") h->exp.scan_nt = value;
-    else if (k == "finalize_wave") h->exp.finalize_wave = value;
-    else if (k == "spec_from") h->exp.spec_from = value;
-    else if (k == "scan_stream") h->exp.scan_stream = value;
-    else if (k == "stream_block") h->exp.stream_block = value;
-    else if (k == "stream_grid") h->exp.stream_grid = value;
-    else if (k == "stream_refill") {
-        if (value < 0 || value > 64) return fail(h, F110_ERR_INVALID, "stream_refill must be 0..64");
-        h->exp.stream_refill = value;
-    }
     else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
     else if (k == "scan_trace_lo") h->exp.scan_trace = (h->exp.scan_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "collide_mode") {
@@ -450,6 +431,9 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
         h->task_thr = (uint32_t)value;
         if (h->task_order) return task_order_setup(h, true);
     }
+    else if (k == "pad_tiled" || k == "scan_nt" || k == "finalize_wave" || k == "spec_from" || k == "scan_stream" || k == "stream_refill" || k == "stream_block" ||
+             k == "stream_grid")
+        return fail(h, F110_ERR_INVALID, "f110_exp_set: '%s' was retired in round 6 with the variant it switched (DESIGN.md section 8)", key);
     else
         return fail(h, F110_ERR_INVALID, "f110_exp_set: unknown key '%s'", key);
     return F110_OK;
@@ -812,7 +796,7 @@ void f110_destroy(f110_sim *h)
     AgentArrays &d = h->dev;
     void *ptrs[] = {d.opp_verts, d.ray_hdr, d.opp_window, d.state, d.steer_buf, d.buf_cnt, d.scan_pose, d.snap_pose, d.dir_start, d.scans, d.collisions,
                     d.collision_idx, d.in_collision, d.step_count, h->d_params, h->d_noise, h->d_scan_angles,
-                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_pad, h->d_dt_pad_t, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k, h->d_params_all};
+                    h->d_beam_cos, h->d_side, h->d_dt_row, h->d_dt_pad, h->d_actions, h->d_poses, h->d_cs, h->d_mask, h->d_path_stats, h->d_k, h->d_params_all};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &ms : h->extra_maps) {
@@ -895,26 +879,6 @@ static int finish_map(f110_sim *h, int H, int W, double res, double ox, double o
                            h->d_dt_pad);
         HIPCHK(h, hipGetLastError());
         k.pad = h->d_dt_pad;
-        k.pad_t = nullptr;
-        if (h->d_dt_pad_t) { (void)hipFree(h->d_dt_pad_t); h->d_dt_pad_t = nullptr; }
-        if (kExperimental && h->exp.pad_tiled) {   // lab: the same table again for the step's march — 1: in 4x4-cell tiles, 2: in row pairs (2 rows x 8 cells per line)
-            const int mode = h->exp.pad_tiled == 2 ? 2 : 1;
-            size_t doubles;
-            if (mode == 2) {
-                k.pad_t_row_bytes = (int32_t)((size_t)k.pad_width * 16);
-                doubles = (((size_t)k.pad_height + 1) / 2) * (size_t)k.pad_width * 2;
-                if ((size_t)k.pad_width * 16 >= (1u << 24) || doubles * 8 >= (1ull << 32)) return fail(h, F110_ERR_INVALID, "pad_tiled=2: the map is too large for 24-bit row-pair pitches");
-            } else {
-                const size_t tiles_w = ((size_t)k.pad_width + 3) / 4, tiles_h = ((size_t)k.pad_height + 3) / 4;
-                k.pad_t_row_bytes = (int32_t)(tiles_w * 128);
-                doubles = tiles_w * tiles_h * 16;
-            }
-            TRY(dmalloc(h, &h->d_dt_pad_t, doubles));
-            hipLaunchKernelGGL(k_build_padded_tiled, grid1d(total, 256), dim3(256), 0, h->stream, h->d_dt_pad, k.pad_width, k.pad_height, (uint32_t)k.pad_t_row_bytes,
-                               mode, h->d_dt_pad_t);
-            HIPCHK(h, hipGetLastError());
-            k.pad_t = h->d_dt_pad_t;
-        }
         if (h->cfg.map_layout == F110_MAP_PADDED_F64) {
             // ONE table per map: the exact paths (k_integrate's first sample, the cold re-march, the unit
             // kernels) address dt[r][c] as table_rm + r * row_bytes + 8 c — point them at the interior of
@@ -2096,24 +2060,14 @@ static int noise_cache_extend(f110_sim *h, int upto)
 // The experimental build adds collide_mode 1 (pair tests fused into k_integrate) / 2 (k_collide in line), the
 // other layouts' kernels, two-pass dedupe and the forced geometries of f110_exp_set.
 // ev[0..3] (or nullptr): profiling events before integrate / before scan / after scan / after finalize.
-enum ScanKind { SCAN_FLAT, SCAN_AGENT, SCAN_AGENT_SCHED, SCAN_DIRS, SCAN_STREAM };
+enum ScanKind { SCAN_FLAT, SCAN_AGENT, SCAN_AGENT_SCHED, SCAN_DIRS };
 
-// the lane-refill scan (k_scan_stream_agent, experimental build: measured slower): needs the PADDED table and
-// a direction table that fits its LDS copy
-constexpr int kStreamRefillDefault = 48;
-static bool stream_scan_applies(const f110_sim *h, int count)
-{
-    (void)count;
-    if (!kExperimental || h->exp.scan_stream <= 0) return false;
-    return padded_family(h->cfg.map_layout) && h->k.pad && h->dir_stride == 0 && h->k.theta_dis <= 2048 && h->k.num_beams >= 128;
-}
 
 static ScanKind pick_scan(const f110_sim *h, int begin, int count)
 {
     const bool padded = padded_family(h->cfg.map_layout) && h->k.pad;
     if (h->dir_stride > 0) return padded ? SCAN_DIRS : SCAN_FLAT;   // (no PADDED table: every beam is marched)
     if (!(h->multi_map || agent_aligned(h))) return SCAN_FLAT;
-    if (stream_scan_applies(h, count)) return SCAN_STREAM;
     if (h->task_order && !h->multi_map && !h->lookups_on && begin == 0 && count == h->N && !h->exp.scan_env_counter) return SCAN_AGENT_SCHED;
     return SCAN_AGENT;
 }
@@ -2129,13 +2083,6 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
     // (the longest-first list counter) follow the same answer
     const ScanKind scan = pick_scan(h, begin, count);
     dev.sched_count_zero = scan == SCAN_AGENT_SCHED ? h->d_tcount + (h->task_epoch & 1u) : nullptr;
-    int stream_threads = 512, stream_blocks = 0;
-    if (scan == SCAN_STREAM) {   // (experimental build only)
-        stream_blocks = h->num_cus * 4;
-        if (h->exp.stream_block > 0) stream_threads = h->exp.stream_block;
-        if (h->exp.stream_grid > 0) stream_blocks = h->exp.stream_grid;
-        stream_blocks = std::max(1, std::min(stream_blocks, (count + stream_threads / 64 - 1) / (stream_threads / 64)));
-    }
     if (dev.noise_rng && (dev.noise_rng == 2 || h->noise_ub >= (long long)dev.noise_rows)) {
         const int apb = dev.noise_rng == 2 ? 16 : 64;   // per-agent streams: every agent needs a row, keep the waves many
         hipLaunchKernelGGL(k_noise_rows, dim3((count + apb - 1) / apb), dim3(256), 0, st, dev, h->noise_gen, B, apb);
@@ -2209,7 +2156,6 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
         j.path_stats = h->path_stats_on ? h->d_path_stats : nullptr;   // (step form: only the ray pass counts here)
 #ifdef F110_EXPERIMENTAL
         j.trace = reinterpret_cast<unsigned long long *>(h->exp.scan_trace);
-        j.pad_win = h->exp.scan_nt ? 1u : 0u;   // lab: non-temporal range stores (finish_beam_with)
 #endif
         j.k_cold = cold_consts(h);
         if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
@@ -2265,56 +2211,12 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
             // which start first, march at the idle chip's latency — does the shorter chain beat the lost throughput?
             if (h->exp.scan_occupancy > 0 && h->scan_block == 64) slds = (size_t)(160 * 1024 / (4 * h->exp.scan_occupancy)) & ~(size_t)255;
 #endif
-#ifdef F110_EXPERIMENTAL
-            // round 5, measured and not adopted: the tail of a long ray marched two samples per round trip where
-            // the table value repeats (march_padded_spec, bit-identical) — 4096 agents 0.0976 -> 0.103-0.111 ms per step for
-            // spec_from 64 ... 4: the chain gets shorter, the kernel that carries both loops gets slower for every ray
-            if (h->exp.spec_from > 0) {
-                j.spec_from = (uint32_t)h->exp.spec_from;
-                if (h->k.ident_rot)
-                    hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
-                else
-                    hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, true, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
-                break;
-            }
-#endif
-#ifdef F110_EXPERIMENTAL
-            if (h->exp.pad_tiled && h->k.pad_t && h->k.ident_rot) {
-                if (h->exp.pad_tiled == 2) hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true, false, false, 2>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
-                else hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true, false, false, 1>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
-                break;
-            }
-#endif
             if (h->k.ident_rot)
                 hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
             else
                 hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, true>), sgrid, block, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
             break;
         }
-#ifdef F110_EXPERIMENTAL
-        case SCAN_STREAM: {
-            j.first_pose = (uint32_t)begin;
-            StreamCtl ctl{};
-            ctl.refill = (uint32_t)(h->exp.stream_refill > 0 ? h->exp.stream_refill : kStreamRefillDefault);
-            ctl.split = 1u;
-            ctl.count = (uint32_t)count;
-            const dim3 sblock((unsigned)stream_threads);
-            const dim3 sgrid((unsigned)stream_blocks);
-            const size_t slds = (size_t)h->k.theta_dis * sizeof(double2);
-#define STREAM_SCAN(PM, ID)                                                                                                                  \
-    do {                                                                                                                                     \
-        if (cnt) hipLaunchKernelGGL((k_scan_stream_agent<PM, ID, true>), sgrid, sblock, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, ctl); \
-        else hipLaunchKernelGGL((k_scan_stream_agent<PM, ID, false>), sgrid, sblock, slds, st, j, h->k, h->d_maps_fast, h->d_maps_full, ctl);    \
-    } while (0)
-            if (stream_threads == 64 && !h->multi_map && h->k.ident_rot && !cnt)
-                hipLaunchKernelGGL((k_scan_stream_agent<false, true, false, true>), dim3((unsigned)ctl.count), dim3(64), 0, st, j, h->k, h->d_maps_fast, h->d_maps_full, ctl);
-            else if (h->multi_map) STREAM_SCAN(true, false);
-            else if (h->k.ident_rot) STREAM_SCAN(false, true);
-            else STREAM_SCAN(false, false);
-#undef STREAM_SCAN
-            break;
-        }
-#endif
         case SCAN_AGENT: {
             const uint32_t tpa = ((uint32_t)B + 63u) / 64u;
             agent_grid(tpa, grid, wpb, h->scan_tasks_per_wave);
@@ -2335,13 +2237,6 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
                     hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, false, true>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
                 else
                     hipLaunchKernelGGL((k_scan_rays_agent<false, false, false, false, true>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
-                break;
-            }
-#endif
-#ifdef F110_EXPERIMENTAL
-            if (h->exp.pad_tiled && h->k.pad_t && h->k.ident_rot && !h->multi_map && !cnt) {
-                if (h->exp.pad_tiled == 2) hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, false, false, false, 2>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
-                else hipLaunchKernelGGL((k_scan_rays_agent<false, true, false, false, false, false, 1>), grid, block, lds, st, j, h->k, h->d_maps_fast, h->d_maps_full, tpa);
                 break;
             }
 #endif
@@ -2389,16 +2284,10 @@ static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const d
                 dev.fused_seq = h->fuse_seq;
                 h->fused_done = true;
             }
-#ifdef F110_EXPERIMENTAL
-            if (h->exp.finalize_wave > 0 && !dev.fused_host) {   // lab: one-wave workgroups (8 or 4 agents each)
-                if (h->exp.finalize_wave == 4) hipLaunchKernelGGL((k_finalize_pair_roles<4, 64>), dim3((count + 3) / 4), dim3(64), 0, st, dev, B);
-                else hipLaunchKernelGGL((k_finalize_pair_roles<8, 64>), dim3((count + 7) / 8), dim3(64), 0, st, dev, B);
-            } else
-#endif
             if (dev.fused_host) {   // the instantiation that carries the f110_step_host epilogue
-                if (lanes <= 8) hipLaunchKernelGGL((k_finalize_pair_roles<32, 256, true>), dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
-                else if (lanes == 16) hipLaunchKernelGGL((k_finalize_pair_roles<16, 256, true>), dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
-                else hipLaunchKernelGGL((k_finalize_pair_roles<4, 256, true>), dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
+                if (lanes <= 8) hipLaunchKernelGGL((k_finalize_pair_roles<32, true>), dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
+                else if (lanes == 16) hipLaunchKernelGGL((k_finalize_pair_roles<16, true>), dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
+                else hipLaunchKernelGGL((k_finalize_pair_roles<4, true>), dim3((count + 3) / 4), dim3(256), 0, st, dev, B);
             } else if (lanes <= 8) hipLaunchKernelGGL(k_finalize_pair_roles<32>, dim3((count + 31) / 32), dim3(256), 0, st, dev, B);
             else if (lanes == 16) hipLaunchKernelGGL(k_finalize_pair_roles<16>, dim3((count + 15) / 16), dim3(256), 0, st, dev, B);
             else hipLaunchKernelGGL(k_finalize_pair_roles<4>, dim3((count + 3) / 4), dim3(256), 0, st, dev, B);

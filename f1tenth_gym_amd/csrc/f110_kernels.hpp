@@ -557,7 +557,7 @@ struct RayJob {
     uint32_t div_magic, div_shift;  // ray / B == umulhi(ray, magic) >> shift (0: plain division)
     int32_t pad_dir, dir_stride;    // k_scan_dirs_agent: distinct directions per agent, rounded up to whole 64-direction tasks
     const void *reserved_dir_ranges;
-    uint32_t first_pose, spec_from; // k_scan_rays_agent: the launch covers agents first_pose .. (env group); SPEC: march_padded_spec from this sample on
+    uint32_t first_pose, reserved_spec; // k_scan_rays_agent: the launch covers agents first_pose .. (env group)
     unsigned long long *lookups_total;  // COUNT variants: table lookups of every marched ray, summed (or nullptr)
     // longest-first task order (k_scan_rays_agent<.., SCHED>): see TaskSched
     TaskSched sched;   // by value: the kernel argument segment is the one read a wave never waits long for
@@ -777,7 +777,7 @@ __device__ __forceinline__ void load_map_fast(ScanConst &km, const MapFast *__re
 #ifndef F110_SCAN_WAVES_EXPR
 #define F110_SCAN_WAVES_EXPR 8
 #endif
-template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false, bool SPEC = false, int TILED = 0>
+template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool SCHED = false, bool ENVCNT = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_SCAN_WAVES_EXPR))) k_scan_rays_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
                                                           const ScanConst *__restrict__ maps_full, uint32_t tasks_per_agent)
 {
@@ -868,9 +868,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
             double ux, uy, cux, cuy;
             padded_position<IDENT>(km, x, y, ux, uy);
             padded_rate<IDENT>(km, cs.x, cs.y, cux, cuy);
-            // SPEC (small batches, round 5): the tail of a long ray two samples per round trip where the table value repeats
-            exact = SPEC ? !march_padded_spec<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl, (int)j.spec_from)
-                         : !march_padded<false, TILED>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl);
+            exact = !march_padded<false>(km, ux, uy, cux, cuy, d0, r, hr, hc, nl);
         }
         if (exact) r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, nl);
         if (COUNT) nl_acc += (uint32_t)nl;   // measurement variant only (bench.py's L-bar)
@@ -925,165 +923,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F110_S
 #endif
 }
 
-#ifdef F110_EXPERIMENTAL   // round 5: built, bit-identical, measured SLOWER than k_scan_rays_agent — lab only (profiles/r05_stream_scan.txt)
-// ---- K2s: the step's ray march with lane refill ("survivor compaction") -----------------
-// k_scan_rays_agent marches 64 consecutive beams in lock step until the LONGEST of them ends: 38 % of the lanes of its
-// gathers are idle at the headline workload.  Here a wave owns an agent's whole scan as a QUEUE of beams: whenever at
-// least `refill` of its lanes have finished their ray, the finished ranges are stored and the free lanes take the next
-// beams of the queue.  A lane's ray is marched with exactly march_padded's arithmetic, whatever lane and whatever
-// company it runs in, so the results are bit-identical by construction (tools/debug/stream_ab.py: 40 cases).
-// tools/debug/compaction_sim.py prices the schemes on the CPU: packing the survivors at fixed sample counts removes
-// < 10 % of the wave-level gathers (the tail of a task is its few longest rays, which packing cannot shorten); lane
-// refill removes 22-32 %.  On the GPU it still loses (65 536 agents: 0.676 ms per step with k_scan_rays_agent; refill
-// 64 = no refill, i.e. the same lock-step scheme run as ONE wave per agent: 0.775; refill 48 / 32 / 16: 0.728 / 0.755 /
-// 0.802 with one-wave workgroups, 0.746 / 0.778 / 0.816 with persistent 8-wave workgroups): a gather's cost is not flat
-// in its active lanes (tools/debug/ta_bench.hip "partially active waves": 17 + ~0.25 cycles per lane), every refill event
-// adds a store + a noise load to the dependent chain, and waves that live for a whole agent schedule worse than waves of
-// three tasks (as "17 tasks per wave" did in round 3).
-//   * persistent workgroups of 8 waves with a (cos, sin) table copy in LDS (new beams' directions are LDS reads), agents
-//     handed out through a counter in LDS; or (ONE) one agent per one-wave workgroup, launched like k_scan_rays_agent.
-struct StreamCtl {
-    uint32_t refill;        // lanes that must be free before the queue is consulted (1..64)
-    uint32_t count;         // queues of this launch: agents (first_pose .. ) x split
-    uint32_t split, pad_;   // queues per agent (1: a wave owns an agent's whole scan)
-};
-
-// share r of nb: agents [lo, lo + size) of the launch
-__device__ __forceinline__ void stream_share(uint32_t r, uint32_t nb, uint32_t count, uint32_t &lo, uint32_t &size)
-{
-    lo = (uint32_t)(((uint64_t)r * count) / nb);
-    size = (uint32_t)(((uint64_t)(r + 1u) * count) / nb) - lo;
-}
-
-template <bool PER_ENV_MAP, bool IDENT, bool COUNT, bool ONE = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8))) k_scan_stream_agent(RayJob j, ScanConst k, const MapFast *__restrict__ maps_fast,
-                                                                                                   const ScanConst *__restrict__ maps_full, StreamCtl ctl)
-{
-    extern __shared__ double2 lds_cs_[];   // [theta_dis]
-    __shared__ uint32_t lds_next;          // the next agent of this workgroup's share
-    // ONE (lab): one agent per one-wave workgroup, launched like k_scan_rays_agent; directions gathered from the HBM table
-    const double2 *lds_cs = ONE ? k.cs : lds_cs_;
-    if (!ONE) {
-        for (int t = threadIdx.x; t < k.theta_dis; t += blockDim.x) lds_cs_[t] = k.cs[t];
-        if (threadIdx.x == 0) lds_next = 0u;
-        __syncthreads();
-    }
-    const int B = k.num_beams;
-    const uint32_t lane = threadIdx.x & 63u;
-    typedef const __attribute__((address_space(4))) uint32_t *cu32_t;
-    // Work distribution.  The launch's agents are cut into gridDim.x equal shares, one per workgroup, XCD-contiguous (the
-    // workgroups of an XCD own neighbouring shares, as in k_scan_rays_agent); a share's agents are handed to whichever of
-    // the workgroup's waves asks next through a counter in LDS.  (Counters in HBM — one per XCD, then one per workgroup
-    // with helpers polling the others — measured 1.6-2.5 ms per launch whatever the batch: 10^5 device-scope atomics and
-    // polls on a few cache lines serialise in one memory channel.)
-    const uint32_t nb = gridDim.x, count = ctl.count;
-    uint32_t own;
-    {
-        const uint32_t q = nb >> 3, rem = nb & 7u, x = blockIdx.x & 7u, i = blockIdx.x >> 3;
-        own = (x < rem ? x * (q + 1u) : rem * (q + 1u) + (x - rem) * q) + i;
-    }
-    uint32_t nl_acc = 0;
-    ScanConst km = k;
-    const ScanConst *cold = j.k_cold;
-    int cur_slot = -1;
-    const int thresh_live = 64 - (int)ctl.refill;
-    uint32_t lo, size;
-    stream_share(own, nb, count, lo, size);
-    for (;;) {
-        uint32_t ai = 0;
-        if (ONE) {
-            if (size == 0xffffffffu) break;   // (second pass)
-            lo = own; ai = 0u; size = 0xffffffffu;
-        } else {
-            if (lane == 0u) ai = atomicAdd(&lds_next, 1u);
-            ai = __builtin_amdgcn_readfirstlane(ai);
-            if (ai >= size) break;
-        }
-        {
-            const uint32_t item = lo + ai;                       // (agent, part): an agent's scan may be cut into `split` queues
-            const uint32_t pl = item / ctl.split, part = item - pl * ctl.split;
-            const uint32_t p = (PER_ENV_MAP && j.order) ? ((cu32_t)j.order)[pl] : j.first_pose + pl;
-            typedef const __attribute__((address_space(4))) RayHdr *chdr_t;
-            const chdr_t h0 = (chdr_t)(j.hdr) + p;
-            const double x = uniform_f64(h0->x), y = uniform_f64(h0->y), start = uniform_f64(h0->start);
-            const double vel = uniform_f64(h0->vel), d0 = uniform_f64(h0->d0);
-            const int row = uniform_i32(h0->noise_row), slot = uniform_i32(h0->map_slot), fast = uniform_i32(h0->fast);
-            if (PER_ENV_MAP && slot != cur_slot) {
-                cold = maps_full + slot;
-                load_map_fast(km, maps_fast, slot);
-                cur_slot = slot;
-            }
-            const double *nrow = row >= 0 ? j.noise + (size_t)row * (size_t)B : j.ranges + (size_t)p * (size_t)B;
-            const char *base = reinterpret_cast<const char *>(km.pad);
-            const int part_len = (B + (int)ctl.split - 1) / (int)ctl.split;
-            int next = (int)part * part_len;                                 // (uniform) the next beam of the queue
-            const int q_end = next + part_len < B ? next + part_len : B;     // (uniform) one past its last beam
-            int b = -1;            // this lane's beam, -1: free
-            double ux = 0., uy = 0., cux = 0., cuy = 0., d = 0., total = 0., nz = 0.;
-            int n = 0;
-            bool redo = false, alive = false;
-            for (;;) {
-                // ---- event: finished rays out, new beams in
-                if (b >= 0 && !alive) {
-                    double r = (total > km.max_range) ? km.max_range : total;
-                    if (redo | (n > km.pad_max_samples)) {   // (about one ray in 10^7, or an agent whose lidar is outside the padded zone)
-                        const double2 cs = lds_cs[beam_dir_index(k, start, b)];
-                        int hr, hc;
-                        r = march_exact_cold<IDENT>(cold, x, y, cs.x, cs.y, d0, hr, hc, n);
-                    }
-                    if (COUNT) nl_acc += (uint32_t)n;
-                    finish_beam_with(j, p, b, p * (uint32_t)B + (uint32_t)b, row != -1 ? r + nz : r, vel);
-                    b = -1;
-                }
-                if (next < q_end) {
-                    const uint64_t fm = __ballot(b < 0);
-                    if (b < 0) {
-                        const int mine = next + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-                        if (mine < q_end) {
-                            b = mine;
-                            const double2 cs = lds_cs[beam_dir_index(k, start, b)];
-                            padded_rate<IDENT>(km, cs.x, cs.y, cux, cuy);
-                            padded_position<IDENT>(km, x, y, ux, uy);
-                            d = d0;
-                            total = d0;
-                            n = 1;
-                            redo = fast == 0;
-                            nz = row != -1 ? nrow[b] : 0.0;
-                            alive = (d > km.eps) & (total <= km.max_range) & !redo;
-                        }
-                    }
-                    next += (int)popc_u64(fm);
-                }
-                if (__ballot(b >= 0) == 0ull) break;   // (the queue is empty and every ray has been written)
-                // ---- march until few enough rays are alive (queue empty: until none is).  (Issuing the gather first and running
-                // the event under it measured slower: 0.746 -> 0.929 ms per step at 65 536 agents.)
-                const int thresh = next < q_end ? thresh_live : 0;
-                uint64_t am = __ballot(alive);
-                while ((int)popc_u64(am) > thresh) {
-                    if (alive) {   // march_padded's loop body, verbatim
-                        ux = fma(d, cux, ux);
-                        uy = fma(d, cuy, uy);
-                        const uint32_t wx = low_word(ux + kFixBig);
-                        const uint32_t wy = low_word(uy + kFixBig);
-                        uint32_t off = mul24(wy >> kFixFracBits, (uint32_t)km.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
-                        if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {
-                            redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
-                            const int fc = (int)floor(ux), fr = (int)floor(uy);
-                            off = mul24((uint32_t)fr, (uint32_t)km.pad_row_bytes) + ((uint32_t)fc << 3);
-                        }
-                        d = *reinterpret_cast<const double *>(base + off);
-                        total += d;
-                        ++n;
-                        alive = (d > km.eps) & (total <= km.max_range) & !redo;
-                    }
-                    am = __ballot(alive);
-                }
-            }
-        }
-    }
-    if (COUNT) wave_add_lookups(j.lookups_total, nl_acc);
-}
-#endif  // F110_EXPERIMENTAL (K2s)
+// (Round 5 built k_scan_stream_agent here — "survivor compaction": a wave owns an agent's whole scan as a queue and re-fills finished
+// lanes; 0.65-0.79 of the wave-level gathers, bit-identical — and measured it 7-20 % slower at every setting: the re-filled wave's rays
+// share fewer lines, and the scan is bound by line traffic, not by instruction count.  Retired in round 6 under the pre-registered
+// stop rule: DESIGN.md §8, profiles/r05_stream_scan.txt, r05_pmc_stream_vs_base.json.)
 
 // iTTC + store for one beam whose noise sample has been added already
 __device__ __forceinline__ void finish_beam_with(const RayJob &j, uint32_t p, int b, uint32_t ray, double r, double vel)
@@ -1091,14 +934,8 @@ __device__ __forceinline__ void finish_beam_with(const RayJob &j, uint32_t p, in
     if (vel != 0.0 && !(r > j.ttc_side_max + j.ttc_k * fabs(vel)) &&
         ttc_beam_hit(r, j.side_dist[b], vel, j.beam_cos[b], j.ttc_thresh))
         j.wall_flag[p] = 1;
-#ifdef F110_EXPERIMENTAL
-    // lab (round 6): the range stream past the caches, so that a SMALL batch's 35 MB of range writes per step stop
-    // evicting the table lines its dependent chains re-read from L2 every launch (RayJob::pad_win is a spare word: 1 = on)
-    if (j.pad_win) {
-        __builtin_nontemporal_store(r, &j.ranges[ray]);
-        return;
-    }
-#endif
+    // (round 6 measured non-temporal range stores here for small batches — does the table stay in L2 when 35 MB of range writes per
+    // step bypass it? — no change at any size, +-0.2 %: profiles/r06_nt_store.txt)
     j.ranges[ray] = r;
 }
 
@@ -1538,26 +1375,21 @@ __device__ __forceinline__ void pair_host_epilogue(const AgentArrays &a, bool ag
 // flattened into one item list (a crashed pair sees windows of up to all beams; fixed lanes per agent serialise there).
 // Same functions on the same operands as k_collide + k_finalize: bit-identical.  (The earlier forms — fixed lanes per
 // agent, the prologue dealt by agent — were measured slower in round 3 and retired in round 5: DESIGN_HISTORY.md.)
-// NT = 256: the product form.  NT = 64 (lab, round 5): the same kernel as ONE wave per workgroup at 8 waves per SIMD — a workgroup
-// that fits any slot a finished scan wave leaves, so that a second env block's finalize can run UNDER the first block's scan
-// (VERDICT r4 item 3); roles then share the wave: corners on lanes 0 .. 4 AG - 1, culls behind them, pair tests behind those.
-// HOST (round 6): the f110_step_host epilogue is a TEMPLATE parameter, not a run-time branch — the instantiation f110_step_device
-// launches does not carry the epilogue's registers (it spilled 80 bytes per lane under the 80-VGPR cap for code it never ran);
-// the HOST instantiation (small, host-synchronised batches) takes the registers it needs at 4 waves per SIMD.
-#ifndef F110_FIN_WAVES
-#define F110_FIN_WAVES 5   // 5 waves per SIMD = up to 96 VGPRs: the body needs 82 and keeps nothing in scratch (at 6 = 80 VGPRs it kept 80 bytes per lane there)
-#endif
-template <int AG, int NT = 256, bool HOST = false>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 64 ? 8 : (HOST ? 4 : F110_FIN_WAVES)))) k_finalize_pair_roles(AgentArrays a, int32_t B)
+// (Round 5 also ran this kernel as one-wave workgroups at 8 waves per SIMD, NT = 64, so that a second env block's finalize fits under
+// the first block's scan: it hides, and costs what it hides — retired in round 6, DESIGN.md §8, profiles/r05_finalize_wave.txt.)
+// The body is a device function of a 256-thread workgroup over the AG agents [first, first + AG) (round 6): k_finalize_pair_roles
+// runs it once per workgroup; k_step_tiny — the whole step of a tiny batch as ONE launch — runs it in its last workgroup.
+template <int AG, bool HOST>
+__device__ __forceinline__ void finalize_pair_body(const AgentArrays &a, int32_t B, const int first, const int end)
 {
-    static_assert((AG & (AG - 1)) == 0 && AG >= 2 && 4 * AG <= NT / 2, "AG is a power of two, 2..32 (NT = 64: 2..8)");
-    constexpr int R1 = NT == 64 ? 4 * AG : 128, R2 = NT == 64 ? 5 * AG : 192;   // first thread of the cull / the pair-test role
+    constexpr int NT = 256;
+    static_assert((AG & (AG - 1)) == 0 && AG >= 2 && 4 * AG <= NT / 2, "AG is a power of two, 2..32");
+    constexpr int R1 = 128, R2 = 192;   // first thread of the cull / the pair-test role
     static_assert(R2 + AG / 2 <= NT, "the three roles fit the workgroup");
     __shared__ double s_rec[AG][12];   // ex, ey, eth, the opponent's box (8), pad
     __shared__ int s_idx[AG][4], s_cl[AG], s_ch[AG], s_hit[AG / 2];
     __shared__ int s_lo[AG], s_cnt[AG], s_off[AG + 1];
     const int t = (int)threadIdx.x;
-    const int first = a.agent_begin + (int)blockIdx.x * AG, end = a.agent_begin + a.agent_count;
     const int N = a.n_agents_total;
     int role = -1, slot = 0, sub = 0;
     if (t < 4 * AG) {                        // waves 0-1: box corner `sub` of agent `slot`'s opponent -> beam index
@@ -1688,16 +1520,26 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 6
             host_block_copy_scans(a.fused_host->hb, a.scans, (size_t)first, (size_t)(live_agents > 0 ? live_agents : 0));
         }
         if (t < 64) pair_host_epilogue(a, agent_thread, first + t);
-        if (a.fused_seq) {
-            HostBlock sig = a.fused_host->hb;
-            sig.seq = a.fused_seq;
-            host_block_signal(sig);
-        }
-        return;
-    }
-    if (a.reseat_poses && agent_thread) {
+    } else if (a.reseat_poses && agent_thread) {
         const int i = first + t, ego = (i & ~1) + a.reseat_ego;
         if (my_hit || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
+    }
+}
+
+// HOST (round 6): the f110_step_host epilogue is a TEMPLATE parameter, not a run-time branch — the instantiation f110_step_device
+// launches does not carry the epilogue's registers; the HOST instantiation (small, host-synchronised batches) runs at 4 waves per SIMD.
+#ifndef F110_FIN_WAVES
+#define F110_FIN_WAVES 5   // 5 waves per SIMD = up to 96 VGPRs: the body needs 82 and keeps nothing in scratch (at 6 = 80 VGPRs it kept 80 bytes per lane
+                           // there for the epilogue it never ran; 35.9 us per launch at 65 536 agents at 4, 5 and 6 waves alike: profiles/r06_finalize_waves.txt)
+#endif
+template <int AG, bool HOST = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HOST ? 4 : F110_FIN_WAVES))) k_finalize_pair_roles(AgentArrays a, int32_t B)
+{
+    finalize_pair_body<AG, HOST>(a, B, a.agent_begin + (int)blockIdx.x * AG, a.agent_begin + a.agent_count);
+    if (HOST && a.fused_seq) {   // F110_STEP_SPIN_WAIT: the completion word, by the last workgroup to get here
+        HostBlock sig = a.fused_host->hb;
+        sig.seq = a.fused_seq;
+        host_block_signal(sig);
     }
 }
 
@@ -2855,16 +2697,6 @@ __global__ void k_dt_from_d2(const uint32_t *__restrict__ d2, size_t n, double r
 
 // PADDED layout: the table inside a border of `b` cells that read dt[-1,-1], what the reference
 // returns for any out-of-bounds sample (laser_models.py:80-81,103)
-// the padded table again in 4x4-cell tiles (lab, march_padded<.., TILED>): one thread per padded cell
-__global__ void k_build_padded_tiled(const double *__restrict__ pad, int Wp, int Hp, uint32_t tile_row_bytes, int mode, double *__restrict__ out)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)Wp * Hp) return;
-    const uint32_t r = (uint32_t)(i / Wp), c = (uint32_t)(i - (size_t)r * Wp);
-    const uint32_t off = mode == 2 ? pair_offset(r, c, tile_row_bytes) : tiled_offset(r, c, tile_row_bytes);   // 1: 4x4 tiles, 2: row pairs
-    *reinterpret_cast<double *>(reinterpret_cast<char *>(out) + off) = pad[i];
-}
-
 __global__ void k_build_padded(const double *__restrict__ rowmajor, int H, int W, int b, int Wp, int Hp, double *__restrict__ pad)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -410,12 +410,12 @@ enum { LAYOUT_ROWMAJOR = 0, LAYOUT_PADDED = 3 };   // (1 = 4x4 tiles and 2 = byt
 struct ScanConst {
     const double *table;   // the distance table dt[r][c] (PADDED: the interior of the padded copy, its row pitch)
     const double *table_rm;  // the same (a separate row-major original only while a map too large for PADDED is loaded)
-    const double *pad_t;          // round 5 (lab): the PADDED table again in 4x4-cell tiles, one 128-byte line per tile (march_padded<.., TILED>); else nullptr
+    const double *reserved_pad_t; // (rounds 5-6: a tiled / row-pair copy of the PADDED table; retired — the field keeps the kernel-argument layout)
     const void *reserved_lut;
     const double2 *cs;     // (cos, sin) of linspace(0, 2pi, theta_dis), interleaved
     int32_t height, width, pad_tiles, theta_dis;
     int32_t num_beams, res_pow2, ident_rot, row_bytes;  // row_bytes = width * 8
-    int32_t pad_t_row_bytes, pad1;   // bytes per row of tiles of pad_t (tiles per row * 128)
+    int32_t reserved_pad_t_row_bytes, pad1;
     double res, inv_res, orig_x, orig_y, orig_c, orig_s;
     double w_res, h_res;   // width*resolution, height*resolution (xy_2_rc :79)
     double oob_value;      // dt[-1,-1]: what an out-of-bounds sample reads (:80-81,:103)
@@ -643,66 +643,24 @@ F110_HD bool padded_start_ok(const ScanConst &k, double ux, double uy)
 // 10^7); the outputs are then meaningless.
 // r/c: cell of the last sample in the reference's convention (-1,-1 out of bounds); untouched when
 // the loop takes no sample.
-// byte offset of padded cell (r, c) in the 4x4-tiled copy: tile (r / 4, c / 4) is one 128-byte line, row-major inside
-F110_HD uint32_t tiled_offset(uint32_t r, uint32_t c, uint32_t tile_row_bytes)
-{
-    return mul24(r >> 2, tile_row_bytes) + ((c >> 2) << 7) + ((r & 3u) << 5) + ((c & 3u) << 3);
-}
-
-// TILED (round 5, lab): the same march reading the 4x4-tiled copy of the padded table.  The scan is bound by the lines its
-// gathers pull through the L1s; a ray that moves across rows changes line at every sample of the row-major table and every
-// 2-3 samples of the tiled one (tools/debug: 11.2 -> 8.5 distinct lines per 64-ray gather), for +6 integer operations.
-// byte offset of padded cell (r, c) in the ROW-PAIR copy (round 6, lab): rows 2p and 2p + 1 interleaved cell by cell, so a
-// 128-byte line holds 8 columns x 2 rows — a ray that moves across rows stays on its line for two rows instead of none
-// (tools/debug/layout_sim.py: 11.4 -> 9.1 distinct lines per 64-ray gather), for two more integer operations per sample
-// (4x4 tiles: 8.6 lines for six).  pair_row_bytes = padded width * 16.
-F110_HD uint32_t pair_offset(uint32_t r, uint32_t c, uint32_t pair_row_bytes)
-{
-    return (mul24(r >> 1, pair_row_bytes) + (c << 4)) | ((r & 1u) << 3);
-}
-
-// the same offset straight from the two fixed-point words (cell = word >> 16): five VALU operations — the row-major form takes
-// three — pinned in assembly because the compiler's own selection of the C expression above takes seven (no SDWA word select for
-// the << 4, no v_and_or_b32)
-F110_HD uint32_t pair_offset_words(uint32_t wx, uint32_t wy, uint32_t pair_row_bytes)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t off, t;
-    asm("v_lshrrev_b32 %0, 17, %2\n\t"
-        "v_lshlrev_b32_sdwa %1, %4, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
-        "v_mad_u32_u24 %0, %0, %5, %1\n\t"
-        "v_lshrrev_b32 %1, 13, %2\n\t"
-        "v_and_or_b32 %0, %1, 8, %0"
-        : "=&v"(off), "=&v"(t)
-        : "v"(wy), "v"(wx), "v"(4u), "s"(pair_row_bytes));
-    return off;
-#else
-    return pair_offset(wy >> kFixFracBits, wx >> kFixFracBits, pair_row_bytes);
-#endif
-}
-
-// TILED: 0 = the row-major padded table (product); 1 = its 4x4-tiled copy; 2 = its row-pair copy (both lab)
-template <int TILED>
-F110_HD uint32_t padded_cell_offset(const ScanConst &k, uint32_t r, uint32_t c)
-{
-    return TILED == 1 ? tiled_offset(r, c, (uint32_t)k.pad_t_row_bytes)
-                      : (TILED == 2 ? pair_offset(r, c, (uint32_t)k.pad_t_row_bytes) : mul24(r, (uint32_t)k.pad_row_bytes) + (c << 3));
-}
-
-template <bool WANT_CELL, int TILED = 0>
+// (Rounds 5-6 also marched a 4x4-tiled copy and a row-pair copy — 2 rows x 8 cells per 128-byte line — of this table behind this
+// function: bit-identical, fewer distinct lines per 64-ray gather (11.4 -> 8.6 / 9.1), paid for in integer operations per sample
+// (+6 / +2); tiles lost 2-3 % at every size, row pairs were neutral from 8192 agents up and -2.5 % below 2048 agents.  Retired in
+// round 6 under the pre-registered stop rule: DESIGN.md §8, profiles/r05_tiled_table.txt, profiles/r06_rowpair*.txt.)
+template <bool WANT_CELL>
 F110_HD bool march_padded(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
                           int &hit_r, int &hit_c, int &lookups)
 {
     double total = d;
     int n = 1;
     bool redo = false;
-    const char *base = reinterpret_cast<const char *>(TILED ? k.pad_t : k.pad);
+    const char *base = reinterpret_cast<const char *>(k.pad);
     while ((d > k.eps) & (total <= k.max_range) & !redo) {
         ux = fma(d, cux, ux);
         uy = fma(d, cuy, uy);
         const uint32_t wx = low_word(ux + kFixBig);
         const uint32_t wy = low_word(uy + kFixBig);
-        uint32_t off = TILED == 2 ? pair_offset_words(wx, wy, (uint32_t)k.pad_t_row_bytes) : padded_cell_offset<TILED>(k, wy >> kFixFracBits, wx >> kFixFracBits);
+        uint32_t off = mul24(wy >> kFixFracBits, (uint32_t)k.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
         if (WANT_CELL) {
             hit_c = (int)(wx >> kFixFracBits);
             hit_r = (int)(wy >> kFixFracBits);
@@ -712,7 +670,7 @@ F110_HD bool march_padded(const ScanConst &k, double ux, double uy, double cux, 
             // cell above: take the floor, and give the ray up if it is closer than kPadGuard
             redo = (fabs(ux - rint(ux)) < kPadGuard) | (fabs(uy - rint(uy)) < kPadGuard);
             const int fc = (int)floor(ux), fr = (int)floor(uy);
-            off = padded_cell_offset<TILED>(k, (uint32_t)fr, (uint32_t)fc);
+            off = mul24((uint32_t)fr, (uint32_t)k.pad_row_bytes) + ((uint32_t)fc << 3);
             if (WANT_CELL) {
                 hit_c = fc;
                 hit_r = fr;
@@ -735,102 +693,8 @@ F110_HD bool march_padded(const ScanConst &k, double ux, double uy, double cux, 
     return !(redo | (n > k.pad_max_samples));
 }
 
-// march_padded with the tail of a LONG ray marched two samples per memory round trip where the table allows it (round 5).
-// A ray that creeps along a wall reads the same few values d = res * sqrt(1, 2, 4, 5 ...) over and over, and every sample
-// costs a full dependent round trip (~200 ns): the chain of the batch's longest ray is what bounds a small batch's scan.
-// From sample `spec_from` on, together with the sample at u_{n+1} = u_n + d_n cu the ray also reads the cell at
-// u_n + 2 d_n cu — where sample n+2 lies IF d_{n+1} turns out equal to d_n, bit for bit.  It then is
-// fma(d_{n+1}, cu, u_{n+1}) with identical operands, i.e. exactly the position, cell and value the plain loop would have
-// produced one round trip later; otherwise the extra value is dropped.  Same guard band, same sample sequence, same
-// lookup count as march_padded — results are bit-identical by construction (host + GPU tests compare them).
-// The speculative cell is read only while total + d <= max_range: it then lies within max_range of the lidar like every
-// real sample, inside the padded table; beyond that the plain loop would not take the sample either.
-template <bool WANT_CELL>
-F110_HD bool march_padded_spec(const ScanConst &k, double ux, double uy, double cux, double cuy, double d, double &range,
-                               int &hit_r, int &hit_c, int &lookups, int spec_from)
-{
-    double total = d;
-    int n = 1;
-    bool redo = false;
-    const char *base = reinterpret_cast<const char *>(k.pad);
-    // the cell of a position (march_padded's body): byte offset, guard-band verdict, cell for WANT_CELL
-    auto cell = [&](double px, double py, bool &give_up, int &cc, int &cr) -> uint32_t {
-        const uint32_t wx = low_word(px + kFixBig);
-        const uint32_t wy = low_word(py + kFixBig);
-        uint32_t off = mul24(wy >> kFixFracBits, (uint32_t)k.pad_row_bytes) + ((wx >> kFixFracBits) << 3);
-        cc = (int)(wx >> kFixFracBits);
-        cr = (int)(wy >> kFixFracBits);
-        give_up = false;
-        if (((wx & 0xffffu) == 0u) | ((wy & 0xffffu) == 0u)) {
-            give_up = (fabs(px - rint(px)) < kPadGuard) | (fabs(py - rint(py)) < kPadGuard);
-            cc = (int)floor(px);
-            cr = (int)floor(py);
-            off = mul24((uint32_t)cr, (uint32_t)k.pad_row_bytes) + ((uint32_t)cc << 3);
-        }
-        return off;
-    };
-    int c1 = 0, r1 = 0;
-    while ((d > k.eps) & (total <= k.max_range) & !redo & (n < spec_from)) {   // the plain loop
-        ux = fma(d, cux, ux);
-        uy = fma(d, cuy, uy);
-        const uint32_t off = cell(ux, uy, redo, c1, r1);
-        if (WANT_CELL) {
-            hit_c = c1;
-            hit_r = r1;
-        }
-        d = *reinterpret_cast<const double *>(base + off);
-        total += d;
-        ++n;
-    }
-    while ((d > k.eps) & (total <= k.max_range) & !redo) {   // two samples per round trip where the value repeats
-        ux = fma(d, cux, ux);
-        uy = fma(d, cuy, uy);
-        const uint32_t off1 = cell(ux, uy, redo, c1, r1);
-        const double sx = fma(d, cux, ux), sy = fma(d, cuy, uy);
-        bool redo2 = false;
-        int c2 = 0, r2 = 0;
-        uint32_t off2 = cell(sx, sy, redo2, c2, r2);
-        if (!(total + d <= k.max_range)) off2 = off1;   // (never accepted then: see above)
-        double v1 = *reinterpret_cast<const double *>(base + off1);
-        double v2 = *reinterpret_cast<const double *>(base + off2);
-#if defined(__HIP_DEVICE_COMPILE__)
-        // both loads are issued before either is waited for (the optimiser otherwise sinks the second one into the branch that
-        // uses it: a second dependent round trip, which is exactly what this loop exists to avoid)
-        asm volatile("" : "+v"(v1), "+v"(v2));
-#endif
-        if (WANT_CELL) {
-            hit_c = c1;
-            hit_r = r1;
-        }
-        const bool same = v1 == d;
-        d = v1;
-        total += v1;
-        ++n;
-        if (same & (d > k.eps) & (total <= k.max_range) & !redo) {
-            ux = sx;
-            uy = sy;
-            redo = redo2;
-            if (WANT_CELL) {
-                hit_c = c2;
-                hit_r = r2;
-            }
-            d = v2;
-            total += v2;
-            ++n;
-        }
-    }
-    if (WANT_CELL && n > 1) {
-        hit_c -= k.pad_border;
-        hit_r -= k.pad_border;
-        if (hit_c < 0 || hit_c >= k.width || hit_r < 0 || hit_r >= k.height) {
-            hit_r = -1;
-            hit_c = -1;
-        }
-    }
-    lookups = n;
-    range = (total > k.max_range) ? k.max_range : total;
-    return !(redo | (n > k.pad_max_samples));
-}
+// (Round 5 also had march_padded_spec here — the tail of a long ray two samples per memory round trip where the table value
+// repeats, bit-identical — measured slower at every setting and retired in round 6: DESIGN.md §8, profiles/r05_spec_march.txt.)
 
 // The exact march for the rays march_padded gives up on, written to keep the fast kernel's
 // register footprint: its constants are fetched from the HBM copy of ScanConst when (if ever) it

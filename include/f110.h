@@ -107,12 +107,11 @@ int f110_is_experimental(void);
  * scan_occupancy, scan_env_counter (fusion probes), integrate_duo (-1|0|1: k_integrate in one wave or two per 64 agents),
  * integrate_fan (-1|0|1), group_split, scan_trace_hi / scan_trace_lo (the two halves of the device address of a caller-owned
  * [launch waves][8] uint64 buffer that every wave of the step's scan kernel stamps with its begin / end clock, CU and samples:
- * tools/debug/scan_timeline.py; 0 = off); round 5: scan_stream (1: the lane-refill scan k_scan_stream_agent), stream_refill,
- * stream_block, stream_grid, spec_from (the tail of long rays two samples per round trip), finalize_wave (8 | 4: the A = 2 finalize as
- * one-wave workgroups), pad_tiled (before the map is loaded; 1: the step's march on a 4x4-tiled copy of the PADDED table, round 6: 2 = on a row-pair copy, 2 rows x 8 cells per
- * line), scan_nt (round 6: 1 = the scan's range stores non-temporal).  Retired in round 5 with the code they
- * switched (numbers in DESIGN_HISTORY.md): dedupe_two_pass, no_window, finalize_lanes / _flat / _roles, pair_always, step_graph,
- * ray_pass / ray_thr / ray_waves. */
+ * tools/debug/scan_timeline.py; 0 = off).  Retired with the code they switched (numbers in DESIGN.md section 8 / DESIGN_HISTORY.md) — round 5:
+ * dedupe_two_pass, no_window, finalize_lanes / _flat / _roles, pair_always, step_graph, ray_pass / ray_thr / ray_waves; round 6 (the
+ * pre-registered stop rule for march variants): scan_stream / stream_refill / stream_block / stream_grid (the lane-refill scan),
+ * spec_from (the speculative tail march), finalize_wave (the A = 2 finalize as one-wave workgroups), pad_tiled (the step's march on a
+ * 4x4-tiled or a row-pair copy of the PADDED table), scan_nt (non-temporal range stores): F110_ERR_INVALID. */
 int f110_exp_set(f110_sim *h, const char *key, int32_t value);
 
 int f110_create(const f110_config *cfg, f110_sim **out);

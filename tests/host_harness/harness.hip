@@ -123,13 +123,12 @@ void hh_padded_stats(long long *out)
     g_pad_fast = g_pad_guard = g_pad_far = 0;
 }
 
-// layout: 0 row-major, 3 padded + fixed-point addressing (+ 100 s: march_padded_spec from sample s on)
+// layout: 0 row-major, 3 padded + fixed-point addressing
 void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, double oy, double oc, double os,
              const double *sines, const double *cosines, int theta_dis, int B, double fov, double eps,
              double max_range, const double *pose, double *ranges, int *hit_rc, int *dir_idx, long long *lookups)
 {
     ScanConst k{};
-    std::vector<double> tiled;
     std::vector<double2> cs(theta_dis);
     for (int i = 0; i < theta_dis; ++i) cs[i] = make_double2(cosines[i], sines[i]);
     k.cs = cs.data();
@@ -150,11 +149,6 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
     k.table = dt;
     k.table_rm = dt;
     std::vector<double> padded;
-    int spec_from = 0;   // layout 3 + 100 * s: the PADDED march with two samples per round trip from sample s on (march_padded_spec)
-    if (layout >= 100) {
-        spec_from = layout / 100;
-        layout = layout % 100;
-    }
     if (layout == 3 && setup_padded(k)) {  // same construction as finish_map() + k_build_padded
         padded.assign((size_t)k.pad_width * k.pad_height, k.oob_value);
         for (int r = 0; r < H; ++r)
@@ -179,8 +173,7 @@ void hh_scan(int layout, const double *dt, int H, int W, double res, double ox, 
                 if (k.ident_rot) { padded_position<true>(k, pose[0], pose[1], ux, uy); padded_rate<true>(k, cs[idx].x, cs[idx].y, cux, cuy); }
                 else { padded_position<false>(k, pose[0], pose[1], ux, uy); padded_rate<false>(k, cs[idx].x, cs[idx].y, cux, cuy); }
                 fast = padded_start_ok(k, ux, uy);
-                if (fast) exact = spec_from ? !march_padded_spec<true>(k, ux, uy, cux, cuy, d0, r, hr, hc, nl, spec_from)
-                                            : !march_padded<true>(k, ux, uy, cux, cuy, d0, r, hr, hc, nl);
+                if (fast) exact = !march_padded<true>(k, ux, uy, cux, cuy, d0, r, hr, hc, nl);
                 if (!fast) ++g_pad_far; else if (exact) ++g_pad_guard; else ++g_pad_fast;
             }
             if (exact) r = k.ident_rot ? march_exact_cold<true>(&k, pose[0], pose[1], cs[idx].x, cs[idx].y, d0, hr, hc, nl)

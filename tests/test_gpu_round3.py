@@ -77,15 +77,18 @@ def test_product_library_refuses_the_lab(amd):
     from f1tenth_gym_amd import _ffi
     if _ffi.VARIANT == "experimental":
         assert _ffi.lib().f110_is_experimental() == 1
-        s = amd.BatchSim(num_envs=2, num_agents=2, exp={"scan_stream": 1})
+        s = amd.BatchSim(num_envs=2, num_agents=2, exp={"integrate_fan": 1})
         with pytest.raises(ValueError):
             s.exp_set("no_such_switch", 1)
         with pytest.raises(ValueError):
             s.exp_set("finalize_flat", 1)       # a switch retired in round 5
+        for key in ("scan_stream", "spec_from", "finalize_wave", "pad_tiled", "scan_nt"):     # ... and round 6's retirements (the stop rule)
+            with pytest.raises(ValueError, match="retired in round 6"):
+                s.exp_set(key, 1)
         s.close()
     else:
         assert _ffi.lib().f110_is_experimental() == 0
-        for kw in ({"step_groups": 3}, {"exp": {"collide_mode": 0}}, {"exp": {"scan_stream": 1}}):
+        for kw in ({"step_groups": 3}, {"exp": {"collide_mode": 0}}, {"exp": {"integrate_fan": 1}}):
             with pytest.raises(_ffi.ExperimentalOnly):
                 amd.BatchSim(num_envs=2, num_agents=2, **kw)
     # retired in round 5 (measured slower in rounds 1-4, numbers in DESIGN_HISTORY.md): refused by BOTH builds

@@ -1,4 +1,4 @@
-"""knob sweep for k_scan_stream_agent (experimental build): F110_LIB_VARIANT=experimental python tools/debug/stream_probe.py N [k=v ...]"""
+"""the bench-like step loop (300 pre-roll + 100 timed steps, in-step re-seats) under lab switches (experimental build): F110_LIB_VARIANT=experimental python tools/debug/stream_probe.py N [k=v ...]  (round 5: written for k_scan_stream_agent; rounds 5-6 timed the tiled / row-pair tables with it)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-6 GPU sessions (one gpurun call each; EVERY command under its own timeout — a hung rocprofv3 cost 20 GPU-minutes once):
 #   gpurun --timeout 1500 -- 'bash tools/gpu_r6.sh test stream'
-# modes: test testfast bench prof pmc tabench rates manyagents | round 6: cfg3 (BASELINE configs[3] at its size, 8 ranks on this one device, RCCL stand-in) fuzztime pair (row-pair table experiment) tiny (one-launch small-batch step)
+# modes: test new testfast bench prof pmc tabench rates manyagents | round 6: cfg3 (BASELINE configs[3] at its size, 8 ranks on this one device, RCCL stand-in) fuzztime envprof
+#   (the modes of round 6's retired experiments — pair pairsweep ntstore pairpmc finwaves — went with their switches: commit 'row-pair experiment measured' has them; outputs: profiles/r06_rowpair*.txt, r06_nt_store.txt, r06_finalize_waves.txt)
 cd "${GRAFT_REPO_ROOT:-.}"
 R="$PWD"; export TMPDIR=/tmp
 OUT=$R/gpurun_out; mkdir -p $OUT
@@ -57,58 +58,6 @@ fuzztime)   # how long the fuzzers take per seed on this box (sizes the in-suite
     for f in fuzz_parity fuzz_envs fuzz_episode; do echo -n "$f seeds 0..39: "; { time timeout 600 python tools/debug/$f.py 0 40 > $OUT/ft_$f.log 2>&1; } 2>&1; tail -1 $OUT/ft_$f.log | cut -c1-200; done
     echo -n "fuzz_units seeds 0..3: "; { time bash -c 'for s in 0 1 2 3; do timeout 300 python tools/debug/fuzz_units.py $s > /dev/null 2>&1 || echo "fuzz_units seed $s FAILED"; done'; } 2>&1; } | tee $OUT/fuzztime.txt
   ;;
-pair)   # round 6's one scan experiment: the PADDED table in row pairs (pad_tiled=2) against row-major (0) and 4x4 tiles (1), experimental build
-  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  tools/debug/tiled_ab.py (parity: 0 / 1 / 2 bit-identical) + tools/debug/stream_probe.py N pad_tiled=0|1|2 (experimental build; 300 pre-roll + 100 timed steps, in-step re-seats), two rounds"
-    F110_LIB_VARIANT=experimental timeout 300 python tools/debug/tiled_ab.py 2>&1 | tail -6
-    for rep in 1 2; do for n in 65536 16384 4096; do for pt in 0 2 1; do F110_LIB_VARIANT=experimental timeout 90 python tools/debug/stream_probe.py $n pad_tiled=$pt 2>&1 | grep agents; done; done; done; } | tee $OUT/rowpair.txt
-  ;;
-pairsweep)   # where do row pairs pay?  small batches (lab build), bench form
-  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  F110_LIB_VARIANT=experimental F110_EXP=pad_tiled=V python bench.py --only-headline --steps 300 --warmup 30 --agents N, two rounds"
-    for rep in 1 2; do for n in 512 1024 2048 4096 6144 8192 12288 16384 32768; do for v in 0 2; do
-      F110_LIB_VARIANT=experimental F110_EXP=pad_tiled=$v timeout 100 python bench.py --only-headline --steps 300 --warmup 30 --agents $n 2>/dev/null | grep "^{" | python -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print('agents %6d pad_tiled %d  %8.2f M agent-steps/s  %.4f ms/step' % ($n, $v, d['value']/1e6, d['ms_per_step']))
-"; done; done; done; } | tee $OUT/pair_sweep.txt
-  ;;
-ntstore)   # non-temporal range stores for the small batch (experimental build): does the table stay in L2 across launches?
-  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  F110_LIB_VARIANT=experimental F110_EXP=scan_nt=V python bench.py --only-headline --steps 300 --warmup 30 --agents N, two rounds"
-    for rep in 1 2; do for n in 4096 2048 8192 65536; do for v in 0 1; do
-      F110_LIB_VARIANT=experimental F110_EXP=scan_nt=$v timeout 100 python bench.py --only-headline --steps 300 --warmup 30 --agents $n 2>/dev/null | grep "^{" | python -c "
-import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print('agents %6d scan_nt %d  %8.2f M agent-steps/s  %.4f ms/step' % ($n, $v, d['value']/1e6, d['ms_per_step']))
-"; done; done; done; } | tee $OUT/nt_store.txt
-  ;;
-pairpmc)   # why: the PMC passes of pmcstream over the scan kernel with pad_tiled = 0 and 2 (experimental build, 65 536 agents)
-  cd /tmp
-  for tag in "rowmajor:pad_tiled=0" "pairs:pad_tiled=2"; do
-    nm=${tag%%:*}; ex=${tag#*:}; i=0
-    for ctrs in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE" "TA_TA_BUSY_sum TD_TD_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
-      i=$((i+1))
-      F110_LIB_VARIANT=experimental F110_EXP=$ex timeout 300 rocprofv3 --pmc $ctrs --kernel-include-regex "k_scan_rays" -T -f csv -d $OUT/pp_$i -o p -- python $R/bench.py $H > $OUT/pp_$i.log 2>&1
-      timeout 60 python $R/tools/summarize_prof.py pmc $OUT/pp_$i $OUT/pairpmc_${nm}_$i.json - 300
-      rm -rf $OUT/pp_$i
-    done
-  done
-  cd "$R"; python - <<'PY'
-import json, glob, os
-root = os.environ.get("GRAFT_REPO_ROOT", ".")
-out = {}
-for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pairpmc_*_*.json"))):
-    nm = os.path.basename(f).split("_")[1]
-    for k, v in json.load(open(f)).items():
-        rec = out.setdefault(nm, {}).setdefault(k, {"csrc": v.get("csrc"), "dispatches": v["dispatches"], "mean_per_dispatch": {}})
-        rec["mean_per_dispatch"].update(v["mean_per_dispatch"])
-json.dump(out, open(os.path.join(root, "gpurun_out", "pmc_pairs_vs_rowmajor.json"), "w"), indent=1, sort_keys=True)
-for nm, ks in out.items():
-    for k, v in ks.items():
-        m = v["mean_per_dispatch"]; cyc = m.get("GRBM_GUI_ACTIVE", 0) / 8.0
-        print(nm, k[:40], "us %.0f" % (cyc / 2400.0), "vmem_rd %.3g valu %.3g" % (m.get("SQ_INSTS_VMEM_RD", 0), m.get("SQ_INSTS_VALU", 0)),
-              "TA %.2f TD %.2f" % (m.get("TA_TA_BUSY_sum", 0) / 256 / max(cyc, 1), m.get("TD_TD_BUSY_sum", 0) / 256 / max(cyc, 1)),
-              "L1 acc %.3g -> L2 req %.3g (L2 hit %.3f)" % (m.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0), m.get("TCP_TCC_READ_REQ_sum", 0), m.get("TCC_HIT_sum", 0) / max(m.get("TCC_REQ_sum", 1), 1)))
-PY
-  ;;
 envprof)   # where F110Env(num_agents=2).step's time goes: per-kernel durations (rocprofv3), host enqueue / wait, Python around the call
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  tools/debug/f110env_loop.py 3000 (F110Env 1 env x 2 agents)"
     for i in 1 2 3; do timeout 120 python tools/debug/f110env_loop.py 3000 2>&1 | tail -1; done
@@ -116,21 +65,6 @@ envprof)   # where F110Env(num_agents=2).step's time goes: per-kernel durations 
     cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -T -f csv -d $OUT/prof_env -o stats -- python $R/tools/debug/f110env_loop.py 3000 > $OUT/prof_env.log 2>&1
     timeout 60 python $R/tools/summarize_prof.py stats $OUT/prof_env $OUT/kernel_stats_f110env.txt 3000; rm -rf $OUT/prof_env; cd "$R"
     cat $OUT/kernel_stats_f110env.txt | head -30; } | tee $OUT/envprof.txt
-  ;;
-finwaves)   # k_finalize_pair_roles at 4 / 5 / 6 waves per SIMD (probe_fin*.so built in the container with -DF110_FIN_WAVES=N): per-kernel HIP events
-  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  probe_finN.so = -DF110_FIN_WAVES=N; bench.py --steps 300 --warmup 30 (roofline replay: HIP events per kernel), agents 65536 and 4096"
-    cp f1tenth_gym_amd/libf110_hip.so /tmp/tree_lib.so
-    for rep in 1 2; do for w in 6 5 4; do
-      [ -f f1tenth_gym_amd/probe_fin$w.so ] || continue
-      cp f1tenth_gym_amd/probe_fin$w.so f1tenth_gym_amd/libf110_hip.so
-      for n in 65536 4096; do
-        timeout 200 python bench.py --agents $n --steps 300 --warmup 30 --no-cpu-baseline --no-dropin --secondary 0 --no-config5 --fixed-pose-steps 0 --steady-steps 0 2>/dev/null | grep '^{' | python -c "
-import sys, json
-d = json.loads(sys.stdin.readline()); r = d['roofline']
-print('waves %d agents %6d  step %.4f ms  %7.2f M/s | scan %.2f us  integrate %.2f us  finalize %.2f us' % ($w, $n, d['ms_per_step'], d['value']/1e6, 1e3*r['kernel_ms_avg'], 1e3*r['integrate_collide_ms_avg'], 1e3*r['finalize_ms_avg']))"
-      done
-    done; done
-    cp /tmp/tree_lib.so f1tenth_gym_amd/libf110_hip.so; } | tee $OUT/finwaves.txt
   ;;
 manyagents)
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  bench.py --only-headline --agents 65520|65536 --agents-per-env A --steps 200 --warmup 20 (product library)"
