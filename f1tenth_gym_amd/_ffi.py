@@ -139,6 +139,7 @@ PROTOTYPES = {
     "f110_comm_gather_obs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "f110_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "f110_step_groups": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p]),
+    "f110_step_launches": (C.c_int, [C.c_void_p, _i32p]),
     "f110_comm_set_overlap": (C.c_int, [C.c_void_p, C.c_int32]),
     "f110_comm_destroy": (C.c_int, [C.c_void_p]),
     "f110_timer_begin": (C.c_int, [C.c_void_p]),

@@ -537,6 +537,12 @@ class BatchSim(object):
         check(_ffi.lib().f110_step_groups(self._h, C.byref(g), C.byref(p), C.byref(l)), self._h)
         return int(g.value), int(p.value), int(l.value)
 
+    def step_launches(self):
+        """1 when the most recent step ran as ONE kernel launch (k_step_tiny: at most 64 agents, one or two per env), else 0"""
+        n = C.c_int32(0)
+        check(_ffi.lib().f110_step_launches(self._h, C.byref(n)), self._h)
+        return int(n.value)
+
     def comm_info(self):
         """(n_ranks, rank) as RCCL reports them"""
         n, r = C.c_int32(0), C.c_int32(-1)

@@ -158,6 +158,14 @@ struct f110_sim {
     bool fused_valid = false, fuse_request = false, fused_done = false;
     unsigned long long fuse_seq = 0;
     long long hs_calls = 0;
+    // the whole step of a tiny batch as ONE launch (k_step_tiny): counters + shadow columns, allocated on first use
+    TinyCtl tiny{};
+    void *tiny_mem = nullptr;
+    int tiny_off = 0;                 // lab A/B (f110_exp_set "step_tiny" = 0): the three-kernel form also for tiny batches
+    int last_launches = 0;            // kernels the most recent step submitted its work as (f110_step_launches)
+    bool tiny_host_request = false;   // f110_step_host with one agent per env on the tiny path: what k_host_block would be handed
+    HostBlock tiny_hb{};
+    int tiny_episode = 0, tiny_auto_reset = 0;
     // timing
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool profiling = false;
@@ -232,6 +240,8 @@ static int join_groups(f110_sim *h)
         (h)->main_dirty = true;                           \
         (h)->touched = true;                              \
     } while (0)
+
+static bool tiny_applies(const f110_sim *h);   // (below, with the step)
 
 // RAII scratch for the unit entry points
 struct Scratch {
@@ -416,6 +426,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "integrate_duo") h->exp.integrate_duo = value;
     else if (k == "integrate_fan") h->exp.integrate_fan = value;
     else if (k == "group_split") h->exp.group_split = value;
+    else if (k == "step_tiny") h->tiny_off = value == 0 ? 1 : 0;
     else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
     else if (k == "scan_trace_lo") h->exp.scan_trace = (h->exp.scan_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "collide_mode") {
@@ -815,6 +826,7 @@ void f110_destroy(f110_sim *h)
     }
     if (h->hb_seq_host) (void)hipHostFree(h->hb_seq_host);
     if (h->d_fused) (void)hipFree(h->d_fused);
+    if (h->tiny_mem) (void)hipFree(h->tiny_mem);
     if (h->hb_blocks_done) (void)hipFree(h->hb_blocks_done);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     if (h->ev_integrated) (void)hipEventDestroy(h->ev_integrated);
@@ -1858,7 +1870,10 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
         h->hb_valid = true;
     }
     const auto t_in = std::chrono::steady_clock::now();
-    const bool spin = (flags & F110_STEP_SPIN_WAIT) && !(flags & F110_STEP_NO_SYNC) && (!out->scans || (h->hb_valid && h->hb_scans_by_kernel));
+    // a tiny batch is one launch whose last workgroup writes the block (k_step_tiny): its completion is ONE word stored by one
+    // workgroup, so the host always waits on that word (no runtime call on the way out)
+    const bool tiny = tiny_applies(h) && !(flags & F110_STEP_NO_FUSE) && !h->dev.reseat_poses;
+    const bool spin = ((flags & F110_STEP_SPIN_WAIT) || tiny) && !(flags & F110_STEP_NO_SYNC) && (!out->scans || (h->hb_valid && h->hb_scans_by_kernel));
     if (spin && !h->hb_seq_host) {
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->hb_seq_host), 64, hipHostMallocDefault));
         *h->hb_seq_host = 0;
@@ -1883,7 +1898,13 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
     // less per step); its parameters live in device memory and are rewritten only when they change
     // (not with F110_STEP_SPIN_WAIT: the completion word needs a system-scope release per workgroup, and the pair kernel
     // has N / 32 of them with the scan's dirty lines still in L2 — measured 0.657 -> 0.767 ms at 32 768 envs)
-    const bool want_fuse = A == 2 && !(flags & F110_STEP_NO_FUSE) && !spin;
+    const bool want_fuse = A == 2 && !(flags & F110_STEP_NO_FUSE) && (!spin || tiny);
+    h->tiny_host_request = tiny && A == 1;
+    if (h->tiny_host_request) {
+        h->tiny_hb = hbk;
+        h->tiny_episode = episode ? 1 : 0;
+        h->tiny_auto_reset = (flags & F110_STEP_AUTO_RESET) ? 1 : 0;
+    }
     if (want_fuse) {
         FusedHost fh{};
         if (episode) fh.ep = h->ep;
@@ -1903,6 +1924,7 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
     h->fused_done = false;
     const int rc_step = f110_step_device(h, d_act);
     h->fuse_request = false;
+    h->tiny_host_request = false;
     if (rc_step != F110_OK) return rc_step;
     ENTER(h);
     if (!h->fused_done) {
@@ -2070,6 +2092,97 @@ static ScanKind pick_scan(const f110_sim *h, int begin, int count)
     if (!(h->multi_map || agent_aligned(h))) return SCAN_FLAT;
     if (h->task_order && !h->multi_map && !h->lookups_on && begin == 0 && count == h->N && !h->exp.scan_env_counter) return SCAN_AGENT_SCHED;
     return SCAN_AGENT;
+}
+
+// ---- the whole step of a tiny batch as ONE launch (k_step_tiny) ----------------------------------------------------------
+// When: at most kTinyMaxAgents agents, one or two per env, the agent-aligned scan on one PADDED map, this step's noise row in the
+// table / row cache (or no noise), nothing that brackets or counts inside the step.  Everything else takes the three kernels.
+static bool tiny_applies(const f110_sim *h)
+{
+    const int A = h->cfg.num_agents;
+    if (h->tiny_off || h->N > kTinyMaxAgents || (A != 1 && A != 2)) return false;
+    if (A == 2 && h->collide_mode != 3) return false;
+    if (h->multi_map || !agent_aligned(h) || h->lookups_on || h->path_stats_on || h->profiling) return false;
+    if (h->dev.noise_rng && (h->dev.noise_rng == 2 || h->noise_ub >= (long long)h->dev.noise_rows)) return false;   // k_noise_rows would have to run first
+    if (kExperimental && (h->exp.scan_env_counter || h->exp.scan_trace || h->exp.scan_occupancy)) return false;
+    return true;
+}
+
+static int tiny_setup(f110_sim *h)
+{
+    if (h->tiny_mem) return F110_OK;
+    const size_t N = (size_t)h->N;
+    // one allocation: [done + pad | wall N | buf_cnt N] int32 then the double columns, then the headers
+    const size_t ints = 16 + 2 * N, dbls = (7 + 2 + 3 + 3 + 1) * N;
+    const size_t bytes = ((ints * 4 + 63) / 64) * 64 + dbls * 8 + N * sizeof(RayHdr);
+    HIPCHK(h, hipMalloc(&h->tiny_mem, bytes));
+    HIPCHK(h, hipMemsetAsync(h->tiny_mem, 0, bytes, h->stream));
+    char *base = static_cast<char *>(h->tiny_mem);
+    TinyCtl &t = h->tiny;
+    t.done = reinterpret_cast<unsigned int *>(base);
+    t.wall = reinterpret_cast<int32_t *>(base) + 16;
+    t.buf_cnt = t.wall + N;
+    double *d = reinterpret_cast<double *>(base + ((ints * 4 + 63) / 64) * 64);
+    t.state = d;            d += 7 * N;
+    t.steer_buf = d;        d += 2 * N;
+    t.scan_pose = d;        d += 3 * N;
+    t.snap_pose = d;        d += 3 * N;
+    t.dir_start = d;        d += N;
+    t.ray_hdr = reinterpret_cast<RayHdr *>(d);
+    t.tasks_per_agent = ((uint32_t)h->k.num_beams + 63u) / 64u;
+    return F110_OK;
+}
+
+static int step_tiny(f110_sim *h, hipStream_t st, const double *d_actions)
+{
+    TRY(tiny_setup(h));
+    const int N = h->N, A = h->cfg.num_agents;
+    AgentArrays dev = h->dev;
+    dev.agent_begin = 0;
+    dev.agent_count = N;
+    dev.sched_count_zero = nullptr;
+    RayJob j{};
+    j.noise = h->dev.noise;
+    j.ttc_side_max = h->ttc_side_max;
+    j.ttc_k = h->dev.ttc_thresh * (1.0 + 1e-9) * h->ttc_cos_max;
+    j.beam_cos = h->dev.beam_cos;
+    j.side_dist = h->dev.side_dist;
+    j.ttc_thresh = h->dev.ttc_thresh;
+    j.k_cold = cold_consts(h);
+    if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
+    h->tiny.tasks_per_agent = ((uint32_t)h->k.num_beams + 63u) / 64u;
+    const dim3 grid(((unsigned)N * h->tiny.tasks_per_agent + 3u) / 4u), block(256);
+    EpisodeArrays ep{};
+    HostBlock hb{};
+    int episode = 0, auto_reset = 0;
+    bool host = false;
+    if (A == 2) {
+        if (h->fuse_request && !dev.reseat_poses) {   // f110_step_host: host block + episode logic as the last workgroup's epilogue
+            dev.fused_host = h->d_fused;
+            dev.fused_seq = h->fuse_seq;
+            h->fused_done = true;
+            host = true;
+        }
+    } else if (h->tiny_host_request && !dev.reseat_poses) {
+        ep = h->ep;
+        hb = h->tiny_hb;
+        episode = h->tiny_episode;
+        auto_reset = h->tiny_auto_reset;
+        h->fused_done = true;
+        host = true;
+    }
+#define TINY(P, I, H_) hipLaunchKernelGGL((k_step_tiny<P, I, H_>), grid, block, 0, st, dev, h->k, j, d_actions, h->tiny, ep, hb, episode, auto_reset)
+    const bool ident = h->k.ident_rot != 0;
+    if (A == 2) {
+        if (host) { if (ident) TINY(true, true, true); else TINY(true, false, true); }
+        else { if (ident) TINY(true, true, false); else TINY(true, false, false); }
+    } else {
+        if (host) { if (ident) TINY(false, true, true); else TINY(false, false, true); }
+        else { if (ident) TINY(false, true, false); else TINY(false, false, false); }
+    }
+#undef TINY
+    h->last_launches = 1;
+    return F110_OK;
 }
 
 static int step_range(f110_sim *h, hipStream_t st, int begin, int count, const double *d_actions, int collide_mode, hipEvent_t *ev)
@@ -2351,6 +2464,13 @@ int f110_step_groups(f110_sim *h, int32_t *groups, int32_t *probes, int32_t *las
     return F110_OK;
 }
 
+int f110_step_launches(f110_sim *h, int32_t *launches)
+{
+    if (!h || !launches) return fail(h, F110_ERR_INVALID, "null argument");
+    *launches = h->last_launches;
+    return F110_OK;
+}
+
 int f110_step_device(f110_sim *h, const double *d_actions)
 {
     if (!h || !d_actions) return fail(h, F110_ERR_INVALID, "null argument");
@@ -2386,9 +2506,13 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     // the env groups need the agent-aligned scan (a launch per agent range); per-kernel profiling
     // brackets the kernels of ONE stream, so a profiled step runs as one block on the main stream
     // (two groups borrow the side stream, which the older collide forms use themselves)
-    const bool grouped = h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0 &&
+    // a tiny batch (the reference's own shape: one env of two cars) is ONE launch: integrate, scan, finalize and — under
+    // f110_step_host — the observation block and the completion word, in k_step_tiny
+    const bool tiny = !prof && tiny_applies(h);
+    const bool grouped = !tiny && h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0 &&
                          !(h->gstreams[0] == h->stream && h->collide_mode != 3 && A > 1) &&
                          (!h->groups_auto || (!h->touched && env_blocks_pay(N, A)));
+    h->last_launches = 0;
     if (!grouped) {
         TRY(join_groups(h));
         h->main_dirty = true;
@@ -2398,7 +2522,9 @@ int f110_step_device(f110_sim *h, const double *d_actions)
                 if (!(ev[i] = prof_event(h))) return fail(h, F110_ERR_HIP, "hipEventCreate failed");
         }
         const int cmode = h->collide_mode;
-        {
+        if (tiny) {
+            TRY(step_tiny(h, h->stream, d_actions));
+        } else {
             TRY(step_range(h, h->stream, 0, N, d_actions, cmode, prof ? ev : nullptr));
         }
     } else {

@@ -241,8 +241,54 @@ __device__ __forceinline__ void collide_agent(const AgentArrays &a, int32_t B, i
 }
 
 // what k_integrate leaves behind for one agent: state, delay buffer, lidar pose, pose snapshot, the ray header
-__device__ __forceinline__ void integrate_store(const AgentArrays &a, const ScanConst &k, int i, int N, const double *st, double b0, double b1,
-                                                int cnt, const double *sp)
+// everything the ray kernel needs per agent, incl. the first table sample that all beams share (trace_ray :129 evaluated at the
+// lidar position; generic exact path)
+__device__ __forceinline__ RayHdr make_ray_hdr(const AgentArrays &a, const ScanConst &k, int i, const double *st, const double *sp, double start)
+{
+    RayHdr hd;
+    ScanConst kr = k;
+    kr.table = k.table_rm;
+    hd.x = sp[0];
+    hd.y = sp[1];
+    hd.start = start;
+    hd.vel = st[3];
+    // a different track per env (f110_set_env_maps): this agent's map constants come from the
+    // registered slot instead of the kernel argument
+    hd.map_slot = a.env_map ? a.env_map[i / a.agents_per_env] : 0;
+    hd.pad_hdr = 0;
+    const ScanConst *km = a.env_map ? a.maps_full + hd.map_slot : &kr;
+    int r0, c0;
+    hd.d0 = sample_distance<LAYOUT_ROWMAJOR, false, false>(*km, nullptr, sp[0], sp[1], r0, c0);
+    int row = -1;
+    if (a.noise_rng) {
+        // k-th scan after reset adds the k-th B-sample draw of the stream (base_classes.py:204,
+        // laser_models.py:450-452): from the row cache, or generated by k_noise_rows (-2)
+        row = a.step_count[i];
+        if (a.noise_rng == 2 || row >= a.noise_rows) row = -2;
+    } else if (a.noise_rows > 0) {
+        row = a.step_count[i];
+        if (row >= a.noise_rows) row %= a.noise_rows;
+    }
+    hd.noise_row = row;
+    hd.i0 = beam_dir_index(k, start, 0);
+    hd.fast = 0;
+    if (km->pad) {
+        double ux, uy;
+        padded_position<false>(*km, sp[0], sp[1], ux, uy);
+        hd.fast = padded_start_ok(*km, ux, uy) ? 1 : 0;
+    }
+    hd.n_dirs = 0;
+    if (k.theta_inc < 1.0) {  // consecutive beams advance the table index by 0 or 1 (mod theta_dis)
+        int span = beam_dir_index(k, start, k.num_beams - 1) - hd.i0;
+        if (span < 0) span += k.theta_dis;
+        hd.n_dirs = span + 1;
+    }
+    return hd;
+}
+
+// what the integration leaves in HBM for one agent (every column but the ray header)
+__device__ __forceinline__ void integrate_store_columns(const AgentArrays &a, int i, int N, const double *st, double b0, double b1, int cnt, const double *sp,
+                                                        double start)
 {
 #pragma unroll
     for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = st[c];
@@ -255,52 +301,17 @@ __device__ __forceinline__ void integrate_store(const AgentArrays &a, const Scan
     a.snap_pose[i] = st[0];
     a.snap_pose[(size_t)N + i] = st[1];
     a.snap_pose[2 * (size_t)N + i] = st[4];
-    const double start = scan_start_index(k, sp[2]);
     a.dir_start[i] = start;
-    {
-        // everything the ray kernel needs per agent, incl. the first table sample that all
-        // beams share (trace_ray :129 evaluated at the lidar position; generic exact path)
-        RayHdr hd;
-        ScanConst kr = k;
-        kr.table = k.table_rm;
-        hd.x = sp[0];
-        hd.y = sp[1];
-        hd.start = start;
-        hd.vel = st[3];
-        // a different track per env (f110_set_env_maps): this agent's map constants come from the
-        // registered slot instead of the kernel argument
-        hd.map_slot = a.env_map ? a.env_map[i / a.agents_per_env] : 0;
-        hd.pad_hdr = 0;
-        const ScanConst *km = a.env_map ? a.maps_full + hd.map_slot : &kr;
-        int r0, c0;
-        hd.d0 = sample_distance<LAYOUT_ROWMAJOR, false, false>(*km, nullptr, sp[0], sp[1], r0, c0);
-        int row = -1;
-        if (a.noise_rng) {
-            // k-th scan after reset adds the k-th B-sample draw of the stream (base_classes.py:204,
-            // laser_models.py:450-452): from the row cache, or generated by k_noise_rows (-2)
-            row = a.step_count[i];
-            if (a.noise_rng == 2 || row >= a.noise_rows) row = -2;
-        } else if (a.noise_rows > 0) {
-            row = a.step_count[i];
-            if (row >= a.noise_rows) row %= a.noise_rows;
-        }
-        hd.noise_row = row;
-        hd.i0 = beam_dir_index(k, start, 0);
-        hd.fast = 0;
-        if (km->pad) {
-            double ux, uy;
-            padded_position<false>(*km, sp[0], sp[1], ux, uy);
-            hd.fast = padded_start_ok(*km, ux, uy) ? 1 : 0;
-        }
-        if (a.path_stats) atomicAdd(&a.path_stats[hd.fast ? 0 : 2], (unsigned long long)k.num_beams);
-        hd.n_dirs = 0;
-        if (k.theta_inc < 1.0) {  // consecutive beams advance the table index by 0 or 1 (mod theta_dis)
-            int span = beam_dir_index(k, start, k.num_beams - 1) - hd.i0;
-            if (span < 0) span += k.theta_dis;
-            hd.n_dirs = span + 1;
-        }
-        a.ray_hdr[i] = hd;
-    }
+}
+
+__device__ __forceinline__ void integrate_store(const AgentArrays &a, const ScanConst &k, int i, int N, const double *st, double b0, double b1,
+                                                int cnt, const double *sp)
+{
+    const double start = scan_start_index(k, sp[2]);
+    integrate_store_columns(a, i, N, st, b0, b1, cnt, sp, start);
+    const RayHdr hd = make_ray_hdr(a, k, i, st, sp, start);
+    if (a.path_stats) atomicAdd(&a.path_stats[hd.fast ? 0 : 2], (unsigned long long)k.num_beams);
+    a.ray_hdr[i] = hd;
     a.in_collision[i] = 0;  // raised by k_scan_rays when any beam's iTTC is under the threshold
     if (a.sched_count_zero && i == a.agent_begin) {
         a.sched_count_zero[0] = 0u;   // this step's task list (TaskSched::count_w)
@@ -1975,11 +1986,9 @@ __global__ void __launch_bounds__(256) k_finalize_multi_tiled(AgentArrays a, int
 }
 
 // single-agent envs: no opponents, one lane per agent is enough
-__global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
+__device__ __forceinline__ void finalize_solo_agent(const AgentArrays &a, int i)
 {
-    const int i = a.agent_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int N = a.n_agents_total;
-    if (i >= a.agent_begin + a.agent_count) return;
     const int wall = a.in_collision[i];
     if (wall) {
         a.state[3 * (size_t)N + i] = 0.;
@@ -1992,6 +2001,13 @@ __global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
     a.collisions[i] = wall ? 1.0 : 0.0;
     a.step_count[i] += 1;
     if (a.reseat_poses && wall) reseat_agent(a, i, true);
+}
+
+__global__ void __launch_bounds__(256) k_finalize_solo(AgentArrays a)
+{
+    const int i = a.agent_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= a.agent_begin + a.agent_count) return;
+    finalize_solo_agent(a, i);
 }
 
 // unit-path helper: AoS poses [M][3] -> pose_x, pose_y, dir_start
@@ -2133,15 +2149,27 @@ __global__ void __launch_bounds__(256) k_pack_episode(AgentArrays a, EpisodeArra
 // A workgroup owns whole envs (envs_per_block of them): phase 1 per agent (toggles + the agent's columns),
 // phase 2 per env (done, current_time), phase 3 per agent (re-seat).  Any pointer may be nullptr.
 // (struct HostBlock, host_block_signal: defined next to AgentArrays)
-__global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays ep, HostBlock hb, int num_envs, int envs_per_block,
-                                                    int episode, int auto_reset)
+// the completion word of a launch whose LAST workgroup runs the host block by itself (k_step_tiny): no counting
+__device__ __forceinline__ void host_block_signal_single(const HostBlock &hb)
+{
+    if (!hb.seq_host) return;
+    __syncthreads();               // every lane's stores are issued
+    if (threadIdx.x == 0) {
+        __threadfence_system();    // ... and visible system-wide before the word
+        __hip_atomic_store(hb.seq_host, hb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The body of k_host_block for the envs [e0, e0 + ne) of a 256-thread workgroup.  SINGLE: the workgroup is the only one that runs
+// it in its launch (k_step_tiny's last workgroup) and signals by itself.
+template <bool SINGLE>
+__device__ __forceinline__ void host_block_body(const AgentArrays &a, const EpisodeArrays &ep, const HostBlock &hb, const int e0, const int ne, int episode,
+                                                int auto_reset)
 {
     __shared__ int s_running[256];    // per local env: agents with fewer than 4 toggles
     __shared__ uint8_t s_done[256];
     const int A = a.agents_per_env, tid = threadIdx.x;
     const size_t N = (size_t)a.n_agents_total;
-    const int e0 = blockIdx.x * envs_per_block;
-    const int ne = min(envs_per_block, num_envs - e0);   // >= 1: the grid is ceil(num_envs / envs_per_block)
     if (episode) {
         for (int le = tid; le < ne; le += 256) s_running[le] = 0;
         __syncthreads();
@@ -2210,7 +2238,8 @@ __global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays
     }
     if (hb.scans) host_block_copy_scans(hb, a.scans, (size_t)e0 * A, (size_t)items);
     if (!episode) {
-        host_block_signal(hb);
+        if (SINGLE) host_block_signal_single(hb);
+        else host_block_signal(hb);
         return;
     }
     __syncthreads();
@@ -2225,7 +2254,8 @@ __global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays
         ep.done[e] = (done && !reseat) ? 1 : 0;
         ep.current_time[e] = reseat ? 0. : ct;
     }
-    host_block_signal(hb);   // the host block is complete here; the re-seat below touches device memory only
+    if (SINGLE) host_block_signal_single(hb);   // the host block is complete here; the re-seat below touches device memory only
+    else host_block_signal(hb);
     if (!auto_reset) return;
     __syncthreads();         // s_done
     for (int idx = tid; idx < items; idx += 256) {
@@ -2243,6 +2273,143 @@ __global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays
         a.step_count[i] = 0;
         ep.near_start[i] = 1;
         ep.toggle[i] = 0.;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays ep, HostBlock hb, int num_envs, int envs_per_block,
+                                                    int episode, int auto_reset)
+{
+    const int e0 = blockIdx.x * envs_per_block;
+    host_block_body<false>(a, ep, hb, e0, min(envs_per_block, num_envs - e0), episode, auto_reset);   // ne >= 1: the grid is ceil(num_envs / envs_per_block)
+}
+
+// ---- K0: the WHOLE step of a tiny batch as one launch (round 6) ------------------------------------------------------------
+// The reference's own shape — F110Env(num_agents = 2).step, one env — is launch- and sync-bound on the GPU: three kernels of 9 + 14 + 9
+// us are reported after ~60 us (profiles/r06_f110env_breakdown.txt).  For N <= kTinyMaxAgents agents and 1 or 2 agents per env this
+// kernel is the step: Simulator.step (base_classes.py:553-612) — update_pose for every agent, the scans, the iTTC test, the pair test,
+// the opponent ray-cast — and, under f110_step_host, F110Env._check_done (f110_env.py:204-246) + the observation block in the caller's
+// page-locked memory + the completion word the host polls.  Same device functions on the same operands as the three kernels: bit-identical
+// (tests/test_gpu_round6.py).
+//   scan phase    one wave per 64-beam task, four per workgroup.  A wave needs its agent's lidar pose and ray header, i.e. the agent's
+//                 INTEGRATION: every lane computes it (advance_vehicle + make_ray_hdr: the same instructions one lane would run), so
+//                 no kernel boundary and no HBM round trip separates integrate from scan.  Nothing live is overwritten meanwhile: the
+//                 wave of an agent's FIRST task stores the new state / delay buffer / poses / header into SHADOW columns, the wall
+//                 flags of the iTTC test go to a flag column of their own.
+//   last block    workgroups count themselves done (release / acquire at agent scope); the one that arrives last copies the shadow
+//                 columns over the live ones and runs the finalize body (finalize_pair_body / finalize_solo_agent) and the host epilogue.
+struct TinyCtl {
+    unsigned int *done;      // workgroups finished this launch (left at 0 by the last one)
+    int32_t *wall;           // [N] this step's iTTC flags (left at 0 by the last workgroup)
+    double *state;           // shadow of AgentArrays: [7][N]
+    double *steer_buf;       // [2][N]
+    int32_t *buf_cnt;        // [N]
+    double *scan_pose;       // [3][N]
+    double *snap_pose;       // [3][N]
+    double *dir_start;       // [N]
+    RayHdr *ray_hdr;         // [N]
+    uint32_t tasks_per_agent, pad_;
+};
+constexpr int kTinyMaxAgents = 64;
+
+template <bool PAIR, bool IDENT, bool HOST>
+__global__ void __launch_bounds__(256) k_step_tiny(AgentArrays a, ScanConst k, RayJob j, const double *__restrict__ actions, TinyCtl ctl, EpisodeArrays ep,
+                                                   HostBlock hb, int episode, int auto_reset)
+{
+    __shared__ int s_last;
+    const int N = a.n_agents_total, B = k.num_beams;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t task = blockIdx.x * 4u + wave;
+    if (task < (uint32_t)N * ctl.tasks_per_agent) {
+        const int i = (int)(task / ctl.tasks_per_agent);
+        const uint32_t sub = task - (uint32_t)i * ctl.tasks_per_agent;
+        // RaceCar.update_pose for agent i, by every lane of the wave (k_integrate's body)
+        const VehicleParams vp = load_params(a.params + (size_t)(a.params_per_agent ? i : i % a.agents_per_env) * NPARAMS);
+        double st[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) st[c] = a.state[(size_t)c * N + i];
+        double b0 = a.steer_buf[i], b1 = a.steer_buf[(size_t)N + i];
+        int cnt = a.buf_cnt[i];
+        const double2 act = reinterpret_cast<const double2 *>(actions)[i];
+        double sp[3];
+        advance_vehicle(st, b0, b1, cnt, act.x, act.y, vp, a.time_step, a.integrator, a.lidar_dist, sp);
+        const double start = scan_start_index(k, sp[2]);
+        const RayHdr hd = make_ray_hdr(a, k, i, st, sp, start);
+        if (sub == 0u && lane == 0u) {   // the agent's new columns, into the shadow (the live ones are still being read)
+            AgentArrays sh = a;
+            sh.state = ctl.state; sh.steer_buf = ctl.steer_buf; sh.buf_cnt = ctl.buf_cnt; sh.scan_pose = ctl.scan_pose;
+            sh.snap_pose = ctl.snap_pose; sh.dir_start = ctl.dir_start;
+            integrate_store_columns(sh, i, N, st, b0, b1, cnt, sp, start);
+            ctl.ray_hdr[i] = hd;
+        }
+        // get_scan for the task's 64 beams (k_scan_rays_agent's body)
+        const int b = (int)(sub * 64u + lane);
+        if (b < B) {
+            const int row = hd.noise_row;
+            const double nz = row >= 0 ? j.noise[(size_t)row * B + b] : 0.0;
+            const double2 cs = k.cs[beam_dir_index(k, start, b)];
+            int hr = -1, hc = -1, nl = 0;
+            double r = 0.;
+            bool exact = hd.fast == 0;
+            if (hd.fast) {
+                double ux, uy, cux, cuy;
+                padded_position<IDENT>(k, hd.x, hd.y, ux, uy);
+                padded_rate<IDENT>(k, cs.x, cs.y, cux, cuy);
+                exact = !march_padded<false>(k, ux, uy, cux, cuy, hd.d0, r, hr, hc, nl);
+            }
+            if (exact) r = march_exact_cold<IDENT>(j.k_cold, hd.x, hd.y, cs.x, cs.y, hd.d0, hr, hc, nl);
+            if (row != -1) r += nz;
+            // check_ttc_jit's predicate for this beam (finish_beam_with), the flag into the step's own column
+            if (hd.vel != 0.0 && !(r > j.ttc_side_max + j.ttc_k * fabs(hd.vel)) && ttc_beam_hit(r, j.side_dist[b], hd.vel, j.beam_cos[b], j.ttc_thresh))
+                ctl.wall[i] = 1;
+            a.scans[(size_t)i * B + b] = r;
+        }
+    }
+    // ---- who is last?
+    __threadfence();     // release: this wave's rows, flags and shadow columns are visible device-wide (other XCDs' L2s included)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int prev = __hip_atomic_fetch_add(ctl.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == gridDim.x - 1u ? 1 : 0;
+        if (s_last) __hip_atomic_store(ctl.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();     // acquire: what the other workgroups released
+    // ---- the last workgroup: shadow -> live, then Simulator.step's tail
+    for (int i = (int)threadIdx.x; i < N; i += 256) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = ctl.state[(size_t)c * N + i];
+        a.steer_buf[i] = ctl.steer_buf[i];
+        a.steer_buf[(size_t)N + i] = ctl.steer_buf[(size_t)N + i];
+        a.buf_cnt[i] = ctl.buf_cnt[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.scan_pose[(size_t)c * N + i] = ctl.scan_pose[(size_t)c * N + i];
+            a.snap_pose[(size_t)c * N + i] = ctl.snap_pose[(size_t)c * N + i];
+        }
+        a.dir_start[i] = ctl.dir_start[i];
+        a.ray_hdr[i] = ctl.ray_hdr[i];
+        a.in_collision[i] = ctl.wall[i];
+        ctl.wall[i] = 0;
+    }
+    __syncthreads();
+    if (PAIR) {
+        constexpr int AG = 4;
+        for (int first = 0; first < N; first += AG) {
+            finalize_pair_body<AG, HOST>(a, B, first, N);
+            __syncthreads();   // the body's LDS is reused by the next group
+        }
+        if (HOST && a.fused_seq) {
+            HostBlock sig = a.fused_host->hb;
+            sig.seq = a.fused_seq;
+            host_block_signal_single(sig);
+        }
+    } else {
+        for (int i = (int)threadIdx.x; i < N; i += 256) finalize_solo_agent(a, i);
+        if (HOST) {
+            __syncthreads();
+            host_block_body<true>(a, ep, hb, 0, N, episode, auto_reset);   // one agent per env: N envs, all in this workgroup (N <= 64)
+        }
     }
 }
 

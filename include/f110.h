@@ -105,7 +105,7 @@ int f110_is_experimental(void);
  * env, beams) case.  Keys: scan_flat, collide_mode (0 side stream | 1 fused into k_integrate | 2 in line | 3 inside k_finalize),
  * task_order, task_thr, task_cap_div (list capacity = tasks / div), task_rev (walk the list from its newest entry), long_prio,
  * scan_occupancy, scan_env_counter (fusion probes), integrate_duo (-1|0|1: k_integrate in one wave or two per 64 agents),
- * integrate_fan (-1|0|1), group_split, scan_trace_hi / scan_trace_lo (the two halves of the device address of a caller-owned
+ * integrate_fan (-1|0|1), group_split, step_tiny (0: tiny batches through the three kernels too — the A/B of k_step_tiny), scan_trace_hi / scan_trace_lo (the two halves of the device address of a caller-owned
  * [launch waves][8] uint64 buffer that every wave of the step's scan kernel stamps with its begin / end clock, CU and samples:
  * tools/debug/scan_timeline.py; 0 = off).  Retired with the code they switched (numbers in DESIGN.md section 8 / DESIGN_HISTORY.md) — round 5:
  * dedupe_two_pass, no_window, finalize_lanes / _flat / _roles, pair_always, step_graph, ray_pass / ray_thr / ray_waves; round 6 (the
@@ -363,6 +363,11 @@ int f110_comm_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scalars, 
  * *probes = candidate streams that observation tried, *last = blocks the most recent f110_step_device was submitted as.
  * Any pointer may be NULL.  Bookkeeping for benchmarks and tests; no reference counterpart. */
 int f110_step_groups(f110_sim *h, int32_t *groups, int32_t *probes, int32_t *last);
+/* *launches = 1 when the most recent f110_*step* ran as ONE kernel launch (round 6: at most 64 agents with one or two cars per env
+ * — the reference's own shape, F110Env(num_agents = 2) on one env — integrate, scan, finalize and, under f110_step_host, the observation
+ * block and the completion word in a single launch, k_step_tiny; results are the same bits), 0 = the per-kernel form.  Bookkeeping for
+ * benchmarks and tests; no reference counterpart. */
+int f110_step_launches(f110_sim *h, int32_t *launches);
 /* size and rank of the communicator as RCCL itself reports them (ncclCommCount / ncclCommUserRank) */
 int f110_comm_info(f110_sim *h, int32_t *n_ranks, int32_t *rank);
 /* enable = 1: the gather OVERLAPS the following step.  The scans are double-buffered (a second

@@ -273,3 +273,94 @@ def test_scan_angles_tables_that_are_not_the_uniform_ramp(amd, table):
         assert envs.check_ttc_jit(g["ttc_scans_" + table][j], g["ttc_vel_" + table][j], sa, g["ttc_cos_" + table], g["ttc_side_" + table], 0.005) == bool(g["ttc_flags_" + table][j])
     assert len(functional._ctx) >= 1
     functional.close_cached_handles()
+
+
+# ------------------------------------------------------------------ the whole step of a tiny batch as ONE launch (k_step_tiny)
+@pytest.mark.parametrize("E,A,mapname", [(1, 2, "example_map"), (1, 1, "example_map"), (32, 2, "example_map"), (33, 1, "berlin"), (7, 2, "skirk"), (64, 1, "example_map")])
+def test_tiny_step_equals_the_three_kernels(amd, E, A, mapname):
+    """k_step_tiny (at most 64 agents, one or two per env: integrate + scan + finalize in ONE launch, the reference's own shape) against
+    the three-kernel form of the same library (lab switch step_tiny = 0): every output bit for bit over 120 steps with wall hits, car
+    contacts, noise from the device generator, in-step re-seats — and the launch count says which form ran"""
+    from _util import load_map_image
+    img, res, origin = load_map_image(mapname)
+    N, T = E * A, 120
+    outs, launches = [], []
+    for tiny in (1, 0):
+        s = amd.BatchSim(num_envs=E, num_agents=A, exp={"step_tiny": tiny})
+        s.set_map_image(img, res, origin); s.set_noise_rng(4242, 0.01)
+        rng = np.random.default_rng(9)
+        if mapname == "example_map":
+            poses = bench_start_poses(E, A, gap_wp=3)
+        else:
+            poses = np.stack([rng.uniform(-0.6, 0.6, N), rng.uniform(-0.6, 0.6, N), rng.uniform(0, 6.28, N)], axis=1)
+        s.reset(poses)
+        d = s.device_array((N, 2)); d_start = s.device_array((N, 3)); d_start.upload(poses)
+        rec = []
+        for t in range(T):
+            if t == 60:
+                s.set_auto_reseat(d_start, 0)      # the second half re-seats crashed envs inside the step
+            d.upload(np.stack([rng.uniform(-0.4, 0.4, N), rng.uniform(1.0, 8.0, N)], axis=1))
+            s.step_device(d)
+            launches.append(s.step_launches())
+            rec.append(s.get("scans", "state", "collisions", "collision_idx", "in_collision", "agent_poses", "step_count"))
+        outs.append(rec); s.close()
+    assert set(launches[:T]) == {1} and set(launches[T:]) == {0}
+    hits = sum(int(r["collisions"].sum()) for r in outs[0])
+    assert hits > 0
+    for t, (ra, rb) in enumerate(zip(*outs)):
+        for key in ra:
+            assert np.array_equal(ra[key], rb[key]), (t, key)
+
+
+def test_tiny_step_through_the_host_block(amd):
+    """f110_step_host on a tiny batch (what F110Env.step and F110VecEnv(device_logic=True) call): the observation block, the episode
+    logic and the completion word come out of the ONE launch's last workgroup — against the same library with step_tiny = 0 (three
+    kernels, the pair kernel's epilogue / k_host_block), one and two agents per env, with the auto-reset"""
+    for E, A in ((1, 2), (3, 1), (16, 2)):
+        recs = []
+        for tiny in (1, 0):
+            os.environ["F110_EXP"] = "step_tiny=%d" % tiny
+            try:
+                env = amd.F110VecEnv(E, map=map_stem("example_map"), map_ext=".png", num_agents=A, auto_reset=True, device_logic=True)
+            finally:
+                del os.environ["F110_EXP"]
+            poses = bench_start_poses(E, A, gap_wp=3).reshape(E, A, 3)
+            out = [env.reset(poses)]
+            rng = np.random.default_rng(3)
+            for t in range(150):
+                out.append(env.step(np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(2.0, 8.0, (E, A))], axis=2)))
+                assert env.sim.batch.step_launches() == tiny
+            recs.append([({k: np.array(v) for k, v in o[0].items()}, np.array(o[2]), {k: np.array(v) for k, v in o[3].items()}) for o in out])
+            env.sim.batch.close()
+        assert sum(int(r[1].sum()) for r in recs[0]) > 0       # episodes ended (and were re-seated) on the way
+        for t, (ra, rb) in enumerate(zip(*recs)):
+            for key in ra[0]:
+                assert np.array_equal(ra[0][key], rb[0][key]), (E, A, t, key)
+            assert np.array_equal(ra[1], rb[1]), (E, A, t, "done")
+            for key in ra[2]:
+                assert np.array_equal(ra[2][key], rb[2][key]), (E, A, t, key)
+
+
+def test_which_batches_take_the_one_launch_step(amd):
+    """the product's dispatch: at most 64 agents with one or two cars per env are ONE launch per step (F110Env's shape); more agents,
+    more cars per env, profiling or a per-agent noise stream take the per-kernel form"""
+    from _util import load_map_image
+    img, res, origin = load_map_image("example_map")
+    for E, A, kw, want in ((1, 2, {}, 1), (32, 2, {}, 1), (64, 1, {}, 1), (33, 2, {}, 0), (2, 3, {}, 0), (1, 2, {"per_agent": True}, 0), (1, 2, {"prof": True}, 0)):
+        s = amd.BatchSim(num_envs=E, num_agents=A)
+        s.set_map_image(img, res, origin)
+        if kw.get("per_agent"):
+            s.set_noise_rng(None, per_agent_seeds=list(range(E * A)))
+        else:
+            s.set_noise_rng(12345, 0.01)
+        s.reset(bench_start_poses(E, A))
+        if kw.get("prof"):
+            s.profile_kernels(True)
+        s.step(np.tile([0.0, 2.0], (E * A, 1)))
+        assert s.step_launches() == want, (E, A, kw)
+        s.close()
+    env = amd.F110Env(map=map_stem("example_map"), map_ext=".png", num_agents=2)
+    env.reset(bench_start_poses(1, 2).reshape(2, 3))
+    env.step(np.array([[0.0, 2.0], [0.0, 2.0]]))
+    assert env.sim.batch.step_launches() == 1
+    env.sim.batch.close()

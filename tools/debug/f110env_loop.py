@@ -13,4 +13,6 @@ t0 = time.perf_counter()
 for _ in range(n):
     env.step(act)
 dt = (time.perf_counter() - t0) / n
-print("F110Env 1 env x 2 agents  %.1f us/step  host stats %s" % (dt * 1e6, env.sim.batch.step_host_stats()))
+c, enq, wait = env.sim.batch.step_host_stats()
+print("F110Env 1 env x 2 agents  %.1f us/step  in f110_step_host: enqueue %.1f us + wait %.1f us  (kernel launches per step: %s)"
+      % (dt * 1e6, enq, wait, {1: "1 = k_step_tiny", 0: "the per-kernel form"}[env.sim.batch.step_launches()]))

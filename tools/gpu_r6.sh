@@ -58,6 +58,11 @@ fuzztime)   # how long the fuzzers take per seed on this box (sizes the in-suite
     for f in fuzz_parity fuzz_envs fuzz_episode; do echo -n "$f seeds 0..39: "; { time timeout 600 python tools/debug/$f.py 0 40 > $OUT/ft_$f.log 2>&1; } 2>&1; tail -1 $OUT/ft_$f.log | cut -c1-200; done
     echo -n "fuzz_units seeds 0..3: "; { time bash -c 'for s in 0 1 2 3; do timeout 300 python tools/debug/fuzz_units.py $s > /dev/null 2>&1 || echo "fuzz_units seed $s FAILED"; done'; } 2>&1; } | tee $OUT/fuzztime.txt
   ;;
+tiny)   # k_step_tiny: the A/B tests (lab build) + the golden / oracle tests that now run through it (product), then F110Env's step time
+  F110_LIB_VARIANT=experimental F110_NESTED_SUITE=1 timeout 900 python -m pytest tests/test_gpu_round6.py -m gpu -q -x -k "tiny or one_launch" > $OUT/pytest_tiny_lab.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_tiny_lab.log; tail -15 $OUT/pytest_tiny_lab.log | cut -c1-250
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round4.py -m gpu -q -x --deselect tests/test_gpu_round2.py::test_fuzz_parity_bounded_seeds --deselect tests/test_gpu_round2.py::test_fuzz_units_seeds > $OUT/pytest_tiny_product.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_tiny_product.log; tail -8 $OUT/pytest_tiny_product.log | cut -c1-250
+  for i in 1 2 3; do timeout 120 python tools/debug/f110env_loop.py 3000 2>&1 | tail -1; done
+  ;;
 envprof)   # where F110Env(num_agents=2).step's time goes: per-kernel durations (rocprofv3), host enqueue / wait, Python around the call
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  tools/debug/f110env_loop.py 3000 (F110Env 1 env x 2 agents)"
     for i in 1 2 3; do timeout 120 python tools/debug/f110env_loop.py 3000 2>&1 | tail -1; done
