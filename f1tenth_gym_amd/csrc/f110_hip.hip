@@ -2508,7 +2508,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     // (two groups borrow the side stream, which the older collide forms use themselves)
     // a tiny batch (the reference's own shape: one env of two cars) is ONE launch: integrate, scan, finalize and — under
     // f110_step_host — the observation block and the completion word, in k_step_tiny
-    const bool tiny = !prof && tiny_applies(h);
+    const bool tiny = !prof && tiny_applies(h) && (h->groups_auto || h->groups <= 1);   // (step_groups = 2 forced: the caller asked for env blocks)
     const bool grouped = !tiny && h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0 &&
                          !(h->gstreams[0] == h->stream && h->collide_mode != 3 && A > 1) &&
                          (!h->groups_auto || (!h->touched && env_blocks_pay(N, A)));

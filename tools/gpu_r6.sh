@@ -63,6 +63,10 @@ tiny)   # k_step_tiny: the A/B tests (lab build) + the golden / oracle tests tha
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round4.py -m gpu -q -x --deselect tests/test_gpu_round2.py::test_fuzz_parity_bounded_seeds --deselect tests/test_gpu_round2.py::test_fuzz_units_seeds > $OUT/pytest_tiny_product.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_tiny_product.log; tail -8 $OUT/pytest_tiny_product.log | cut -c1-250
   for i in 1 2 3; do timeout 120 python tools/debug/f110env_loop.py 3000 2>&1 | tail -1; done
   ;;
+tinyab)   # one launch vs three kernels on the shapes k_step_tiny serves (lab build carries the switch)
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  F110_LIB_VARIANT=experimental python tools/debug/tiny_ab.py"
+    F110_LIB_VARIANT=experimental timeout 600 python tools/debug/tiny_ab.py 2>&1 | tail -6; } | tee $OUT/tiny_ab.txt
+  ;;
 envprof)   # where F110Env(num_agents=2).step's time goes: per-kernel durations (rocprofv3), host enqueue / wait, Python around the call
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  tools/debug/f110env_loop.py 3000 (F110Env 1 env x 2 agents)"
     for i in 1 2 3; do timeout 120 python tools/debug/f110env_loop.py 3000 2>&1 | tail -1; done
