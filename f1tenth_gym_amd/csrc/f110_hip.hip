@@ -163,7 +163,8 @@ struct f110_sim {
     void *tiny_mem = nullptr;
     int tiny_off = 0;                 // lab A/B (f110_exp_set "step_tiny" = 0): the three-kernel form also for tiny batches
     int last_launches = 0;            // kernels the most recent step submitted its work as (f110_step_launches)
-    bool tiny_host_request = false;   // f110_step_host with one agent per env on the tiny path: what k_host_block would be handed
+    bool tiny_request = false;        // f110_step_host: this step is one k_step_tiny launch
+    bool tiny_host_request = false;   // ... with one agent per env: what k_host_block would be handed
     HostBlock tiny_hb{};
     int tiny_episode = 0, tiny_auto_reset = 0;
     // timing
@@ -1872,7 +1873,7 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
     const auto t_in = std::chrono::steady_clock::now();
     // a tiny batch is one launch whose last workgroup writes the block (k_step_tiny): its completion is ONE word stored by one
     // workgroup, so the host always waits on that word (no runtime call on the way out)
-    const bool tiny = tiny_applies(h) && !(flags & F110_STEP_NO_FUSE) && !h->dev.reseat_poses;
+    const bool tiny = tiny_applies(h) && !(flags & (F110_STEP_NO_FUSE | F110_STEP_NO_SYNC)) && !h->dev.reseat_poses;
     const bool spin = ((flags & F110_STEP_SPIN_WAIT) || tiny) && !(flags & F110_STEP_NO_SYNC) && (!out->scans || (h->hb_valid && h->hb_scans_by_kernel));
     if (spin && !h->hb_seq_host) {
         HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&h->hb_seq_host), 64, hipHostMallocDefault));
@@ -1899,6 +1900,7 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
     // (not with F110_STEP_SPIN_WAIT: the completion word needs a system-scope release per workgroup, and the pair kernel
     // has N / 32 of them with the scan's dirty lines still in L2 — measured 0.657 -> 0.767 ms at 32 768 envs)
     const bool want_fuse = A == 2 && !(flags & F110_STEP_NO_FUSE) && (!spin || tiny);
+    h->tiny_request = tiny;
     h->tiny_host_request = tiny && A == 1;
     if (h->tiny_host_request) {
         h->tiny_hb = hbk;
@@ -1924,7 +1926,7 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
     h->fused_done = false;
     const int rc_step = f110_step_device(h, d_act);
     h->fuse_request = false;
-    h->tiny_host_request = false;
+    h->tiny_request = h->tiny_host_request = false;
     if (rc_step != F110_OK) return rc_step;
     ENTER(h);
     if (!h->fused_done) {
@@ -2095,8 +2097,12 @@ static ScanKind pick_scan(const f110_sim *h, int begin, int count)
 }
 
 // ---- the whole step of a tiny batch as ONE launch (k_step_tiny) ----------------------------------------------------------
-// When: at most kTinyMaxAgents agents, one or two per env, the agent-aligned scan on one PADDED map, this step's noise row in the
-// table / row cache (or no noise), nothing that brackets or counts inside the step.  Everything else takes the three kernels.
+// When: a HOST-SYNCHRONISED step (f110_step_host that waits: F110Env.step, F110VecEnv.step) of at most kTinyMaxAgents = 4 agents, one or
+// two per env — the reference's own shape — with the agent-aligned scan on one PADDED map, this step's noise row in the table / row cache
+// (or no noise), nothing that brackets or counts inside the step.  Measured where it was tried beyond that (profiles/r06_tiny_ab.txt, one
+// launch against three kernels): F110Env with 2 cars 73.5 -> 69.5 us per step, with 1 car 69.3 -> 58.4 us; but 16 agents 79 -> 99 us and 64
+// agents 86 -> 197 us (the last workgroup finalizes every agent by itself), and a device-resident loop of one env 53.1 -> 56.4 us (nothing
+// waits between its steps, so the longer single kernel is all it sees).  Everything else takes the per-kernel form.
 static bool tiny_applies(const f110_sim *h)
 {
     const int A = h->cfg.num_agents;
@@ -2105,6 +2111,7 @@ static bool tiny_applies(const f110_sim *h)
     if (h->multi_map || !agent_aligned(h) || h->lookups_on || h->path_stats_on || h->profiling) return false;
     if (h->dev.noise_rng && (h->dev.noise_rng == 2 || h->noise_ub >= (long long)h->dev.noise_rows)) return false;   // k_noise_rows would have to run first
     if (kExperimental && (h->exp.scan_env_counter || h->exp.scan_trace || h->exp.scan_occupancy)) return false;
+    if (!h->groups_auto && h->groups > 1) return false;   // step_groups = 2 forced: the caller asked for env blocks
     return true;
 }
 
@@ -2508,7 +2515,7 @@ int f110_step_device(f110_sim *h, const double *d_actions)
     // (two groups borrow the side stream, which the older collide forms use themselves)
     // a tiny batch (the reference's own shape: one env of two cars) is ONE launch: integrate, scan, finalize and — under
     // f110_step_host — the observation block and the completion word, in k_step_tiny
-    const bool tiny = !prof && tiny_applies(h) && (h->groups_auto || h->groups <= 1);   // (step_groups = 2 forced: the caller asked for env blocks)
+    const bool tiny = h->tiny_request && !prof;   // (f110_step_host decided: tiny_applies)
     const bool grouped = !tiny && h->groups > 1 && !prof && (h->multi_map || agent_aligned(h)) && h->dir_stride == 0 &&
                          !(h->gstreams[0] == h->stream && h->collide_mode != 3 && A > 1) &&
                          (!h->groups_auto || (!h->touched && env_blocks_pay(N, A)));

@@ -2285,7 +2285,7 @@ __global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays
 
 // ---- K0: the WHOLE step of a tiny batch as one launch (round 6) ------------------------------------------------------------
 // The reference's own shape — F110Env(num_agents = 2).step, one env — is launch- and sync-bound on the GPU: three kernels of 9 + 14 + 9
-// us are reported after ~60 us (profiles/r06_f110env_breakdown.txt).  For N <= kTinyMaxAgents agents and 1 or 2 agents per env this
+// us are reported after ~60 us (profiles/r06_f110env_breakdown.txt).  For a host-synchronised step of N <= kTinyMaxAgents agents, 1 or 2 per env, this
 // kernel is the step: Simulator.step (base_classes.py:553-612) — update_pose for every agent, the scans, the iTTC test, the pair test,
 // the opponent ray-cast — and, under f110_step_host, F110Env._check_done (f110_env.py:204-246) + the observation block in the caller's
 // page-locked memory + the completion word the host polls.  Same device functions on the same operands as the three kernels: bit-identical
@@ -2309,7 +2309,7 @@ struct TinyCtl {
     RayHdr *ray_hdr;         // [N]
     uint32_t tasks_per_agent, pad_;
 };
-constexpr int kTinyMaxAgents = 64;
+constexpr int kTinyMaxAgents = 4;   // (measured: beyond a handful of agents the per-kernel form wins, f110_hip.hip tiny_applies)
 
 template <bool PAIR, bool IDENT, bool HOST>
 __global__ void __launch_bounds__(256) k_step_tiny(AgentArrays a, ScanConst k, RayJob j, const double *__restrict__ actions, TinyCtl ctl, EpisodeArrays ep,

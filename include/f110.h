@@ -363,9 +363,9 @@ int f110_comm_gather_obs(f110_sim *h, void *d_recv_scans, void *d_recv_scalars, 
  * *probes = candidate streams that observation tried, *last = blocks the most recent f110_step_device was submitted as.
  * Any pointer may be NULL.  Bookkeeping for benchmarks and tests; no reference counterpart. */
 int f110_step_groups(f110_sim *h, int32_t *groups, int32_t *probes, int32_t *last);
-/* *launches = 1 when the most recent f110_*step* ran as ONE kernel launch (round 6: at most 64 agents with one or two cars per env
- * — the reference's own shape, F110Env(num_agents = 2) on one env — integrate, scan, finalize and, under f110_step_host, the observation
- * block and the completion word in a single launch, k_step_tiny; results are the same bits), 0 = the per-kernel form.  Bookkeeping for
+/* *launches = 1 when the most recent step ran as ONE kernel launch (round 6: a waiting f110_step_host of at most 4 agents with one or two
+ * cars per env — the reference's own shape, F110Env(num_agents = 1 | 2) on one env — integrate, scan, finalize, the observation block and
+ * the completion word in a single launch, k_step_tiny; results are the same bits), 0 = the per-kernel form.  Bookkeeping for
  * benchmarks and tests; no reference counterpart. */
 int f110_step_launches(f110_sim *h, int32_t *launches);
 /* size and rank of the communicator as RCCL itself reports them (ncclCommCount / ncclCommUserRank) */

@@ -276,91 +276,89 @@ def test_scan_angles_tables_that_are_not_the_uniform_ramp(amd, table):
 
 
 # ------------------------------------------------------------------ the whole step of a tiny batch as ONE launch (k_step_tiny)
-@pytest.mark.parametrize("E,A,mapname", [(1, 2, "example_map"), (1, 1, "example_map"), (32, 2, "example_map"), (33, 1, "berlin"), (7, 2, "skirk"), (64, 1, "example_map")])
-def test_tiny_step_equals_the_three_kernels(amd, E, A, mapname):
-    """k_step_tiny (at most 64 agents, one or two per env: integrate + scan + finalize in ONE launch, the reference's own shape) against
-    the three-kernel form of the same library (lab switch step_tiny = 0): every output bit for bit over 120 steps with wall hits, car
-    contacts, noise from the device generator, in-step re-seats — and the launch count says which form ran"""
-    from _util import load_map_image
-    img, res, origin = load_map_image(mapname)
-    N, T = E * A, 120
-    outs, launches = [], []
+def _tiny_env(amd, tiny, E, A, **kw):
+    os.environ["F110_EXP"] = "step_tiny=%d" % tiny        # (read by the host when the handle is made; the product library refuses it: lab-only test)
+    try:
+        return amd.F110VecEnv(E, map=map_stem(kw.pop("track", "example_map")), map_ext=".png", num_agents=A, **kw)
+    finally:
+        del os.environ["F110_EXP"]
+
+
+@pytest.mark.parametrize("E,A,track,device_logic", [(1, 2, "example_map", True), (1, 1, "example_map", True), (2, 2, "example_map", True), (4, 1, "berlin", True),
+                                                    (3, 1, "skirk", False), (1, 2, "berlin", False), (2, 2, "example_map", False)])
+def test_tiny_step_equals_the_three_kernels(amd, E, A, track, device_logic):
+    """k_step_tiny (a host-synchronised step of at most 4 agents, one or two per env: integrate + scan + finalize + observation block +
+    completion word in ONE launch — the reference's own shape) against the three-kernel form of the same library (lab switch
+    step_tiny = 0): every observation, `done`, the lap bookkeeping and the device-side state bit for bit over 400 steps with wall hits,
+    contacts, noise from the device generator, auto-resets; the launch count says which form ran.  device_logic=False is Simulator.step's
+    form (every column incl. the scans in the block, episode logic on the host), True is F110VecEnv's (episode logic in the kernel)"""
+    T = 400
+    recs, finals = [], []
     for tiny in (1, 0):
-        s = amd.BatchSim(num_envs=E, num_agents=A, exp={"step_tiny": tiny})
-        s.set_map_image(img, res, origin); s.set_noise_rng(4242, 0.01)
+        env = _tiny_env(amd, tiny, E, A, track=track, auto_reset=True, device_logic=device_logic)
         rng = np.random.default_rng(9)
-        if mapname == "example_map":
-            poses = bench_start_poses(E, A, gap_wp=3)
-        else:
-            poses = np.stack([rng.uniform(-0.6, 0.6, N), rng.uniform(-0.6, 0.6, N), rng.uniform(0, 6.28, N)], axis=1)
-        s.reset(poses)
-        d = s.device_array((N, 2)); d_start = s.device_array((N, 3)); d_start.upload(poses)
-        rec = []
-        for t in range(T):
-            if t == 60:
-                s.set_auto_reseat(d_start, 0)      # the second half re-seats crashed envs inside the step
-            d.upload(np.stack([rng.uniform(-0.4, 0.4, N), rng.uniform(1.0, 8.0, N)], axis=1))
-            s.step_device(d)
-            launches.append(s.step_launches())
-            rec.append(s.get("scans", "state", "collisions", "collision_idx", "in_collision", "agent_poses", "step_count"))
-        outs.append(rec); s.close()
-    assert set(launches[:T]) == {1} and set(launches[T:]) == {0}
-    if A == 2 or E > 8:
-        assert sum(int(r["collisions"].sum()) for r in outs[0]) > 0     # wall hits / contacts on the way (a single car may drive clean)
-    for t, (ra, rb) in enumerate(zip(*outs)):
-        for key in ra:
-            assert np.array_equal(ra[key], rb[key]), (t, key)
-
-
-def test_tiny_step_through_the_host_block(amd):
-    """f110_step_host on a tiny batch (what F110Env.step and F110VecEnv(device_logic=True) call): the observation block, the episode
-    logic and the completion word come out of the ONE launch's last workgroup — against the same library with step_tiny = 0 (three
-    kernels, the pair kernel's epilogue / k_host_block), one and two agents per env, with the auto-reset"""
-    for E, A in ((1, 2), (3, 1), (16, 2)):
-        recs = []
-        for tiny in (1, 0):
-            os.environ["F110_EXP"] = "step_tiny=%d" % tiny
-            try:
-                env = amd.F110VecEnv(E, map=map_stem("example_map"), map_ext=".png", num_agents=A, auto_reset=True, device_logic=True)
-            finally:
-                del os.environ["F110_EXP"]
+        if track == "example_map":
             poses = bench_start_poses(E, A, gap_wp=3).reshape(E, A, 3)
-            out = [env.reset(poses)]
-            rng = np.random.default_rng(3)
-            for t in range(150):
-                out.append(env.step(np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(2.0, 8.0, (E, A))], axis=2)))
-                assert env.sim.batch.step_launches() == tiny
-            recs.append([({k: np.array(v) for k, v in o[0].items()}, np.array(o[2]), {k: np.array(v) for k, v in o[3].items()}) for o in out])
-            env.sim.batch.close()
-        assert sum(int(r[1].sum()) for r in recs[0]) > 0       # episodes ended (and were re-seated) on the way
-        for t, (ra, rb) in enumerate(zip(*recs)):
-            for key in ra[0]:
-                assert np.array_equal(ra[0][key], rb[0][key]), (E, A, t, key)
-            assert np.array_equal(ra[1], rb[1]), (E, A, t, "done")
-            for key in ra[2]:
-                assert np.array_equal(ra[2][key], rb[2][key]), (E, A, t, key)
+        else:
+            poses = np.stack([rng.uniform(-0.6, 0.6, (E, A)), rng.uniform(-0.6, 0.6, (E, A)), rng.uniform(0, 6.28, (E, A))], axis=2)
+        out = [env.reset(poses)]
+        for t in range(T):
+            out.append(env.step(np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(2.0, 8.0, (E, A))], axis=2)))
+            assert env.sim.batch.step_launches() == tiny, t
+        recs.append([({k: np.array(v) for k, v in o[0].items()}, np.array(o[2]), {k: np.array(v) for k, v in o[3].items()}) for o in out])
+        finals.append(env.sim.batch.get("scans", "state", "collisions", "collision_idx", "in_collision", "agent_poses", "step_count"))
+        env.sim.batch.close()
+    assert sum(int(r[1].sum()) for r in recs[0]) > 0       # episodes ended (and were re-seated) on the way
+    for t, (ra, rb) in enumerate(zip(*recs)):
+        for key in ra[0]:
+            assert np.array_equal(ra[0][key], rb[0][key]), (t, key)
+        assert np.array_equal(ra[1], rb[1]), (t, "done")
+        for key in ra[2]:
+            assert np.array_equal(ra[2][key], rb[2][key]), (t, key)
+    for key in finals[0]:
+        assert np.array_equal(finals[0][key], finals[1][key]), key
 
 
-def test_which_batches_take_the_one_launch_step(amd):
-    """the product's dispatch: at most 64 agents with one or two cars per env are ONE launch per step (F110Env's shape); more agents,
-    more cars per env, profiling or a per-agent noise stream take the per-kernel form"""
+def test_which_steps_take_the_one_launch_form(amd):
+    """the product's dispatch: a WAITING f110_step_host of at most 4 agents with one or two cars per env is ONE launch (F110Env.step,
+    F110VecEnv.step on one or two envs); more agents, more cars per env, step_async, the device-resident entry points, profiling or a
+    per-agent noise stream take the per-kernel form"""
     from _util import load_map_image
+    kw = dict(map=map_stem("example_map"), map_ext=".png")
+    for A in (1, 2):
+        env = amd.F110Env(num_agents=A, **kw)
+        env.reset(bench_start_poses(1, A).reshape(A, 3))
+        env.step(np.tile([0.0, 2.0], (A, 1)))
+        assert env.sim.batch.step_launches() == 1, A
+        env.sim.batch.close()
+    for E, A, want in ((2, 2, 1), (4, 1, 1), (3, 2, 0), (5, 1, 0), (1, 3, 0)):
+        v = amd.F110VecEnv(E, num_agents=A, device_logic=True, **kw)
+        v.reset(bench_start_poses(E, A).reshape(E, A, 3))
+        v.step(np.tile([0.0, 2.0], (E, A, 1)))
+        assert v.sim.batch.step_launches() == want, (E, A)
+        if want:
+            v.step_async(np.tile([0.0, 2.0], (E, A, 1))); v.step_wait()
+            assert v.sim.batch.step_launches() == 0, "step_async does not wait inside the call: the per-kernel form"
+        v.sim.batch.close()
     img, res, origin = load_map_image("example_map")
-    for E, A, kw, want in ((1, 2, {}, 1), (32, 2, {}, 1), (64, 1, {}, 1), (33, 2, {}, 0), (2, 3, {}, 0), (1, 2, {"per_agent": True}, 0), (1, 2, {"prof": True}, 0)):
-        s = amd.BatchSim(num_envs=E, num_agents=A)
+    for mode in ("step", "step_device", "per_agent_noise", "profiling"):
+        s = amd.BatchSim(num_envs=1, num_agents=2)
         s.set_map_image(img, res, origin)
-        if kw.get("per_agent"):
-            s.set_noise_rng(None, per_agent_seeds=list(range(E * A)))
+        if mode == "per_agent_noise":
+            s.set_noise_rng(None, per_agent_seeds=[1, 2])
         else:
             s.set_noise_rng(12345, 0.01)
-        s.reset(bench_start_poses(E, A))
-        if kw.get("prof"):
+        s.reset(bench_start_poses(1, 2))
+        act = np.tile([0.0, 2.0], (2, 1))
+        if mode == "profiling":
             s.profile_kernels(True)
-        s.step(np.tile([0.0, 2.0], (E * A, 1)))
-        assert s.step_launches() == want, (E, A, kw)
+        if mode == "step":
+            s.step(act)
+        elif mode == "step_device":
+            d = s.device_array((2, 2)); d.upload(act); s.step_device(d)
+        else:
+            hb = s.host_block(("state", "collisions"))
+            hb.actions[...] = act
+            s.step_host(hb)
+        assert s.step_launches() == 0, mode
         s.close()
-    env = amd.F110Env(map=map_stem("example_map"), map_ext=".png", num_agents=2)
-    env.reset(bench_start_poses(1, 2).reshape(2, 3))
-    env.step(np.array([[0.0, 2.0], [0.0, 2.0]]))
-    assert env.sim.batch.step_launches() == 1
-    env.sim.batch.close()
