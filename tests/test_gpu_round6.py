@@ -303,7 +303,7 @@ def test_tiny_step_equals_the_three_kernels(amd, E, A, track, device_logic):
             poses = np.stack([rng.uniform(-0.6, 0.6, (E, A)), rng.uniform(-0.6, 0.6, (E, A)), rng.uniform(0, 6.28, (E, A))], axis=2)
         out = [env.reset(poses)]
         for t in range(T):
-            out.append(env.step(np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(2.0, 8.0, (E, A))], axis=2)))
+            out.append(env.step(np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(4.0, 12.0, (E, A))], axis=2)))     # fast and blind: wall hits, contacts, re-seats
             assert env.sim.batch.step_launches() == tiny, t
         recs.append([({k: np.array(v) for k, v in o[0].items()}, np.array(o[2]), {k: np.array(v) for k, v in o[3].items()}) for o in out])
         finals.append(env.sim.batch.get("scans", "state", "collisions", "collision_idx", "in_collision", "agent_poses", "step_count"))
