@@ -301,11 +301,13 @@ def test_tiny_step_equals_the_three_kernels(amd, E, A, track, device_logic):
             poses = bench_start_poses(E, A, gap_wp=3).reshape(E, A, 3)
         else:
             poses = np.stack([rng.uniform(-0.6, 0.6, (E, A)), rng.uniform(-0.6, 0.6, (E, A)), rng.uniform(0, 6.28, (E, A))], axis=2)
-        out = [env.reset(poses)]
+        def snap(o):     # (device_logic=True hands out VIEWS of the page-locked block, overwritten by the next step: copy now)
+            return ({k: np.array(v) for k, v in o[0].items()}, np.array(o[2]), {k: np.array(v) for k, v in o[3].items()})
+        out = [snap(env.reset(poses))]
         for t in range(T):
-            out.append(env.step(np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(4.0, 12.0, (E, A))], axis=2)))     # fast and blind: wall hits, contacts, re-seats
+            out.append(snap(env.step(np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(4.0, 12.0, (E, A))], axis=2))))     # fast and blind: wall hits, contacts, re-seats
             assert env.sim.batch.step_launches() == tiny, t
-        recs.append([({k: np.array(v) for k, v in o[0].items()}, np.array(o[2]), {k: np.array(v) for k, v in o[3].items()}) for o in out])
+        recs.append(out)
         finals.append(env.sim.batch.get("scans", "state", "collisions", "collision_idx", "in_collision", "agent_poses", "step_count"))
         env.sim.batch.close()
     assert sum(int(r[1].sum()) for r in recs[0]) > 0       # episodes ended (and were re-seated) on the way
