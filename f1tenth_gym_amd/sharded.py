@@ -124,7 +124,9 @@ class ShardedVecEnv(object):
             self._out = ({k: (alloc(v) if isinstance(v, np.ndarray) else v) for k, v in o0.items()}, alloc(np.asarray(d0)),
                          {k: alloc(v) for k, v in i0.items()})
         obs, done, info = self._out
-        for k, (o, _, d, i) in enumerate(parts):
+
+        def fill(k, _shard=None):
+            o, _, d, i = parts[k]
             lo, hi = self.bounds[k], self.bounds[k + 1]
             for name, v in o.items():
                 if isinstance(v, np.ndarray):
@@ -132,6 +134,12 @@ class ShardedVecEnv(object):
             done[lo:hi] = d
             for name, v in i.items():
                 info[name][lo:hi] = v
+        nbytes = sum(v.nbytes for v in obs.values() if isinstance(v, np.ndarray))
+        if nbytes >= (8 << 20) and len(parts) > 1:
+            self._each(fill)          # big observations (scans): every worker copies its own block, the copies overlap
+        else:
+            for k in range(len(parts)):
+                fill(k)
         return obs, self.timestep, done, info
 
     # ------------------------------------------------------------------ the env API (F110VecEnv's, over all shards)
@@ -254,6 +262,9 @@ class ShardedVecEnv(object):
         return False
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():     # the worker threads are daemons: at interpreter shutdown they no longer answer
+            return
         try:
             self.close()
         except Exception:  # noqa: BLE001

@@ -127,6 +127,26 @@ def test_sharded_vec_env_gathers_the_observation_on_one_device(amd):
     assert r["checks"] == 12 * 4 + 12 * 1      # 12 steps x 4 receiving shards (all-gather), then 12 x the one root
 
 
+def test_sharded_vec_env_gather_through_real_rccl_world_size_one(amd):
+    """the same gather path on the REAL librccl (a communicator of one rank is all one device allows): ShardedVecEnv(devices=[0],
+    gather_obs=True) — comm init from the worker thread, the all-gather on the shard's stream, gathered_views() == the step's observation"""
+    E, A = 12, 2
+    sh = amd.ShardedVecEnv(E, devices=[0], gather_obs=True, map=map_stem("example_map"), map_ext=".png", num_agents=A,
+                           obs_fields=("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "ang_vels_z", "collisions"))
+    assert sh.shards[0].sim.batch.comm_info() == (1, 0)
+    obs = sh.reset(bench_start_poses(E, A).reshape(E, A, 3))[0]
+    rng = np.random.default_rng(4)
+    for t in range(8):
+        obs = sh.step(np.stack([rng.uniform(-0.3, 0.3, (E, A)), rng.uniform(1.0, 6.0, (E, A))], axis=2))[0]
+        sh.sync()
+        d_s, d_c = sh.gathered_views()[0]
+        assert np.array_equal(d_s.download()[0], obs["scans"].reshape(E * A, -1)), t
+        want = np.stack([obs[k].reshape(-1) for k in ("poses_x", "poses_y", "poses_theta", "linear_vels_x")] + [np.zeros(E * A)]
+                        + [obs[k].reshape(-1) for k in ("ang_vels_z", "collisions")])
+        assert np.array_equal(d_c.download()[0], want), t
+    sh.close()
+
+
 # ------------------------------------------------------------------ the rest of `from f110_gym.envs import *` (star_exports.npz: reference-run)
 FTOL = 1e-12
 
