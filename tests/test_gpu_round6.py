@@ -117,6 +117,25 @@ def test_sharded_vec_env_equals_one_handle(amd, devices, sizes, device_logic):
     sh.close(); one.sim.batch.close()
 
 
+def test_sharded_vec_env_big_observation_blocks(amd):
+    """600 envs over three handles: 10 MB of scans per step, which the shards' worker threads copy into the assembled arrays
+    themselves (the parallel branch of ShardedVecEnv._assemble) — against one handle"""
+    E, A = 600, 2
+    kw = dict(map=map_stem("example_map"), map_ext=".png", num_agents=A, auto_reset=True)
+    one = amd.F110VecEnv(E, device_logic=True, **kw)
+    sh = amd.ShardedVecEnv(E, devices=[0, 0, 0], **kw)
+    poses = bench_start_poses(E, A, gap_wp=4).reshape(E, A, 3)
+    a, b = one.reset(poses), sh.reset(poses)
+    rng = np.random.default_rng(6)
+    for t in range(8):
+        for key in a[0]:
+            assert np.array_equal(np.asarray(a[0][key]), np.asarray(b[0][key])), (t, key)
+        assert np.array_equal(a[2], b[2])
+        act = np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(2.0, 8.0, (E, A))], axis=2)
+        a, b = one.step(act), sh.step(act)
+    sh.close(); one.sim.batch.close()
+
+
 def test_sharded_vec_env_gathers_the_observation_on_one_device(amd):
     """gather_obs=True: after each step every shard's device holds every shard's scans + scalars = the single handle's observation in
     blocks (all-gather float64, and float32 to one root) — four handles on device 0, the RCCL stand-in (tests/rccl_stub/sharded_gather.py)"""
