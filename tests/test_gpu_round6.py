@@ -403,3 +403,17 @@ def test_which_steps_take_the_one_launch_form(amd):
             s.step_host(hb)
         assert s.step_launches() == 0, mode
         s.close()
+
+
+NESTED = bool(os.environ.get("F110_NESTED_SUITE"))
+
+
+@pytest.mark.parametrize("first", range(0, 200, 50))
+def test_fuzz_host_block_step_vs_oracle(amd, first):
+    """tools/debug/fuzz_host.py, seeds 0 .. 199: f110_step_host — every column of the page-locked block after every step — against the
+    CPU oracle on random configurations weighted towards tiny batches, where the step is ONE launch (k_step_tiny); the library's choice of
+    form is asserted per step"""
+    spec = importlib.util.spec_from_file_location("fuzz_host", os.path.join(ROOT, "tools", "debug", "fuzz_host.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    bad = [sd for sd in range(first, first + (3 if NESTED else 50)) if not fz.run(sd, verbose=False)]
+    assert not bad, bad
