@@ -58,6 +58,17 @@ fuzztime)   # how long the fuzzers take per seed on this box (sizes the in-suite
     for f in fuzz_parity fuzz_envs fuzz_episode; do echo -n "$f seeds 0..39: "; { time timeout 600 python tools/debug/$f.py 0 40 > $OUT/ft_$f.log 2>&1; } 2>&1; tail -1 $OUT/ft_$f.log | cut -c1-200; done
     echo -n "fuzz_units seeds 0..3: "; { time bash -c 'for s in 0 1 2 3; do timeout 300 python tools/debug/fuzz_units.py $s > /dev/null 2>&1 || echo "fuzz_units seed $s FAILED"; done'; } 2>&1; } | tee $OUT/fuzztime.txt
   ;;
+fuzzlong)   # the fuzzers by hand, far beyond the seeds the suite runs (supplementary evidence: profiles/r06_fuzz.txt)
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  the GPU fuzzers on seed ranges BEYOND the suite's (HIP path vs CPU oracle / host logic; a line per fuzzer: seeds, ok count, failed seeds)"
+    for spec in "fuzz_host 200 1400" "fuzz_parity 300 1500" "fuzz_envs 200 800" "fuzz_episode 300 1500"; do
+      set -- $spec
+      timeout 1200 python tools/debug/$1.py $2 $3 > $OUT/fl_$1.log 2>&1
+      echo "$1 seeds $2..$(( $3 - 1 )): $(grep -c '^ok' $OUT/fl_$1.log) ok, $(grep -c MISMATCH $OUT/fl_$1.log) mismatches, $(tail -1 $OUT/fl_$1.log)"
+      [ "$1" = fuzz_host ] && echo "   of which one launch per step (k_step_tiny): $(grep -c 'one launch per step' $OUT/fl_$1.log)"
+    done
+    bad=0; for sd in $(seq 12 41); do timeout 300 python tools/debug/fuzz_units.py $sd > $OUT/fl_units.log 2>&1 || bad=$((bad+1)); grep -q "False" $OUT/fl_units.log && bad=$((bad+1)); done
+    echo "fuzz_units seeds 12..41: $bad seed(s) with a failure or an inexact line"; } | tee $OUT/fuzz_long.txt
+  ;;
 tiny)   # k_step_tiny: the A/B tests (lab build) + the golden / oracle tests that now run through it (product), then F110Env's step time
   F110_LIB_VARIANT=experimental F110_NESTED_SUITE=1 timeout 900 python -m pytest tests/test_gpu_round6.py -m gpu -q -x -k "tiny or one_launch" > $OUT/pytest_tiny_lab.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_tiny_lab.log; tail -15 $OUT/pytest_tiny_lab.log | cut -c1-250
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round4.py -m gpu -q -x --deselect tests/test_gpu_round2.py::test_fuzz_parity_bounded_seeds --deselect tests/test_gpu_round2.py::test_fuzz_units_seeds > $OUT/pytest_tiny_product.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_tiny_product.log; tail -8 $OUT/pytest_tiny_product.log | cut -c1-250
