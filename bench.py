@@ -768,9 +768,18 @@ def dropin_rates(args):
     env.reset(start_poses_for(shard_envs(1, 0), A))
     act = np.array([[0.05, 3.0], [-0.05, 2.5]] * A)[:A]
     dt = timed(lambda: env.step(act), 3000, 200)
+    launches = env.sim.batch.step_launches()
     env.sim.batch.close()
     out["f110env_1env"] = {"workload": "F110Env(num_agents=%d).step(action): 1 env, host actions, obs dict with scans (BASELINE configs[0] through the HIP path)" % A,
-                           "us_per_step": 1e6 * dt, "env_steps_per_s": 1.0 / dt, "value": A / dt, "unit": "agent-steps/s"}
+                           "us_per_step": 1e6 * dt, "env_steps_per_s": 1.0 / dt, "value": A / dt, "unit": "agent-steps/s",
+                           "kernel_launches_per_step": {1: "1 (k_step_tiny)", 0: "per-kernel form"}.get(launches, launches)}
+    # the reference's example loop (examples/waypoint_follow.py:272-285): ONE car
+    env = amd.F110Env(**dict(kw, num_agents=1))
+    env.reset(start_poses_for(shard_envs(1, 0), 1))
+    dt1 = timed(lambda: env.step(np.array([[0.05, 3.0]])), 3000, 200)
+    env.sim.batch.close()
+    out["f110env_1env_1car"] = {"workload": "F110Env(num_agents=1).step(action): the reference's example loop shape", "us_per_step": 1e6 * dt1, "value": 1.0 / dt1,
+                                "unit": "agent-steps/s"}
     for E in (2048, 32768):
         poses = start_poses_for(shard_envs(E, 0), A).reshape(E, A, 3)
         act = np.stack([a.reshape(E, A, 2) for a in action_sets(1, E * A, seed=1000)])[0]
@@ -1097,6 +1106,7 @@ def main(argv=None, ident=None):
         if not args.no_dropin and args.beams == 1080 and args.map_tiles == 1:
             line["config"]["dropin"] = dropin_rates(args)
             line["config"]["configs0_f110env_us_per_step"] = line["config"]["dropin"]["f110env_1env"]["us_per_step"]
+            line["config"]["configs0_f110env_1car_us_per_step"] = line["config"]["dropin"]["f110env_1env_1car"]["us_per_step"]
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             line["parity_gate"] = parity_gate(args, rdv)

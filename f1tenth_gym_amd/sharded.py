@@ -235,7 +235,9 @@ class ShardedVecEnv(object):
         """per shard (= per device): (scans DeviceArray [shards][N_k][B], scalars DeviceArray [shards][7][N_k] in
         BatchSim.OBS_SCALARS order) — every shard's observation of the step just taken, on this shard's GPU; valid once
         the shard's stream has passed the gather (`sync()` or stream-ordered work on device_views()['stream']).
-        With gather_root=k only shard k's buffers are written."""
+        With gather_root=k only shard k's buffers are written.  The scans are the step's; the scalar block is packed from the device
+        state when the gather runs, i.e. AFTER an `auto_reset` re-seat: a finished env shows its start pose there (its `done` and the
+        step's own scalars are in what step() returned)."""
         if self._gather is None:
             raise ValueError("built without gather_obs")
         return list(zip(self._gather["scans"], self._gather["scalars"]))
