@@ -136,6 +136,15 @@ def test_sharded_vec_env_big_observation_blocks(amd):
     sh.close(); one.sim.batch.close()
 
 
+def test_example_sharded_vec_env_runs(amd):
+    """examples/sharded_vec_env.py: two handles on device 0, with and without bringing the scans to the host"""
+    ex = os.path.join(ROOT, "examples", "sharded_vec_env.py")
+    for extra in ([], ["--scans"]):
+        out = subprocess.run([sys.executable, ex, "--envs", "256", "--devices", "0,0", "--steps", "40"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             text=True, timeout=600)
+        assert out.returncode == 0 and "agent-steps/s" in out.stdout and "2 handle(s)" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+
+
 def test_sharded_vec_env_gathers_the_observation_on_one_device(amd):
     """gather_obs=True: after each step every shard's device holds every shard's scans + scalars = the single handle's observation in
     blocks (all-gather float64, and float32 to one root) — four handles on device 0, the RCCL stand-in (tests/rccl_stub/sharded_gather.py)"""
