@@ -69,6 +69,12 @@ fuzzlong)   # the fuzzers by hand, far beyond the seeds the suite runs (suppleme
     bad=0; for sd in $(seq 12 41); do timeout 300 python tools/debug/fuzz_units.py $sd > $OUT/fl_units.log 2>&1 || bad=$((bad+1)); grep -q "False" $OUT/fl_units.log && bad=$((bad+1)); done
     echo "fuzz_units seeds 12..41: $bad seed(s) with a failure or an inexact line"; } | tee $OUT/fuzz_long.txt
   ;;
+soak)   # long auto-reset loops on the final sources: does memory stay flat, do the forms keep agreeing with themselves?
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  tools/debug/long_run_memory.py 300000 E (F110VecEnv device_logic auto_reset, noise from a 64-row cache: episodes beyond it continue from the carried stream state)"
+    echo "## 16 envs x 2 (the per-kernel host path)"; timeout 600 python tools/debug/long_run_memory.py 300000 16 2>&1 | tail -13
+    echo "## 2 envs x 2 (4 agents: k_step_tiny while every live episode is inside the row cache, the per-kernel form with k_noise_rows beyond it — the run switches between the two forms thousands of times)"; timeout 600 python tools/debug/long_run_memory.py 300000 2 2>&1 | tail -13
+    echo "## ShardedVecEnv: 4096 envs x 2 over four handles on device 0, 20 000 steps"; timeout 900 python examples/sharded_vec_env.py --envs 4096 --devices 0,0,0,0 --steps 20000 2>&1 | tail -2; } | tee $OUT/soak.txt
+  ;;
 tiny)   # k_step_tiny: the A/B tests (lab build) + the golden / oracle tests that now run through it (product), then F110Env's step time
   F110_LIB_VARIANT=experimental F110_NESTED_SUITE=1 timeout 900 python -m pytest tests/test_gpu_round6.py -m gpu -q -x -k "tiny or one_launch" > $OUT/pytest_tiny_lab.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_tiny_lab.log; tail -15 $OUT/pytest_tiny_lab.log | cut -c1-250
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round4.py -m gpu -q -x --deselect tests/test_gpu_round2.py::test_fuzz_parity_bounded_seeds --deselect tests/test_gpu_round2.py::test_fuzz_units_seeds > $OUT/pytest_tiny_product.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_tiny_product.log; tail -8 $OUT/pytest_tiny_product.log | cut -c1-250
