@@ -414,6 +414,19 @@ def test_which_steps_take_the_one_launch_form(amd):
         s.close()
 
 
+@pytest.mark.parametrize("A", [2, 1])
+def test_f110env_episodes_switch_between_the_step_forms_vs_oracle(amd, A):
+    """tools/debug/f110env_soak.py: F110Env driven reset() / step() until done / reset() ... against the oracle at every step, the noise
+    generator's row cache cut to 64 rows — episodes that outlive it leave the one-launch form for the per-kernel form in mid-episode,
+    the next reset() brings it back: both forms and the switches between them must show up, and nothing may differ"""
+    spec = importlib.util.spec_from_file_location("f110env_soak", os.path.join(ROOT, "tools", "debug", "f110env_soak.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    res = m.run(episodes=25, A=A, verbose=False)
+    assert res, "mismatch against the oracle"
+    forms, switches = res
+    assert forms[1] > 100 and forms[0] > 100 and switches >= 4, (forms, switches)
+
+
 NESTED = bool(os.environ.get("F110_NESTED_SUITE"))
 
 
