@@ -29,12 +29,13 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--gather", action="store_true", help="all-gather the observation over the shards after every step")
     ap.add_argument("--scans", action="store_true", help="also bring the scans to the host every step (8.6 KB per agent)")
+    ap.add_argument("--threaded", type=int, default=-1, help="1 / 0: step the shards from one worker thread each / enqueue all then wait all (default: the class decides)")
     args = ap.parse_args(argv)
     E, A = args.envs, args.agents
     devices = [int(d) for d in args.devices.split(",")]
     fields = ("poses_x", "poses_y", "collisions") + (("scans",) if args.scans else ())
     env = amd.ShardedVecEnv(E, devices=devices, gather_obs=args.gather, map=workload.map_stem("example_map"), map_ext=".png", num_agents=A,
-                            auto_reset=True, obs_fields=fields)
+                            auto_reset=True, obs_fields=fields, threaded_step=None if args.threaded < 0 else bool(args.threaded))
     obs, _, done, info = env.reset(workload.bench_start_poses(E, A).reshape(E, A, 3))
     rng = np.random.default_rng(0)
     act = np.stack([rng.uniform(-0.2, 0.2, (E, A)), rng.uniform(2.0, 6.0, (E, A))], axis=2)
@@ -49,8 +50,9 @@ def main(argv=None):
         n_done += int(done.sum())
     env.sync()
     dt = (time.perf_counter() - t0) / args.steps
-    print("%d envs x %d agents over %d handle(s) on devices %s: %.3f ms per step, %.1f M agent-steps/s; %d episodes ended and were re-seated%s"
-          % (E, A, len(devices), devices, dt * 1e3, E * A / dt / 1e6, n_done, "; observation gathered to every device" if args.gather else ""))
+    print("%d envs x %d agents over %d handle(s) on devices %s (%s): %.3f ms per step, %.1f M agent-steps/s; %d episodes ended and were re-seated%s"
+          % (E, A, len(devices), devices, "one worker thread per shard" if env.threaded_step else "enqueue all, then wait all", dt * 1e3, E * A / dt / 1e6, n_done,
+             "; observation gathered to every device" if args.gather else ""))
     if args.gather:
         d_scans, d_scal = env.gathered_views()[0]
         print("shard 0 holds scans %s and scalars %s of every shard" % (d_scans.shape, d_scal.shape))

@@ -70,7 +70,7 @@ def _wait(pending):
 
 
 class ShardedVecEnv(object):
-    def __init__(self, num_envs, devices=(0,), gather_obs=False, gather_f32=False, gather_root=None, shard_sizes=None, **kwargs):
+    def __init__(self, num_envs, devices=(0,), gather_obs=False, gather_f32=False, gather_root=None, shard_sizes=None, threaded_step=None, **kwargs):
         self.num_envs = E = int(num_envs)
         self.devices = [int(d) for d in devices]
         K = len(self.devices)
@@ -101,6 +101,14 @@ class ShardedVecEnv(object):
             self.close()
             raise
         self.device_logic = self.shards[0].device_logic
+        # How step() reaches the shards.  With the episode logic on the devices a shard's step splits into an enqueue that returns at
+        # once and a wait (F110VecEnv.step_async / step_wait): the caller's thread enqueues every shard, then waits for every shard —
+        # the GPUs run side by side and no thread hand-off (two futex wake-ups per shard and step) is paid.  The worker threads carry
+        # the step when it cannot be split (host-side episode logic) or when the observation includes the scans (each worker copies its
+        # own block out of its page-locked memory: those copies are what should overlap).  threaded_step=True / False forces one form.
+        if threaded_step is None:
+            threaded_step = not self.device_logic or "scans" in self.shards[0].obs_fields
+        self.threaded_step = bool(threaded_step) or not self.device_logic
         self._out = None
         self._gather = None
         if gather_obs:
@@ -154,7 +162,12 @@ class ShardedVecEnv(object):
     def step(self, actions):
         acts = [None] * len(self.shards) if actions is None else \
             self._slices(np.asarray(actions, dtype=np.float64).reshape(self.num_envs, self.num_agents, 2))
-        parts = self._each(lambda k, s: s.step(acts[k]))
+        if self.threaded_step:
+            parts = self._each(lambda k, s: s.step(acts[k]))
+        else:
+            for k, s in enumerate(self.shards):      # enqueue everywhere (returns at once) ...
+                s._step_device(acts[k], sync=False)
+            parts = [s.step_wait() for s in self.shards]   # ... then wait everywhere
         self._after_step()
         return self._assemble(parts)
 

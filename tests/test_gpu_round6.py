@@ -91,7 +91,9 @@ def test_sharded_vec_env_equals_one_handle(amd, devices, sizes, device_logic):
     E, A, T = 37, 2, 70
     kw = dict(map=map_stem("example_map"), map_ext=".png", num_agents=A, auto_reset=True, device_logic=device_logic)
     one = amd.F110VecEnv(E, **kw)
-    sh = amd.ShardedVecEnv(E, devices=devices, shard_sizes=sizes, **kw)
+    # (both ways of reaching the shards: enqueue-all-then-wait-all from the caller's thread, and one worker thread per shard)
+    sh = amd.ShardedVecEnv(E, devices=devices, shard_sizes=sizes, threaded_step=(len(devices) == 3), **kw)
+    assert sh.threaded_step == (len(devices) == 3 or not device_logic)
     assert sh.shard_sizes == (sizes or [E // len(devices) + (1 if k < E % len(devices) else 0) for k in range(len(devices))])
     poses = bench_start_poses(E, A, gap_wp=4).reshape(E, A, 3)
 
