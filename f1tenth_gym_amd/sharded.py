@@ -125,6 +125,8 @@ class ShardedVecEnv(object):
     def _assemble(self, parts):
         """parts[k] = (obs, reward, done, info) of shard k -> one tuple over the global env axis.  The output arrays are
         allocated once and refilled (like F110VecEnv's views they are OVERWRITTEN by the next step: copy what you keep)."""
+        if len(parts) == 1:
+            return parts[0]           # one shard: its own tuple (views of its page-locked block, as F110VecEnv hands them out)
         if self._out is None:
             def alloc(v):
                 return np.empty((self.num_envs,) + v.shape[1:], dtype=v.dtype)
@@ -142,9 +144,9 @@ class ShardedVecEnv(object):
             done[lo:hi] = d
             for name, v in i.items():
                 info[name][lo:hi] = v
-        nbytes = sum(v.nbytes for v in obs.values() if isinstance(v, np.ndarray))
-        if nbytes >= (8 << 20) and len(parts) > 1:
-            self._each(fill)          # big observations (scans): every worker copies its own block, the copies overlap
+        nbytes = sum(v.nbytes for v in obs.values() if isinstance(v, np.ndarray)) + sum(v.nbytes for v in info.values()) + done.nbytes
+        if nbytes >= (1 << 20):
+            self._each(fill)          # more than a thread hand-off's worth of bytes: every worker copies its own block, the copies overlap
         else:
             for k in range(len(parts)):
                 fill(k)
