@@ -145,8 +145,10 @@ class ShardedVecEnv(object):
             for name, v in i.items():
                 info[name][lo:hi] = v
         nbytes = sum(v.nbytes for v in obs.values() if isinstance(v, np.ndarray)) + sum(v.nbytes for v in info.values()) + done.nbytes
-        if nbytes >= (1 << 20):
-            self._each(fill)          # more than a thread hand-off's worth of bytes: every worker copies its own block, the copies overlap
+        if nbytes >= (8 << 20):
+            # big blocks (the scans): every worker copies its own, the copies overlap.  Below that the hand-offs cost more than the
+            # copies (measured: 32 768 envs over 8 handles, 4.6 MB per step: 1.24 ms serial, 1.63 ms through the workers)
+            self._each(fill)
         else:
             for k in range(len(parts)):
                 fill(k)
