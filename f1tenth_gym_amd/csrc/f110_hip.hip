@@ -49,6 +49,10 @@ struct ExpSwitches {
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
     int group_split = 0;       // two env groups: percent of the envs in the first (0 = even)
     int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
+    int tiny_start_probe = 0;  // k_step_tiny tells the host when its first workgroup starts (f110_step_host times launch -> start -> done)
+    long probe_calls = 0;
+    double probe_us[3] = {0, 0, 0};
+    uint64_t tiny_trace = 0;   // device address of a caller-owned [workgroups][16] uint64 buffer: k_step_tiny's phase stamps (0 = off)
     uint64_t scan_trace = 0;   // device address of a caller-owned [waves][8] uint64 buffer: clock stamps, hardware id, samples of every scan wave (0 = off)
 };
 
@@ -109,6 +113,14 @@ struct f110_sim {
     U128 *d_rng_state = nullptr, *d_rng_seed = nullptr, *d_rng_rowstate = nullptr;
     int noise_rows_ready = 0;        // rows of the row cache generated so far
     int noise_rows_alloc = 0;        // rows the row cache has memory for (grows on demand up to dev.noise_rows)
+    // the next rows are generated AHEAD of need on a stream of their own (noise_start_ahead): a row is 12.8 us of one wave, the rows of a
+    // stream come one after the other, and a step that waits for them pays that in full (measured, F110Env: +13 us on every step of a first episode)
+    hipStream_t noise_stream = nullptr;
+    hipEvent_t ev_noise = nullptr, ev_noise_src = nullptr;
+    bool noise_ahead = false;        // rows [noise_rows_ready, noise_ahead_upto) are being generated into noise_ahead_block
+    int noise_ahead_upto = 0, noise_ahead_alloc = 0;
+    double *noise_ahead_block = nullptr;
+    std::vector<double *> noise_retired;   // earlier, smaller blocks of the cache (steps in flight may read them): freed with the cache
     long long noise_ub = 0;          // upper bound of any agent's step_count (steps since the last full reset)
     unsigned long long *d_lookups = nullptr;  // f110_scan_lookup_count
     bool lookups_on = false;
@@ -163,6 +175,7 @@ struct f110_sim {
     void *tiny_mem = nullptr;
     int tiny_off = 0;                 // lab A/B (f110_exp_set "step_tiny" = 0): the three-kernel form also for tiny batches
     int last_launches = 0;            // kernels the most recent step submitted its work as (f110_step_launches)
+    const double *tiny_actions_host = nullptr;   // f110_step_host -> step_tiny: the caller's [N][2] actions (host memory), for this call
     bool tiny_request = false;        // f110_step_host: this step is one k_step_tiny launch
     bool tiny_host_request = false;   // ... with one agent per env: what k_host_block would be handed
     HostBlock tiny_hb{};
@@ -243,6 +256,7 @@ static int join_groups(f110_sim *h)
     } while (0)
 
 static bool tiny_applies(const f110_sim *h);   // (below, with the step)
+static void noise_release(f110_sim *h);        // (below, with the noise entry points)
 
 // RAII scratch for the unit entry points
 struct Scratch {
@@ -428,6 +442,16 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
     else if (k == "integrate_fan") h->exp.integrate_fan = value;
     else if (k == "group_split") h->exp.group_split = value;
     else if (k == "step_tiny") h->tiny_off = value == 0 ? 1 : 0;
+    else if (k == "tiny_start_probe") {   // 1: k_step_tiny's first workgroup reports its start to the host; 0: print launch -> start -> word and stop
+        if (!value && h->exp.tiny_start_probe && h->exp.probe_calls)
+            std::fprintf(stderr, "[tiny_start_probe] %ld steps: call -> launched %.2f us, launched -> first wave seen %.2f us, first wave seen -> completion word seen %.2f us\n",
+                         h->exp.probe_calls, h->exp.probe_us[0] / h->exp.probe_calls, h->exp.probe_us[1] / h->exp.probe_calls, h->exp.probe_us[2] / h->exp.probe_calls);
+        h->exp.tiny_start_probe = value;
+        h->exp.probe_calls = 0;
+        h->exp.probe_us[0] = h->exp.probe_us[1] = h->exp.probe_us[2] = 0;
+    }
+    else if (k == "tiny_trace_hi") h->exp.tiny_trace = (h->exp.tiny_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
+    else if (k == "tiny_trace_lo") h->exp.tiny_trace = (h->exp.tiny_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
     else if (k == "scan_trace_lo") h->exp.scan_trace = (h->exp.scan_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "collide_mode") {
@@ -800,6 +824,10 @@ void f110_destroy(f110_sim *h)
     for (hipEvent_t ge : h->gevents)
         if (ge) (void)hipEventDestroy(ge);
     if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+    noise_release(h);
+    if (h->noise_stream) (void)hipStreamDestroy(h->noise_stream);
+    if (h->ev_noise) (void)hipEventDestroy(h->ev_noise);
+    if (h->ev_noise_src) (void)hipEventDestroy(h->ev_noise_src);
     {
         void *rp[] = {h->d_env_done, h->d_tflags[0], h->d_tflags[1], h->d_tlist[0], h->d_tlist[1], h->d_tcount, h->d_zig_k, h->d_zig_w, h->d_zig_f, h->d_jump, h->d_rng_state, h->d_rng_seed, h->d_rng_rowstate, h->d_lookups};
         for (void *p : rp)
@@ -1203,9 +1231,16 @@ int f110_set_params(f110_sim *h, int32_t agent_idx, const double *p)
 }
 
 static int noise_cache_extend(f110_sim *h, int upto);
+static int noise_adopt(f110_sim *h);
 
 static void noise_release(f110_sim *h)
 {
+    if (h->noise_stream) (void)hipStreamSynchronize(h->noise_stream);
+    if (h->noise_ahead && h->noise_ahead_block && h->noise_ahead_block != h->d_noise) (void)hipFree(h->noise_ahead_block);
+    h->noise_ahead = false;
+    h->noise_ahead_block = nullptr;
+    for (double *p : h->noise_retired) (void)hipFree(p);
+    h->noise_retired.clear();
     if (h->d_noise) { (void)hipFree(h->d_noise); h->d_noise = nullptr; }
     if (h->d_rng_state) { (void)hipFree(h->d_rng_state); h->d_rng_state = nullptr; }
     if (h->d_rng_seed) { (void)hipFree(h->d_rng_seed); h->d_rng_seed = nullptr; }
@@ -1289,6 +1324,7 @@ int f110_noise_prepare(f110_sim *h, int32_t rows)
     if (!h) return fail(nullptr, F110_ERR_INVALID, "null handle");
     ENTER(h);
     if (h->dev.noise_rng != 1) return F110_OK;
+    TRY(noise_adopt(h));
     return noise_cache_extend(h, rows);
 }
 
@@ -1884,8 +1920,9 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
     const double *d_act = h->d_actions;
     if (mapped_actions)
         d_act = h->hb_actions_dev;   // k_integrate reads the [N][2] block over PCIe, once, coalesced
-    else
+    else if (!tiny)                  // (k_step_tiny gets the actions as kernel arguments)
         HIPCHK(h, hipMemcpyAsync(h->d_actions, h_actions, sizeof(double) * 2 * N, hipMemcpyHostToDevice, h->stream));
+    h->tiny_actions_host = tiny ? h_actions : nullptr;
     const int A = h->cfg.num_agents;
     HostBlock hbk = h->hb_dev;
     if (spin) {
@@ -1927,6 +1964,7 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
     const int rc_step = f110_step_device(h, d_act);
     h->fuse_request = false;
     h->tiny_request = h->tiny_host_request = false;
+    h->tiny_actions_host = nullptr;
     if (rc_step != F110_OK) return rc_step;
     ENTER(h);
     if (!h->fused_done) {
@@ -1944,6 +1982,16 @@ int f110_step_host(f110_sim *h, const double *h_actions, const f110_host_block *
         const unsigned long long want = h->hb_seq;
         const volatile unsigned long long *w = h->hb_seq_host;
         bool seen = false;
+        if (kExperimental && h->exp.tiny_start_probe && tiny && h->tiny.start_word) {
+            for (long it = 0; it < 200000000L && __atomic_load_n(w + 1, __ATOMIC_ACQUIRE) != want; ++it) __builtin_ia32_pause();
+            const auto t_start = std::chrono::steady_clock::now();
+            for (long it = 0; it < 200000000L && __atomic_load_n(w, __ATOMIC_ACQUIRE) != want; ++it) __builtin_ia32_pause();
+            const auto t_done = std::chrono::steady_clock::now();
+            h->exp.probe_calls += 1;
+            h->exp.probe_us[0] += std::chrono::duration<double, std::micro>(t_enq - t_in).count();
+            h->exp.probe_us[1] += std::chrono::duration<double, std::micro>(t_start - t_enq).count();
+            h->exp.probe_us[2] += std::chrono::duration<double, std::micro>(t_done - t_start).count();
+        }
         for (long it = 0; it < 2000000000L; ++it) {
             if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == want) {
                 seen = true;
@@ -2058,8 +2106,7 @@ static int noise_cache_extend(f110_sim *h, int upto)
         double *bigger = nullptr;
         TRY(dmalloc(h, &bigger, (size_t)want * B));
         HIPCHK(h, hipMemcpyAsync(bigger, h->d_noise, sizeof(double) * (size_t)h->noise_rows_ready * B, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));   // earlier steps may still read the old block
-        (void)hipFree(h->d_noise);
+        h->noise_retired.push_back(h->d_noise);   // earlier steps (env blocks on their own streams) may still read the old block
         h->d_noise = bigger;
         h->dev.noise = bigger;
         h->noise_rows_alloc = want;
@@ -2094,6 +2141,60 @@ static ScanKind pick_scan(const f110_sim *h, int begin, int count)
     if (!(h->multi_map || agent_aligned(h))) return SCAN_FLAT;
     if (h->task_order && !h->multi_map && !h->lookups_on && begin == 0 && count == h->N && !h->exp.scan_env_counter) return SCAN_AGENT_SCHED;
     return SCAN_AGENT;
+}
+
+// The next doubling of the row cache, started on the noise stream when HALF of the rows there are have been used: generation (12.8 us a
+// row) is faster than any step loop uses rows (a step of one env takes 30 us and more), so the rows are there when the episode reaches
+// them and no step waits.  The rows so far are immutable; a cache that outgrows its memory continues in a new block (old rows copied
+// on the same stream), which becomes THE cache at adoption — kernels get the block's address with every launch.
+static int noise_start_ahead(f110_sim *h)
+{
+    const int cap = h->dev.noise_rows, ready = h->noise_rows_ready;
+    const int upto = (int)std::min<long long>(cap, 2LL * ready);
+    if (h->noise_ahead || upto <= ready) return F110_OK;
+    if (!h->noise_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->noise_stream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_noise, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_noise_src, hipEventDisableTiming));
+    }
+    const size_t B = (size_t)h->cfg.num_beams;
+    // behind whatever produced the rows so far (the main stream: f110_set_noise_rng, a step that could not wait; or this stream)
+    HIPCHK(h, hipEventRecord(h->ev_noise_src, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->noise_stream, h->ev_noise_src, 0));
+    double *block = h->d_noise;
+    int alloc = h->noise_rows_alloc;
+    if (upto > alloc) {
+        alloc = std::min(cap, std::max(2 * alloc, upto));
+        block = nullptr;
+        TRY(dmalloc(h, &block, (size_t)alloc * B));
+        HIPCHK(h, hipMemcpyAsync(block, h->d_noise, sizeof(double) * (size_t)ready * B, hipMemcpyDeviceToDevice, h->noise_stream));
+    }
+    hipLaunchKernelGGL(k_noise_cache, dim3(1), dim3(64), 0, h->noise_stream, h->noise_gen, h->dev.rng_inc, h->d_rng_rowstate, block, ready, upto, h->cfg.num_beams);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev_noise, h->noise_stream));
+    h->noise_ahead = true;
+    h->noise_ahead_upto = upto;
+    h->noise_ahead_alloc = alloc;
+    h->noise_ahead_block = block;
+    return F110_OK;
+}
+
+// ... and taken over by the main stream (which waits for them, if they are not there yet)
+static int noise_adopt(f110_sim *h)
+{
+    if (!h->noise_ahead) return F110_OK;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_noise, 0));
+    if (h->noise_ahead_block != h->d_noise) {
+        h->noise_retired.push_back(h->d_noise);
+        h->d_noise = h->noise_ahead_block;
+        h->dev.noise = h->d_noise;
+        h->noise_rows_alloc = h->noise_ahead_alloc;
+    }
+    h->noise_rows_ready = h->noise_ahead_upto;
+    h->noise_ahead = false;
+    h->noise_ahead_block = nullptr;
+    h->main_dirty = true;
+    return F110_OK;
 }
 
 // ---- the whole step of a tiny batch as ONE launch (k_step_tiny) ----------------------------------------------------------
@@ -2158,6 +2259,20 @@ static int step_tiny(f110_sim *h, hipStream_t st, const double *d_actions)
     j.k_cold = cold_consts(h);
     if (!j.k_cold) return fail(h, F110_ERR_HIP, "f110_step_device: constant upload failed");
     h->tiny.tasks_per_agent = ((uint32_t)h->k.num_beams + 63u) / 64u;
+    h->tiny.trace = kExperimental ? reinterpret_cast<unsigned long long *>(h->exp.tiny_trace) : nullptr;
+    h->tiny.act_inline = 0;
+    if (h->tiny_actions_host && N <= kTinyMaxAgents) {   // f110_step_host: the caller's actions travel with the launch
+        std::memcpy(h->tiny.act, h->tiny_actions_host, sizeof(double) * 2 * (size_t)N);
+        h->tiny.act_inline = 1;
+    }
+    h->tiny.start_word = nullptr;
+    h->tiny.skip = kExperimental && h->exp.tiny_start_probe == 2 ? 1 : 0;
+    if (kExperimental && h->exp.tiny_start_probe && h->hb_seq_host && h->fuse_seq) {
+        void *p = nullptr;
+        TRY(map_host_ptr(h, h->hb_seq_host, &p, "completion word"));
+        h->tiny.start_word = reinterpret_cast<unsigned long long *>(p) + 1;
+        h->tiny.start_seq = h->hb_seq;
+    }
     const dim3 grid(((unsigned)N * h->tiny.tasks_per_agent + 3u) / 4u), block(256);
     EpisodeArrays ep{};
     HostBlock hb{};
@@ -2504,10 +2619,16 @@ int f110_step_device(f110_sim *h, const double *d_actions)
         h->comm_swap_next = false;
     }
     // shared noise stream: the row cache must reach the longest live episode (or its capacity)
-    if (h->dev.noise_rng == 1 && h->noise_ub >= h->noise_rows_ready && h->noise_rows_ready < h->dev.noise_rows) {
-        TRY(join_groups(h));
-        const long long want = std::max<long long>(2LL * h->noise_rows_ready, h->noise_ub + 1);
-        TRY(noise_cache_extend(h, (int)std::min<long long>(want, h->dev.noise_rows)));
+    if (h->dev.noise_rng == 1 && h->noise_rows_ready < h->dev.noise_rows) {
+        if (h->noise_ub >= h->noise_rows_ready) {
+            TRY(join_groups(h));
+            TRY(noise_adopt(h));   // the rows generated ahead
+            if (h->noise_ub >= h->noise_rows_ready && h->noise_rows_ready < h->dev.noise_rows) {   // (not enough: in line, this step waits)
+                const long long want = std::max<long long>(2LL * h->noise_rows_ready, h->noise_ub + 1);
+                TRY(noise_cache_extend(h, (int)std::min<long long>(want, h->dev.noise_rows)));
+            }
+        }
+        if (!h->noise_ahead && 2 * (h->noise_ub + 1) >= h->noise_rows_ready) TRY(noise_start_ahead(h));
     }
     const bool prof = h->profiling && h->prof_used + 4 <= 4 * 65536;
     // the env groups need the agent-aligned scan (a launch per agent range); per-kernel profiling

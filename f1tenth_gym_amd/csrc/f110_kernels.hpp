@@ -2308,7 +2308,13 @@ struct TinyCtl {
     double *dir_start;       // [N]
     RayHdr *ray_hdr;         // [N]
     uint32_t tasks_per_agent, pad_;
+    unsigned long long *trace;   // lab timeline probe: [workgroups][16] stamps of the 100 MHz clock (nullptr = off)
+    int act_inline;              // 1: the actions are `act` below (f110_step_host copied them into the launch: no read over PCIe inside the step)
+    int skip;                    // lab: 1 = the launch only reports start and completion (what does the dispatch itself cost?)
+    double act[8];               // [kTinyMaxAgents][2] (steer, velocity)
+    unsigned long long *start_word, start_seq;   // lab: a word in page-locked host memory the first workgroup stores start_seq to as it starts
 };
+static_assert(sizeof(TinyCtl::act) == 8 * sizeof(double), "TinyCtl::act holds kTinyMaxAgents actions");
 constexpr int kTinyMaxAgents = 4;   // (measured: beyond a handful of agents the per-kernel form wins, f110_hip.hip tiny_applies)
 
 template <bool PAIR, bool IDENT, bool HOST>
@@ -2319,6 +2325,25 @@ __global__ void __launch_bounds__(256) k_step_tiny(AgentArrays a, ScanConst k, R
     const int N = a.n_agents_total, B = k.num_beams;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t task = blockIdx.x * 4u + wave;
+#ifdef F110_EXPERIMENTAL
+#define TINY_STAMP(slot)                                                                                         \
+    do {                                                                                                         \
+        if (ctl.trace && threadIdx.x == 0) ctl.trace[16ull * blockIdx.x + (slot)] = wall_clock64();             \
+    } while (0)
+#else
+#define TINY_STAMP(slot) do { } while (0)
+#endif
+    TINY_STAMP(0);   // the workgroup's first wave is running
+#ifdef F110_EXPERIMENTAL
+    if (ctl.start_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ctl.start_word, ctl.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (ctl.skip) {   // the dispatch alone: start word, completion word, nothing else
+        if (ctl.start_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ctl.start_word - 1, ctl.start_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+#endif
+    AgentArrays sh = a;      // the step's view: what integration produces and the tail works on
+    sh.state = ctl.state; sh.steer_buf = ctl.steer_buf; sh.buf_cnt = ctl.buf_cnt; sh.scan_pose = ctl.scan_pose;
+    sh.snap_pose = ctl.snap_pose; sh.dir_start = ctl.dir_start; sh.ray_hdr = ctl.ray_hdr; sh.in_collision = ctl.wall;
     if (task < (uint32_t)N * ctl.tasks_per_agent) {
         const int i = (int)(task / ctl.tasks_per_agent);
         const uint32_t sub = task - (uint32_t)i * ctl.tasks_per_agent;
@@ -2329,17 +2354,27 @@ __global__ void __launch_bounds__(256) k_step_tiny(AgentArrays a, ScanConst k, R
         for (int c = 0; c < 7; ++c) st[c] = a.state[(size_t)c * N + i];
         double b0 = a.steer_buf[i], b1 = a.steer_buf[(size_t)N + i];
         int cnt = a.buf_cnt[i];
-        const double2 act = reinterpret_cast<const double2 *>(actions)[i];
+        double2 act;
+        if (ctl.act_inline) {   // (i < 4: selects on kernel arguments)
+            act.x = i == 0 ? ctl.act[0] : i == 1 ? ctl.act[2] : i == 2 ? ctl.act[4] : ctl.act[6];
+            act.y = i == 0 ? ctl.act[1] : i == 1 ? ctl.act[3] : i == 2 ? ctl.act[5] : ctl.act[7];
+        } else {
+            act = reinterpret_cast<const double2 *>(actions)[i];
+        }
         double sp[3];
         advance_vehicle(st, b0, b1, cnt, act.x, act.y, vp, a.time_step, a.integrator, a.lidar_dist, sp);
         const double start = scan_start_index(k, sp[2]);
         const RayHdr hd = make_ray_hdr(a, k, i, st, sp, start);
+#ifdef F110_EXPERIMENTAL
+        if (ctl.trace) {
+            double probe = hd.d0;
+            asm volatile("" : "+v"(probe));   // (the header's table sample has arrived)
+        }
+#endif
+        TINY_STAMP(1);   // integration + ray header done (wave 0 of the workgroup)
         if (sub == 0u && lane == 0u) {   // the agent's new columns, into the shadow (the live ones are still being read)
-            AgentArrays sh = a;
-            sh.state = ctl.state; sh.steer_buf = ctl.steer_buf; sh.buf_cnt = ctl.buf_cnt; sh.scan_pose = ctl.scan_pose;
-            sh.snap_pose = ctl.snap_pose; sh.dir_start = ctl.dir_start;
             integrate_store_columns(sh, i, N, st, b0, b1, cnt, sp, start);
-            ctl.ray_hdr[i] = hd;
+            sh.ray_hdr[i] = hd;
         }
         // get_scan for the task's 64 beams (k_scan_rays_agent's body)
         const int b = (int)(sub * 64u + lane);
@@ -2360,14 +2395,20 @@ __global__ void __launch_bounds__(256) k_step_tiny(AgentArrays a, ScanConst k, R
             if (row != -1) r += nz;
             // check_ttc_jit's predicate for this beam (finish_beam_with), the flag into the step's own column
             if (hd.vel != 0.0 && !(r > j.ttc_side_max + j.ttc_k * fabs(hd.vel)) && ttc_beam_hit(r, j.side_dist[b], hd.vel, j.beam_cos[b], j.ttc_thresh))
-                ctl.wall[i] = 1;
+                sh.in_collision[i] = 1;
             a.scans[(size_t)i * B + b] = r;
         }
     }
+    TINY_STAMP(2);   // wave 0's beams marched and stored
     // ---- who is last?
-    __threadfence();     // release: this wave's rows, flags and shadow columns are visible device-wide (other XCDs' L2s included)
+    // Release, once per workgroup: every wave waits for its own stores to be in L2 (vmcnt 0), the barrier collects the waves, and ONE
+    // lane writes the L2 back at agent scope before it counts the workgroup done (a fence by every wave measured 7 us here, the
+    // write-backs queueing behind one another: profiles/r06_launch_latency.txt).
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+    TINY_STAMP(3);   // every wave of the workgroup has its stores in L2
     if (threadIdx.x == 0) {
+        __threadfence();     // this workgroup's rows, flags and shadow columns are visible device-wide (other XCDs' L2s included)
         const unsigned int prev = __hip_atomic_fetch_add(ctl.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev == gridDim.x - 1u ? 1 : 0;
         if (s_last) __hip_atomic_store(ctl.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2375,42 +2416,49 @@ __global__ void __launch_bounds__(256) k_step_tiny(AgentArrays a, ScanConst k, R
     __syncthreads();
     if (!s_last) return;
     __threadfence();     // acquire: what the other workgroups released
-    // ---- the last workgroup: shadow -> live, then Simulator.step's tail
-    for (int i = (int)threadIdx.x; i < N; i += 256) {
-#pragma unroll
-        for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = ctl.state[(size_t)c * N + i];
-        a.steer_buf[i] = ctl.steer_buf[i];
-        a.steer_buf[(size_t)N + i] = ctl.steer_buf[(size_t)N + i];
-        a.buf_cnt[i] = ctl.buf_cnt[i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            a.scan_pose[(size_t)c * N + i] = ctl.scan_pose[(size_t)c * N + i];
-            a.snap_pose[(size_t)c * N + i] = ctl.snap_pose[(size_t)c * N + i];
-        }
-        a.dir_start[i] = ctl.dir_start[i];
-        a.ray_hdr[i] = ctl.ray_hdr[i];
-        a.in_collision[i] = ctl.wall[i];
-        ctl.wall[i] = 0;
-    }
-    __syncthreads();
+    TINY_STAMP(4);   // the last workgroup knows it is the last
+    // ---- the last workgroup: Simulator.step's tail ON the shadow columns (sh; its in_collision is the step's flag column), the host
+    //      block and the completion word — and only then shadow -> live, which nobody waits for
+    TINY_STAMP(5);
     if (PAIR) {
         constexpr int AG = 4;
         for (int first = 0; first < N; first += AG) {
-            finalize_pair_body<AG, HOST>(a, B, first, N);
+            finalize_pair_body<AG, HOST>(sh, B, first, N);
             __syncthreads();   // the body's LDS is reused by the next group
         }
+        TINY_STAMP(6);   // finalize + host block stores issued
         if (HOST && a.fused_seq) {
             HostBlock sig = a.fused_host->hb;
             sig.seq = a.fused_seq;
             host_block_signal_single(sig);
         }
+        TINY_STAMP(7);   // completion word stored
     } else {
-        for (int i = (int)threadIdx.x; i < N; i += 256) finalize_solo_agent(a, i);
+        for (int i = (int)threadIdx.x; i < N; i += 256) finalize_solo_agent(sh, i);
         if (HOST) {
             __syncthreads();
-            host_block_body<true>(a, ep, hb, 0, N, episode, auto_reset);   // one agent per env: N envs, all in this workgroup (N <= 64)
+            host_block_body<true>(sh, ep, hb, 0, N, episode, auto_reset);   // one agent per env: N envs, all in this workgroup (N <= 64)
         }
+        TINY_STAMP(7);
     }
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < N; i += 256) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) a.state[(size_t)c * N + i] = sh.state[(size_t)c * N + i];
+        a.steer_buf[i] = sh.steer_buf[i];
+        a.steer_buf[(size_t)N + i] = sh.steer_buf[(size_t)N + i];
+        a.buf_cnt[i] = sh.buf_cnt[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a.scan_pose[(size_t)c * N + i] = sh.scan_pose[(size_t)c * N + i];
+            a.snap_pose[(size_t)c * N + i] = sh.snap_pose[(size_t)c * N + i];
+        }
+        a.dir_start[i] = sh.dir_start[i];
+        a.ray_hdr[i] = sh.ray_hdr[i];
+        a.in_collision[i] = sh.in_collision[i];
+        sh.in_collision[i] = 0;      // (the flag column is left clear for the next launch)
+    }
+#undef TINY_STAMP
 }
 
 // The scalar part of Simulator.step's observation (base_classes.py:594-610), packed for the RCCL

@@ -81,6 +81,19 @@ tiny)   # k_step_tiny: the A/B tests (lab build) + the golden / oracle tests tha
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round2.py tests/test_gpu_round4.py -m gpu -q -x --deselect tests/test_gpu_round2.py::test_fuzz_parity_bounded_seeds --deselect tests/test_gpu_round2.py::test_fuzz_units_seeds > $OUT/pytest_tiny_product.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_tiny_product.log; tail -8 $OUT/pytest_tiny_product.log | cut -c1-250
   for i in 1 2 3; do timeout 120 python tools/debug/f110env_loop.py 3000 2>&1 | tail -1; done
   ;;
+latency)   # where a host-synchronised step of ONE env spends its time: the launch floor, k_step_tiny's phases, the host's view, the first episode
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')"
+    echo "## tools/debug/launch_latency2.hip: one launch + a completion word in page-locked memory, polled (no library of ours involved)"
+    hipcc --offload-arch=gfx950 -O2 -o /tmp/ll2 tools/debug/launch_latency2.hip 2>/dev/null && timeout 120 /tmp/ll2
+    echo "## tools/debug/tiny_timeline.py (lab build: phase stamps of the 100 MHz clock inside k_step_tiny)"
+    for a in 2 1; do F110_LIB_VARIANT=experimental timeout 300 python tools/debug/tiny_timeline.py $a 2000; done
+    echo "## tools/debug/tiny_start_probe.py (lab build: the first workgroup tells the host when it starts)"
+    for a in 2 1; do F110_LIB_VARIANT=experimental timeout 300 python tools/debug/tiny_start_probe.py $a 4000; done
+    echo "## tools/debug/tiny_drift.py (product build): BatchSim.step_host per block of 1000 steps from a fresh handle — the noise rows of a first episode are generated ahead of need"
+    for a in 2 1; do timeout 300 python tools/debug/tiny_drift.py $a 10 | head -24; done
+    echo "## tools/debug/f110env_loop.py 3000 (product build, a fresh F110Env each)"
+    for i in 1 2 3; do timeout 120 python tools/debug/f110env_loop.py 3000 2>&1 | tail -1; done; } 2>&1 | tee $OUT/launch_latency.txt
+  ;;
 tinyab)   # one launch vs three kernels on the shapes k_step_tiny serves (lab build carries the switch)
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  F110_LIB_VARIANT=experimental python tools/debug/tiny_ab.py"
     F110_LIB_VARIANT=experimental timeout 600 python tools/debug/tiny_ab.py 2>&1 | tail -6; } | tee $OUT/tiny_ab.txt
