@@ -447,18 +447,24 @@ def test_fuzz_host_block_step_vs_oracle(amd, first):
 def test_noise_rows_generated_ahead_of_need_are_numpys_stream(amd, E, A):
     """the shared noise stream (laser_models.py:450-452, rng re-seeded at reset: base_classes.py:204) is cached row by row; the next
     doubling of the cache is generated AHEAD of need on a stream of its own and taken over by the step that reaches it (f110_hip.hip
-    noise_start_ahead / noise_adopt), its memory continuing in a bigger block.  Cars at rest: scan(t) = range + row(t) with the SAME range
+    noise_start_ahead / noise_adopt), its memory continuing in a bigger block.  Cars at rest: scan(t) = min(range + row(t), opponent) with the SAME range
     every step, so row(t) must be NumPy's default_rng(12345).normal(0, 0.01, 1080) stream bit for bit — over 1400 steps (doublings at 256,
     512, 1024, two of them into new memory), a reset in the middle (rows start over, generation stays pending) and in both step forms
     (one launch for <= 4 agents, the per-kernel form for 96)"""
     B, T = 1080, 1400
     rows = np.random.default_rng(12345).normal(0., 0.01, size=(T + 2, B))
     poses = bench_start_poses(E, A)
-    quiet = amd.BatchSim(num_envs=E, num_agents=A, num_beams=B)
-    quiet.set_map(map_stem("example_map") + ".yaml", ".png")
-    quiet.reset(poses); quiet.step(np.zeros((E * A, 2)))
-    base = quiet.get("scans")["scans"].copy()
-    quiet.close()
+    def quiet_scans(envs, agents):
+        q = amd.BatchSim(num_envs=envs, num_agents=agents, num_beams=B)
+        q.set_map(map_stem("example_map") + ".yaml", ".png")
+        q.reset(poses); q.step(np.zeros((E * A, 2)))
+        out = q.get("scans")["scans"].copy()
+        q.close()
+        return out
+    free = quiet_scans(E * A, 1)                 # every car alone on the map
+    seen = quiet_scans(E, A)                     # ... and with its opponent in view (ray_cast_agents lowers the beams that hit it)
+    opp = np.where(seen < free, seen, np.inf)    # laser_models.py ray_cast: `if range < scan[i]: scan[i] = range`, applied AFTER the noise
+    assert A == 1 or np.isfinite(opp).any()
     s = amd.BatchSim(num_envs=E, num_agents=A, num_beams=B)
     s.set_map(map_stem("example_map") + ".yaml", ".png"); s.set_noise_rng(12345, 0.01)
     s.reset(poses)
@@ -471,6 +477,6 @@ def test_noise_rows_generated_ahead_of_need_are_numpys_stream(amd, E, A):
         s.step_host(hb)
         assert s.step_launches() == (1 if E * A <= 4 else 0)
         got = hb.views["scans"]
-        assert np.array_equal(got, base + rows[t_row][None, :]), (t, t_row, float(np.abs(got - base - rows[t_row]).max()))
+        assert np.array_equal(got, np.minimum(free + rows[t_row][None, :], opp)), (t, t_row)
         t_row += 1
     s.close()
