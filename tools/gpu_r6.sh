@@ -90,7 +90,7 @@ latency)   # where a host-synchronised step of ONE env spends its time: the laun
     echo "## tools/debug/tiny_start_probe.py (lab build: the first workgroup tells the host when it starts)"
     for a in 2 1; do F110_LIB_VARIANT=experimental timeout 300 python tools/debug/tiny_start_probe.py $a 4000; done
     echo "## tools/debug/tiny_drift.py (product build): BatchSim.step_host per block of 1000 steps from a fresh handle — the noise rows of a first episode are generated ahead of need"
-    for a in 2 1; do timeout 300 python tools/debug/tiny_drift.py $a 10 | head -24; done
+    for a in 2 1; do timeout 300 python tools/debug/tiny_drift.py $a 8; done
     echo "## tools/debug/f110env_loop.py 3000 (product build, a fresh F110Env each)"
     for i in 1 2 3; do timeout 120 python tools/debug/f110env_loop.py 3000 2>&1 | tail -1; done; } 2>&1 | tee $OUT/launch_latency.txt
   ;;
