@@ -425,8 +425,21 @@ def test_f110env_episodes_switch_between_the_step_forms_vs_oracle(amd, A):
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
     res = m.run(episodes=25, A=A, verbose=False)
     assert res, "mismatch against the oracle"
-    forms, switches = res
+    forms, switches, _ = res
     assert forms[1] > 100 and forms[0] > 100 and switches >= 4, (forms, switches)
+
+
+@pytest.mark.parametrize("A", [2, 1])
+def test_f110env_long_episodes_on_the_default_noise_cache_vs_oracle(amd, A):
+    """the same with the DEFAULT cache (rows generated ahead of need on their own stream, doublings from 256 on) and cars that crawl: episodes
+    live through several doublings and re-allocations of the cache, later episodes replay its rows — every step against the oracle, all of
+    them in the one-launch form"""
+    spec = importlib.util.spec_from_file_location("f110env_soak", os.path.join(ROOT, "tools", "debug", "f110env_soak.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    res = m.run(episodes=5, A=A, cap=2600, rows=0, slow=True, verbose=False)
+    assert res, "mismatch against the oracle"
+    forms, switches, longest = res
+    assert forms[0] == 0 and switches == 0 and longest > 1100, (forms, switches, longest)
 
 
 NESTED = bool(os.environ.get("F110_NESTED_SUITE"))

@@ -1,7 +1,9 @@
 """F110Env(num_agents = A) driven like the reference's users drive it — reset(), step() until done, reset() ... — against the CPU oracle at
 EVERY step, with the device noise generator's row cache cut to 64 rows: an episode that outlives the cache leaves the one-launch form
 (k_step_tiny) for the per-kernel form with k_noise_rows in MID-EPISODE, the next reset() brings the one-launch form back.  Prints one line.
-    python tools/debug/f110env_soak.py [episodes=100] [agents=2]"""
+    python tools/debug/f110env_soak.py [episodes=100] [agents=2] [cache rows=64] [longest episode=400] [slow=0]
+cache rows 0 = the default cache (16 384 rows, generated AHEAD of need on their own stream in doublings from 256: noise_start_ahead); with
+slow=1 the cars crawl, so that episodes live through several doublings."""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,16 +15,18 @@ import f1tenth_gym_amd as amd
 from f1tenth_gym_amd import workload
 
 
-def run(episodes=100, A=2, cap=400, verbose=True):
+def run(episodes=100, A=2, cap=400, verbose=True, rows=64, slow=False):
     dt, res, origin = oracle_map_dt("example_map")
     env = amd.F110Env(map=map_stem("example_map"), map_ext=".png", num_agents=A, seed=12345)
-    env.sim.batch.set_noise_rng(12345, 0.01, cache_rows=64)
+    if rows:
+        env.sim.batch.set_noise_rng(12345, 0.01, cache_rows=rows)
     ref = orc.SimOracle(1, A); ref.set_map_dt(dt, res, origin)
     ref.set_noise(np.random.default_rng(12345).normal(0., 0.01, size=(cap + 3, 1080)))
     rng = np.random.default_rng(5)
     forms = {0: 0, 1: 0}
     steps = switches = 0
     worst = 0.0
+    longest = 0
     for ep in range(episodes):
         poses = workload.start_poses(np.array([int(rng.integers(0, 783))]), A, gap_wp=int(rng.integers(3, 9)))
         obs, _, done, _ = env.reset(poses)
@@ -39,9 +43,12 @@ def run(episodes=100, A=2, cap=400, verbose=True):
                 print("MISMATCH episode", ep, "step", t, "form", last)
                 return False
             if done or t >= cap:
+                longest = max(longest, t)
                 break
             if t % 15 == 0:
                 act = np.stack([rng.uniform(-0.25, 0.25, A), rng.uniform(1.0, 6.0, A)], axis=1)
+                if slow:
+                    act = np.stack([rng.uniform(-0.08, 0.08, A), rng.uniform(0.2, 0.7, A)], axis=1)
             obs, _, done, _ = env.step(act)
             ref.step(act)
             form = env.sim.batch.step_launches()
@@ -52,10 +59,11 @@ def run(episodes=100, A=2, cap=400, verbose=True):
     env.sim.batch.close()
     if verbose:
         print("F110Env x %d car(s): %d episodes, %d steps vs the oracle at every step: no mismatch (largest scan difference %.1e relative); %d steps as ONE launch, "
-              "%d in the per-kernel form (row cache of 64 outlived), %d switches between the forms in mid-episode / at reset" % (A, episodes, steps, worst, forms[1], forms[0], switches))
-    return forms, switches
+              "%d in the per-kernel form (row cache of %s outlived), %d switches between the forms in mid-episode / at reset; longest episode %d steps" % (A, episodes, steps, worst, forms[1], forms[0], rows or "16384 (default)", switches, longest))
+    return forms, switches, longest
 
 
 if __name__ == "__main__":
-    ok = run(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 2)
+    arg = lambda k, d: int(sys.argv[k]) if len(sys.argv) > k else d
+    ok = run(arg(1, 100), arg(2, 2), cap=arg(4, 400), rows=arg(3, 64), slow=bool(arg(5, 0)))
     sys.exit(0 if ok else 1)

@@ -74,6 +74,7 @@ soak)   # long auto-reset loops on the final sources: does memory stay flat, do 
     echo "## 16 envs x 2 (the per-kernel host path)"; timeout 600 python tools/debug/long_run_memory.py 300000 16 2>&1 | tail -13
     echo "## 2 envs x 2 (4 agents: k_step_tiny for the first 64 steps, then — the upper bound of any live episode's age has outgrown the 64-row cache and nothing resets it short of a full reset — the per-kernel form with k_noise_rows)"; timeout 600 python tools/debug/long_run_memory.py 300000 2 2>&1 | tail -13
     echo "## F110Env against the oracle at every step, 400 episodes, row cache of 64: the forms switch in mid-episode and at reset()"; timeout 900 python tools/debug/f110env_soak.py 400 2 2>&1 | tail -2; timeout 900 python tools/debug/f110env_soak.py 400 1 2>&1 | tail -2
+    echo "## ... and with the default cache (rows ahead of need, doublings from 256), cars that crawl: long episodes through the doublings, later episodes replaying the rows"; timeout 900 python tools/debug/f110env_soak.py 40 2 0 6000 1 2>&1 | tail -2; timeout 900 python tools/debug/f110env_soak.py 40 1 0 6000 1 2>&1 | tail -2
     echo "## ShardedVecEnv: 4096 envs x 2 over four handles on device 0, 20 000 steps"; timeout 900 python examples/sharded_vec_env.py --envs 4096 --devices 0,0,0,0 --steps 20000 2>&1 | tail -2; } | tee $OUT/soak.txt
   ;;
 tiny)   # k_step_tiny: the A/B tests (lab build) + the golden / oracle tests that now run through it (product), then F110Env's step time
