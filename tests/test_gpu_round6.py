@@ -493,3 +493,35 @@ def test_noise_rows_generated_ahead_of_need_are_numpys_stream(amd, E, A):
         assert np.array_equal(got, np.minimum(free + rows[t_row][None, :], opp)), (t, t_row)
         t_row += 1
     s.close()
+
+
+@pytest.mark.parametrize("groups", [2, 0, 1])
+def test_noise_rows_ahead_of_need_under_env_blocks(amd, groups):
+    """... and when the steps run as two env blocks on two streams (step_device back to back, step_groups 2 / automatic): the block
+    streams must see the adopted rows (and the cache's new memory) exactly as the main stream does.  Cars at rest, bursts of device steps
+    through the doublings at 256, 512 and 1024; after every burst the scans are min(range + row(t), opponent) with NumPy's row t"""
+    E, A, B = 300, 2, 1080
+    rows = np.random.default_rng(12345).normal(0., 0.01, size=(1400, B))
+    poses = bench_start_poses(E, A)
+
+    def quiet_scans(envs, agents):
+        q = amd.BatchSim(num_envs=envs, num_agents=agents, num_beams=B)
+        q.set_map(map_stem("example_map") + ".yaml", ".png")
+        q.reset(poses); q.step(np.zeros((E * A, 2)))
+        out = q.get("scans")["scans"].copy()
+        q.close()
+        return out
+    free, seen = quiet_scans(E * A, 1), quiet_scans(E, A)
+    opp = np.where(seen < free, seen, np.inf)
+    s = amd.BatchSim(num_envs=E, num_agents=A, num_beams=B, step_groups=groups)
+    s.set_map(map_stem("example_map") + ".yaml", ".png"); s.set_noise_rng(12345, 0.01)
+    s.reset(poses)
+    d_act = s.device_array((E * A, 2)); d_act.upload(np.zeros((E * A, 2)))
+    t = 0
+    for burst in (100, 27, 1, 130, 255, 3, 1, 500, 40, 250):
+        for _ in range(burst):
+            s.step_device(d_act)
+        t += burst
+        got = s.get("scans")["scans"]
+        assert np.array_equal(got, np.minimum(free + rows[t - 1][None, :], opp)), (groups, t)
+    s.close()
