@@ -230,6 +230,7 @@ class BatchSim(object):
         h = C.c_void_p()
         check(L.f110_create(C.byref(cfg), C.byref(h)), None)
         self._h = h.value
+        self._f_step_host = _ffi.lib().f110_step_host
         # NumPy-computed tables (bit-identical to the reference's)
         s, c = trig_tables(self.theta_dis)
         check(L.f110_set_trig_tables(self._h, dptr(s), dptr(c), self.theta_dis), self._h)
@@ -652,6 +653,13 @@ class BatchSim(object):
             a = as_f64(actions, (self.N, 2))
             ptr = a.ctypes.data
         rc = _ffi.lib().f110_step_host(self._h, ptr, hb.struct_ref, flags)
+        if rc:
+            check(rc, self._h)
+
+    def step_host_inplace(self, hb):
+        """step_host(hb) with its defaults (the actions as the caller left them in hb.actions, read in place; wait by polling), without
+        the argument handling: the single-env loop counts microseconds"""
+        rc = self._f_step_host(self._h, hb.actions_ptr, hb.struct_ref, _ffi.STEP_POLL | _ffi.STEP_ACTIONS_MAPPED)
         if rc:
             check(rc, self._h)
 

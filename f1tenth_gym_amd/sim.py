@@ -169,41 +169,50 @@ class Simulator(object):
             if hb is None:
                 hb = self._hb = self._b.host_block(("scans", "state", "agent_poses", "collisions", "collision_idx", "in_collision"))
             hb.actions[...] = actions
-            self._b.step_host(hb)
+            self._b.step_host_inplace(hb)
             v = hb.views
-            o = {"scans": v["scans"].copy(), "state": v["state"].T.copy(), "agent_poses": v["agent_poses"].T.copy(),
-                 "collisions": v["collisions"].copy(), "collision_idx": v["collision_idx"].copy(),
-                 "in_collision": v["in_collision"].copy()}
+            scans, s7 = v["scans"].copy(), v["state"].copy()      # s7: [7][N], the block's own layout
+            poses, coll, cidx, inc = v["agent_poses"].T.copy(), v["collisions"].copy(), v["collision_idx"].copy(), v["in_collision"].copy()
         else:
             # big batches through this (host-logic) path: the observation straight into fresh arrays — a page-locked staging
             # block of hundreds of MB and a second host copy would cost more than the call it saves
             self._b.step(actions)
             o = self._b.get("scans", "state", "agent_poses", "collisions", "collision_idx", "in_collision")
+            scans, s7, poses, coll, cidx, inc = o["scans"], o["state"].T, o["agent_poses"], o["collisions"], o["collision_idx"], o["in_collision"]
         self._steps_since_full_reset += 1
-        self._state = o["state"]
-        self._in_collision = o["in_collision"]
-        st = o["state"]
+        self._state = s7.T            # [N][7]
+        self._in_collision = inc
         if not self._batched:
-            self.agent_poses = o["agent_poses"]
-            self.collisions = o["collisions"]
-            self.collision_idx = o["collision_idx"]
-            # base_classes.py:594-610 — python lists of per-agent values
-            observations = {'ego_idx': self.ego_idx,
-                            'scans': [o["scans"][i] for i in range(A)],
-                            'poses_x': [st[i, 0] for i in range(A)],
-                            'poses_y': [st[i, 1] for i in range(A)],
-                            'poses_theta': [st[i, 4] for i in range(A)],
-                            'linear_vels_x': [st[i, 3] for i in range(A)],
-                            'linear_vels_y': [0. for _ in range(A)],
-                            'ang_vels_z': [st[i, 5] for i in range(A)],
-                            'collisions': self.collisions}
+            self.agent_poses = poses
+            self.collisions = coll
+            self.collision_idx = cidx
+            # base_classes.py:594-610 — python lists of per-agent values (rows of s7: x, y, steer, v, yaw, yaw rate, slip)
+            x, y, vx, th, w = s7[0], s7[1], s7[3], s7[4], s7[5]
+            if A == 2:      # (the reference's default: spelled out, a list comprehension costs a frame each)
+                observations = {'ego_idx': self.ego_idx, 'scans': [scans[0], scans[1]], 'poses_x': [x[0], x[1]], 'poses_y': [y[0], y[1]],
+                                'poses_theta': [th[0], th[1]], 'linear_vels_x': [vx[0], vx[1]], 'linear_vels_y': [0., 0.],
+                                'ang_vels_z': [w[0], w[1]], 'collisions': coll}
+            elif A == 1:
+                observations = {'ego_idx': self.ego_idx, 'scans': [scans[0]], 'poses_x': [x[0]], 'poses_y': [y[0]], 'poses_theta': [th[0]],
+                                'linear_vels_x': [vx[0]], 'linear_vels_y': [0.], 'ang_vels_z': [w[0]], 'collisions': coll}
+            else:
+                r = range(A)
+                observations = {'ego_idx': self.ego_idx,
+                                'scans': [scans[i] for i in r],
+                                'poses_x': [x[i] for i in r],
+                                'poses_y': [y[i] for i in r],
+                                'poses_theta': [th[i] for i in r],
+                                'linear_vels_x': [vx[i] for i in r],
+                                'linear_vels_y': [0. for _ in r],
+                                'ang_vels_z': [w[i] for i in r],
+                                'collisions': coll}
         else:
-            self.agent_poses = o["agent_poses"].reshape(E, A, 3)
-            self.collisions = o["collisions"].reshape(E, A)
-            self.collision_idx = o["collision_idx"].reshape(E, A)
-            st = st.reshape(E, A, 7)
+            self.agent_poses = poses.reshape(E, A, 3)
+            self.collisions = coll.reshape(E, A)
+            self.collision_idx = cidx.reshape(E, A)
+            st = self._state.reshape(E, A, 7)
             observations = {'ego_idx': self.ego_idx,
-                            'scans': o["scans"].reshape(E, A, -1),
+                            'scans': scans.reshape(E, A, -1),
                             'poses_x': st[:, :, 0], 'poses_y': st[:, :, 1], 'poses_theta': st[:, :, 4],
                             'linear_vels_x': st[:, :, 3], 'linear_vels_y': np.zeros((E, A)),
                             'ang_vels_z': st[:, :, 5], 'collisions': self.collisions}
