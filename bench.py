@@ -767,11 +767,17 @@ def dropin_rates(args):
     env = amd.F110Env(**kw)
     env.reset(start_poses_for(shard_envs(1, 0), A))
     act = np.array([[0.05, 3.0], [-0.05, 2.5]] * A)[:A]
-    dt = timed(lambda: env.step(act), 3000, 200)
+    for _ in range(200):
+        env.step(act)
+    env.sim.batch.step_host_stats()
+    dt = timed(lambda: env.step(act), 3000, 0)
+    _, enq, wait = env.sim.batch.step_host_stats()
     launches = env.sim.batch.step_launches()
     env.sim.batch.close()
-    out["f110env_1env"] = {"workload": "F110Env(num_agents=%d).step(action): 1 env, host actions, obs dict with scans (BASELINE configs[0] through the HIP path)" % A,
+    out["f110env_1env"] = {"workload": "F110Env(num_agents=%d).step(action): 1 env, host actions, obs dict with scans (BASELINE configs[0] through the HIP path), "
+                                       "the first 3200 steps of a fresh env" % A,
                            "us_per_step": 1e6 * dt, "env_steps_per_s": 1.0 / dt, "value": A / dt, "unit": "agent-steps/s",
+                           "in_f110_step_host_us": {"enqueue": enq, "wait": wait}, "python_around_the_call_us": 1e6 * dt - enq - wait,
                            "kernel_launches_per_step": {1: "1 (k_step_tiny)", 0: "per-kernel form"}.get(launches, launches)}
     # the reference's example loop (examples/waypoint_follow.py:272-285): ONE car
     env = amd.F110Env(**dict(kw, num_agents=1))
