@@ -49,6 +49,7 @@ struct ExpSwitches {
     int integrate_duo = -1;    // 0: k_integrate<0> (one wave per 64 agents), 1: k_integrate_duo, -1 = default (duo)
     int group_split = 0;       // two env groups: percent of the envs in the first (0 = even)
     int integrate_fan = -1;    // 0 / 1: k_integrate_fan (thirteen waves per 64 agents, RK4) off / on at every size, -1 = default (small batches)
+    int tiny_general_tail = 0;
     int tiny_start_probe = 0;  // k_step_tiny tells the host when its first workgroup starts (f110_step_host times launch -> start -> done)
     long probe_calls = 0;
     double probe_us[3] = {0, 0, 0};
@@ -450,6 +451,7 @@ int f110_exp_set(f110_sim *h, const char *key, int32_t value)
         h->exp.probe_calls = 0;
         h->exp.probe_us[0] = h->exp.probe_us[1] = h->exp.probe_us[2] = 0;
     }
+    else if (k == "tiny_general_tail") h->exp.tiny_general_tail = value;   // 1: one env of two cars finishes in finalize_pair_body (the tail before finalize_duo_tiny)
     else if (k == "tiny_trace_hi") h->exp.tiny_trace = (h->exp.tiny_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
     else if (k == "tiny_trace_lo") h->exp.tiny_trace = (h->exp.tiny_trace & ~0xffffffffull) | (uint64_t)(uint32_t)value;
     else if (k == "scan_trace_hi") h->exp.scan_trace = (h->exp.scan_trace & 0xffffffffull) | ((uint64_t)(uint32_t)value << 32);
@@ -2266,7 +2268,7 @@ static int step_tiny(f110_sim *h, hipStream_t st, const double *d_actions)
         h->tiny.act_inline = 1;
     }
     h->tiny.start_word = nullptr;
-    h->tiny.skip = kExperimental && h->exp.tiny_start_probe == 2 ? 1 : 0;
+    h->tiny.skip = kExperimental ? (h->exp.tiny_start_probe == 2 ? 1 : (h->exp.tiny_general_tail ? 2 : 0)) : 0;
     if (kExperimental && h->exp.tiny_start_probe && h->hb_seq_host && h->fuse_seq) {
         void *p = nullptr;
         TRY(map_host_ptr(h, h->hb_seq_host, &p, "completion word"));
@@ -2293,6 +2295,9 @@ static int step_tiny(f110_sim *h, hipStream_t st, const double *d_actions)
         h->fused_done = true;
         host = true;
     }
+    if (host && A == 2) h->tiny.fh = h->fused_host_copy;   // (what d_fused holds: f110_step_host keeps the two equal)
+    // one env of two cars: finalize_duo_tiny puts the scans into the caller's block early (its idle wave copies, the window lanes follow)
+    h->tiny.host_scans = (host && h->hb_valid && h->hb_scans_by_kernel && A == 2 && N == 2 && !(kExperimental && h->exp.tiny_general_tail)) ? h->hb_dev.scans : nullptr;
 #define TINY(P, I, H_) hipLaunchKernelGGL((k_step_tiny<P, I, H_>), grid, block, 0, st, dev, h->k, j, d_actions, h->tiny, ep, hb, episode, auto_reset)
     const bool ident = h->k.ident_rot != 0;
     if (A == 2) {

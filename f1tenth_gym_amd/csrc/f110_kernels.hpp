@@ -161,7 +161,8 @@ __device__ __forceinline__ void host_block_copy_scans(const HostBlock &hb, const
 __device__ __forceinline__ void host_block_signal(const HostBlock &hb)
 {
     if (!hb.seq_host) return;
-    __syncthreads();               // every lane's stores are issued
+    __builtin_amdgcn_s_waitcnt(0); // every wave's stores into the host block have been acknowledged (a workgroup barrier alone does not wait for them) ...
+    __syncthreads();               // ... in every wave of the workgroup
     if (threadIdx.x == 0) {
         __threadfence_system();    // ... and visible system-wide before the count
         const unsigned int prev = __hip_atomic_fetch_add(hb.blocks_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -1273,12 +1274,9 @@ __global__ void __launch_bounds__(256) k_finalize(AgentArrays a, int32_t B)
 // wave 0; the two agents of an env are lanes t, t ^ 1) once the kernel's own work is finished: the agent's columns into
 // the caller's page-locked block, F110Env._check_done for the env, the in-place re-seat.  Same arithmetic as
 // k_host_block / k_episode (tests: the VecEnv forms agree, the reference's 2-agent episodes).
-__device__ __forceinline__ void pair_host_epilogue(const AgentArrays &a, bool agent_thread, int i)
+__device__ __forceinline__ void pair_host_epilogue_with(const AgentArrays &a, const EpisodeArrays &ep, const HostBlock &hb, const int episode, const int auto_reset,
+                                                        bool agent_thread, int i)
 {
-    const FusedHost *fp = a.fused_host;
-    const EpisodeArrays ep = fp->ep;
-    const HostBlock hb = fp->hb;
-    const int episode = fp->episode, auto_reset = fp->auto_reset;
     const size_t N = (size_t)a.n_agents_total;
     double col = 0.;
     int running = 0;
@@ -1374,6 +1372,15 @@ __device__ __forceinline__ void pair_host_epilogue(const AgentArrays &a, bool ag
             ep.toggle[iu] = 0.;
         }
     }
+}
+
+// ... with the parameters where the launcher left them in device memory (k_finalize_pair_roles; k_step_tiny's general body)
+__device__ __forceinline__ void pair_host_epilogue(const AgentArrays &a, bool agent_thread, int i)
+{
+    const FusedHost *fp = a.fused_host;
+    const EpisodeArrays ep = fp->ep;
+    const HostBlock hb = fp->hb;
+    pair_host_epilogue_with(a, ep, hb, fp->episode, fp->auto_reset, agent_thread, i);
 }
 
 // ---- K3r: finalize for two-agent envs — pair test, opponent window and ray-cast in one kernel (rounds 2-3) ----------
@@ -1533,6 +1540,149 @@ __device__ __forceinline__ void finalize_pair_body(const AgentArrays &a, int32_t
         if (t < 64) pair_host_epilogue(a, agent_thread, first + t);
     } else if (a.reseat_poses && agent_thread) {
         const int i = first + t, ego = (i & ~1) + a.reseat_ego;
+        if (my_hit || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
+    }
+}
+
+// finalize_pair_body for ONE env of two agents that is the whole batch (k_step_tiny, N = 2): the same functions on the same operands,
+// without the machinery for 32 agents per workgroup — the window lengths need no prefix scan (each half of the workgroup takes one
+// agent's window), the agent's own columns are finished by the lane that runs its host epilogue (no barrier between the two), and the
+// scans go into the host block EARLY: wave 1, which has no role, copies the 2 x B ranges while the role lanes do their trigonometry,
+// and the beams the opponent shortens follow as they are found — instead of a 17 KB copy at the end of the chain.  (Storing them from
+// the scan waves was tried first: their release then waits for the stores' acknowledgements over PCIe, +2.4 us where -2.6 were saved.)
+// Three barriers instead of six on the step's critical path (profiles/r06_launch_latency.txt: the tail was 9.4 of the kernel's 32 us).
+template <bool HOST>
+__device__ __forceinline__ void finalize_duo_tiny(const AgentArrays &a, int32_t B, double *__restrict__ host_scans, const FusedHost &fh)
+{
+    __shared__ double d_rec[2][12];   // ex, ey, eth, the opponent's box (8), pad
+    __shared__ int d_idx[2][4], d_cl[2], d_ch[2], d_hit;
+    const int t = (int)threadIdx.x;
+    constexpr int N = 2;
+    int role = -1, slot = 0, sub = 0;
+    if (t < 8) {                        // box corner `sub` of agent `slot`'s opponent -> beam index
+        role = 0; slot = t >> 2; sub = t & 3;
+    } else if (t >= 128 && t < 130) {   // wave 2: disc cull of agent `slot`
+        role = 1; slot = t - 128;
+    } else if (t == 192) {              // wave 3: the pair test
+        role = 2;
+    }
+    if (HOST && host_scans && t >= 64 && t < 128) {
+        const size_t n = (size_t)N * (size_t)B;
+        size_t q = (size_t)(t - 64);
+        for (; q + 192 < n; q += 256) {   // four independent loads in flight per lane, then the four stores
+            const double v0 = a.scans[q], v1 = a.scans[q + 64], v2 = a.scans[q + 128], v3 = a.scans[q + 192];
+            host_scans[q] = v0;
+            host_scans[q + 64] = v1;
+            host_scans[q + 128] = v2;
+            host_scans[q + 192] = v3;
+        }
+        for (; q < n; q += 64) host_scans[q] = a.scans[q];
+        __builtin_amdgcn_s_waitcnt(0);   // acknowledged before a window lane may store a shortened beam over one of them
+    }
+    if (role >= 0) {
+        const int i = slot, me = i & 1, o = i ^ 1;
+        const double ex = a.state[i], ey = a.state[(size_t)N + i];
+        const double th_live = a.state[4 * (size_t)N + i];
+        const double ox = a.snap_pose[o], oy = a.snap_pose[(size_t)N + o], oth = a.snap_pose[2 * (size_t)N + o];
+        if (role == 2) {
+            int hit = 0;
+            const double reach = sqrt(a.box_length * a.box_length + a.box_width * a.box_width) + 1e-3;
+            const double cdx = ox - ex, cdy = oy - ey;
+            if (cdx * cdx + cdy * cdy <= reach * reach) {
+                double mine[8], other[8];
+                box_vertices(ex, ey, th_live, a.box_length, a.box_width, mine);
+                box_vertices(ox, oy, oth, a.box_length, a.box_width, other);
+                hit = gjk_overlap(mine, other) ? 1 : 0;
+            }
+            d_hit = hit;
+        } else {
+            const int wall = a.in_collision[i];
+            const double eth = wall ? 0.0 : th_live;
+            const size_t prow = (size_t)(a.params_per_agent ? i : me) * NPARAMS;
+            const double blen = a.params[prow + P_LENGTH], bwid = a.params[prow + P_WIDTH];
+            double v[8];
+            box_vertices(ox, oy, oth, blen, bwid, v);
+            double ce_, se_;
+            cos_sin(eth, ce_, se_);
+            const double head = atan2(se_, ce_);
+            const double px = role == 1 ? ox : (sub == 0 ? v[0] : (sub == 1 ? v[2] : (sub == 2 ? v[4] : v[6])));
+            const double py = role == 1 ? oy : (sub == 0 ? v[1] : (sub == 1 ? v[3] : (sub == 2 ? v[5] : v[7])));
+            const double dx = px - ex, dy = py - ey;
+            const double norm = sqrt(dx * dx + dy * dy);
+            const double qx = role == 0 ? dx / norm : dx, qy = role == 0 ? dy / norm : dy;
+            const double dir = atan2(qy, qx);
+            if (role == 0) {
+                d_idx[slot][sub] = vertex_beam_from_angles(head, dir, a.scan_angles, B, a.angle_inc);
+                if (sub == 0) {
+                    d_rec[slot][0] = ex;
+                    d_rec[slot][1] = ey;
+                    d_rec[slot][2] = eth;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) d_rec[slot][3 + c] = v[c];
+                }
+            } else {
+                int cl, ch;
+                disc_beam_range_from(norm, eth, dir, head, 0.5 * sqrt(blen * blen + bwid * bwid), a.scan_angles, B, a.angle_inc, cl, ch);
+                d_cl[slot] = cl;
+                d_ch[slot] = ch;
+            }
+        }
+    }
+    __syncthreads();
+    // agent t's own columns, by lane t of wave 0 — the lane that runs its host epilogue below
+    const bool agent_thread = t < N;
+    const int my_hit = d_hit;
+    if (agent_thread) {
+        const int i = t, me = i & 1;
+        const int wall = a.in_collision[i];
+        if (wall) {
+            a.state[3 * (size_t)N + i] = 0.;
+            a.state[4 * (size_t)N + i] = 0.;
+            a.state[5 * (size_t)N + i] = 0.;
+            a.state[6 * (size_t)N + i] = 0.;
+        }
+        a.collisions[i] = (my_hit || wall) ? 1.0 : 0.0;
+        a.collision_idx[i] = my_hit ? (double)(1 - me) : -1.0;
+        a.step_count[i] += 1;
+    }
+    {   // agent `ag`'s opponent window, by its half of the workgroup
+        const int ag = t >> 7, tt = t & 127;
+        const int i0 = d_idx[ag][0], i1 = d_idx[ag][1], i2 = d_idx[ag][2], i3 = d_idx[ag][3];
+        const int cl = d_cl[ag], ch = d_ch[ag];
+        int ref_lo = i0 < i1 ? i0 : i1, t2 = i2 < i3 ? i2 : i3;
+        ref_lo = ref_lo < t2 ? ref_lo : t2;
+        int ref_hi = i0 > i1 ? i0 : i1;
+        t2 = i2 > i3 ? i2 : i3;
+        ref_hi = ref_hi > t2 ? ref_hi : t2;
+        const int lo = ref_lo > cl ? ref_lo : cl;
+        const int hi = ref_hi < ch ? ref_hi : ch;
+        const int cnt = hi >= lo ? hi - lo + 1 : 0;
+        const double bex = d_rec[ag][0], bey = d_rec[ag][1], beth = d_rec[ag][2];
+        double bv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) bv[c] = d_rec[ag][3 + c];
+        double *sc = a.scans + (size_t)ag * B;
+        for (int item = tt; item < cnt; item += 128) {
+            const int b = lo + item;
+            const double bt = beth + a.scan_angles[b];
+            const double r0 = sc[b];
+            double v3x, v3y;
+            sincos(bt + kPi / 2., &v3y, &v3x);
+            const double r = box_range(bex, bey, v3x, v3y, bv, r0);
+            if (r < r0) {
+                sc[b] = r;
+                if (HOST && host_scans) host_scans[(size_t)ag * B + b] = r;
+            }
+        }
+    }
+    if (HOST) {   // (fh: the epilogue's parameters as kernel arguments — a.fused_host holds the same in device memory, a load behind every barrier here)
+        if (fh.hb.scans && !host_scans) {   // (not copied early: the copy, once every window is done)
+            __syncthreads();
+            host_block_copy_scans(fh.hb, a.scans, 0, (size_t)N);
+        }
+        if (t < 64) pair_host_epilogue_with(a, fh.ep, fh.hb, fh.episode, fh.auto_reset, agent_thread, t);
+    } else if (a.reseat_poses && agent_thread) {
+        const int i = t, ego = a.reseat_ego;
         if (my_hit || a.in_collision[ego] != 0) reseat_agent(a, i, i == ego);
     }
 }
@@ -2153,7 +2303,8 @@ __global__ void __launch_bounds__(256) k_pack_episode(AgentArrays a, EpisodeArra
 __device__ __forceinline__ void host_block_signal_single(const HostBlock &hb)
 {
     if (!hb.seq_host) return;
-    __syncthreads();               // every lane's stores are issued
+    __builtin_amdgcn_s_waitcnt(0); // every wave's stores into the host block have been acknowledged ...
+    __syncthreads();               // ... in every wave of the workgroup
     if (threadIdx.x == 0) {
         __threadfence_system();    // ... and visible system-wide before the word
         __hip_atomic_store(hb.seq_host, hb.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2309,8 +2460,11 @@ struct TinyCtl {
     RayHdr *ray_hdr;         // [N]
     uint32_t tasks_per_agent, pad_;
     unsigned long long *trace;   // lab timeline probe: [workgroups][16] stamps of the 100 MHz clock (nullptr = off)
+    double *host_scans;          // N = 2: the caller's page-locked scans [2][B] (device view) — finalize_duo_tiny copies the ranges there while its
+                                 // role lanes work, and the beams the opponent shortens as they are found (nullptr: no scans in the block)
+    FusedHost fh;                // N = 2 under f110_step_host: the host epilogue's parameters (what a.fused_host points at), by value
     int act_inline;              // 1: the actions are `act` below (f110_step_host copied them into the launch: no read over PCIe inside the step)
-    int skip;                    // lab: 1 = the launch only reports start and completion (what does the dispatch itself cost?)
+    int skip;                    // lab (2 = N == 2 takes finalize_pair_body instead of finalize_duo_tiny: the A/B of the tail); 1 = the launch only reports start and completion (what does the dispatch itself cost?)
     double act[8];               // [kTinyMaxAgents][2] (steer, velocity)
     unsigned long long *start_word, start_seq;   // lab: a word in page-locked host memory the first workgroup stores start_seq to as it starts
 };
@@ -2336,7 +2490,7 @@ __global__ void __launch_bounds__(256) k_step_tiny(AgentArrays a, ScanConst k, R
     TINY_STAMP(0);   // the workgroup's first wave is running
 #ifdef F110_EXPERIMENTAL
     if (ctl.start_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ctl.start_word, ctl.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (ctl.skip) {   // the dispatch alone: start word, completion word, nothing else
+    if (ctl.skip == 1) {   // the dispatch alone: start word, completion word, nothing else
         if (ctl.start_word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(ctl.start_word - 1, ctl.start_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
@@ -2402,8 +2556,7 @@ __global__ void __launch_bounds__(256) k_step_tiny(AgentArrays a, ScanConst k, R
     TINY_STAMP(2);   // wave 0's beams marched and stored
     // ---- who is last?
     // Release, once per workgroup: every wave waits for its own stores to be in L2 (vmcnt 0), the barrier collects the waves, and ONE
-    // lane writes the L2 back at agent scope before it counts the workgroup done (a fence by every wave measured 7 us here, the
-    // write-backs queueing behind one another: profiles/r06_launch_latency.txt).
+    // lane writes the L2 back at agent scope before it counts the workgroup done (a fence by every wave is 34 L2 write-backs where 9 do).
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     TINY_STAMP(3);   // every wave of the workgroup has its stores in L2
@@ -2421,18 +2574,29 @@ __global__ void __launch_bounds__(256) k_step_tiny(AgentArrays a, ScanConst k, R
     //      block and the completion word — and only then shadow -> live, which nobody waits for
     TINY_STAMP(5);
     if (PAIR) {
-        constexpr int AG = 4;
-        for (int first = 0; first < N; first += AG) {
-            finalize_pair_body<AG, HOST>(sh, B, first, N);
-            __syncthreads();   // the body's LDS is reused by the next group
+        if (N == 2 && ctl.skip != 2) {   // the reference's own shape: one env of two cars  (skip 2: lab A/B, the general body)
+            finalize_duo_tiny<HOST>(sh, B, HOST ? ctl.host_scans : nullptr, ctl.fh);
+            TINY_STAMP(6);
+            if (HOST && a.fused_seq) {
+                HostBlock sig = ctl.fh.hb;
+                sig.seq = a.fused_seq;
+                host_block_signal_single(sig);
+            }
+            TINY_STAMP(7);
+        } else {
+            constexpr int AG = 4;
+            for (int first = 0; first < N; first += AG) {
+                finalize_pair_body<AG, HOST>(sh, B, first, N);
+                __syncthreads();   // the body's LDS is reused by the next group
+            }
+            TINY_STAMP(6);   // finalize + host block stores issued
+            if (HOST && a.fused_seq) {
+                HostBlock sig = a.fused_host->hb;
+                sig.seq = a.fused_seq;
+                host_block_signal_single(sig);
+            }
+            TINY_STAMP(7);   // completion word stored
         }
-        TINY_STAMP(6);   // finalize + host block stores issued
-        if (HOST && a.fused_seq) {
-            HostBlock sig = a.fused_host->hb;
-            sig.seq = a.fused_seq;
-            host_block_signal_single(sig);
-        }
-        TINY_STAMP(7);   // completion word stored
     } else {
         for (int i = (int)threadIdx.x; i < N; i += 256) finalize_solo_agent(sh, i);
         if (HOST) {

@@ -525,3 +525,32 @@ def test_noise_rows_ahead_of_need_under_env_blocks(amd, groups):
         got = s.get("scans")["scans"]
         assert np.array_equal(got, np.minimum(free + rows[t - 1][None, :], opp)), (groups, t)
     s.close()
+
+
+def test_duo_tail_equals_the_general_pair_body(amd):
+    """k_step_tiny finishes one env of two cars in finalize_duo_tiny (three barriers, the scans copied into the host block by the idle
+    wave while the role lanes work, shortened beams written through) — against finalize_pair_body in the same kernel (lab switch
+    tiny_general_tail): the host block and the device state bit for bit over 600 fast, blind steps with wall hits, contacts, auto-resets"""
+    outs = []
+    for general in (0, 1):
+        s = amd.BatchSim(num_envs=1, num_agents=2)
+        s.set_map(map_stem("example_map") + ".yaml", ".png"); s.set_noise_rng(12345, 0.01)
+        s.exp_set("tiny_general_tail", general)
+        s.episode_init(0)
+        poses = bench_start_poses(1, 2, gap_wp=3)
+        s.episode_reset(poses)
+        hb = s.host_block(("scans", "state", "agent_poses", "collisions", "collision_idx", "in_collision", "done", "lap_counts", "toggles"))
+        rng = np.random.default_rng(3)
+        rec = []
+        for t in range(600):
+            hb.actions[...] = np.stack([rng.uniform(-0.4, 0.4, 2), rng.uniform(3.0, 11.0, 2)], axis=1)
+            s.step_host(hb, auto_reset=True)
+            assert s.step_launches() == 1
+            rec.append({k: v.copy() for k, v in hb.views.items()})
+        rec.append(s.get("scans", "state", "collisions", "collision_idx", "in_collision", "agent_poses", "step_count"))
+        outs.append(rec)
+        s.close()
+    assert sum(int(r["done"][0]) for r in outs[0][:-1]) > 2 and sum(float(r["collisions"].sum()) for r in outs[0][:-1]) > 2
+    for t, (ra, rb) in enumerate(zip(*outs)):
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k]), (t, k)

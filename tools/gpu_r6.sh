@@ -69,6 +69,15 @@ fuzzlong)   # the fuzzers by hand, far beyond the seeds the suite runs (suppleme
     bad=0; for sd in $(seq 12 41); do timeout 300 python tools/debug/fuzz_units.py $sd > $OUT/fl_units.log 2>&1 || bad=$((bad+1)); grep -q "False" $OUT/fl_units.log && bad=$((bad+1)); done
     echo "fuzz_units seeds 12..41: $bad seed(s) with a failure or an inexact line"; } | tee $OUT/fuzz_long.txt
   ;;
+fuzzmore)   # ... and a second, disjoint set of seed ranges (appended to the same record)
+  { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  a second set of seed ranges"
+    for spec in "fuzz_host 1400 3000" "fuzz_parity 1500 3000" "fuzz_envs 800 1600" "fuzz_episode 1500 3000"; do
+      set -- $spec
+      timeout 1500 python tools/debug/$1.py $2 $3 > $OUT/fm_$1.log 2>&1
+      echo "$1 seeds $2..$(( $3 - 1 )): $(grep -c '^ok' $OUT/fm_$1.log) ok, $(grep -c MISMATCH $OUT/fm_$1.log) mismatches, $(tail -1 $OUT/fm_$1.log)"
+      [ "$1" = fuzz_host ] && echo "   of which one launch per step (k_step_tiny): $(grep -c 'one launch per step' $OUT/fm_$1.log)"
+    done; } | tee $OUT/fuzz_more.txt
+  ;;
 soak)   # long auto-reset loops on the final sources: does memory stay flat, do the forms keep agreeing with themselves?
   { echo "# csrc $(python -c 'from f1tenth_gym_amd import build; print(build.src_hash())')  tools/debug/long_run_memory.py 300000 E (F110VecEnv device_logic auto_reset, noise from a 64-row cache: episodes beyond it continue from the carried stream state)"
     echo "## 16 envs x 2 (the per-kernel host path)"; timeout 600 python tools/debug/long_run_memory.py 300000 16 2>&1 | tail -13
