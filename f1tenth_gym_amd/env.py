@@ -51,6 +51,7 @@ class _LapLogic(object):
         self.lap_times = np.zeros((num_envs, num_agents))
         self.lap_counts = np.zeros((num_envs, num_agents))
         self.current_time = np.zeros((num_envs,))
+        self._c0, self._s0, self._sx0, self._sy0 = 1.0, 0.0, [0.0] * num_agents, [0.0] * num_agents
 
     def reset(self, poses, env_mask=None):
         m = np.ones((self.E,), dtype=bool) if env_mask is None else np.asarray(env_mask, dtype=bool)
@@ -64,6 +65,9 @@ class _LapLogic(object):
         th = -self.start_thetas[:, self.ego]
         self.rot_c[m] = np.cos(th)[m]
         self.rot_s[m] = np.sin(th)[m]
+        # update_single's constants as plain floats (env 0): the single-env step counts microseconds
+        self._c0, self._s0 = float(self.rot_c[0]), float(self.rot_s[0])
+        self._sx0, self._sy0 = [float(v) for v in self.start_xs[0]], [float(v) for v in self.start_ys[0]]
 
     def update_single(self, poses_x, poses_y, collisions, timestep):
         """update() for ONE env in plain Python floats: the same IEEE operations in the same order, without ~25 NumPy
@@ -71,13 +75,13 @@ class _LapLogic(object):
         counts).  returns done (bool), checkpoint_done [A]"""
         ct = float(self.current_time[0]) + timestep
         self.current_time[0] = ct
-        c, s = float(self.rot_c[0]), float(self.rot_s[0])
-        sx, sy = self.start_xs[0], self.start_ys[0]
+        c, s = self._c0, self._s0
+        sx, sy = self._sx0, self._sy0
         near, tog = self.near_starts[0], self.toggle_list[0]
         all4 = True
         for i in range(self.A):
-            px = float(poses_x[i]) - float(sx[i])
-            py = float(poses_y[i]) - float(sy[i])
+            px = float(poses_x[i]) - sx[i]
+            py = float(poses_y[i]) - sy[i]
             dx = c * px + (-s) * py
             ty = s * px + c * py
             if ty > 2:
