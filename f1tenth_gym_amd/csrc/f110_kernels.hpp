@@ -2446,8 +2446,9 @@ __global__ void __launch_bounds__(256) k_host_block(AgentArrays a, EpisodeArrays
 //                 no kernel boundary and no HBM round trip separates integrate from scan.  Nothing live is overwritten meanwhile: the
 //                 wave of an agent's FIRST task stores the new state / delay buffer / poses / header into SHADOW columns, the wall
 //                 flags of the iTTC test go to a flag column of their own.
-//   last block    workgroups count themselves done (release / acquire at agent scope); the one that arrives last copies the shadow
-//                 columns over the live ones and runs the finalize body (finalize_pair_body / finalize_solo_agent) and the host epilogue.
+//   last block    workgroups count themselves done (one release per workgroup, acquire by the last, at agent scope); the one that arrives
+//                 last runs the finalize body (finalize_duo_tiny / finalize_pair_body / finalize_solo_agent) and the host epilogue ON the
+//                 shadow columns, stores the completion word, and only then copies the shadow columns over the live ones.
 struct TinyCtl {
     unsigned int *done;      // workgroups finished this launch (left at 0 by the last one)
     int32_t *wall;           // [N] this step's iTTC flags (left at 0 by the last workgroup)
