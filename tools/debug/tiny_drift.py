@@ -1,4 +1,4 @@
-"""(lab build for the third argument)  Does the host-synchronised tiny step's time depend on how long the loop has been running?  Per block of 1000 steps: seconds since the loop
+"""Does the host-synchronised tiny step's time depend on how long the loop has been running?  Per block of 1000 steps: seconds since the loop
 started, in-call enqueue + wait.  Then a pause (the GPU idles) and again.    python tools/debug/tiny_drift.py [agents per env = 2] [blocks = 14]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,8 +15,6 @@ poses = workload.bench_start_poses(1, A)
 s.reset(poses)
 hb = s.host_block(("scans", "state", "agent_poses", "collisions", "collision_idx", "in_collision"))
 hb.actions[...] = np.tile([0.05, 3.0], (A, 1))
-if len(sys.argv) > 3:
-    s.exp_set("tiny_query_every", int(sys.argv[3])); print("hipStreamQuery every %s steps" % sys.argv[3])
 for phase, pause in (("from a cold start", 0.0), ("after a 0.2 s pause", 0.2), ("after a 2 s pause", 2.0)):
     time.sleep(pause)
     s.reset(poses)
