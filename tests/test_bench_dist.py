@@ -32,7 +32,20 @@ rdv.close()
 
 
 def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+    """a port nobody listens on, taken BELOW the kernel's ephemeral range (32768+): a port from bind(0) can be handed to another process's
+    outgoing connection between this probe and the rank that binds it"""
+    import random
+    for _ in range(200):
+        p = random.randint(20000, 29999)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", p))
+        except OSError:
+            continue
+        finally:
+            s.close()
+        return p
+    raise RuntimeError("no free port in 20000..29999")
 
 
 def test_two_rank_rendezvous_and_sharding():

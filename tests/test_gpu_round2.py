@@ -515,7 +515,20 @@ def test_bench_two_launched_ranks_on_one_gpu():
     prints one line for the whole job"""
     import json
     import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import random
+    port = None
+    for _ in range(200):      # below the kernel's ephemeral range: a port from bind(0) can go to somebody's outgoing connection meanwhile
+        cand = random.randint(20000, 29999)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", cand))
+            port = cand
+            break
+        except OSError:
+            pass
+        finally:
+            s.close()
+    assert port is not None
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
