@@ -554,3 +554,33 @@ def test_duo_tail_equals_the_general_pair_body(amd):
     for t, (ra, rb) in enumerate(zip(*outs)):
         for k in ra:
             assert np.array_equal(ra[k], rb[k]), (t, k)
+
+
+def test_host_logic_vec_env_through_both_observation_paths(amd):
+    """Simulator.step brings the observation back through the page-locked block (one ABI call) up to 32 MB of scans and by plain copies above it
+    (a staging block of hundreds of MB would cost more than the call it saves): 2100 envs x 2 cars sit ABOVE the line, the same envs in two
+    halves below it — every observation key, `done` and the lap arrays of the big env equal those of the halves, over steps with wall hits"""
+    E, A = 2100, 2
+    kw = dict(map=map_stem("example_map"), map_ext=".png", num_agents=A)
+    poses = bench_start_poses(E, A, gap_wp=4).reshape(E, A, 3)
+    big = amd.F110VecEnv(E, **kw)
+    halves = [amd.F110VecEnv(E // 2, **kw) for _ in range(2)]
+    assert E * A * 1080 * 8 > (32 << 20) >= (E // 2) * A * 1080 * 8
+    ob, _, db, ib = big.reset(poses)
+    parts = [h.reset(poses[k * (E // 2):(k + 1) * (E // 2)]) for k, h in enumerate(halves)]
+    rng = np.random.default_rng(4)
+    hit = 0.0
+    for t in range(90):
+        if t % 15 == 1:
+            act = np.stack([rng.uniform(-0.4, 0.4, (E, A)), rng.uniform(6.0, 14.0, (E, A))], axis=2)
+        if t:
+            ob, _, db, ib = big.step(act)
+            parts = [h.step(act[k * (E // 2):(k + 1) * (E // 2)]) for k, h in enumerate(halves)]
+        for key in ("scans", "poses_x", "poses_y", "poses_theta", "linear_vels_x", "linear_vels_y", "ang_vels_z", "collisions", "lap_times", "lap_counts"):
+            assert np.array_equal(np.asarray(ob[key]), np.concatenate([np.asarray(p[0][key]) for p in parts])), (t, key)
+        assert np.array_equal(db, np.concatenate([p[2] for p in parts])), t
+        assert np.array_equal(ib["checkpoint_done"], np.concatenate([p[3]["checkpoint_done"] for p in parts])), t
+        hit += float(np.asarray(ob["collisions"]).sum())
+    assert hit > 0
+    for e in [big] + halves:
+        e.sim.batch.close()
